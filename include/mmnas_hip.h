@@ -1,0 +1,289 @@
+/*
+ * mmnas_hip.h -- C ABI of libmmnas_hip.so, the MI355X (gfx950) implementation of the MMNas
+ * candidate-operator hot path.
+ *
+ * The reference (MILVLG/mmnas) is pure Python on ATen and has no FFI of its own; each entry
+ * point below replaces the ATen kernel group behind one reference operator and cites it
+ * (paths relative to the reference root; modules.py = mmnas/model/modules.py).  The binding a
+ * maintainer adds on the reference side is the ctypes stub in INTEGRATION.md; ours is
+ * mmnas_amd/_lib.py.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory (HBM) unless marked host.
+ *   - all tensors are dense row-major fp32; masks are uint8 (non-zero = padded key).
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Every call only enqueues
+ *     work on that stream: no allocation, no synchronisation, graph-capturable.
+ *   - return value: 0 on success, negative MMNAS_E_* otherwise; mmnas_last_error() gives the text.
+ *   - scratch/saved buffers are caller-owned; sizes come from the *_plan() functions.
+ */
+#ifndef MMNAS_HIP_H
+#define MMNAS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMNAS_ABI_VERSION 1
+
+enum {
+  MMNAS_OK = 0,
+  MMNAS_E_SHAPE = -1,    /* unsupported / inconsistent shape (message says which) */
+  MMNAS_E_ARG = -2,      /* null pointer or bad flag combination */
+  MMNAS_E_LAUNCH = -3    /* hipGetLastError() after a launch */
+};
+
+/* operator flags */
+enum {
+  MMNAS_F_NORM = 1,      /* trailing LayerNorm (modules.py:268-269) */
+  MMNAS_F_RESIDUAL = 2,  /* x + core(x) (modules.py:263-264) */
+  MMNAS_F_MASK = 4,      /* key-padding mask present */
+  MMNAS_F_REL = 8,       /* relation bias (RelMHAtt, modules.py:231-235) */
+  MMNAS_F_SELF = 16,     /* query and key/value source are the same tensor */
+  MMNAS_F_TRAIN = 32     /* dropout active */
+};
+
+int mmnas_abi_version(void);
+const char* mmnas_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dropout generator.  nn.Dropout sites of the reference (modules.py:22,135-137,176,256,347)
+ * draw from ATen's Philox stream; ours is counter-based: keep(idx) is a pure function of
+ * (seed, site, idx) so backward kernels replay the forward mask instead of storing it
+ * (definition: mmnas_amd/csrc/rng.h; CPU restatement for the tests: oracle/dropout_rng.py).
+ * mmnas_dropout_mask writes the float multiplier (0 or 1/(1-p)) for idx = 0..n-1.
+ * ------------------------------------------------------------------------------------------ */
+int mmnas_dropout_mask(float* out, size_t n, float p, uint64_t seed, uint32_t site, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Grouped fp32 GEMM on v_mfma_f32_32x32x2_f32 with fused epilogue.
+ * Replaces the mm/addmm/bmm calls behind nn.Linear in modules.py:18,38,172-175 and their
+ * autograd backward.  For group g (independent problems launched together):
+ *     C_g[M_g,N] = epilogue( alpha * sum_{s<nseg} op(A_{g,s}) * op(B_{g,s}) )
+ *   layout MMNAS_GEMM_NT : A[M,K] (lda), B[N,K] (ldb)        y = x W^T        (forward)
+ *   layout MMNAS_GEMM_NN : A[M,K] (lda), B[K,N] (ldb)        dx = dy W        (data gradient)
+ *   layout MMNAS_GEMM_TN : A[K,M] (lda), B[K,N] (ldb)        dW = dy^T x      (weight gradient)
+ *   epilogue, in this order: + bias[N]; relu; * dropout(seed, site, idx = row*N+col);
+ *                            * (gate[row*ldgate+col] > 0 ? gate_scale : 0); + residual[row*ldres+col]
+ *   split_k > 1 (TN only): K is cut into split_k slices whose partial products are added to C
+ *   with float atomics -- C must hold the value to accumulate onto (zeros for a plain product).
+ * ------------------------------------------------------------------------------------------ */
+enum { MMNAS_GEMM_NT = 0, MMNAS_GEMM_NN = 1, MMNAS_GEMM_TN = 2 };
+
+typedef struct mmnas_gemm_group {
+  int M;
+  const float* A[3];
+  const float* B[3];
+  float* C;
+  const float* bias;      /* [N] or NULL */
+  const float* residual;  /* [M, ldres] or NULL */
+  const float* gate;      /* [M, ldgate] or NULL */
+} mmnas_gemm_group;
+
+typedef struct mmnas_gemm_desc {
+  int layout, ngroups, nseg;
+  int N, K;
+  int lda, ldb, ldc, ldres, ldgate;
+  int relu, split_k;
+  float alpha, gate_scale;
+  float drop_p;           /* 0 = no dropout */
+  uint32_t drop_site;
+  uint64_t drop_seed;
+  mmnas_gemm_group g[3];
+} mmnas_gemm_desc;
+
+int mmnas_gemm(const mmnas_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm with Bessel-corrected std and eps added to the std (modules.py:52-56).
+ *   fwd : y = a*(x-mean)/(std+eps)+b, x,y [M,d]
+ *   bwd : dx [M,d]; da,db [d] are ACCUMULATED (atomics) -- zero them for a plain gradient.
+ *         If ddrop != NULL it receives dx * dropout(seed, site, idx=row*d+col) (the gradient
+ *         that flows into the operator core through the output dropout, modules.py:261).
+ *         If dcol != NULL, dcol[d] += column sums of ddrop (bias gradient of the last linear).
+ * d % 4 == 0, d <= 4096.
+ * ------------------------------------------------------------------------------------------ */
+int mmnas_layernorm_fwd(const float* x, const float* a, const float* b, float* y,
+                        int M, int d, float eps, void* stream);
+int mmnas_layernorm_bwd(const float* x, const float* a, const float* dy, float* dx,
+                        float* da, float* db, float* ddrop, float* dcol,
+                        float drop_p, uint64_t seed, uint32_t site,
+                        int M, int d, float eps, void* stream);
+
+/* out[N] += column sums of x[M,N] (bias gradients). */
+int mmnas_colsum(const float* x, float* out, int M, int N, int ldx, void* stream);
+
+/* Element-wise helpers (modules.py:96-119 and the bare registry entries ops_adapter.py:25-29).
+ * kind: 0 zero, 1 relu, 2 leaky-relu(0.01), 3 gelu-tanh (modules.py:109).
+ * bwd computes dx = dy * f'(x). */
+int mmnas_eltwise_fwd(int kind, const float* x, float* y, size_t n, void* stream);
+int mmnas_eltwise_bwd(int kind, const float* x, const float* dy, float* dx, size_t n, void* stream);
+/* y = dropout(x) * scale-free copy with optional residual: y = res + x*dropmask (n elements, idx = i) */
+int mmnas_drop_add(const float* x, const float* res, float* y, size_t n, float drop_p, uint64_t seed,
+                   uint32_t site, void* stream);
+/* nn.GLU over the last dim (modules.py:116-119): h [M,2C] -> y[M,C] = h[:, :C]*sigmoid(h[:, C:]);
+ * optional relu and dropout after it (GLU(layers=2) unit_0 path, modules.py:145). */
+int mmnas_glu_fwd(const float* h, float* y, int M, int C, int relu, float drop_p, uint64_t seed,
+                  uint32_t site, void* stream);
+int mmnas_glu_bwd(const float* h, const float* dy, float* dh, int M, int C, int relu, float drop_p,
+                  uint64_t seed, uint32_t site, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Relation bias of RelMHAtt (modules.py:231-235):
+ *   biasT[b,h,k,q] = log(max(relu(rel[b,q,k,:] . Wr[h,:] + br[h]), 1e-6))
+ * rel [B,Sq,Sk,R] is read exactly once (the HBM-bound kernel of the path); the bias is written
+ * key-major ([B,H,Sk,Sq]) so the attention core reads it coalesced along the query lanes.
+ * bwd: dpre = dbiasT / r where r > 1e-6, else 0;  drel[b,q,k,:] = sum_h dpre*Wr[h,:] (overwritten
+ * or, with accumulate_drel != 0, added to); dWr [H,R], dbr [H] accumulated with atomics.
+ * R % 4 == 0, R <= 256, H <= 32.
+ * ------------------------------------------------------------------------------------------ */
+int mmnas_rel_bias_fwd(const float* rel, const float* Wr, const float* br, float* biasT,
+                       int B, int Sq, int Sk, int R, int H, void* stream);
+int mmnas_rel_bias_bwd(const float* rel, const float* Wr, const float* br, const float* dbiasT,
+                       float* drel, float* dWr, float* dbr, int accumulate_drel,
+                       int B, int Sq, int Sk, int R, int H, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention core: MHAtt.att (modules.py:191-199) for all (batch, head) pairs.
+ *   Z = Q K^T / sqrt(dh) (+ biasT) ; Z[mask] = -1e9 ; P = softmax(Z) ; A = dropout(P) ; O = A V
+ * Q [B*Sq, ldq], K,V [B*Sk, ldk/ldv], head h occupies columns [h*dh, (h+1)*dh).
+ * O [B*Sq, ldo] same column convention; lse [B,H,Sq] = log-sum-exp of each score row (saved
+ * for backward instead of the map).  dropout idx = ((b*H+h)*Sq+q)*Sk+k.
+ * Limits: dh in {16,32,64,128,256}; Sk <= 256.
+ * bwd recomputes P from (Q,K,lse): dQ,dK,dV (same layouts as Q,K,V) are overwritten;
+ * dbiasT [B,H,Sk,Sq] (nullable) receives dZ.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mmnas_mha_desc {
+  int B, H, Sq, Sk, dh;
+  int ldq, ldk, ldv, ldo;
+  const float* Q; const float* K; const float* V;
+  const uint8_t* mask;     /* [B,Sk] or NULL */
+  const float* biasT;      /* [B,H,Sk,Sq] or NULL */
+  float* O;                /* fwd: out.  bwd: unused (may be NULL) */
+  float* lse;              /* fwd: out.  bwd: in */
+  float drop_p; uint32_t drop_site; uint64_t drop_seed;
+  /* backward only */
+  const float* dO;         /* [B*Sq, ldo] */
+  float* dQ; float* dK; float* dV;
+  float* dbiasT;           /* [B,H,Sk,Sq] or NULL */
+  float* delta;            /* scratch [B,H,Sq] */
+} mmnas_mha_desc;
+
+int mmnas_mha_core_fwd(const mmnas_mha_desc* d, void* stream);
+int mmnas_mha_core_bwd(const mmnas_mha_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Operator level: one call = one reference operator forward (or backward).
+ *
+ * Attention family -- SelfAtt (modules.py:260-271), RelSelfAtt (:286-298), GuidedAtt (:313-325),
+ * UniimgAtt (:415-428, caller concatenates x and y into xkv):
+ *   y = LN( xq + drop( merge( att( xq Wq^T, xkv Wk^T, xkv Wv^T ) ) ) )
+ * dropout sites: 0 = attention map, 1 = operator output.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mmnas_att_op {
+  int B, Sq, Sk, d, di, H, dh, R;
+  int flags;
+  float drop_p, eps;
+  uint64_t seed;
+  const float* xq;         /* [B*Sq, d] */
+  const float* xkv;        /* [B*Sk, d] (== xq when MMNAS_F_SELF) */
+  const uint8_t* mask;     /* [B,Sk] */
+  const float* rel;        /* [B,Sq,Sk,R] */
+  const float* Wq; const float* Wk; const float* Wv;   /* [di, d]  mhatt.linear_{q,k,v}.weight */
+  const float* Wm;         /* [d, di]  mhatt.linear_merge.weight */
+  const float* Wr; const float* br;                    /* [H,R],[H] mhatt.linear_r */
+  const float* ln_a; const float* ln_b;                /* [d] ln.a_2, ln.b_2 */
+  float* y;                /* [B*Sq, d] */
+  void* save;              /* saved-for-backward block, mmnas_att_op_plan().save_bytes */
+  void* ws;                /* scratch, max(ws_fwd_bytes, ws_bwd_bytes) */
+  /* backward */
+  const float* dy;         /* [B*Sq, d] */
+  float* dxq;              /* [B*Sq, d] overwritten (total input gradient when MMNAS_F_SELF) */
+  float* dxkv;             /* [B*Sk, d] overwritten (ignored when MMNAS_F_SELF) */
+  float* drel;             /* [B,Sq,Sk,R] overwritten, or NULL to skip */
+  float* dWq; float* dWk; float* dWv; float* dWm;      /* accumulated (+=) */
+  float* dWr; float* dbr; float* dln_a; float* dln_b;  /* accumulated (+=) */
+} mmnas_att_op;
+
+typedef struct mmnas_plan {
+  size_t save_bytes, ws_fwd_bytes, ws_bwd_bytes;
+} mmnas_plan;
+
+int mmnas_att_op_plan(const mmnas_att_op* op, mmnas_plan* plan);   /* host only */
+int mmnas_att_op_fwd(const mmnas_att_op* op, void* stream);
+int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MLP family: a chain of nl (1..3) Linear layers with ReLU+dropout between them, then the common
+ * epilogue.  FeedForward (modules.py:351-362): nl = 2, dims {d, mid_k*d, d};
+ * FeedForward_deep (:389-400): nl = 3, dims {d, 2d, 2d, d}.
+ *   h_0 = x ; h_{i+1} = drop_i(relu(h_i W_i^T + b_i)) for i < nl-1 ; core = h_{nl-1} W^T + b
+ *   y = LN( x + drop_out(core) )
+ * dropout sites: hidden layer i -> site {0,2}[i], operator output -> site 1.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mmnas_mlp_op {
+  int M, nl;
+  int dims[4];             /* dims[0] = dims[nl] = d */
+  int flags;
+  float drop_p, eps;
+  uint64_t seed;
+  const float* x;          /* [M, d] */
+  const float* W[3];       /* W[i]: [dims[i+1], dims[i]] */
+  const float* b[3];
+  const float* ln_a; const float* ln_b;
+  float* y;
+  void* save; void* ws;
+  const float* dy;
+  float* dx;               /* overwritten */
+  float* dW[3]; float* db[3];                          /* accumulated (+=) */
+  float* dln_a; float* dln_b;
+} mmnas_mlp_op;
+
+int mmnas_mlp_op_plan(const mmnas_mlp_op* op, mmnas_plan* plan);
+int mmnas_mlp_op_fwd(const mmnas_mlp_op* op, void* stream);
+int mmnas_mlp_op_bwd(const mmnas_mlp_op* op, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 1-D convolutions over the sequence axis of x[B,S,d] (channels last, zero "same" padding, odd
+ * kernel size k <= 11): building blocks of StdConv (modules.py:465-491: im2col -> mmnas_gemm) and
+ * SepConv (modules.py:431-462: depthwise stencil -> pointwise mmnas_gemm).
+ *   im2col : col[m, t*d + c] = x[b, s+t-k/2, c] (0 outside the sequence), m = b*S+s
+ *   col2im : dx[m, c] = sum_t dcol[(b, s-t+k/2), t*d + c]            (its adjoint)
+ *   dwconv : y[m,c] = bias[c] + sum_t w[c,t] x[b, s+t-k/2, c]   (w = depthwise_conv.weight [d,1,k])
+ *            bwd overwrites dx and ACCUMULATES dw [d,k], db [d].
+ * ------------------------------------------------------------------------------------------ */
+int mmnas_im2col_seq(const float* x, float* col, int B, int S, int d, int k, void* stream);
+int mmnas_col2im_seq(const float* dcol, float* dx, int B, int S, int d, int k, void* stream);
+int mmnas_dwconv_seq_fwd(const float* x, const float* w, const float* bias, float* y,
+                         int B, int S, int d, int k, void* stream);
+int mmnas_dwconv_seq_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw,
+                         float* db, int B, int S, int d, int k, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Data-parallel helper: gather/scatter a list of gradient segments into/from one contiguous
+ * staging buffer so that a sampled sub-network's gradients travel in a single RCCL all-reduce
+ * (replaces DDP's bucket copies, search_vqa.py:210,292).  `segs` is a device array of
+ * nseg {ptr, offset(floats), n(floats)} records; direction 0 = pack (src -> staging*scale),
+ * 1 = unpack (staging*scale -> dst).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mmnas_segment { float* ptr; uint64_t offset; uint64_t n; } mmnas_segment;
+int mmnas_pack_segments(const mmnas_segment* segs, int nseg, float* staging, float scale,
+                        int direction, void* stream);
+
+/* Fused Adam over a flat fp32 parameter buffer (net_optim.step(), search_vqa.py:300 through
+ * mmnas/utils/optimizer.py): torch.optim.Adam arithmetic with bias correction at `step`.
+ * If sumsq != NULL (device scalar holding the squared global gradient norm) the gradient is first
+ * scaled by min(1, max_norm / (sqrt(*sumsq) + 1e-6)) -- clip_grad_norm_, search_vqa.py:296-298 --
+ * without a host round trip. */
+int mmnas_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, const float* sumsq, float max_norm,
+                    int step, void* stream);
+/* out[0] += sum of squares of g[0..n) (for clip_grad_norm_). */
+int mmnas_sumsq(const float* g, size_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMNAS_HIP_H */

@@ -1,0 +1,153 @@
+"""ctypes binding of libmmnas_hip.so (include/mmnas_hip.h).
+
+There is deliberately no fallback: if the shared library is missing, or a tensor is not a
+contiguous fp32 HIP tensor, the call raises.  The product path never computes on the CPU.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libmmnas_hip.so')
+
+F_NORM, F_RESIDUAL, F_MASK, F_REL, F_SELF, F_TRAIN = 1, 2, 4, 8, 16, 32
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+
+_fp = C.c_void_p  # device pointers travel as void*
+
+
+class GemmGroup(C.Structure):
+    _fields_ = [('M', C.c_int), ('A', _fp * 3), ('B', _fp * 3), ('C', _fp), ('bias', _fp),
+                ('residual', _fp), ('gate', _fp)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [('layout', C.c_int), ('ngroups', C.c_int), ('nseg', C.c_int), ('N', C.c_int), ('K', C.c_int),
+                ('lda', C.c_int), ('ldb', C.c_int), ('ldc', C.c_int), ('ldres', C.c_int), ('ldgate', C.c_int),
+                ('relu', C.c_int), ('split_k', C.c_int), ('alpha', C.c_float), ('gate_scale', C.c_float),
+                ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64),
+                ('g', GemmGroup * 3)]
+
+
+class MhaDesc(C.Structure):
+    _fields_ = [('B', C.c_int), ('H', C.c_int), ('Sq', C.c_int), ('Sk', C.c_int), ('dh', C.c_int),
+                ('ldq', C.c_int), ('ldk', C.c_int), ('ldv', C.c_int), ('ldo', C.c_int),
+                ('Q', _fp), ('K', _fp), ('V', _fp), ('mask', _fp), ('biasT', _fp), ('O', _fp), ('lse', _fp),
+                ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64),
+                ('dO', _fp), ('dQ', _fp), ('dK', _fp), ('dV', _fp), ('dbiasT', _fp), ('delta', _fp)]
+
+
+class AttOp(C.Structure):
+    _fields_ = [('B', C.c_int), ('Sq', C.c_int), ('Sk', C.c_int), ('d', C.c_int), ('di', C.c_int),
+                ('H', C.c_int), ('dh', C.c_int), ('R', C.c_int), ('flags', C.c_int),
+                ('drop_p', C.c_float), ('eps', C.c_float), ('seed', C.c_uint64),
+                ('xq', _fp), ('xkv', _fp), ('mask', _fp), ('rel', _fp),
+                ('Wq', _fp), ('Wk', _fp), ('Wv', _fp), ('Wm', _fp), ('Wr', _fp), ('br', _fp),
+                ('ln_a', _fp), ('ln_b', _fp), ('y', _fp), ('save', _fp), ('ws', _fp),
+                ('dy', _fp), ('dxq', _fp), ('dxkv', _fp), ('drel', _fp),
+                ('dWq', _fp), ('dWk', _fp), ('dWv', _fp), ('dWm', _fp), ('dWr', _fp), ('dbr', _fp),
+                ('dln_a', _fp), ('dln_b', _fp)]
+
+
+class Plan(C.Structure):
+    _fields_ = [('save_bytes', C.c_size_t), ('ws_fwd_bytes', C.c_size_t), ('ws_bwd_bytes', C.c_size_t)]
+
+
+class MlpOp(C.Structure):
+    _fields_ = [('M', C.c_int), ('nl', C.c_int), ('dims', C.c_int * 4), ('flags', C.c_int),
+                ('drop_p', C.c_float), ('eps', C.c_float), ('seed', C.c_uint64),
+                ('x', _fp), ('W', _fp * 3), ('b', _fp * 3), ('ln_a', _fp), ('ln_b', _fp), ('y', _fp),
+                ('save', _fp), ('ws', _fp), ('dy', _fp), ('dx', _fp), ('dW', _fp * 3), ('db', _fp * 3),
+                ('dln_a', _fp), ('dln_b', _fp)]
+
+
+class Segment(C.Structure):
+    _fields_ = [('ptr', _fp), ('offset', C.c_uint64), ('n', C.c_uint64)]
+
+
+# every symbol include/mmnas_hip.h declares: name -> (restype, argtypes)
+_i, _f, _u32, _u64, _sz = C.c_int, C.c_float, C.c_uint32, C.c_uint64, C.c_size_t
+SYMBOLS = {
+    'mmnas_abi_version': (_i, []),
+    'mmnas_last_error': (C.c_char_p, []),
+    'mmnas_dropout_mask': (_i, [_fp, _sz, _f, _u64, _u32, _fp]),
+    'mmnas_gemm': (_i, [C.POINTER(GemmDesc), _fp]),
+    'mmnas_layernorm_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _fp]),
+    'mmnas_layernorm_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _u64, _u32, _i, _i, _f, _fp]),
+    'mmnas_colsum': (_i, [_fp, _fp, _i, _i, _i, _fp]),
+    'mmnas_eltwise_fwd': (_i, [_i, _fp, _fp, _sz, _fp]),
+    'mmnas_eltwise_bwd': (_i, [_i, _fp, _fp, _fp, _sz, _fp]),
+    'mmnas_drop_add': (_i, [_fp, _fp, _fp, _sz, _f, _u64, _u32, _fp]),
+    'mmnas_glu_fwd': (_i, [_fp, _fp, _i, _i, _i, _f, _u64, _u32, _fp]),
+    'mmnas_glu_bwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _f, _u64, _u32, _fp]),
+    'mmnas_rel_bias_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp]),
+    'mmnas_rel_bias_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
+    'mmnas_mha_core_fwd': (_i, [C.POINTER(MhaDesc), _fp]),
+    'mmnas_mha_core_bwd': (_i, [C.POINTER(MhaDesc), _fp]),
+    'mmnas_att_op_plan': (_i, [C.POINTER(AttOp), C.POINTER(Plan)]),
+    'mmnas_att_op_fwd': (_i, [C.POINTER(AttOp), _fp]),
+    'mmnas_att_op_bwd': (_i, [C.POINTER(AttOp), _fp]),
+    'mmnas_mlp_op_plan': (_i, [C.POINTER(MlpOp), C.POINTER(Plan)]),
+    'mmnas_mlp_op_fwd': (_i, [C.POINTER(MlpOp), _fp]),
+    'mmnas_mlp_op_bwd': (_i, [C.POINTER(MlpOp), _fp]),
+    'mmnas_im2col_seq': (_i, [_fp, _fp, _i, _i, _i, _i, _fp]),
+    'mmnas_col2im_seq': (_i, [_fp, _fp, _i, _i, _i, _i, _fp]),
+    'mmnas_dwconv_seq_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),
+    'mmnas_dwconv_seq_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),
+    'mmnas_pack_segments': (_i, [_fp, _i, _fp, _f, _i, _fp]),
+    'mmnas_adam_step': (_i, [_fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _fp, _f, _i, _fp]),
+    'mmnas_sumsq': (_i, [_fp, _sz, _fp, _fp]),
+}
+
+_lib = None
+
+
+class MMNasHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded shared library (loads on first use; raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MMNasHipError(
+                'libmmnas_hip.so not found at %s -- build it with `python -c "import __graft_entry__ as g; '
+                'g.build()"` or `make -C mmnas_amd/csrc`.  There is no CPU fallback.' % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError here = header and library disagree
+            fn.restype = res
+            fn.argtypes = args
+        if l.mmnas_abi_version() != 1:
+            raise MMNasHipError('libmmnas_hip.so ABI version %d != 1' % l.mmnas_abi_version())
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise MMNasHipError('libmmnas_hip: %s (code %d)' % (lib().mmnas_last_error().decode(), rc))
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor, or None (NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MMNasHipError('mmnas_amd operators run on the MI355X only: got a %s tensor (no CPU fallback)'
+                            % t.device)
+    if not t.is_contiguous():
+        raise MMNasHipError('non-contiguous tensor passed to the HIP boundary')
+    return t.data_ptr()
+
+
+def fptr(t):
+    if t is not None and t.dtype != torch.float32:
+        raise MMNasHipError('expected float32, got %s' % t.dtype)
+    return ptr(t)
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

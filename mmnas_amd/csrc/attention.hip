@@ -1,0 +1,519 @@
+// Attention core of MHAtt.att / RelMHAtt.forward (modules.py:191-199, 231-241) for every
+// (batch, head) pair:  Z = Q K^T / sqrt(dh) (+ rel bias);  Z[mask] = -1e9;  P = softmax(Z);
+// A = dropout(P);  O = A V  -- and its backward, recomputing P from the saved row statistics.
+//
+// MI355X mapping (all products on v_mfma_f32_32x32x2_f32, exact fp32):
+//   * forward / dQ kernels are QUERY-owner: a wave owns 32 queries and computes the TRANSPOSED
+//     score tile S^T = K Q^T, so a lane holds one query column and its registers hold the keys:
+//     the softmax row reduction is in-register plus one cross-half shuffle, and the probability
+//     tile is already in MFMA A-operand form for O = A V (accumulator-as-operand, no LDS trip).
+//   * the dK/dV kernel is KEY-owner (a wave owns 32 keys, sweeps the queries): S = Q K^T puts the
+//     key on the lane, so A^T dO and dZ^T Q again take the accumulator tile as the A operand.
+//     Recomputing S in both kernels (7 products instead of 5) avoids any transpose through LDS or
+//     cross-workgroup reduction; the core is ~10 % of an attention operator's FLOPs.
+//   * Q/K/V/dO head slices are staged through LDS as [row][dh_chunk + 4] (ds_read_b128 fragment
+//     reads conflict-free), head dim processed in chunks of <= 64 so dh = 16..256 share one code.
+//   * the relation bias is stored key-major [B,H,Sk,Sq]: query-owner lanes read it coalesced.
+// Row statistics: stats[b,h,q] = (row max, 1 / row sum) -- two floats, because a fully masked row
+// has max = -1e9 where a single log-sum-exp float would lose log(sum).
+#include <string.h>
+#include "common.h"
+
+namespace mmnas {
+
+struct MhaK {
+  int B, H, Sq, Sk, dh, nch;
+  int ldq, ldk, ldv, ldo;
+  const float* Q; const float* K; const float* V;
+  const uint8_t* mask; const float* biasT;
+  float* O; float* stats;
+  DropCfg drop; float scale;
+  const float* dO; float* dQ; float* dK; float* dV; float* dbiasT; float* delta;
+};
+
+// rows x DHC floats from global (row stride ld) into LDS [rows][DHC+4]; rows >= nvalid are zero
+template <int ROWS, int DHC, int NT>
+__device__ __forceinline__ void load_tile(float* __restrict__ dst, const float* __restrict__ src, int nvalid,
+                                          int ld, int tid) {
+  constexpr int F4 = DHC / 4, LD = DHC + 4;
+  for (int f = tid; f < ROWS * F4; f += NT) {
+    const int r = f / F4, c4 = f - r * F4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nvalid) v = *reinterpret_cast<const float4*>(src + (size_t)r * ld + 4 * c4);
+    *reinterpret_cast<float4*>(dst + r * LD + 4 * c4) = v;
+  }
+}
+
+#define MFMA4(ACC, AF, BF)            \
+  ACC = mfma32(AF.x, BF.x, ACC);      \
+  ACC = mfma32(AF.y, BF.y, ACC);      \
+  ACC = mfma32(AF.z, BF.z, ACC);      \
+  ACC = mfma32(AF.w, BF.w, ACC);
+
+// ------------------------------------------------------------------------------------------
+// forward: grid (ceil(Sq / (32 NW)), H, B), block 64 NW.  NKC = key chunks of 32 (all keys).
+// ------------------------------------------------------------------------------------------
+template <int DHC, int NKC, int NW>
+__global__ void __launch_bounds__(64 * NW) mha_fwd_kernel(const MhaK p) {
+  constexpr int LD = DHC + 4, NT = 64 * NW, JC = DHC >= 32 ? DHC / 32 : 1;
+  __shared__ __attribute__((aligned(16))) float Qs[32 * NW * LD];
+  __shared__ __attribute__((aligned(16))) float KVs[32 * NKC * LD];
+  __shared__ float sMask[32 * NKC];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32 * NW;
+  const int Sq = p.Sq, Sk = p.Sk;
+  const bool active = q0 + 32 * w < Sq;  // wave-uniform
+
+  for (int k = tid; k < 32 * NKC; k += NT)
+    sMask[k] = (p.mask && k < Sk && p.mask[(size_t)b * Sk + k]) ? 1.f : 0.f;
+
+  f32x16 acc[NKC];
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[kc][r] = 0.f;
+
+  // ---- S^T = K Q^T over the head-dim chunks ----
+  for (int c = 0; c < p.nch; ++c) {
+    if (c) __syncthreads();
+    load_tile<32 * NW, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + q0) * p.ldq + h * p.dh + c * DHC, Sq - q0, p.ldq, tid);
+    load_tile<32 * NKC, DHC, NT>(KVs, p.K + (size_t)(b * Sk) * p.ldk + h * p.dh + c * DHC, Sk, p.ldk, tid);
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < DHC / 8; ++s) {
+        const float4 qf = *reinterpret_cast<const float4*>(Qs + (32 * w + l31) * LD + 8 * s + 4 * hh);
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+          const float4 kf = *reinterpret_cast<const float4*>(KVs + (32 * kc + l31) * LD + 8 * s + 4 * hh);
+          MFMA4(acc[kc], kf, qf)
+        }
+      }
+    }
+  }
+
+  // ---- softmax over the keys of this lane's query (registers + the other half-wave) ----
+  const int qi = q0 + 32 * w + l31;
+  const bool qok = qi < Sq;
+  const size_t bh = (size_t)b * p.H + h;
+  float m = -INFINITY;
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = 32 * kc + acc_row(r, hh);
+      float v = acc[kc][r] * p.scale;
+      if (key < Sk) {
+        if (p.biasT && qok) v += p.biasT[(bh * Sk + key) * Sq + qi];
+        if (sMask[key] != 0.f) v = -1e9f;
+      } else {
+        v = -INFINITY;
+      }
+      acc[kc][r] = v;
+      m = fmaxf(m, v);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = expf(acc[kc][r] - m);
+      acc[kc][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  if (qok && hh == 0) {
+    p.stats[(bh * Sq + qi) * 2] = m;
+    p.stats[(bh * Sq + qi) * 2 + 1] = inv;
+  }
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float a = acc[kc][r] * inv;
+      if (p.drop.thresh) {
+        const int key = 32 * kc + acc_row(r, hh);
+        a *= drop_mult(p.drop, (uint32_t)((bh * Sq + qi) * Sk + key));
+      }
+      acc[kc][r] = a;
+    }
+
+  // ---- O = A V, head-dim chunk by chunk (A tile = the accumulators, as MFMA A operand) ----
+  for (int c = 0; c < p.nch; ++c) {
+    __syncthreads();
+    load_tile<32 * NKC, DHC, NT>(KVs, p.V + (size_t)(b * Sk) * p.ldv + h * p.dh + c * DHC, Sk, p.ldv, tid);
+    __syncthreads();
+    if (!active) continue;
+    f32x16 o[JC];
+#pragma unroll
+    for (int jc = 0; jc < JC; ++jc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[jc][r] = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kc + acc_row(r, hh);
+#pragma unroll
+        for (int jc = 0; jc < JC; ++jc) {
+          const float bv = (DHC >= 32 || l31 < DHC) ? KVs[key * LD + 32 * jc + l31] : 0.f;
+          o[jc] = mfma32(acc[kc][r], bv, o[jc]);
+        }
+      }
+#pragma unroll
+    for (int jc = 0; jc < JC; ++jc) {
+      const int col = 32 * jc + l31;
+      if (col < DHC) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int q = q0 + 32 * w + acc_row(r, hh);
+          if (q < Sq) p.O[(size_t)(b * Sq + q) * p.ldo + h * p.dh + c * DHC + col] = o[jc][r];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// delta[b,h,q] = sum_j dO[b,q,h,j] * O[b,q,h,j]  ( = sum_k dA[q,k] A[q,k])
+// ------------------------------------------------------------------------------------------
+__global__ void mha_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O, float* __restrict__ delta,
+                                 int B, int H, int Sq, int dh, int ldo) {
+  const long n = (long)B * Sq * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int h = (int)(i % H);
+    const long row = i / H;  // b*Sq + q
+    const float4* a = reinterpret_cast<const float4*>(dO + row * ldo + h * dh);
+    const float4* o = reinterpret_cast<const float4*>(O + row * ldo + h * dh);
+    float s = 0.f;
+    for (int j = 0; j < dh / 4; ++j) {
+      const float4 x = a[j], y = o[j];
+      s += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    }
+    const int b = (int)(row / Sq), q = (int)(row - (long)b * Sq);
+    delta[((size_t)b * H + h) * Sq + q] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, query-owner: dQ (head-dim chunk oc) and dZ -> dbiasT.
+// grid (ceil(Sq / (32 NW)), H * nch, B); keys swept in blocks of 32 NKC.
+// ------------------------------------------------------------------------------------------
+template <int DHC, int NKC, int NW>
+__global__ void __launch_bounds__(64 * NW) mha_bwd_q_kernel(const MhaK p) {
+  constexpr int LD = DHC + 4, NT = 64 * NW, JC = DHC >= 32 ? DHC / 32 : 1, KB = 32 * NKC;
+  __shared__ __attribute__((aligned(16))) float Qs[32 * NW * LD];
+  __shared__ __attribute__((aligned(16))) float Gs[32 * NW * LD];   // dO
+  __shared__ __attribute__((aligned(16))) float Ks[KB * LD];
+  __shared__ __attribute__((aligned(16))) float Vs[KB * LD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y % p.H, oc = blockIdx.y / p.H, q0 = blockIdx.x * 32 * NW;
+  const int Sq = p.Sq, Sk = p.Sk;
+  const bool active = q0 + 32 * w < Sq;
+  const int qi = q0 + 32 * w + l31;
+  const bool qok = qi < Sq;
+  const size_t bh = (size_t)b * p.H + h;
+  float m = 0.f, inv = 0.f, del = 0.f;
+  if (qok) {
+    m = p.stats[(bh * Sq + qi) * 2];
+    inv = p.stats[(bh * Sq + qi) * 2 + 1];
+    del = p.delta[bh * Sq + qi];
+  }
+  f32x16 dq[JC];
+#pragma unroll
+  for (int jc = 0; jc < JC; ++jc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[jc][r] = 0.f;
+
+  for (int kb = 0; kb < Sk; kb += KB) {
+    f32x16 acc[NKC], dacc[NKC];
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[kc][r] = 0.f; dacc[kc][r] = 0.f; }
+    for (int c = 0; c < p.nch; ++c) {
+      __syncthreads();
+      const int co = h * p.dh + c * DHC;
+      load_tile<32 * NW, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + q0) * p.ldq + co, Sq - q0, p.ldq, tid);
+      load_tile<32 * NW, DHC, NT>(Gs, p.dO + (size_t)(b * Sq + q0) * p.ldo + co, Sq - q0, p.ldo, tid);
+      load_tile<KB, DHC, NT>(Ks, p.K + (size_t)(b * Sk + kb) * p.ldk + co, Sk - kb, p.ldk, tid);
+      load_tile<KB, DHC, NT>(Vs, p.V + (size_t)(b * Sk + kb) * p.ldv + co, Sk - kb, p.ldv, tid);
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int s = 0; s < DHC / 8; ++s) {
+          const int fo = 8 * s + 4 * hh;
+          const float4 qf = *reinterpret_cast<const float4*>(Qs + (32 * w + l31) * LD + fo);
+          const float4 gf = *reinterpret_cast<const float4*>(Gs + (32 * w + l31) * LD + fo);
+#pragma unroll
+          for (int kc = 0; kc < NKC; ++kc) {
+            const float4 kf = *reinterpret_cast<const float4*>(Ks + (32 * kc + l31) * LD + fo);
+            const float4 vf = *reinterpret_cast<const float4*>(Vs + (32 * kc + l31) * LD + fo);
+            MFMA4(acc[kc], kf, qf)
+            MFMA4(dacc[kc], vf, gf)
+          }
+        }
+      }
+    }
+    // dZ^T for this key block (in place of acc)
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb + 32 * kc + acc_row(r, hh);
+        float dz = 0.f;
+        if (key < Sk && qok) {
+          float v = acc[kc][r] * p.scale;
+          if (p.biasT) v += p.biasT[(bh * Sk + key) * Sq + qi];
+          const bool masked = p.mask && p.mask[(size_t)b * Sk + key];
+          if (masked) v = -1e9f;
+          const float pr = expf(v - m) * inv;
+          const float dm = p.drop.thresh ? drop_mult(p.drop, (uint32_t)((bh * Sq + qi) * Sk + key)) : 1.f;
+          dz = masked ? 0.f : pr * (dacc[kc][r] * dm - del);
+          if (p.dbiasT && oc == 0) p.dbiasT[(bh * Sk + key) * Sq + qi] = dz;
+        }
+        acc[kc][r] = dz * p.scale;
+      }
+    if (p.nch > 1) {
+      __syncthreads();
+      load_tile<KB, DHC, NT>(Ks, p.K + (size_t)(b * Sk + kb) * p.ldk + h * p.dh + oc * DHC, Sk - kb, p.ldk, tid);
+      __syncthreads();
+    }
+    if (active) {
+#pragma unroll
+      for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kl = 32 * kc + acc_row(r, hh);
+#pragma unroll
+          for (int jc = 0; jc < JC; ++jc) {
+            const float bv = (DHC >= 32 || l31 < DHC) ? Ks[kl * LD + 32 * jc + l31] : 0.f;
+            dq[jc] = mfma32(acc[kc][r], bv, dq[jc]);
+          }
+        }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int jc = 0; jc < JC; ++jc) {
+      const int col = 32 * jc + l31;
+      if (col < DHC) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int q = q0 + 32 * w + acc_row(r, hh);
+          if (q < Sq) p.dQ[(size_t)(b * Sq + q) * p.ldq + h * p.dh + oc * DHC + col] = dq[jc][r];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, key-owner: dK, dV (head-dim chunk oc).  grid (ceil(Sk / (32 NW)), H * nch, B);
+// queries swept 32 at a time.
+// ------------------------------------------------------------------------------------------
+template <int DHC, int NW>
+__global__ void __launch_bounds__(64 * NW) mha_bwd_kv_kernel(const MhaK p) {
+  constexpr int LD = DHC + 4, NT = 64 * NW, JC = DHC >= 32 ? DHC / 32 : 1;
+  __shared__ __attribute__((aligned(16))) float Qs[32 * LD];
+  __shared__ __attribute__((aligned(16))) float Gs[32 * LD];
+  __shared__ __attribute__((aligned(16))) float Ks[32 * NW * LD];
+  __shared__ __attribute__((aligned(16))) float Vs[32 * NW * LD];
+  __shared__ float sM[32], sInv[32], sDel[32];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y % p.H, oc = blockIdx.y / p.H, k0 = blockIdx.x * 32 * NW;
+  const int Sq = p.Sq, Sk = p.Sk;
+  const bool active = k0 + 32 * w < Sk;
+  const int key = k0 + 32 * w + l31;
+  const bool kok = key < Sk;
+  const bool masked = kok && p.mask && p.mask[(size_t)b * Sk + key];
+  const size_t bh = (size_t)b * p.H + h;
+  f32x16 dk[JC], dv[JC];
+#pragma unroll
+  for (int jc = 0; jc < JC; ++jc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[jc][r] = 0.f; dv[jc][r] = 0.f; }
+
+  for (int qc = 0; qc < Sq; qc += 32) {
+    f32x16 acc, dacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; dacc[r] = 0.f; }
+    for (int c = 0; c < p.nch; ++c) {
+      __syncthreads();
+      const int co = h * p.dh + c * DHC;
+      load_tile<32, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + qc) * p.ldq + co, Sq - qc, p.ldq, tid);
+      load_tile<32, DHC, NT>(Gs, p.dO + (size_t)(b * Sq + qc) * p.ldo + co, Sq - qc, p.ldo, tid);
+      if (p.nch > 1 || qc == 0) {
+        load_tile<32 * NW, DHC, NT>(Ks, p.K + (size_t)(b * Sk + k0) * p.ldk + co, Sk - k0, p.ldk, tid);
+        load_tile<32 * NW, DHC, NT>(Vs, p.V + (size_t)(b * Sk + k0) * p.ldv + co, Sk - k0, p.ldv, tid);
+      }
+      if (c == 0 && tid < 32) {
+        const int q = qc + tid;
+        const bool ok = q < Sq;
+        sM[tid] = ok ? p.stats[(bh * Sq + q) * 2] : 0.f;
+        sInv[tid] = ok ? p.stats[(bh * Sq + q) * 2 + 1] : 0.f;
+        sDel[tid] = ok ? p.delta[bh * Sq + q] : 0.f;
+      }
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int s = 0; s < DHC / 8; ++s) {
+          const int fo = 8 * s + 4 * hh;
+          const float4 qf = *reinterpret_cast<const float4*>(Qs + l31 * LD + fo);
+          const float4 gf = *reinterpret_cast<const float4*>(Gs + l31 * LD + fo);
+          const float4 kf = *reinterpret_cast<const float4*>(Ks + (32 * w + l31) * LD + fo);
+          const float4 vf = *reinterpret_cast<const float4*>(Vs + (32 * w + l31) * LD + fo);
+          MFMA4(acc, qf, kf)    // S[query][key]
+          MFMA4(dacc, gf, vf)   // dA[query][key]
+        }
+      }
+    }
+    // A and dZ for (query = register row, key = lane)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ql = acc_row(r, hh), q = qc + ql;
+      float a = 0.f, dz = 0.f;
+      if (q < Sq && kok) {
+        float v = acc[r] * p.scale;
+        if (p.biasT) v += p.biasT[(bh * Sk + key) * Sq + q];
+        if (masked) v = -1e9f;
+        const float pr = expf(v - sM[ql]) * sInv[ql];
+        const float dm = p.drop.thresh ? drop_mult(p.drop, (uint32_t)((bh * Sq + q) * Sk + key)) : 1.f;
+        a = pr * dm;
+        dz = masked ? 0.f : pr * (dacc[r] * dm - sDel[ql]) * p.scale;
+      }
+      acc[r] = a;
+      dacc[r] = dz;
+    }
+    if (p.nch > 1) {
+      __syncthreads();
+      const int co = h * p.dh + oc * DHC;
+      load_tile<32, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + qc) * p.ldq + co, Sq - qc, p.ldq, tid);
+      load_tile<32, DHC, NT>(Gs, p.dO + (size_t)(b * Sq + qc) * p.ldo + co, Sq - qc, p.ldo, tid);
+      __syncthreads();
+    }
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = acc_row(r, hh);
+#pragma unroll
+        for (int jc = 0; jc < JC; ++jc) {
+          const bool cok = (DHC >= 32 || l31 < DHC);
+          const float gv = cok ? Gs[ql * LD + 32 * jc + l31] : 0.f;
+          const float qv = cok ? Qs[ql * LD + 32 * jc + l31] : 0.f;
+          dv[jc] = mfma32(acc[r], gv, dv[jc]);    // dV[key][j] += A[q][key] dO[q][j]
+          dk[jc] = mfma32(dacc[r], qv, dk[jc]);   // dK[key][j] += dZ[q][key] Q[q][j] / sqrt(dh)
+        }
+      }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int jc = 0; jc < JC; ++jc) {
+      const int col = 32 * jc + l31;
+      if (col < DHC) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kr = k0 + 32 * w + acc_row(r, hh);
+          if (kr < Sk) {
+            p.dK[(size_t)(b * Sk + kr) * p.ldk + h * p.dh + oc * DHC + col] = dk[jc][r];
+            p.dV[(size_t)(b * Sk + kr) * p.ldv + h * p.dh + oc * DHC + col] = dv[jc][r];
+          }
+        }
+      }
+    }
+  }
+}
+
+static int fill(const mmnas_mha_desc* d, MhaK& k, bool bwd) {
+  MMNAS_REQUIRE(d, MMNAS_E_ARG, "mha: null descriptor");
+  MMNAS_REQUIRE(d->B > 0 && d->H > 0 && d->Sq > 0 && d->Sk > 0, MMNAS_E_SHAPE, "mha: B=%d H=%d Sq=%d Sk=%d", d->B,
+                d->H, d->Sq, d->Sk);
+  MMNAS_REQUIRE(d->dh == 16 || d->dh == 32 || d->dh == 64 || d->dh == 128 || d->dh == 256, MMNAS_E_SHAPE,
+                "mha: head dim %d not in {16,32,64,128,256}", d->dh);
+  MMNAS_REQUIRE(d->Sk <= 256, MMNAS_E_SHAPE, "mha: Sk=%d > 256 keys not supported", d->Sk);
+  MMNAS_REQUIRE(d->Q && d->K && d->V && d->lse, MMNAS_E_ARG, "mha: null Q/K/V/stats");
+  MMNAS_REQUIRE(d->ldq % 4 == 0 && d->ldk % 4 == 0 && d->ldv % 4 == 0 && d->ldo % 4 == 0, MMNAS_E_SHAPE,
+                "mha: row strides must be multiples of 4 floats");
+  MMNAS_REQUIRE((((uintptr_t)d->Q | (uintptr_t)d->K | (uintptr_t)d->V) & 15) == 0, MMNAS_E_ARG,
+                "mha: Q/K/V must be 16-byte aligned");
+  MMNAS_REQUIRE((double)d->B * d->H * d->Sq * d->Sk < 4294967296.0, MMNAS_E_SHAPE, "mha: score tensor too large");
+  k.B = d->B; k.H = d->H; k.Sq = d->Sq; k.Sk = d->Sk; k.dh = d->dh;
+  k.ldq = d->ldq; k.ldk = d->ldk; k.ldv = d->ldv; k.ldo = d->ldo;
+  k.Q = d->Q; k.K = d->K; k.V = d->V; k.mask = d->mask; k.biasT = d->biasT; k.O = d->O; k.stats = d->lse;
+  k.drop = make_drop(d->drop_p, d->drop_seed, d->drop_site);
+  k.scale = 1.0f / sqrtf((float)d->dh);
+  k.dO = d->dO; k.dQ = d->dQ; k.dK = d->dK; k.dV = d->dV; k.dbiasT = d->dbiasT; k.delta = d->delta;
+  if (bwd) {
+    MMNAS_REQUIRE(d->dO && d->dQ && d->dK && d->dV && d->delta && d->O, MMNAS_E_ARG, "mha_bwd: null gradient buffer");
+    MMNAS_REQUIRE((((uintptr_t)d->dO | (uintptr_t)d->O) & 15) == 0, MMNAS_E_ARG, "mha_bwd: dO/O alignment");
+  } else {
+    MMNAS_REQUIRE(d->O, MMNAS_E_ARG, "mha_fwd: null output");
+  }
+  return MMNAS_OK;
+}
+
+template <int DHC>
+static void launch_fwd(const MhaK& k, hipStream_t st) {
+  const int nkc = cdiv(k.Sk, 32);
+#define FWD(NKC, NW) hipLaunchKernelGGL((mha_fwd_kernel<DHC, NKC, NW>), dim3(cdiv(k.Sq, 32 * NW), k.H, k.B), \
+                                        dim3(64 * NW), 0, st, k)
+  if (k.Sq <= 32) {
+    if (nkc <= 1) FWD(1, 1); else if (nkc <= 2) FWD(2, 1); else if (nkc <= 4) FWD(4, 1); else FWD(8, 1);
+  } else if (k.Sq <= 64) {
+    if (nkc <= 1) FWD(1, 2); else if (nkc <= 2) FWD(2, 2); else if (nkc <= 4) FWD(4, 2); else FWD(8, 2);
+  } else {
+    if (nkc <= 1) FWD(1, 4); else if (nkc <= 2) FWD(2, 4); else if (nkc <= 4) FWD(4, 4); else FWD(8, 4);
+  }
+#undef FWD
+}
+
+template <int DHC>
+static void launch_bwd(const MhaK& k, hipStream_t st) {
+  const int nkc = cdiv(k.Sk, 32);
+#define BQ(NKC, NW) hipLaunchKernelGGL((mha_bwd_q_kernel<DHC, NKC, NW>), dim3(cdiv(k.Sq, 32 * NW), k.H * k.nch, k.B), \
+                                       dim3(64 * NW), 0, st, k)
+  if (k.Sq <= 32) { if (nkc <= 1) BQ(1, 1); else BQ(2, 1); }
+  else if (k.Sq <= 64) { if (nkc <= 1) BQ(1, 2); else BQ(2, 2); }
+  else { if (nkc <= 1) BQ(1, 4); else BQ(2, 4); }
+#undef BQ
+#define BKV(NW) hipLaunchKernelGGL((mha_bwd_kv_kernel<DHC, NW>), dim3(cdiv(k.Sk, 32 * NW), k.H * k.nch, k.B), \
+                                   dim3(64 * NW), 0, st, k)
+  if (nkc <= 1) BKV(1); else if (nkc <= 2) BKV(2); else BKV(4);
+#undef BKV
+}
+
+}  // namespace mmnas
+
+using namespace mmnas;
+
+extern "C" int mmnas_mha_core_fwd(const mmnas_mha_desc* d, void* stream) {
+  MhaK k;
+  int rc = fill(d, k, false);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (k.dh >= 64) { k.nch = k.dh / 64; launch_fwd<64>(k, st); }
+  else if (k.dh == 32) { k.nch = 1; launch_fwd<32>(k, st); }
+  else { k.nch = 1; launch_fwd<16>(k, st); }
+  return check_launch("mha_core_fwd");
+}
+
+extern "C" int mmnas_mha_core_bwd(const mmnas_mha_desc* d, void* stream) {
+  MhaK k;
+  int rc = fill(d, k, true);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  {
+    const long n = (long)k.B * k.Sq * k.H;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mha_delta_kernel, dim3(blocks), dim3(256), 0, st, k.dO, (const float*)d->O, k.delta, k.B, k.H,
+                       k.Sq, k.dh, k.ldo);
+  }
+  if (k.dh >= 64) { k.nch = k.dh / 64; launch_bwd<64>(k, st); }
+  else if (k.dh == 32) { k.nch = 1; launch_bwd<32>(k, st); }
+  else { k.nch = 1; launch_bwd<16>(k, st); }
+  return check_launch("mha_core_bwd");
+}

@@ -1,0 +1,41 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/mmnas_hip.h"
+#include "rng.h"
+
+namespace mmnas {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define MMNAS_REQUIRE(cond, code, ...) \
+  do { if (!(cond)) { ::mmnas::set_error(__VA_ARGS__); return (code); } } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Row of the 32x32 MFMA accumulator held in register r of a lane in half `hh` (= lane >> 5):
+// C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * hh.
+__device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace mmnas

@@ -1,0 +1,167 @@
+// 1-D convolutions over the sequence axis of x[B,S,d] (channels last), zero "same" padding:
+// SepConv = depthwise k-tap stencil + pointwise GEMM (modules.py:431-462), StdConv = dense k-tap
+// Conv1d (modules.py:465-491).  The dense conv runs on the MFMA GEMM through an explicit im2col
+// (row m=(b,s) -> [k*d] window), its gradient through the transposed gather (col2im); the depthwise
+// stencil is a streaming HBM-bound kernel.  k in {3,5,7,11}; these operators are registry-only
+// (in no shipped search space or arch/*.json), so they are built for parity, not for the roofline.
+#include "common.h"
+
+namespace mmnas {
+
+__global__ void im2col_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int S, int d, int k) {
+  const int pad = k / 2, d4 = d / 4;
+  const size_t n = (size_t)B * S * k * d4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % d4);
+    const int t = (int)((i / d4) % k);
+    const size_t m = i / ((size_t)d4 * k);
+    const int s = (int)(m % S);
+    const int ss = s + t - pad;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ss >= 0 && ss < S) v = *reinterpret_cast<const float4*>(x + (m + (ss - s)) * d + 4 * c4);
+    *reinterpret_cast<float4*>(col + (m * k + t) * d + 4 * c4) = v;
+  }
+}
+
+__global__ void col2im_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B, int S, int d, int k) {
+  const int pad = k / 2, d4 = d / 4;
+  const size_t n = (size_t)B * S * d4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % d4);
+    const size_t m = i / d4;
+    const int s = (int)(m % S);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < k; ++t) {
+      const int so = s - t + pad;  // the output row whose window tap t reads row s
+      if (so >= 0 && so < S) {
+        const float4 v = *reinterpret_cast<const float4*>(dcol + ((m + (so - s)) * k + t) * d + 4 * c4);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    }
+    *reinterpret_cast<float4*>(dx + m * d + 4 * c4) = a;
+  }
+}
+
+// y[m,c] = bias[c] + sum_t w[c,t] * x[b, s+t-pad, c]
+__global__ void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                  const float* __restrict__ bias, float* __restrict__ y, int B, int S, int d, int k) {
+  const int pad = k / 2;
+  const size_t n = (size_t)B * S * d;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % d);
+    const size_t m = i / d;
+    const int s = (int)(m % S);
+    float a = bias ? bias[c] : 0.f;
+    for (int t = 0; t < k; ++t) {
+      const int ss = s + t - pad;
+      if (ss >= 0 && ss < S) a += w[c * k + t] * x[(m + (ss - s)) * d + c];
+    }
+    y[i] = a;
+  }
+}
+
+// dx[m,c] = sum_t w[c,t] * dy[b, s-t+pad, c]
+__global__ void dwconv_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                    int B, int S, int d, int k) {
+  const int pad = k / 2;
+  const size_t n = (size_t)B * S * d;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % d);
+    const size_t m = i / d;
+    const int s = (int)(m % S);
+    float a = 0.f;
+    for (int t = 0; t < k; ++t) {
+      const int so = s - t + pad;
+      if (so >= 0 && so < S) a += w[c * k + t] * dy[(m + (so - s)) * d + c];
+    }
+    dx[i] = a;
+  }
+}
+
+// dw[c,t] += sum_m dy[m,c] x[b,s+t-pad,c];  db[c] += sum_m dy[m,c].  thread = channel, grid.y = row split
+template <int KMAX>
+__global__ void dwconv_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                    float* __restrict__ db, int B, int S, int d, int k, int rows_per_block) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  const int pad = k / 2;
+  const long M = (long)B * S;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  float acc[KMAX];
+#pragma unroll
+  for (int t = 0; t < KMAX; ++t) acc[t] = 0.f;
+  float accb = 0.f;
+  for (long m = r0; m < r1; ++m) {
+    const int s = (int)(m % S);
+    const float g = dy[m * d + c];
+    accb += g;
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) {
+      const int ss = s + t - pad;
+      if (t < k && ss >= 0 && ss < S) acc[t] += g * x[(m + (ss - s)) * d + c];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < KMAX; ++t)
+    if (t < k) atomicAdd(dw + c * k + t, acc[t]);
+  if (db) atomicAdd(db + c, accb);
+}
+
+static inline int nblocks(size_t n) { size_t b = (n + 255) / 256; return (int)(b < 4096 ? (b ? b : 1) : 4096); }
+
+static int conv_check(const char* who, int B, int S, int d, int k) {
+  MMNAS_REQUIRE(B > 0 && S > 0 && d > 0, MMNAS_E_SHAPE, "%s: B=%d S=%d d=%d", who, B, S, d);
+  MMNAS_REQUIRE(k >= 1 && k <= 11 && (k & 1), MMNAS_E_SHAPE, "%s: kernel size %d (odd, <= 11)", who, k);
+  return MMNAS_OK;
+}
+
+}  // namespace mmnas
+
+using namespace mmnas;
+
+extern "C" int mmnas_im2col_seq(const float* x, float* col, int B, int S, int d, int k, void* stream) {
+  MMNAS_REQUIRE(x && col, MMNAS_E_ARG, "im2col_seq: null pointer");
+  int rc = conv_check("im2col_seq", B, S, d, k);
+  if (rc) return rc;
+  MMNAS_REQUIRE(d % 4 == 0, MMNAS_E_SHAPE, "im2col_seq: d=%d %% 4", d);
+  hipLaunchKernelGGL(im2col_kernel, dim3(nblocks((size_t)B * S * k * d / 4)), dim3(256), 0, (hipStream_t)stream, x, col,
+                     B, S, d, k);
+  return check_launch("im2col_seq");
+}
+
+extern "C" int mmnas_col2im_seq(const float* dcol, float* dx, int B, int S, int d, int k, void* stream) {
+  MMNAS_REQUIRE(dcol && dx, MMNAS_E_ARG, "col2im_seq: null pointer");
+  int rc = conv_check("col2im_seq", B, S, d, k);
+  if (rc) return rc;
+  MMNAS_REQUIRE(d % 4 == 0, MMNAS_E_SHAPE, "col2im_seq: d=%d %% 4", d);
+  hipLaunchKernelGGL(col2im_kernel, dim3(nblocks((size_t)B * S * d / 4)), dim3(256), 0, (hipStream_t)stream, dcol, dx,
+                     B, S, d, k);
+  return check_launch("col2im_seq");
+}
+
+extern "C" int mmnas_dwconv_seq_fwd(const float* x, const float* w, const float* bias, float* y, int B, int S, int d,
+                                    int k, void* stream) {
+  MMNAS_REQUIRE(x && w && y, MMNAS_E_ARG, "dwconv_seq_fwd: null pointer");
+  int rc = conv_check("dwconv_seq_fwd", B, S, d, k);
+  if (rc) return rc;
+  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(nblocks((size_t)B * S * d)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                     y, B, S, d, k);
+  return check_launch("dwconv_seq_fwd");
+}
+
+extern "C" int mmnas_dwconv_seq_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                                    int B, int S, int d, int k, void* stream) {
+  MMNAS_REQUIRE(x && w && dy && dx && dw, MMNAS_E_ARG, "dwconv_seq_bwd: null pointer");
+  int rc = conv_check("dwconv_seq_bwd", B, S, d, k);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dwconv_bwd_x_kernel, dim3(nblocks((size_t)B * S * d)), dim3(256), 0, st, dy, w, dx, B, S, d, k);
+  const long M = (long)B * S;
+  int splits = (int)((M + 63) / 64);
+  if (splits > 256) splits = 256;
+  const int rpb = (int)((M + splits - 1) / splits);
+  hipLaunchKernelGGL(dwconv_bwd_w_kernel<11>, dim3(cdiv(d, 256), cdiv(M, rpb)), dim3(256), 0, st, x, dy, dw, db, B, S, d,
+                     k, rpb);
+  return check_launch("dwconv_seq_bwd");
+}

@@ -1,0 +1,328 @@
+// Row-wise and element-wise kernels of the operator epilogues: the reference's hand-written
+// LayerNorm (modules.py:44-56: Bessel-corrected std, eps added to the std), bias-gradient column
+// sums, the activation registry entries (modules.py:96-119, ops_adapter.py:25-29) and nn.GLU.
+// All are HBM-bound: one pass over the data, 16-byte accesses, one wave per row.
+#include "common.h"
+
+namespace mmnas {
+
+// ---------------------------------------------------------------- LayerNorm forward
+template <int NV>
+__global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                     const float* __restrict__ b, float* __restrict__ y,
+                                                     int M, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * d;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    v[i] = (c < d) ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < d) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+  }
+  const float sd = sqrtf(wave_sum(ss) / (float)(d - 1));
+  const float inv = 1.0f / (sd + eps);
+  float* yr = y + (size_t)row * d;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < d) {
+      const float4 av = *reinterpret_cast<const float4*>(a + c);
+      const float4 bv = *reinterpret_cast<const float4*>(b + c);
+      float4 o;
+      o.x = av.x * v[i].x * inv + bv.x; o.y = av.y * v[i].y * inv + bv.y;
+      o.z = av.z * v[i].z * inv + bv.z; o.w = av.w * v[i].w * inv + bv.w;
+      *reinterpret_cast<float4*>(yr + c) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm backward
+// dx = (g - mean(g))/s - c * sum(g*c) / ((n-1) * sd * s^2),  g = dy*a, c = x-mean, s = sd+eps
+// (pinned by oracle.layer_norm_backward against the reference's autograd).
+template <int NV>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                     const float* __restrict__ dy, float* __restrict__ dx,
+                                                     float* __restrict__ da, float* __restrict__ db,
+                                                     float* __restrict__ ddrop, float* __restrict__ dcol,
+                                                     DropCfg drop, int M, int d, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 acc_a[NV], acc_b[NV], acc_c[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    acc_a[i] = make_float4(0.f, 0.f, 0.f, 0.f); acc_b[i] = acc_a[i]; acc_c[i] = acc_a[i];
+  }
+  float4 av[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    av[i] = (c < d) ? *reinterpret_cast<const float4*>(a + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float* xr = x + (size_t)row * d;
+    const float* gr = dy + (size_t)row * d;
+    float4 v[NV], g[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < d) {
+        v[i] = *reinterpret_cast<const float4*>(xr + c);
+        g[i] = *reinterpret_cast<const float4*>(gr + c);
+      } else {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f); g[i] = v[i];
+      }
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float ss = 0.f, sg = 0.f, sgc = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < d) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        const float gx = g[i].x * av[i].x, gy = g[i].y * av[i].y, gz = g[i].z * av[i].z, gw = g[i].w * av[i].w;
+        sg += (gx + gy) + (gz + gw);
+        sgc += (gx * v[i].x + gy * v[i].y) + (gz * v[i].z + gw * v[i].w);
+      }
+    }
+    ss = wave_sum(ss); sg = wave_sum(sg); sgc = wave_sum(sgc);
+    const float sd = sqrtf(ss / (float)(d - 1));
+    const float sden = sd + eps;
+    const float inv = 1.0f / sden;
+    const float mg = sg / (float)d;
+    const float k2 = sgc / ((float)(d - 1) * sd * sden * sden);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < d) {
+        float4 o;
+        o.x = (g[i].x * av[i].x - mg) * inv - v[i].x * k2;
+        o.y = (g[i].y * av[i].y - mg) * inv - v[i].y * k2;
+        o.z = (g[i].z * av[i].z - mg) * inv - v[i].z * k2;
+        o.w = (g[i].w * av[i].w - mg) * inv - v[i].w * k2;
+        *reinterpret_cast<float4*>(dx + (size_t)row * d + c) = o;
+        acc_a[i].x += g[i].x * v[i].x * inv; acc_a[i].y += g[i].y * v[i].y * inv;
+        acc_a[i].z += g[i].z * v[i].z * inv; acc_a[i].w += g[i].w * v[i].w * inv;
+        acc_b[i].x += g[i].x; acc_b[i].y += g[i].y; acc_b[i].z += g[i].z; acc_b[i].w += g[i].w;
+        if (ddrop) {
+          if (drop.thresh) {
+            const uint32_t base = (uint32_t)row * (uint32_t)d + (uint32_t)c;
+            o.x *= drop_mult(drop, base); o.y *= drop_mult(drop, base + 1);
+            o.z *= drop_mult(drop, base + 2); o.w *= drop_mult(drop, base + 3);
+          }
+          *reinterpret_cast<float4*>(ddrop + (size_t)row * d + c) = o;
+          acc_c[i].x += o.x; acc_c[i].y += o.y; acc_c[i].z += o.z; acc_c[i].w += o.w;
+        }
+      }
+    }
+  }
+  // reduce the per-wave column partials across the 4 waves, then one atomic per column per block
+  __shared__ float red[3][4][64 * 4];  // [which][wave][lane*4 + j], reused per i
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    __syncthreads();
+    *reinterpret_cast<float4*>(&red[0][wave][lane * 4]) = acc_a[i];
+    *reinterpret_cast<float4*>(&red[1][wave][lane * 4]) = acc_b[i];
+    *reinterpret_cast<float4*>(&red[2][wave][lane * 4]) = acc_c[i];
+    __syncthreads();
+    if (wave == 0 && c < d) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int o = lane * 4 + j;
+        const float sa = (red[0][0][o] + red[0][1][o]) + (red[0][2][o] + red[0][3][o]);
+        const float sb = (red[1][0][o] + red[1][1][o]) + (red[1][2][o] + red[1][3][o]);
+        if (da) atomicAdd(da + c + j, sa);
+        if (db) atomicAdd(db + c + j, sb);
+        if (dcol) atomicAdd(dcol + c + j, (red[2][0][o] + red[2][1][o]) + (red[2][2][o] + red[2][3][o]));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- column sums
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                     int M, int N, int ldx, int rows_per_block) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  float s0 = 0.f, s1 = 0.f;
+  int r = r0;
+  for (; r + 1 < r1; r += 2) {
+    s0 += x[(size_t)r * ldx + col];
+    s1 += x[(size_t)(r + 1) * ldx + col];
+  }
+  if (r < r1) s0 += x[(size_t)r * ldx + col];
+  atomicAdd(out + col, s0 + s1);
+}
+
+// ---------------------------------------------------------------- element-wise
+__device__ __forceinline__ float act_fwd(int kind, float x) {
+  switch (kind) {
+    case 0: return x * 0.f;
+    case 1: return fmaxf(x, 0.f);
+    case 2: return x > 0.f ? x : 0.01f * x;
+    default: {
+      const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+      return 0.5f * x * (1.f + tanhf(u));
+    }
+  }
+}
+__device__ __forceinline__ float act_bwd(int kind, float x) {
+  switch (kind) {
+    case 0: return 0.f;
+    case 1: return x > 0.f ? 1.f : 0.f;
+    case 2: return x > 0.f ? 1.f : 0.01f;
+    default: {
+      const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+      const float t = tanhf(u);
+      return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * 0.7978845608028654f * (1.f + 3.f * 0.044715f * x * x);
+    }
+  }
+}
+
+__global__ void eltwise_fwd_kernel(int kind, const float* __restrict__ x, float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = act_fwd(kind, x[i]);
+}
+__global__ void eltwise_bwd_kernel(int kind, const float* __restrict__ x, const float* __restrict__ dy,
+                                   float* __restrict__ dx, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dx[i] = dy[i] * act_bwd(kind, x[i]);
+}
+__global__ void drop_add_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y,
+                                size_t n, DropCfg drop) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v = x[i];
+    if (drop.thresh) v *= drop_mult(drop, (uint32_t)i);
+    y[i] = res ? res[i] + v : v;
+  }
+}
+
+__global__ void glu_fwd_kernel(const float* __restrict__ h, float* __restrict__ y, int M, int C, int relu,
+                               DropCfg drop) {
+  const size_t n = (size_t)M * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = i / C, c = i - m * C;
+    const float a = h[m * 2 * C + c], b = h[m * 2 * C + C + c];
+    float v = a / (1.f + expf(-b));
+    if (relu) v = fmaxf(v, 0.f);
+    if (drop.thresh) v *= drop_mult(drop, (uint32_t)i);
+    y[i] = v;
+  }
+}
+__global__ void glu_bwd_kernel(const float* __restrict__ h, const float* __restrict__ dy, float* __restrict__ dh,
+                               int M, int C, int relu, DropCfg drop) {
+  const size_t n = (size_t)M * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = i / C, c = i - m * C;
+    const float a = h[m * 2 * C + c], b = h[m * 2 * C + C + c];
+    const float sg = 1.f / (1.f + expf(-b));
+    float g = dy[i];
+    if (drop.thresh) g *= drop_mult(drop, (uint32_t)i);
+    if (relu && !(a * sg > 0.f)) g = 0.f;
+    dh[m * 2 * C + c] = g * sg;
+    dh[m * 2 * C + C + c] = g * a * sg * (1.f - sg);
+  }
+}
+
+static inline int blocks_for(size_t n) { size_t b = (n + 255) / 256; return (int)(b < 2048 ? (b ? b : 1) : 2048); }
+
+}  // namespace mmnas
+
+using namespace mmnas;
+
+extern "C" int mmnas_layernorm_fwd(const float* x, const float* a, const float* b, float* y, int M, int d,
+                                   float eps, void* stream) {
+  MMNAS_REQUIRE(x && a && b && y, MMNAS_E_ARG, "layernorm_fwd: null pointer");
+  MMNAS_REQUIRE(M > 0 && d >= 4 && d % 4 == 0 && d <= 2048, MMNAS_E_SHAPE,
+                "layernorm_fwd: M=%d d=%d (need d %% 4 == 0, 4 <= d <= 2048)", M, d);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(cdiv(M, 4)), block(256);
+  const int nv = cdiv(d, 256);
+  if (nv <= 1) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, st, x, a, b, y, M, d, eps);
+  else if (nv <= 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, st, x, a, b, y, M, d, eps);
+  else if (nv <= 4) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, st, x, a, b, y, M, d, eps);
+  else hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, st, x, a, b, y, M, d, eps);
+  return check_launch("layernorm_fwd");
+}
+
+extern "C" int mmnas_layernorm_bwd(const float* x, const float* a, const float* dy, float* dx, float* da,
+                                   float* db, float* ddrop, float* dcol, float drop_p, uint64_t seed,
+                                   uint32_t site, int M, int d, float eps, void* stream) {
+  MMNAS_REQUIRE(x && a && dy && dx, MMNAS_E_ARG, "layernorm_bwd: null pointer");
+  MMNAS_REQUIRE(M > 0 && d >= 4 && d % 4 == 0 && d <= 2048, MMNAS_E_SHAPE,
+                "layernorm_bwd: M=%d d=%d (need d %% 4 == 0, 4 <= d <= 2048)", M, d);
+  MMNAS_REQUIRE(dcol == nullptr || ddrop != nullptr, MMNAS_E_ARG, "layernorm_bwd: dcol needs ddrop");
+  hipStream_t st = (hipStream_t)stream;
+  int nb = cdiv(M, 4);
+  if (nb > 512) nb = 512;
+  dim3 grid(nb), block(256);
+  const DropCfg dc = make_drop(drop_p, seed, site);
+  const int nv = cdiv(d, 256);
+#define LNB(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, 0, st, x, a, dy, dx, da, db, ddrop, dcol, dc, M, d, eps)
+  if (nv <= 1) LNB(1); else if (nv <= 2) LNB(2); else if (nv <= 4) LNB(4); else LNB(8);
+#undef LNB
+  return check_launch("layernorm_bwd");
+}
+
+extern "C" int mmnas_colsum(const float* x, float* out, int M, int N, int ldx, void* stream) {
+  MMNAS_REQUIRE(x && out && M > 0 && N > 0 && ldx >= N, MMNAS_E_ARG, "colsum: bad arguments");
+  int splits = cdiv(M, 64);
+  if (splits > 128) splits = 128;
+  const int rpb = cdiv(M, splits);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, x, out, M,
+                     N, ldx, rpb);
+  return check_launch("colsum");
+}
+
+extern "C" int mmnas_eltwise_fwd(int kind, const float* x, float* y, size_t n, void* stream) {
+  MMNAS_REQUIRE(kind >= 0 && kind <= 3 && x && y, MMNAS_E_ARG, "eltwise_fwd: bad arguments");
+  if (n == 0) return MMNAS_OK;
+  hipLaunchKernelGGL(eltwise_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, kind, x, y, n);
+  return check_launch("eltwise_fwd");
+}
+extern "C" int mmnas_eltwise_bwd(int kind, const float* x, const float* dy, float* dx, size_t n, void* stream) {
+  MMNAS_REQUIRE(kind >= 0 && kind <= 3 && x && dy && dx, MMNAS_E_ARG, "eltwise_bwd: bad arguments");
+  if (n == 0) return MMNAS_OK;
+  hipLaunchKernelGGL(eltwise_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, kind, x, dy, dx, n);
+  return check_launch("eltwise_bwd");
+}
+extern "C" int mmnas_drop_add(const float* x, const float* res, float* y, size_t n, float drop_p, uint64_t seed,
+                              uint32_t site, void* stream) {
+  MMNAS_REQUIRE(x && y && n < (1ull << 32), MMNAS_E_ARG, "drop_add: bad arguments");
+  if (n == 0) return MMNAS_OK;
+  hipLaunchKernelGGL(drop_add_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, res, y, n,
+                     make_drop(drop_p, seed, site));
+  return check_launch("drop_add");
+}
+extern "C" int mmnas_glu_fwd(const float* h, float* y, int M, int C, int relu, float drop_p, uint64_t seed,
+                             uint32_t site, void* stream) {
+  MMNAS_REQUIRE(h && y && M > 0 && C > 0, MMNAS_E_ARG, "glu_fwd: bad arguments");
+  hipLaunchKernelGGL(glu_fwd_kernel, dim3(blocks_for((size_t)M * C)), dim3(256), 0, (hipStream_t)stream, h, y, M, C,
+                     relu, make_drop(drop_p, seed, site));
+  return check_launch("glu_fwd");
+}
+extern "C" int mmnas_glu_bwd(const float* h, const float* dy, float* dh, int M, int C, int relu, float drop_p,
+                             uint64_t seed, uint32_t site, void* stream) {
+  MMNAS_REQUIRE(h && dy && dh && M > 0 && C > 0, MMNAS_E_ARG, "glu_bwd: bad arguments");
+  hipLaunchKernelGGL(glu_bwd_kernel, dim3(blocks_for((size_t)M * C)), dim3(256), 0, (hipStream_t)stream, h, dy, dh, M,
+                     C, relu, make_drop(drop_p, seed, site));
+  return check_launch("glu_bwd");
+}

@@ -1,0 +1,121 @@
+// Error plumbing, ABI version, and the small utility kernels of the C ABI:
+// dropout-mask materialisation (tests / mask replay), segment pack/unpack for the data-parallel
+// gradient exchange, fused Adam and sum-of-squares for the optimizer step.
+#include <stdarg.h>
+#include <string.h>
+#include "common.h"
+
+namespace mmnas {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return MMNAS_E_LAUNCH;
+  }
+  return MMNAS_OK;
+}
+
+__global__ void dropout_mask_kernel(float* out, size_t n, DropCfg c) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = c.thresh ? drop_mult(c, (uint32_t)i) : 1.0f;
+}
+
+__global__ void pack_kernel(const mmnas_segment* segs, float* staging, float scale, int direction) {
+  const mmnas_segment s = segs[blockIdx.y];
+  float* stg = staging + s.offset;
+  const size_t n4 = (((uintptr_t)s.ptr & 15) == 0 && ((uintptr_t)stg & 15) == 0) ? (s.n >> 2) : 0;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float4* p4 = reinterpret_cast<float4*>(s.ptr);
+  float4* s4 = reinterpret_cast<float4*>(stg);
+  for (size_t i = t0; i < n4; i += stride) {
+    if (direction == 0) { float4 v = p4[i]; v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; s4[i] = v; }
+    else { float4 v = s4[i]; v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; p4[i] = v; }
+  }
+  for (size_t i = (n4 << 2) + t0; i < s.n; i += stride) {
+    if (direction == 0) stg[i] = s.ptr[i] * scale; else s.ptr[i] = stg[i] * scale;
+  }
+}
+
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1,
+                            float b2, float eps, float wd, const float* sumsq, float max_norm, float c1, float c2) {
+  float gscale = 1.f;
+  if (sumsq) gscale = fminf(1.f, max_norm / (sqrtf(*sumsq) + 1e-6f));
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    // torch.optim.Adam: denom = sqrt(v)/sqrt(1-b2^t) + eps ; p -= lr/(1-b1^t) * m/denom
+    p[i] = pi - (lr / c1) * mi / (sqrtf(vi) / c2 + eps);
+  }
+}
+
+__global__ void sumsq_kernel(const float* g, size_t n, float* out) {
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    s += g[i] * g[i];
+  s = wave_sum(s);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+}  // namespace mmnas
+
+using namespace mmnas;
+
+extern "C" int mmnas_abi_version(void) { return MMNAS_ABI_VERSION; }
+extern "C" const char* mmnas_last_error(void) { return g_err; }
+
+extern "C" int mmnas_dropout_mask(float* out, size_t n, float p, uint64_t seed, uint32_t site, void* stream) {
+  MMNAS_REQUIRE(out || n == 0, MMNAS_E_ARG, "mmnas_dropout_mask: null output");
+  if (n == 0) return MMNAS_OK;
+  MMNAS_REQUIRE(n < (1ull << 32), MMNAS_E_SHAPE, "mmnas_dropout_mask: n too large");
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, n,
+                     make_drop(p, seed, site));
+  return check_launch("dropout_mask");
+}
+
+extern "C" int mmnas_pack_segments(const mmnas_segment* segs, int nseg, float* staging, float scale,
+                                   int direction, void* stream) {
+  if (nseg <= 0) return MMNAS_OK;
+  MMNAS_REQUIRE(segs && staging, MMNAS_E_ARG, "mmnas_pack_segments: null pointer");
+  hipLaunchKernelGGL(pack_kernel, dim3(64, nseg), dim3(256), 0, (hipStream_t)stream, segs, staging, scale, direction);
+  return check_launch("pack_segments");
+}
+
+extern "C" int mmnas_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, const float* sumsq, float max_norm,
+                               int step, void* stream) {
+  if (n == 0) return MMNAS_OK;
+  MMNAS_REQUIRE(p && g && m && v && step >= 1, MMNAS_E_ARG, "mmnas_adam_step: bad arguments");
+  const float c1 = 1.f - powf(beta1, (float)step);
+  const float c2 = sqrtf(1.f - powf(beta2, (float)step));
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                     beta2, eps, weight_decay, sumsq, max_norm, c1, c2);
+  return check_launch("adam_step");
+}
+
+extern "C" int mmnas_sumsq(const float* g, size_t n, float* out, void* stream) {
+  if (n == 0) return MMNAS_OK;
+  MMNAS_REQUIRE(g && out, MMNAS_E_ARG, "mmnas_sumsq: null pointer");
+  const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  return check_launch("sumsq");
+}

@@ -1,0 +1,7 @@
+"""Fixed-architecture network for visual grounding -- exported under the reference's module path and class names
+(mmnas/model/full_vgd.py); implementation shared in nets.py."""
+from .nets import Cell_Full, Backbone_Full, NetFullBase
+
+
+class Net_Full(NetFullBase):
+    TASK = 'vgd'

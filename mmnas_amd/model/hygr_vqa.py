@@ -1,0 +1,7 @@
+"""Supernet for VQA -- exported under the reference's module path and class names
+(mmnas/model/hygr_vqa.py); implementation shared in nets.py."""
+from .nets import Cell_Search, Backbone_Search, NetSearchBase
+
+
+class Net_Search(NetSearchBase):
+    TASK = 'vqa'

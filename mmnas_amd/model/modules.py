@@ -1,0 +1,372 @@
+"""Candidate operators with the reference's class names, constructor signatures, call signature
+``op(x, y, x_mask, y_mask, rel_embed)`` and state_dict keys (mmnas/model/modules.py), executing on
+the MI355X through libmmnas_hip.so.  Parameters live in ordinary nn.Linear / nn.Conv1d
+containers so checkpoints of the reference load unchanged; the containers are never
+called -- their tensors are handed to the HIP operators in mmnas_amd.ops.
+
+No CPU path exists here: a CPU tensor raises MMNasHipError at the HIP boundary.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+__all__ = ['FC', 'MLP', 'LayerNorm', 'AttFlat', 'Identity', 'Zero', 'GELU', 'ReLU', 'LeakyReLU',
+           'GatedLinear', 'GLU', 'MHAtt', 'RelMHAtt', 'SelfAtt', 'RelSelfAtt', 'GuidedAtt', 'FeedForward',
+           'FeedForward_deep', 'UniimgAtt', 'SepConv', 'StdConv']
+
+
+def _seed(mod, p):
+    return ops.next_seed() if (mod.training and p > 0) else 0
+
+
+class FC(nn.Module):
+    """Linear -> ReLU -> dropout (modules.py:13-31)."""
+
+    def __init__(self, in_size, out_size, dropout_r=0., use_relu=True):
+        super().__init__()
+        self.dropout_r = dropout_r
+        self.use_relu = use_relu
+        self.linear = nn.Linear(in_size, out_size)
+
+    def forward(self, x):
+        h = ops.linear(x, self.linear.weight, self.linear.bias, relu=self.use_relu)
+        if self.dropout_r > 0 and self.training:
+            h = ops.drop_add(h, None, self.dropout_r, ops.next_seed(), 0)
+        return h
+
+
+class MLP(nn.Module):
+    """FC followed by a Linear (modules.py:34-41)."""
+
+    def __init__(self, in_size, mid_size, out_size, dropout_r=0., use_relu=True):
+        super().__init__()
+        self.fc = FC(in_size, mid_size, dropout_r=dropout_r, use_relu=use_relu)
+        self.linear = nn.Linear(mid_size, out_size)
+
+    def forward(self, x):
+        return ops.linear(self.fc(x), self.linear.weight, self.linear.bias)
+
+
+class LayerNorm(nn.Module):
+    """a_2 * (x - mean) / (std_unbiased + eps) + b_2 (modules.py:44-56)."""
+
+    def __init__(self, size, eps=1e-6, dim=-1):
+        super().__init__()
+        if dim != -1:
+            raise ValueError('LayerNorm over a dim other than the last is not used by any operator')
+        self.eps = eps
+        self.dim = dim
+        self.a_2 = nn.Parameter(torch.ones(size))
+        self.b_2 = nn.Parameter(torch.zeros(size))
+
+    def forward(self, x):
+        return ops.layer_norm(x, self.a_2, self.b_2, self.eps)
+
+
+class AttFlat(nn.Module):
+    """Attentional pooling head (modules.py:59-85).  The two GEMM stages run on the HIP GEMM;
+    the masked softmax over <= 100 positions and the weighted sum are torch device ops."""
+
+    def __init__(self, __C):
+        super().__init__()
+        self.glimpses = __C.ATTFLAT_GLIMPSES
+        self.mlp = MLP(in_size=__C.HSIZE, mid_size=__C.ATTFLAT_MLP_SIZE, out_size=__C.ATTFLAT_GLIMPSES,
+                       dropout_r=__C.DROPOUT_R, use_relu=True)
+        self.linear_merge = nn.Linear(__C.HSIZE * __C.ATTFLAT_GLIMPSES, __C.ATTFLAT_OUT_SIZE)
+
+    def forward(self, x, x_mask=None):
+        att = self.mlp(x)
+        if x_mask is not None:
+            att = att.masked_fill(x_mask.squeeze(1).squeeze(1).unsqueeze(2), -1e9)
+        att = torch.softmax(att, dim=1)
+        pooled = torch.cat([torch.sum(att[:, :, g:g + 1] * x, dim=1) for g in range(self.glimpses)], dim=1)
+        return ops.linear(pooled, self.linear_merge.weight, self.linear_merge.bias)
+
+
+class Identity(nn.Module):
+    """'skip_connect' (modules.py:88-93)."""
+
+    def forward(self, x, y=None, x_mask=None, y_mask=None, rel_embed=None):
+        return x
+
+
+class Zero(nn.Module):
+    """'none' (modules.py:96-101): x * 0."""
+
+    def forward(self, x, y=None, x_mask=None, y_mask=None, rel_embed=None):
+        return ops.eltwise(x, 0)
+
+
+class ReLU(nn.Module):
+    """'relu' registry entry (ops_adapter.py:27).  The reference registers a bare nn.ReLU whose
+    forward takes one argument; this accepts the 5-argument cell signature as well."""
+
+    def forward(self, x, y=None, x_mask=None, y_mask=None, rel_embed=None):
+        return ops.eltwise(x, 1)
+
+
+class LeakyReLU(nn.Module):
+    """'leakyrelu' registry entry (ops_adapter.py:29), slope 0.01."""
+
+    def forward(self, x, y=None, x_mask=None, y_mask=None, rel_embed=None):
+        return ops.eltwise(x, 2)
+
+
+class GELU(nn.Module):
+    """tanh-form GELU (modules.py:104-109)."""
+
+    def forward(self, x, y=None, x_mask=None, y_mask=None, rel_embed=None):
+        return ops.eltwise(x, 3)
+
+
+class GatedLinear(nn.Module):
+    """Linear to 2*out then nn.GLU (modules.py:112-119)."""
+
+    def __init__(self, input_size, output_size):
+        super().__init__()
+        self.linear = nn.Linear(input_size, output_size * 2)
+
+    def forward(self, x, y=None, x_mask=None, y_mask=None, rel_embed=None, relu=False, drop_p=0.0, seed=0):
+        return ops.glu(ops.linear(x, self.linear.weight, self.linear.bias), relu=relu, drop_p=drop_p, seed=seed, site=0)
+
+
+class _Wrapped(nn.Module):
+    """dropout -> residual -> LayerNorm epilogue shared by the composed operators (modules.py:261-271)."""
+
+    def _finish(self, x, core):
+        p = self.drop_p if self.training else 0.0
+        if self.residual or p > 0:
+            z = ops.drop_add(core, x if self.residual else None, p, _seed(self, p), 1)
+        else:
+            z = core
+        return self.ln(z) if self.norm else z
+
+
+class GLU(_Wrapped):
+    """gated_linear_{1,2} (modules.py:122-155)."""
+
+    def __init__(self, __C, norm=False, residual=False, layers=1):
+        super().__init__()
+        assert layers in [1, 2]
+        self.layers, self.norm, self.residual = layers, norm, residual
+        self.drop_p = __C.DROPOUT_R
+        if layers == 1:
+            self.unit = GatedLinear(__C.HSIZE, __C.HSIZE)
+        else:
+            self.unit_0 = GatedLinear(__C.HSIZE, __C.HSIZE * 2)
+            self.unit_1 = GatedLinear(__C.HSIZE * 2, __C.HSIZE)
+        if norm:
+            self.ln = LayerNorm(__C.HSIZE)
+
+    def forward(self, x, y=None, x_mask=None, y_mask=None, rel_embed=None):
+        if self.layers == 1:
+            core = self.unit(x)
+        else:
+            p = self.drop_p if self.training else 0.0
+            core = self.unit_1(self.unit_0(x, relu=True, drop_p=p, seed=_seed(self, p)))
+        return self._finish(x, core)
+
+
+class MHAtt(nn.Module):
+    """Parameter container + stand-alone multi-head attention (modules.py:158-199)."""
+
+    def __init__(self, __C, base=64, hsize_k=None, bias=False):
+        super().__init__()
+        if bias:
+            raise ValueError('the reference never enables projection biases (modules.py:159)')
+        self.HBASE = base
+        self.HSIZE_INSIDE = int(__C.HSIZE * hsize_k) if hsize_k else __C.HSIZE
+        assert self.HSIZE_INSIDE % self.HBASE == 0
+        self.HHEAD = int(self.HSIZE_INSIDE / self.HBASE)
+        self.drop_p = __C.DROPOUT_R
+        self.linear_v = nn.Linear(__C.HSIZE, self.HSIZE_INSIDE, bias=False)
+        self.linear_k = nn.Linear(__C.HSIZE, self.HSIZE_INSIDE, bias=False)
+        self.linear_q = nn.Linear(__C.HSIZE, self.HSIZE_INSIDE, bias=False)
+        self.linear_merge = nn.Linear(self.HSIZE_INSIDE, __C.HSIZE, bias=False)
+
+    def run(self, xq, xkv, mask, rel, ln, norm, residual, training):
+        lr = getattr(self, 'linear_r', None)
+        return ops.attention_op(
+            xq, xkv, mask, rel if lr is not None else None,
+            self.linear_q.weight, self.linear_k.weight, self.linear_v.weight, self.linear_merge.weight,
+            lr.weight if lr is not None else None, lr.bias if lr is not None else None,
+            ln.a_2 if norm else None, ln.b_2 if norm else None,
+            dh=self.HBASE, norm=norm, residual=residual, drop_p=self.drop_p, training=training,
+            eps=ln.eps if norm else 1e-6)
+
+    def forward(self, v, k, q, mask=None):
+        if v is not k:
+            raise NotImplementedError('every reference call site passes the same tensor as key and value source')
+        # stand-alone call: only the attention-map dropout applies (modules.py:197); the operator
+        # wrappers below add the output dropout / residual / LayerNorm
+        return _bare_attention(self, q, None if q is k else k, mask, None)
+
+
+class RelMHAtt(MHAtt):
+    """MHAtt plus the relation bias log(clamp(relu(linear_r(rel)), 1e-6)) (modules.py:202-245)."""
+
+    def __init__(self, __C, base=64, hsize_k=None, bias=False):
+        super().__init__(__C, base=base, hsize_k=hsize_k, bias=bias)
+        self.linear_r = nn.Linear(__C.REL_SIZE, self.HHEAD, bias=True)
+
+    def forward(self, v, k, q, mask=None, rel_embed=None):
+        assert rel_embed is not None
+        if v is not k:
+            raise NotImplementedError('every reference call site passes the same tensor as key and value source')
+        return _bare_attention(self, q, None if q is k else k, mask, rel_embed)
+
+
+def _bare_attention(m, xq, xkv, mask, rel):
+    """MHAtt/RelMHAtt called directly (no output dropout / residual / LayerNorm).  The fused
+    operator always pairs the attention-map dropout with the output dropout, so a stand-alone call
+    is supported in eval mode or with DROPOUT_R = 0; no reference call site needs more."""
+    if m.training and m.drop_p > 0:
+        raise NotImplementedError('stand-alone MHAtt in training mode with dropout: use the operator wrappers')
+    return m.run(xq, xkv, mask, rel, None, False, False, False)
+
+
+class _AttWrapper(nn.Module):
+    def __init__(self, __C, norm, residual):
+        super().__init__()
+        self.norm, self.residual = norm, residual
+        if norm:
+            self.ln = LayerNorm(__C.HSIZE)
+
+    def _run(self, xq, xkv, mask, rel):
+        return self.mhatt.run(xq, xkv, mask, rel, self.ln if self.norm else None, self.norm, self.residual,
+                              self.training)
+
+
+class SelfAtt(_AttWrapper):
+    """LN(x + drop(MHAtt(x, x, x, x_mask))) (modules.py:248-271)."""
+
+    def __init__(self, __C, norm=False, residual=False, base=64, hsize_k=None):
+        super().__init__(__C, norm, residual)
+        self.mhatt = MHAtt(__C, base=base, hsize_k=hsize_k)
+
+    def forward(self, x, y=None, x_mask=None, y_mask=None, rel_embed=None):
+        return self._run(x, None, x_mask, None)
+
+
+class RelSelfAtt(_AttWrapper):
+    """Self-attention with relation bias (modules.py:274-298)."""
+
+    def __init__(self, __C, norm=False, residual=False, base=64, hsize_k=None):
+        super().__init__(__C, norm, residual)
+        self.mhatt = RelMHAtt(__C, base=base, hsize_k=hsize_k)
+
+    def forward(self, x, y=None, x_mask=None, y_mask=None, rel_embed=None):
+        assert rel_embed is not None
+        return self._run(x, None, x_mask, rel_embed)
+
+
+class GuidedAtt(_AttWrapper):
+    """q = x, k = v = y, mask = y_mask (modules.py:301-325)."""
+
+    def __init__(self, __C, norm=False, residual=False, base=64, hsize_k=None):
+        super().__init__(__C, norm, residual)
+        self.mhatt = MHAtt(__C, base=base, hsize_k=hsize_k)
+
+    def forward(self, x, y=None, x_mask=None, y_mask=None, rel_embed=None):
+        assert y is not None
+        return self._run(x, y, y_mask, None)
+
+
+class UniimgAtt(_AttWrapper):
+    """k = v = cat(x, y), no mask (modules.py:403-428)."""
+
+    def __init__(self, __C, norm=False, residual=False, base=64, hsize_k=None):
+        super().__init__(__C, norm, residual)
+        self.mhatt = MHAtt(__C, base=base, hsize_k=hsize_k)
+
+    def forward(self, x, y=None, x_mask=None, y_mask=None, rel_embed=None):
+        assert y is not None
+        return self._run(x, torch.cat((x, y), dim=1), None, None)
+
+
+class FeedForward(nn.Module):
+    """LN(x + drop(W2 drop(relu(W1 x + b1)) + b2)) (modules.py:328-362)."""
+
+    def __init__(self, __C, norm=False, residual=False, mid_k=None):
+        super().__init__()
+        self.norm, self.residual = norm, residual
+        self.drop_p = __C.DROPOUT_R
+        self.MID_SIZE = __C.HSIZE * mid_k if mid_k else __C.HSIZE * 4
+        self.mlp = MLP(in_size=__C.HSIZE, mid_size=self.MID_SIZE, out_size=__C.HSIZE, dropout_r=__C.DROPOUT_R,
+                       use_relu=True)
+        if norm:
+            self.ln = LayerNorm(__C.HSIZE)
+
+    def forward(self, x, y=None, x_mask=None, y_mask=None, rel_embed=None):
+        m = self.mlp
+        return ops.mlp_op(x, [m.fc.linear.weight, m.linear.weight], [m.fc.linear.bias, m.linear.bias],
+                          self.ln.a_2 if self.norm else None, self.ln.b_2 if self.norm else None,
+                          norm=self.norm, residual=self.residual, drop_p=self.drop_p, training=self.training,
+                          eps=self.ln.eps if self.norm else 1e-6)
+
+
+class FeedForward_deep(nn.Module):
+    """Three-layer variant (modules.py:365-400)."""
+
+    def __init__(self, __C, norm=False, residual=False, mid_k=None):
+        super().__init__()
+        self.norm, self.residual = norm, residual
+        self.drop_p = __C.DROPOUT_R
+        self.MID_SIZE = __C.HSIZE * mid_k if mid_k else __C.HSIZE * 2
+        self.fc = FC(__C.HSIZE, self.MID_SIZE, dropout_r=__C.DROPOUT_R, use_relu=True)
+        self.mlp = MLP(in_size=self.MID_SIZE, mid_size=self.MID_SIZE, out_size=__C.HSIZE, dropout_r=__C.DROPOUT_R,
+                       use_relu=True)
+        if norm:
+            self.ln = LayerNorm(__C.HSIZE)
+
+    def forward(self, x, y=None, x_mask=None, y_mask=None, rel_embed=None):
+        m = self.mlp
+        return ops.mlp_op(x, [self.fc.linear.weight, m.fc.linear.weight, m.linear.weight],
+                          [self.fc.linear.bias, m.fc.linear.bias, m.linear.bias],
+                          self.ln.a_2 if self.norm else None, self.ln.b_2 if self.norm else None,
+                          norm=self.norm, residual=self.residual, drop_p=self.drop_p, training=self.training,
+                          eps=self.ln.eps if self.norm else 1e-6)
+
+
+class SepConv(_Wrapped):
+    """Depthwise k-tap conv over the sequence + pointwise conv (modules.py:431-462)."""
+
+    def __init__(self, __C, norm=False, residual=False, k=3):
+        super().__init__()
+        self.norm, self.residual, self.k = norm, residual, k
+        self.drop_p = __C.DROPOUT_R
+        d = __C.HSIZE
+        self.depthwise_conv = nn.Conv1d(d, d, kernel_size=k, groups=d, padding=k // 2, bias=True)
+        self.pointwise_conv = nn.Conv1d(d, d, kernel_size=1, padding=0, bias=True)
+        nn.init.kaiming_normal_(self.depthwise_conv.weight)
+        nn.init.constant_(self.depthwise_conv.bias, 0.0)
+        nn.init.kaiming_normal_(self.pointwise_conv.weight)
+        nn.init.constant_(self.pointwise_conv.bias, 0.0)
+        if norm:
+            self.ln = LayerNorm(d)
+
+    def forward(self, x, y=None, x_mask=None, y_mask=None, rel_embed=None):
+        t = ops.depthwise_conv_seq(x, self.depthwise_conv.weight, self.depthwise_conv.bias)
+        d = x.shape[-1]
+        core = ops.linear(t, self.pointwise_conv.weight.view(d, d), self.pointwise_conv.bias)
+        return self._finish(x, core)
+
+
+class StdConv(_Wrapped):
+    """Dense k-tap Conv1d over the sequence (modules.py:465-491)."""
+
+    def __init__(self, __C, norm=False, residual=False, k=3):
+        super().__init__()
+        self.norm, self.residual, self.k = norm, residual, k
+        self.drop_p = __C.DROPOUT_R
+        d = __C.HSIZE
+        self.conv = nn.Conv1d(d, d, kernel_size=k, padding=k // 2, bias=True)
+        nn.init.kaiming_normal_(self.conv.weight)
+        nn.init.constant_(self.conv.bias, 0.0)
+        if norm:
+            self.ln = LayerNorm(d)
+
+    def forward(self, x, y=None, x_mask=None, y_mask=None, rel_embed=None):
+        core = ops.conv_seq(x, self.conv.weight, self.conv.bias)
+        return self._finish(x, core)

@@ -1,0 +1,309 @@
+"""Cells, backbones and the task networks (mmnas/model/{hygr,full}_{vqa,vgd,itm}.py) over the HIP
+candidate operators.  One implementation serves the three tasks; the per-task modules
+(hygr_vqa.py ... full_itm.py) export it under the reference's class names.  Module/attribute names
+-- including the reference's ``backnone`` spelling (hygr_vqa.py:77) -- are kept so state_dicts are
+interchangeable.
+
+Stem and head: embedding + LSTM stay on torch (MIOpen); every Linear (imgfeat_linear, the relation
+embeddings, AttFlat, the projections) and every LayerNorm run on the HIP GEMM / LayerNorm kernels.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..utils.ops_adapter import OpsAdapter
+from .mixed import MixedOp, sample_indices
+from .modules import AttFlat, LayerNorm
+
+OPS_ADAPTER = OpsAdapter()
+
+# MCAN-style prior the supernet's alphas start from (hygr_vqa.py:138-156)
+_PRIOR = {'enc': ['self_att_64', 'feed_forward'] * 6,
+          'dec': ['rel_self_att_64', 'guided_att_64', 'feed_forward'] * 6}
+
+
+class _Cell(nn.Module):
+    def forward(self, s, pre=None, s_mask=None, pre_mask=None, rel_embed=None):
+        for node in self.dag:
+            s = sum(op(s, pre, s_mask, pre_mask, rel_embed) for op in node)
+        return s
+
+
+class Cell_Search(_Cell):
+    """NODES[type] sequential nodes, one MixedOp each (hygr_vqa.py:12-27)."""
+
+    def __init__(self, __C, type):
+        super().__init__()
+        self.dag = nn.ModuleList(
+            [nn.ModuleList([MixedOp(__C, type + '_safe')]) for _ in range(__C.NODES[type])])
+
+
+class Cell_Full(_Cell):
+    """Nodes built from __C.GENOTYPE[type]; a node may sum several operators (full_vqa.py:9-28)."""
+
+    def __init__(self, __C, type):
+        super().__init__()
+        self.NODES = len(__C.GENOTYPE[type])
+        self.dag = nn.ModuleList(
+            [nn.ModuleList([OPS_ADAPTER.OPS[n](__C, norm=__C.OPS_NORM, residual=__C.OPS_RESIDUAL) for n in node])
+             for node in __C.GENOTYPE[type]])
+
+
+class _Backbone(nn.Module):
+    CELL = None
+
+    def __init__(self, __C):
+        super().__init__()
+        self.cells_enc = nn.ModuleList([self.CELL(__C, type='enc') for _ in range(__C.LAYERS)])
+        self.cells_dec = nn.ModuleList([self.CELL(__C, type='dec') for _ in range(__C.LAYERS)])
+
+    def forward(self, x, y, x_mask, y_mask, x_rel_embed, y_rel_embed):
+        # encoder cells over the language stream, then decoder cells over the image stream with
+        # pre = final language state (hygr_vqa.py:45-52)
+        for cell in self.cells_enc:
+            x = cell(s=x, s_mask=x_mask, rel_embed=x_rel_embed)
+        for cell in self.cells_dec:
+            y = cell(s=y, pre=x, s_mask=y_mask, pre_mask=x_mask, rel_embed=y_rel_embed)
+        return x, y
+
+
+class Backbone_Search(_Backbone):
+    CELL = Cell_Search
+
+
+class Backbone_Full(_Backbone):
+    CELL = Cell_Full
+
+
+def make_mask(feature):
+    """True where a whole feature row is zero = padding (hygr_vqa.py:121-122)."""
+    return (torch.sum(torch.abs(feature), dim=-1) == 0).unsqueeze(1).unsqueeze(2)
+
+
+class _Net(nn.Module):
+    TASK = 'vqa'
+    SEARCH = False
+
+    def _build(self, __C, init_dict):
+        self._cfg = __C
+        d = __C.HSIZE
+        self.embedding = nn.Embedding(num_embeddings=init_dict['token_size'], embedding_dim=__C.WORD_EMBED_SIZE)
+        self.embedding.weight.data.copy_(torch.from_numpy(init_dict['pretrained_emb']))
+        self.lstm = nn.LSTM(input_size=__C.WORD_EMBED_SIZE, hidden_size=d, num_layers=1, batch_first=True)
+        feat = __C.FRCNFEAT_SIZE
+        if __C.BBOX_FEATURE:
+            self.bboxfeat_linear = nn.Linear(5, __C.BBOXFEAT_EMB_SIZE)
+            feat += __C.BBOXFEAT_EMB_SIZE
+        self.imgfeat_linear = nn.Linear(feat, d)
+        self.backnone = (Backbone_Search if self.SEARCH else Backbone_Full)(__C)
+        self.attflat_x = AttFlat(__C)
+        if self.TASK == 'vgd':
+            self.attfc_y = nn.Linear(d, __C.ATTFLAT_OUT_SIZE)      # full_vgd.py:78
+        else:
+            self.attflat_y = AttFlat(__C)
+        self.proj_norm = LayerNorm(__C.ATTFLAT_OUT_SIZE)
+        if self.TASK == 'vgd':
+            self.proj_scores = nn.Linear(__C.ATTFLAT_OUT_SIZE, 1)
+            self.proj_reg = nn.Linear(__C.ATTFLAT_OUT_SIZE, 4)
+        elif self.TASK == 'itm':
+            self.proj = nn.Linear(__C.ATTFLAT_OUT_SIZE, 1)
+        else:
+            self.proj = nn.Linear(__C.ATTFLAT_OUT_SIZE, init_dict['ans_size'])
+        # only the VQA / ITM supernets embed the token relations (hygr_vqa.py:83, hygr_itm.py:77;
+        # hygr_vgd.py has linear_y_rel only; the fixed-arch nets never do)
+        if self.SEARCH and self.TASK in ('vqa', 'itm'):
+            self.linear_x_rel = nn.Linear(3, __C.REL_SIZE)
+        self.linear_y_rel = nn.Linear(4, __C.REL_SIZE)
+
+    @staticmethod
+    def make_mask(feature):
+        return make_mask(feature)
+
+    def forward(self, input):
+        frcn_feat, bbox_feat, y_rel_embed, ques_ix, x_rel_embed = input
+        C = self._cfg
+        x_mask = make_mask(ques_ix.unsqueeze(2))
+        y_mask = make_mask(frcn_feat)
+        x_in, _ = self.lstm(self.embedding(ques_ix))
+        if C.BBOX_FEATURE:
+            bb = ops.linear(bbox_feat, self.bboxfeat_linear.weight, self.bboxfeat_linear.bias)
+            frcn_feat = torch.cat((frcn_feat, bb), dim=-1)
+        y_in = ops.linear(frcn_feat, self.imgfeat_linear.weight, self.imgfeat_linear.bias)
+        if hasattr(self, 'linear_x_rel'):
+            x_rel_embed = ops.linear(x_rel_embed, self.linear_x_rel.weight, self.linear_x_rel.bias, relu=True)
+        y_rel_embed = ops.linear(y_rel_embed, self.linear_y_rel.weight, self.linear_y_rel.bias, relu=True)
+        x_out, y_out = self.backnone(x_in, y_in, x_mask, y_mask, x_rel_embed, y_rel_embed)
+        x_out = self.attflat_x(x_out, x_mask)
+        if self.TASK == 'vgd':  # per-object scores + box regression (full_vgd.py:105-114)
+            y_out = ops.linear(y_out, self.attfc_y.weight, self.attfc_y.bias)
+            xy = self.proj_norm(x_out.unsqueeze(1) + y_out)
+            scores = ops.linear(xy, self.proj_scores.weight, self.proj_scores.bias).squeeze(-1)
+            if C.SCORES_LOSS == 'kld':
+                scores = F.log_softmax(scores, dim=-1)
+            return scores, ops.linear(xy, self.proj_reg.weight, self.proj_reg.bias)
+        y_out = self.attflat_y(y_out, y_mask)
+        xy = self.proj_norm(x_out + y_out)
+        out = ops.linear(xy, self.proj.weight, self.proj.bias)
+        if self.TASK == 'itm':  # matching score (full_itm.py:109-112)
+            return torch.sigmoid(out.squeeze(-1))
+        return out
+
+
+class NetFullBase(_Net):
+    """Fixed architecture read from __C.GENOTYPE (full_vqa.py:56-114)."""
+    SEARCH = False
+
+    def __init__(self, __C, init_dict):
+        super().__init__()
+        self._build(__C, init_dict)
+
+
+class NetSearchBase(_Net):
+    """Supernet (hygr_vqa.py:55-297): every cell node is a MixedOp."""
+    SEARCH = True
+
+    def __init__(self, __C, init_dict):
+        super().__init__()
+        self._redundant_modules = None
+        self._unused_modules = None
+        self._build(__C, init_dict)
+        self.init_arch()
+        self._net_weights = [(n, p) for n, p in self.named_parameters()
+                             if 'alpha_prob' not in n and 'alpha_gate' not in n]
+        self._flat = None
+
+    # -- architecture parameters ------------------------------------------------------------
+    def init_arch(self):
+        C = self._cfg
+        self._alphas_prob = [(n, p) for n, p in self.named_parameters() if 'alpha_prob' in n]
+        self._alphas_gate = [(n, p) for n, p in self.named_parameters() if 'alpha_gate' in n]
+        for p in self.alpha_prob_parameters():
+            if C.ALPHA_INIT_TYPE == 'normal':
+                p.data.normal_(0, 1e-3)
+            elif C.ALPHA_INIT_TYPE == 'uniform':
+                p.data.uniform_(-1e-3, 1e-3)
+        # ... then overwritten by the +1/-1 prior, as the reference does (hygr_vqa.py:142-156)
+        prior = _PRIOR['enc'][:12] + _PRIOR['dec']
+        for ix, (name, (_, p)) in enumerate(zip(prior, self._alphas_prob)):
+            space = OPS_ADAPTER.Used_OPS['enc_safe' if ix < 12 else 'dec_safe']
+            v = np.full(len(space), -1.0, dtype=np.float32)
+            v[space.index(name)] = 1.0
+            p.data = torch.from_numpy(v)
+
+    @property
+    def redundant_modules(self):
+        if self._redundant_modules is None:
+            self._redundant_modules = [m for m in self.modules() if isinstance(m, MixedOp)]
+        return self._redundant_modules
+
+    def _flat_alphas(self):
+        """Re-home every node's alpha_prob / alpha_gate as views of two [n_nodes, 4] device buffers so
+        sampling, gate writes and the alpha-gradient are one batched operation per step."""
+        mops = self.redundant_modules
+        dev = mops[0].alpha_prob.device
+        if self._flat is not None and self._flat[0].device == dev and \
+                mops[0].alpha_prob.data_ptr() == self._flat[0].data_ptr():
+            return self._flat
+        n = len(mops)
+        width = max(m.n_choices for m in mops)
+        prob = torch.full((n, width), float('-inf'), device=dev)
+        gate = torch.zeros((n, width), device=dev)
+        for i, m in enumerate(mops):
+            prob[i, :m.n_choices] = m.alpha_prob.data
+            gate[i, :m.n_choices] = m.alpha_gate.data
+            m.alpha_prob.data = prob[i, :m.n_choices]
+            m.alpha_gate.data = gate[i, :m.n_choices]
+        self._flat = (prob, gate)
+        return self._flat
+
+    def reset_binary_gates(self):
+        """binarize() every node (hygr_vqa.py:168-173) with one device->host and one host->device copy."""
+        prob, gate = self._flat_alphas()
+        probs = torch.softmax(prob.detach(), dim=1).cpu()
+        g = torch.zeros(prob.shape)
+        for i, m in enumerate(self.redundant_modules):
+            act, inact = sample_indices(probs[i, :m.n_choices], MixedOp.MODE)
+            m.set_active(act, inact, write_gate=False)
+            g[i, act[0]] = 1.0
+            m.clear_candidate_grads()
+        gate.copy_(g)
+
+    def set_sampled(self, plan):
+        """Install an explicit list of (active, inactive) choices, one per node (tests, replay)."""
+        _, gate = self._flat_alphas()
+        g = torch.zeros(gate.shape)
+        for i, (m, (act, inact)) in enumerate(zip(self.redundant_modules, plan)):
+            m.set_active(act, inact, write_gate=False)
+            g[i, act[0]] = 1.0
+        gate.copy_(g)
+
+    def unused_modules_off(self):
+        """Temporarily replace the candidates that take no part in this step by None (hygr_vqa.py:175-187)."""
+        self._unused_modules = []
+        for m in self.redundant_modules:
+            involved = m.active_index + (m.inactive_index if MixedOp.MODE in ('full', 'two') else [])
+            unused = {}
+            for i in range(m.n_choices):
+                if i not in involved:
+                    unused[i] = m.candidate_ops[i]
+                    m.candidate_ops[i] = None
+            self._unused_modules.append(unused)
+
+    def unused_modules_back(self):
+        if self._unused_modules is None:
+            return
+        for m, unused in zip(self.redundant_modules, self._unused_modules):
+            for i, op in unused.items():
+                m.candidate_ops[i] = op
+        self._unused_modules = None
+
+    def set_arch_param_grad(self):
+        for m in self.redundant_modules:
+            m.set_arch_param_grad()
+
+    def rescale_updated_arch_param(self):
+        for m in self.redundant_modules:
+            m.rescale_updated_arch_param()
+
+    def set_chosen_op_active(self):
+        for m in self.redundant_modules:
+            m.set_chosen_op_active()
+
+    # -- parameter views used by the search loop (hygr_vqa.py:218-240) -------------------------
+    def alpha_prob_parameters(self):
+        for _, p in self._alphas_prob:
+            yield p
+
+    def alpha_gate_parameters(self):
+        for _, p in self._alphas_gate:
+            yield p
+
+    def named_alpha_prob_parameters(self):
+        return iter(self._alphas_prob)
+
+    def named_alpha_gate_parameters(self):
+        return iter(self._alphas_gate)
+
+    def net_parameters(self):
+        for _, p in self._net_weights:
+            yield p
+
+    def named_net_parameters(self):
+        return iter(self._net_weights)
+
+    # -- read-out (hygr_vqa.py:242-297) ----------------------------------------------------------
+    def genotype(self):
+        gene = {'enc': [], 'dec': []}
+        for n, p in self._alphas_prob:
+            kind = 'enc' if 'cells_enc' in n else 'dec'
+            gene[kind].append([OPS_ADAPTER.Used_OPS[kind][int(torch.argmax(p.data))]])
+        return gene
+
+    def genotype_weights(self):
+        w = {'w_enc': [], 'w_dec': []}
+        with torch.no_grad():
+            for n, p in self._alphas_prob:
+                w['w_enc' if 'cells_enc' in n else 'w_dec'].append(F.softmax(p, dim=-1).cpu().numpy())
+        return w

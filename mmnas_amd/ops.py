@@ -1,0 +1,506 @@
+"""Autograd bridge between PyTorch tensors (device memory, streams: plumbing) and the C ABI of
+libmmnas_hip.so (the product).  One ctypes call per operator forward and one per backward; every
+buffer the kernels touch is allocated here through torch's caching allocator and handed over as a
+raw device pointer together with the current HIP stream.
+"""
+import ctypes as C
+import threading
+
+import torch
+
+from . import _lib as L
+
+# ------------------------------------------------------------------------------------------
+# dropout seeds: every operator call in training mode draws a fresh 64-bit seed; kernels derive
+# each keep decision from (seed, site, element index) -- see csrc/rng.h
+# ------------------------------------------------------------------------------------------
+_seed_lock = threading.Lock()
+_seed_state = {'base': None, 'counter': 0}
+
+
+def manual_seed(seed):
+    """Re-seed the dropout stream (also done lazily from torch.initial_seed())."""
+    with _seed_lock:
+        _seed_state['base'] = int(seed) & 0xFFFFFFFFFFFFFFFF
+        _seed_state['counter'] = 0
+
+
+def next_seed():
+    with _seed_lock:
+        if _seed_state['base'] is None:
+            _seed_state['base'] = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        _seed_state['counter'] += 1
+        x = (_seed_state['base'] * 0x9E3779B97F4A7C15 + _seed_state['counter'] * 0xD1B54A32D192ED03)
+        return x & 0xFFFFFFFFFFFFFFFF
+
+
+_plan_cache = {}
+
+
+def _bytes(n, dev):
+    return torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise L.MMNasHipError('mmnas_amd operators compute in float32; got %s' % t.dtype)
+    return t.contiguous()
+
+
+def _mask_u8(mask, B, Sk):
+    """bool [B,1,1,Sk] (hygr_vqa.py:121-122) -> uint8 [B,Sk] sharing storage."""
+    if mask is None:
+        return None
+    m = mask.reshape(B, Sk)
+    if m.dtype == torch.bool:
+        m = m.contiguous().view(torch.uint8)
+    elif m.dtype != torch.uint8:
+        m = (m != 0).to(torch.uint8)
+    return m.contiguous()
+
+
+# ------------------------------------------------------------------------------------------
+# attention family
+# ------------------------------------------------------------------------------------------
+class AttentionOp(torch.autograd.Function):
+    """SelfAtt / RelSelfAtt / GuidedAtt / UniimgAtt forward+backward (modules.py:248-325,403-428)."""
+
+    @staticmethod
+    def forward(ctx, xq, xkv, mask, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, ln_b, dh, norm, residual, drop_p,
+                training, seed, eps):
+        lib = L.lib()
+        self_att = xkv is None or xkv is xq
+        xq = _f32c(xq)
+        xkv = xq if self_att else _f32c(xkv)
+        B, Sq, d = xq.shape
+        Sk = xkv.shape[1]
+        di = Wq.shape[0]
+        H = di // dh
+        dev = xq.device
+        flags = (L.F_NORM if norm else 0) | (L.F_RESIDUAL if residual else 0)
+        if self_att:
+            flags |= L.F_SELF
+        m8 = _mask_u8(mask, B, Sk)
+        if m8 is not None:
+            flags |= L.F_MASK
+        if rel is not None:
+            rel = _f32c(rel)
+            if rel.shape != (B, Sq, Sk, Wr.shape[1]):
+                raise L.MMNasHipError('rel_embed shape %s, expected %s' % (tuple(rel.shape), (B, Sq, Sk, Wr.shape[1])))
+            flags |= L.F_REL
+        if training and drop_p > 0:
+            flags |= L.F_TRAIN
+        op = L.AttOp()
+        op.B, op.Sq, op.Sk, op.d, op.di, op.H, op.dh = B, Sq, Sk, d, di, H, dh
+        op.R = Wr.shape[1] if rel is not None else 0
+        op.flags, op.drop_p, op.eps, op.seed = flags, float(drop_p), float(eps), int(seed)
+        key = ('att', B, Sq, Sk, d, di, H, op.R, flags)
+        plan = _plan_cache.get(key)
+        if plan is None:
+            p = L.Plan()
+            L.check(lib.mmnas_att_op_plan(C.byref(op), C.byref(p)))
+            plan = (p.save_bytes, p.ws_bwd_bytes)
+            _plan_cache[key] = plan
+        y = torch.empty_like(xq)
+        save = _bytes(plan[0], dev)
+        Wq, Wk, Wv, Wm = _f32c(Wq), _f32c(Wk), _f32c(Wv), _f32c(Wm)
+        op.xq, op.xkv, op.mask, op.rel = L.fptr(xq), L.fptr(xkv), L.ptr(m8), L.fptr(rel)
+        op.Wq, op.Wk, op.Wv, op.Wm = L.fptr(Wq), L.fptr(Wk), L.fptr(Wv), L.fptr(Wm)
+        if rel is not None:
+            Wr, br = _f32c(Wr), _f32c(br)
+            op.Wr, op.br = L.fptr(Wr), L.fptr(br)
+        if norm:
+            ln_a, ln_b = _f32c(ln_a), _f32c(ln_b)
+            op.ln_a, op.ln_b = L.fptr(ln_a), L.fptr(ln_b)
+        op.y, op.save = L.fptr(y), L.ptr(save)
+        L.check(lib.mmnas_att_op_fwd(C.byref(op), L.stream()))
+        ctx.op = op
+        ctx.plan = plan
+        ctx.self_att = self_att
+        ctx.has_rel = rel is not None
+        ctx.norm = norm
+        ctx.keep = (xq, xkv, m8, rel, Wq, Wk, Wv, Wm, Wr if rel is not None else None,
+                    br if rel is not None else None, ln_a if norm else None, save)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        op = ctx.op
+        xq, xkv, m8, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, save = ctx.keep
+        dev = xq.device
+        dy = _f32c(dy)
+        d, di = op.d, op.di
+        sizes = [di * d, di * d, di * d, d * di]
+        if ctx.has_rel:
+            sizes += [Wr.numel(), br.numel()]
+        if ctx.norm:
+            sizes += [d, d]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        parts = list(torch.split(flat, sizes))
+        dWq, dWk, dWv, dWm = (parts[0].view(di, d), parts[1].view(di, d), parts[2].view(di, d), parts[3].view(d, di))
+        i = 4
+        dWr = dbr = dla = dlb = None
+        if ctx.has_rel:
+            dWr, dbr = parts[i].view_as(Wr), parts[i + 1]
+            i += 2
+        if ctx.norm:
+            dla, dlb = parts[i], parts[i + 1]
+        dxq = torch.empty_like(xq)
+        dxkv = None if ctx.self_att else torch.empty_like(xkv)
+        want_drel = ctx.has_rel and ctx.needs_input_grad[3]
+        drel = torch.empty_like(rel) if want_drel else None
+        ws = _bytes(ctx.plan[1], dev)
+        op.dy, op.dxq, op.dxkv, op.drel = L.fptr(dy), L.fptr(dxq), L.fptr(dxkv), L.fptr(drel)
+        op.dWq, op.dWk, op.dWv, op.dWm = L.fptr(dWq), L.fptr(dWk), L.fptr(dWv), L.fptr(dWm)
+        op.dWr, op.dbr, op.dln_a, op.dln_b = L.fptr(dWr), L.fptr(dbr), L.fptr(dla), L.fptr(dlb)
+        op.ws = L.ptr(ws)
+        L.check(lib.mmnas_att_op_bwd(C.byref(op), L.stream()))
+        ctx.keep = None
+        return (dxq, dxkv, None, drel, dWq, dWk, dWv, dWm, dWr, dbr, dla, dlb,
+                None, None, None, None, None, None, None)
+
+
+def attention_op(xq, xkv, mask, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, ln_b, *, dh, norm, residual, drop_p,
+                 training, eps=1e-6, seed=None):
+    if seed is None:
+        seed = next_seed() if (training and drop_p > 0) else 0
+    return AttentionOp.apply(xq, xkv, mask, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, ln_b, dh, norm, residual,
+                             float(drop_p), bool(training), seed, eps)
+
+
+# ------------------------------------------------------------------------------------------
+# MLP family
+# ------------------------------------------------------------------------------------------
+class MlpOp(torch.autograd.Function):
+    """FeedForward / FeedForward_deep forward+backward (modules.py:328-400)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_a, ln_b, norm, residual, drop_p, training, seed, eps, *wb):
+        lib = L.lib()
+        x = _f32c(x)
+        nl = len(wb) // 2
+        Ws = [_f32c(w) for w in wb[:nl]]
+        bs = [(_f32c(b) if b is not None else None) for b in wb[nl:]]
+        d = x.shape[-1]
+        M = x.numel() // d
+        dev = x.device
+        flags = (L.F_NORM if norm else 0) | (L.F_RESIDUAL if residual else 0)
+        if training and drop_p > 0:
+            flags |= L.F_TRAIN
+        op = L.MlpOp()
+        op.M, op.nl = M, nl
+        dims = [d] + [w.shape[0] for w in Ws]
+        for i, v in enumerate(dims):
+            op.dims[i] = v
+        op.flags, op.drop_p, op.eps, op.seed = flags, float(drop_p), float(eps), int(seed)
+        key = ('mlp', M, tuple(dims), flags)
+        plan = _plan_cache.get(key)
+        if plan is None:
+            p = L.Plan()
+            L.check(lib.mmnas_mlp_op_plan(C.byref(op), C.byref(p)))
+            plan = (p.save_bytes, p.ws_bwd_bytes)
+            _plan_cache[key] = plan
+        y = torch.empty_like(x)
+        save = _bytes(plan[0], dev)
+        op.x, op.y, op.save = L.fptr(x), L.fptr(y), L.ptr(save)
+        for i in range(nl):
+            op.W[i] = L.fptr(Ws[i])
+            op.b[i] = L.fptr(bs[i])
+        if norm:
+            ln_a, ln_b = _f32c(ln_a), _f32c(ln_b)
+            op.ln_a, op.ln_b = L.fptr(ln_a), L.fptr(ln_b)
+        L.check(lib.mmnas_mlp_op_fwd(C.byref(op), L.stream()))
+        ctx.op, ctx.plan, ctx.nl, ctx.norm = op, plan, nl, norm
+        ctx.keep = (x, Ws, bs, ln_a if norm else None, save)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        op = ctx.op
+        x, Ws, bs, ln_a, save = ctx.keep
+        dev = x.device
+        dy = _f32c(dy)
+        nl = ctx.nl
+        sizes = [w.numel() for w in Ws] + [(b.numel() if b is not None else 0) for b in bs]
+        if ctx.norm:
+            sizes += [op.dims[0], op.dims[0]]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        parts = list(torch.split(flat, sizes))
+        dWs = [parts[i].view_as(Ws[i]) for i in range(nl)]
+        dbs = [(parts[nl + i] if bs[i] is not None else None) for i in range(nl)]
+        dla = dlb = None
+        if ctx.norm:
+            dla, dlb = parts[2 * nl], parts[2 * nl + 1]
+        dx = torch.empty_like(x)
+        ws = _bytes(ctx.plan[1], dev)
+        op.dy, op.dx, op.ws = L.fptr(dy), L.fptr(dx), L.ptr(ws)
+        for i in range(nl):
+            op.dW[i] = L.fptr(dWs[i])
+            op.db[i] = L.fptr(dbs[i])
+        op.dln_a, op.dln_b = L.fptr(dla), L.fptr(dlb)
+        L.check(lib.mmnas_mlp_op_bwd(C.byref(op), L.stream()))
+        ctx.keep = None
+        return (dx, dla, dlb, None, None, None, None, None, None) + tuple(dWs) + tuple(dbs)
+
+
+def mlp_op(x, weights, biases, ln_a, ln_b, *, norm, residual, drop_p, training, eps=1e-6, seed=None):
+    if seed is None:
+        seed = next_seed() if (training and drop_p > 0) else 0
+    return MlpOp.apply(x, ln_a, ln_b, norm, residual, float(drop_p), bool(training), seed, eps,
+                       *weights, *biases)
+
+
+# ------------------------------------------------------------------------------------------
+# building blocks for the registry-only operators (GLU, convs, activations) and for LayerNorm
+# ------------------------------------------------------------------------------------------
+def gemm(layout, groups, N, K, lda, ldb, ldc, nseg=1, relu=False, split_k=1, alpha=1.0, drop=None,
+         gate_scale=1.0, ldres=0, ldgate=0):
+    """Thin wrapper over mmnas_gemm.  groups: list of dict(M, A=[..], B=[..], C, bias, residual, gate)."""
+    g = L.GemmDesc()
+    g.layout, g.ngroups, g.nseg, g.N, g.K = layout, len(groups), nseg, N, K
+    g.lda, g.ldb, g.ldc, g.ldres, g.ldgate = lda, ldb, ldc, ldres, ldgate
+    g.relu, g.split_k, g.alpha, g.gate_scale = int(relu), split_k, alpha, gate_scale
+    if drop is not None:
+        g.drop_p, g.drop_seed, g.drop_site = drop
+    for i, grp in enumerate(groups):
+        gg = g.g[i]
+        gg.M = grp['M']
+        for s in range(nseg):
+            gg.A[s] = L.fptr(grp['A'][s])
+            gg.B[s] = L.fptr(grp['B'][s])
+        gg.C = L.fptr(grp['C'])
+        gg.bias = L.fptr(grp.get('bias'))
+        gg.residual = L.fptr(grp.get('residual'))
+        gg.gate = L.fptr(grp.get('gate'))
+    L.check(L.lib().mmnas_gemm(C.byref(g), L.stream()))
+
+
+def _wgrad_split(M, N, K):
+    tiles = max(1, ((M + 127) // 128) * ((N + 127) // 128))
+    if tiles < 24:
+        tiles = max(1, ((M + 63) // 64) * ((N + 63) // 64))
+    return max(1, min((512 + tiles - 1) // tiles, max(K // 64, 1)))
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) on the MFMA GEMM (nn.Linear, modules.py:18,115)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, relu):
+        x, W = _f32c(x), _f32c(W)
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = W.shape[0]
+        y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+        gemm(L.GEMM_NT, [dict(M=M, A=[x], B=[W], C=y, bias=(_f32c(b) if b is not None else None))],
+             N, K, K, K, N, relu=relu)
+        ctx.save_for_backward(x, W, y if relu else None)
+        ctx.has_bias, ctx.relu = b is not None, relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, y = ctx.saved_tensors
+        dy = _f32c(dy)
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = W.shape[0]
+        if ctx.relu:
+            dy = dy * (y > 0)
+        dx = torch.empty_like(x)
+        gemm(L.GEMM_NN, [dict(M=M, A=[dy], B=[W], C=dx)], K, N, N, K, K)
+        dW = torch.zeros_like(W)
+        gemm(L.GEMM_TN, [dict(M=N, A=[dy], B=[x], C=dW)], K, M, N, K, K, split_k=_wgrad_split(N, K, M))
+        db = None
+        if ctx.has_bias:
+            db = torch.zeros(N, dtype=torch.float32, device=x.device)
+            L.check(L.lib().mmnas_colsum(L.fptr(dy), L.fptr(db), M, N, N, L.stream()))
+        return dx, dW, db, None
+
+
+def linear(x, W, b=None, relu=False):
+    return LinearFn.apply(x, W, b, relu)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """LayerNorm of modules.py:44-56 (unbiased std, eps on the std)."""
+
+    @staticmethod
+    def forward(ctx, x, a, b, eps):
+        x, a, b = _f32c(x), _f32c(a), _f32c(b)
+        d = x.shape[-1]
+        M = x.numel() // d
+        y = torch.empty_like(x)
+        L.check(L.lib().mmnas_layernorm_fwd(L.fptr(x), L.fptr(a), L.fptr(b), L.fptr(y), M, d, eps, L.stream()))
+        ctx.save_for_backward(x, a)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a = ctx.saved_tensors
+        dy = _f32c(dy)
+        d = x.shape[-1]
+        M = x.numel() // d
+        dx = torch.empty_like(x)
+        dab = torch.zeros(2, d, dtype=torch.float32, device=x.device)
+        L.check(L.lib().mmnas_layernorm_bwd(L.fptr(x), L.fptr(a), L.fptr(dy), L.fptr(dx), L.fptr(dab[0]),
+                                            L.fptr(dab[1]), None, None, 0.0, 0, 0, M, d, ctx.eps, L.stream()))
+        return dx, dab[0], dab[1], None
+
+
+def layer_norm(x, a, b, eps=1e-6):
+    return LayerNormFn.apply(x, a, b, eps)
+
+
+class EltwiseFn(torch.autograd.Function):
+    """kind: 0 zero (modules.py:96-101), 1 relu, 2 leaky-relu, 3 gelu-tanh (modules.py:104-109)."""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        L.check(L.lib().mmnas_eltwise_fwd(kind, L.fptr(x), L.fptr(y), x.numel(), L.stream()))
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        L.check(L.lib().mmnas_eltwise_bwd(ctx.kind, L.fptr(x), L.fptr(dy), L.fptr(dx), x.numel(), L.stream()))
+        return dx, None
+
+
+def eltwise(x, kind):
+    return EltwiseFn.apply(x, kind)
+
+
+class GluFn(torch.autograd.Function):
+    """nn.GLU (+ optional relu, dropout) of GatedLinear / GLU (modules.py:112-155)."""
+
+    @staticmethod
+    def forward(ctx, h, relu, drop_p, seed, site):
+        h = _f32c(h)
+        C2 = h.shape[-1]
+        Cc = C2 // 2
+        M = h.numel() // C2
+        y = torch.empty(h.shape[:-1] + (Cc,), dtype=torch.float32, device=h.device)
+        L.check(L.lib().mmnas_glu_fwd(L.fptr(h), L.fptr(y), M, Cc, int(relu), drop_p, seed, site, L.stream()))
+        ctx.save_for_backward(h)
+        ctx.args = (M, Cc, int(relu), drop_p, seed, site)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        M, Cc, relu, drop_p, seed, site = ctx.args
+        dh = torch.empty_like(h)
+        L.check(L.lib().mmnas_glu_bwd(L.fptr(h), L.fptr(dy), L.fptr(dh), M, Cc, relu, drop_p, seed, site, L.stream()))
+        return dh, None, None, None, None
+
+
+def glu(h, relu=False, drop_p=0.0, seed=0, site=0):
+    return GluFn.apply(h, relu, float(drop_p), int(seed), int(site))
+
+
+class DropAddFn(torch.autograd.Function):
+    """z = res + dropout(x): the common operator epilogue (modules.py:261-266) for composed operators."""
+
+    @staticmethod
+    def forward(ctx, x, res, drop_p, seed, site):
+        x = _f32c(x)
+        res = _f32c(res) if res is not None else None
+        y = torch.empty_like(x)
+        L.check(L.lib().mmnas_drop_add(L.fptr(x), L.fptr(res), L.fptr(y), x.numel(), drop_p, seed, site, L.stream()))
+        ctx.args = (drop_p, seed, site, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        drop_p, seed, site, has_res = ctx.args
+        dy = _f32c(dy)
+        if drop_p > 0:
+            dx = torch.empty_like(dy)
+            L.check(L.lib().mmnas_drop_add(L.fptr(dy), None, L.fptr(dx), dy.numel(), drop_p, seed, site, L.stream()))
+        else:
+            dx = dy
+        return dx, (dy if has_res else None), None, None, None
+
+
+def drop_add(x, res, drop_p=0.0, seed=0, site=1):
+    return DropAddFn.apply(x, res, float(drop_p), int(seed), int(site))
+
+
+class Im2ColFn(torch.autograd.Function):
+    """x[B,S,d] -> col[B,S,k*d] sliding windows over the sequence (StdConv, modules.py:480-481)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        x = _f32c(x)
+        B, S, d = x.shape
+        col = torch.empty(B, S, k * d, dtype=torch.float32, device=x.device)
+        L.check(L.lib().mmnas_im2col_seq(L.fptr(x), L.fptr(col), B, S, d, k, L.stream()))
+        ctx.dims = (B, S, d, k)
+        return col
+
+    @staticmethod
+    def backward(ctx, dcol):
+        B, S, d, k = ctx.dims
+        dcol = _f32c(dcol)
+        dx = torch.empty(B, S, d, dtype=torch.float32, device=dcol.device)
+        L.check(L.lib().mmnas_col2im_seq(L.fptr(dcol), L.fptr(dx), B, S, d, k, L.stream()))
+        return dx, None
+
+
+def conv_seq(x, weight, bias):
+    """Dense Conv1d over the sequence axis: weight [d_out, d_in, k] (conv.weight, modules.py:472)."""
+    co, ci, k = weight.shape
+    col = Im2ColFn.apply(x, k)
+    wp = weight.permute(0, 2, 1).reshape(co, k * ci)  # [co, t*ci + c] to match the window layout
+    return linear(col, wp, bias)
+
+
+class DwConvFn(torch.autograd.Function):
+    """Depthwise k-tap stencil over the sequence axis (depthwise_conv, modules.py:438-439)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _f32c(x), _f32c(w)
+        B, S, d = x.shape
+        k = w.shape[-1]
+        y = torch.empty_like(x)
+        L.check(L.lib().mmnas_dwconv_seq_fwd(L.fptr(x), L.fptr(w), L.fptr(_f32c(b) if b is not None else None),
+                                             L.fptr(y), B, S, d, k, L.stream()))
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _f32c(dy)
+        B, S, d = x.shape
+        k = w.shape[-1]
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        db = torch.zeros(d, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        L.check(L.lib().mmnas_dwconv_seq_bwd(L.fptr(x), L.fptr(w), L.fptr(dy), L.fptr(dx), L.fptr(dw), L.fptr(db),
+                                             B, S, d, k, L.stream()))
+        return dx, dw, db
+
+
+def depthwise_conv_seq(x, weight, bias):
+    return DwConvFn.apply(x, weight, bias)
+
+
+def dropout_mask(n, p, seed, site, device):
+    """Materialise the multiplier stream of one dropout site (tests / mask replay)."""
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    L.check(L.lib().mmnas_dropout_mask(L.fptr(out), n, float(p), int(seed), int(site), L.stream()))
+    return out

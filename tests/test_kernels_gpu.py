@@ -1,0 +1,356 @@
+"""Kernel-level parity (GPU): each C-ABI kernel against a plain torch fp64 CPU reference of the
+same op.  Tolerance 1e-3 relative (BASELINE.json north_star); fp32-MFMA kernels land near 1e-6."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import TOL, rel_err
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def _lib():
+    from mmnas_amd import _lib as L
+    return L
+
+
+def g(t):
+    return torch.as_tensor(t).to(DEV).contiguous()
+
+
+def rnd(rs, *shape):
+    return rs.standard_normal(shape).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- dropout RNG
+def test_dropout_mask_matches_numpy_restatement():
+    from mmnas_amd import ops
+    from oracle import dropout_rng
+    for p, seed, site, n in ((0.1, 0x123456789ABCDEF0, 0, 100003), (0.5, 7, 1, 4096), (0.0, 9, 2, 100)):
+        got = ops.dropout_mask(n, p, seed, site, DEV).cpu().numpy()
+        ref = dropout_rng.scaled_mask(seed, site, (n,), p)
+        assert np.array_equal(got, ref)
+        if p > 0:
+            assert abs((got == 0).mean() - p) < 0.01
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('layout', ['NT', 'NN', 'TN'])
+@pytest.mark.parametrize('M,N,K', [(896, 512, 512), (300, 192, 160), (64, 64, 32), (21, 3129, 1024),
+                                   (130, 1, 64), (257, 130, 100), (6400, 256, 256)])
+@pytest.mark.parametrize('tile', [0, 64, 128])
+def test_gemm_layouts(layout, M, N, K, tile, monkeypatch):
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    if tile and (M * N > 400000):
+        pytest.skip('big case only with the default tile choice')
+    rs = np.random.RandomState(M * 7 + N * 3 + K)
+    if layout == 'NT':
+        A, B = rnd(rs, M, K), rnd(rs, N, K)
+        ref = torch.from_numpy(A).double() @ torch.from_numpy(B).double().t()
+        lda, ldb = K, K
+    elif layout == 'NN':
+        A, B = rnd(rs, M, K), rnd(rs, K, N)
+        ref = torch.from_numpy(A).double() @ torch.from_numpy(B).double()
+        lda, ldb = K, N
+    else:
+        A, B = rnd(rs, K, M), rnd(rs, K, N)
+        ref = torch.from_numpy(A).double().t() @ torch.from_numpy(B).double()
+        lda, ldb = M, N
+    Ad, Bd = g(A), g(B)
+    Cd = torch.zeros(M, N, device=DEV)
+    if tile:
+        monkeypatch.setenv('MMNAS_GEMM_TILE', str(tile))  # read by mmnas_gemm on every call
+    else:
+        monkeypatch.delenv('MMNAS_GEMM_TILE', raising=False)
+    split = 1
+    if layout == 'TN' and K >= 256:
+        split = 3
+    lay = {'NT': L.GEMM_NT, 'NN': L.GEMM_NN, 'TN': L.GEMM_TN}[layout]
+    ops.gemm(lay, [dict(M=M, A=[Ad], B=[Bd], C=Cd)], N, K, lda, ldb, N, split_k=split)
+    err = rel_err(Cd.cpu().numpy(), ref.numpy())
+    assert err < 1e-5, err
+
+
+def test_gemm_groups_segments_epilogue():
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    from oracle import dropout_rng
+    rs = np.random.RandomState(5)
+    M, N, K = 200, 96, 64
+    # three K-segments accumulated + bias + relu + dropout + residual
+    As = [rnd(rs, M, K) for _ in range(3)]
+    Bs = [rnd(rs, N, K) for _ in range(3)]
+    bias, res = rnd(rs, N), rnd(rs, M, N)
+    seed, site, p = 12345678901234, 1, 0.25
+    C = torch.empty(M, N, device=DEV)
+    ops.gemm(L.GEMM_NT, [dict(M=M, A=[g(a) for a in As], B=[g(b) for b in Bs], C=C, bias=g(bias), residual=g(res))],
+             N, K, K, K, N, nseg=3, relu=True, drop=(p, seed, site), ldres=N)
+    acc = sum(torch.from_numpy(a).double() @ torch.from_numpy(b).double().t() for a, b in zip(As, Bs))
+    ref = torch.relu(acc + torch.from_numpy(bias).double())
+    ref = ref * torch.from_numpy(dropout_rng.scaled_mask(seed, site, (M, N), p)).double() + torch.from_numpy(res).double()
+    assert rel_err(C.cpu().numpy(), ref.numpy()) < 1e-5
+    # three groups with different M, gate epilogue on one of them
+    Ms = [70, 200, 33]
+    A = [rnd(rs, m, K) for m in Ms]
+    B = [rnd(rs, N, K) for _ in Ms]
+    gate = rnd(rs, Ms[1], N)
+    Cs = [torch.empty(m, N, device=DEV) for m in Ms]
+    groups = [dict(M=m, A=[g(a)], B=[g(b)], C=c) for m, a, b, c in zip(Ms, A, B, Cs)]
+    ops.gemm(L.GEMM_NT, groups, N, K, K, K, N)
+    for a, b, c in zip(A, B, Cs):
+        assert rel_err(c.cpu().numpy(), (torch.from_numpy(a).double() @ torch.from_numpy(b).double().t()).numpy()) < 1e-5
+    C1 = torch.empty(Ms[1], N, device=DEV)
+    ops.gemm(L.GEMM_NT, [dict(M=Ms[1], A=[g(A[1])], B=[g(B[1])], C=C1, gate=g(gate))], N, K, K, K, N,
+             gate_scale=2.0, ldgate=N)
+    ref = (torch.from_numpy(A[1]).double() @ torch.from_numpy(B[1]).double().t()) * (torch.from_numpy(gate) > 0).double() * 2.0
+    assert rel_err(C1.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+def test_gemm_split_k_accumulates_onto_c():
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    rs = np.random.RandomState(6)
+    K, M, N = 6400, 256, 256
+    A, B, C0 = rnd(rs, K, M), rnd(rs, K, N), rnd(rs, M, N)
+    C = g(C0)
+    ops.gemm(L.GEMM_TN, [dict(M=M, A=[g(A)], B=[g(B)], C=C)], N, K, M, N, N, split_k=16)
+    ref = torch.from_numpy(C0).double() + torch.from_numpy(A).double().t() @ torch.from_numpy(B).double()
+    assert rel_err(C.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+# ----------------------------------------------------------------------------- LayerNorm & friends
+@pytest.mark.parametrize('M,d', [(15, 128), (6400, 512), (64, 1024), (7, 2048), (33, 36)])
+def test_layernorm(M, d):
+    from mmnas_amd import ops
+    from oracle import mmnas_oracle as O
+    rs = np.random.RandomState(d + M)
+    x, a, b, gy = rnd(rs, M, d) * 2 + 0.3, 1 + 0.2 * rnd(rs, d), 0.1 * rnd(rs, d), rnd(rs, M, d)
+    xd, ad, bd = g(x).requires_grad_(True), g(a).requires_grad_(True), g(b).requires_grad_(True)
+    y = ops.layer_norm(xd, ad, bd)
+    y.backward(g(gy))
+    X, A, Bb = (torch.from_numpy(v).double() for v in (x, a, b))
+    yr = O.layer_norm(X, A, Bb)
+    dx, da, db = O.layer_norm_backward(X, A, torch.from_numpy(gy).double())
+    assert rel_err(y.detach().cpu().numpy(), yr.numpy()) < 1e-5
+    assert rel_err(xd.grad.cpu().numpy(), dx.numpy()) < 1e-4
+    assert rel_err(ad.grad.cpu().numpy(), da.numpy()) < 1e-4
+    assert rel_err(bd.grad.cpu().numpy(), db.numpy()) < 1e-4
+
+
+def test_layernorm_bwd_dropout_and_colsum_outputs():
+    import mmnas_amd._lib as L
+    from oracle import dropout_rng, mmnas_oracle as O
+    rs = np.random.RandomState(3)
+    M, d, p, seed = 50, 256, 0.2, 99
+    x, a, gy = rnd(rs, M, d), 1 + 0.1 * rnd(rs, d), rnd(rs, M, d)
+    dx, dd = torch.empty(M, d, device=DEV), torch.empty(M, d, device=DEV)
+    dab = torch.zeros(3, d, device=DEV)
+    L.check(L.lib().mmnas_layernorm_bwd(L.fptr(g(x)), L.fptr(g(a)), L.fptr(g(gy)), L.fptr(dx), L.fptr(dab[0]),
+                                        L.fptr(dab[1]), L.fptr(dd), L.fptr(dab[2]), p, seed, 1, M, d, 1e-6, L.stream()))
+    rdx, _, _ = O.layer_norm_backward(torch.from_numpy(x).double(), torch.from_numpy(a).double(), torch.from_numpy(gy).double())
+    rdd = rdx * torch.from_numpy(dropout_rng.scaled_mask(seed, 1, (M, d), p)).double()
+    assert rel_err(dx.cpu().numpy(), rdx.numpy()) < 1e-4
+    assert rel_err(dd.cpu().numpy(), rdd.numpy()) < 1e-4
+    assert rel_err(dab[2].cpu().numpy(), rdd.sum(0).numpy()) < 1e-4
+
+
+def test_colsum_eltwise_glu_dropadd():
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    from oracle import dropout_rng, mmnas_oracle as O
+    rs = np.random.RandomState(8)
+    x = rnd(rs, 777, 300)
+    out = torch.zeros(300, device=DEV)
+    L.check(L.lib().mmnas_colsum(L.fptr(g(x)), L.fptr(out), 777, 300, 300, L.stream()))
+    assert rel_err(out.cpu().numpy(), x.astype(np.float64).sum(0)) < 1e-5
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    gy = rnd(rs, 777, 300)
+    refs = {0: xt * 0., 1: torch.relu(xt), 2: torch.nn.functional.leaky_relu(xt, 0.01), 3: O.gelu_tanh(xt)}
+    for kind, r in refs.items():
+        xd = g(x).requires_grad_(True)
+        y = ops.eltwise(xd, kind)
+        y.backward(g(gy))
+        xt.grad = None
+        r.backward(torch.from_numpy(gy).double())
+        assert rel_err(y.detach().cpu().numpy(), r.detach().numpy()) < 1e-5, kind
+        assert rel_err(xd.grad.cpu().numpy(), xt.grad.numpy()) < 1e-5, kind
+    # GLU with relu + dropout
+    h = rnd(rs, 60, 256)
+    hd = g(h).requires_grad_(True)
+    seed, p = 4242, 0.3
+    y = ops.glu(hd, relu=True, drop_p=p, seed=seed, site=0)
+    gy = rnd(rs, 60, 128)
+    y.backward(g(gy))
+    ht = torch.from_numpy(h).double().requires_grad_(True)
+    a, b = ht.chunk(2, -1)
+    r = torch.relu(a * torch.sigmoid(b)) * torch.from_numpy(dropout_rng.scaled_mask(seed, 0, (60, 128), p)).double()
+    r.backward(torch.from_numpy(gy).double())
+    assert rel_err(y.detach().cpu().numpy(), r.detach().numpy()) < 1e-5
+    assert rel_err(hd.grad.cpu().numpy(), ht.grad.numpy()) < 1e-5
+    # drop_add
+    xx, rr = rnd(rs, 40, 64), rnd(rs, 40, 64)
+    z = ops.drop_add(g(xx), g(rr), 0.5, 77, 1)
+    ref = rr + xx * dropout_rng.scaled_mask(77, 1, (40, 64), 0.5)
+    assert rel_err(z.cpu().numpy(), ref) < 1e-6
+
+
+# ----------------------------------------------------------------------------- relation bias
+@pytest.mark.parametrize('B,Sq,Sk,R,H', [(2, 7, 7, 64, 2), (2, 100, 100, 64, 8), (1, 9, 9, 64, 16), (3, 5, 5, 64, 1),
+                                         (2, 6, 6, 32, 4), (1, 5, 5, 64, 32)])
+def test_rel_bias(B, Sq, Sk, R, H):
+    import mmnas_amd._lib as L
+    rs = np.random.RandomState(B * 100 + Sq + H)
+    rel = np.maximum(rnd(rs, B, Sq, Sk, R), 0)
+    Wr, br = rnd(rs, H, R) / 8, 0.1 * rnd(rs, H)
+    gb = rnd(rs, B, H, Sk, Sq)
+    reld, Wd, bd = g(rel), g(Wr), g(br)
+    biasT = torch.empty(B, H, Sk, Sq, device=DEV)
+    L.check(L.lib().mmnas_rel_bias_fwd(L.fptr(reld), L.fptr(Wd), L.fptr(bd), L.fptr(biasT), B, Sq, Sk, R, H, L.stream()))
+    relt = torch.from_numpy(rel).double().requires_grad_(True)
+    Wt = torch.from_numpy(Wr).double().requires_grad_(True)
+    bt = torch.from_numpy(br).double().requires_grad_(True)
+    r = torch.relu(relt @ Wt.t() + bt)                      # [B,Sq,Sk,H]
+    bias = torch.log(torch.clamp(r, min=1e-6)).permute(0, 3, 2, 1)  # -> [B,H,Sk,Sq]
+    assert rel_err(biasT.cpu().numpy(), bias.detach().numpy()) < 1e-4
+    bias.backward(torch.from_numpy(gb).double())
+    drel = torch.empty_like(reld)
+    dW, db = torch.zeros(H, R, device=DEV), torch.zeros(H, device=DEV)
+    L.check(L.lib().mmnas_rel_bias_bwd(L.fptr(reld), L.fptr(Wd), L.fptr(bd), L.fptr(g(gb)), L.fptr(drel), L.fptr(dW),
+                                       L.fptr(db), 0, B, Sq, Sk, R, H, L.stream()))
+    assert rel_err(drel.cpu().numpy(), relt.grad.numpy()) < TOL
+    assert rel_err(dW.cpu().numpy(), Wt.grad.numpy()) < TOL
+    assert rel_err(db.cpu().numpy(), bt.grad.numpy()) < TOL
+
+
+# ----------------------------------------------------------------------------- attention core
+def _mha_ref(Q, K, V, mask, biasT, H, dh, dmask=None):
+    B, Sq, _ = Q.shape
+    Sk = K.shape[1]
+    q = Q.reshape(B, Sq, H, dh).permute(0, 2, 1, 3)
+    k = K.reshape(B, Sk, H, dh).permute(0, 2, 1, 3)
+    v = V.reshape(B, Sk, H, dh).permute(0, 2, 1, 3)
+    z = q @ k.transpose(-1, -2) / math.sqrt(dh)
+    if biasT is not None:
+        z = z + biasT.permute(0, 1, 3, 2)
+    if mask is not None:
+        z = z.masked_fill(mask.reshape(B, 1, 1, Sk), -1e9)
+    a = torch.softmax(z, -1)
+    if dmask is not None:
+        a = a * dmask
+    return (a @ v).permute(0, 2, 1, 3).reshape(B, Sq, H * dh)
+
+
+@pytest.mark.parametrize('B,H,Sq,Sk,dh,use_mask,use_bias,p', [
+    (2, 2, 7, 7, 64, True, False, 0.0), (2, 8, 100, 100, 64, True, True, 0.0), (2, 8, 100, 14, 64, True, False, 0.1),
+    (3, 4, 14, 14, 64, True, False, 0.0), (2, 2, 36, 50, 64, True, False, 0.0), (2, 4, 9, 9, 32, True, True, 0.0),
+    (2, 8, 9, 15, 16, False, False, 0.0), (2, 2, 9, 9, 128, True, False, 0.0), (2, 1, 7, 12, 256, True, True, 0.0),
+    (1, 2, 130, 130, 64, True, False, 0.0), (2, 2, 50, 200, 64, True, True, 0.2), (2, 4, 70, 33, 32, True, False, 0.0)])
+def test_mha_core(B, H, Sq, Sk, dh, use_mask, use_bias, p):
+    import ctypes as C
+    import mmnas_amd._lib as L
+    from oracle import dropout_rng
+    rs = np.random.RandomState(B + H * 3 + Sq * 5 + Sk * 7 + dh)
+    di = H * dh
+    Q, K, V, dO = rnd(rs, B, Sq, di), rnd(rs, B, Sk, di), rnd(rs, B, Sk, di), rnd(rs, B, Sq, di)
+    mask = np.zeros((B, Sk), np.bool_)
+    if use_mask:
+        for b in range(1, B):
+            mask[b, int(rs.randint(1, Sk)):] = True
+        if B > 1:
+            mask[B - 1] = True      # fully padded sample: uniform softmax
+    biasT = (rnd(rs, B, H, Sk, Sq) * 2) if use_bias else None
+    seed = 31337
+    Qd, Kd, Vd, dOd = g(Q), g(K), g(V), g(dO)
+    m8 = g(mask.astype(np.uint8)) if use_mask else None
+    bd = g(biasT) if use_bias else None
+    O_ = torch.empty(B, Sq, di, device=DEV)
+    stats = torch.empty(B, H, Sq, 2, device=DEV)
+    d = L.MhaDesc()
+    d.B, d.H, d.Sq, d.Sk, d.dh = B, H, Sq, Sk, dh
+    d.ldq = d.ldk = d.ldv = d.ldo = di
+    d.Q, d.K, d.V, d.mask, d.biasT, d.O, d.lse = (L.fptr(Qd), L.fptr(Kd), L.fptr(Vd), L.ptr(m8), L.fptr(bd),
+                                                 L.fptr(O_), L.fptr(stats))
+    d.drop_p, d.drop_site, d.drop_seed = p, 0, seed
+    L.check(L.lib().mmnas_mha_core_fwd(C.byref(d), L.stream()))
+    Qt, Kt, Vt = (torch.from_numpy(v).double().requires_grad_(True) for v in (Q, K, V))
+    bt = torch.from_numpy(biasT).double().requires_grad_(True) if use_bias else None
+    dm = torch.from_numpy(dropout_rng.scaled_mask(seed, 0, (B, H, Sq, Sk), p)).double() if p > 0 else None
+    ref = _mha_ref(Qt, Kt, Vt, torch.from_numpy(mask) if use_mask else None, bt, H, dh, dm)
+    assert rel_err(O_.cpu().numpy(), ref.detach().numpy()) < 1e-5
+    ref.backward(torch.from_numpy(dO).double())
+    dQ, dK, dV = torch.empty_like(Qd), torch.empty_like(Kd), torch.empty_like(Vd)
+    dbT = torch.empty(B, H, Sk, Sq, device=DEV) if use_bias else None
+    delta = torch.empty(B, H, Sq, device=DEV)
+    d.dO, d.dQ, d.dK, d.dV, d.dbiasT, d.delta = L.fptr(dOd), L.fptr(dQ), L.fptr(dK), L.fptr(dV), L.fptr(dbT), L.fptr(delta)
+    L.check(L.lib().mmnas_mha_core_bwd(C.byref(d), L.stream()))
+    assert rel_err(dQ.cpu().numpy(), Qt.grad.numpy()) < 1e-4
+    assert rel_err(dK.cpu().numpy(), Kt.grad.numpy()) < 1e-4
+    assert rel_err(dV.cpu().numpy(), Vt.grad.numpy()) < 1e-4
+    if use_bias:
+        assert rel_err(dbT.cpu().numpy(), bt.grad.numpy()) < 1e-4
+
+
+# ----------------------------------------------------------------------------- convs
+@pytest.mark.parametrize('k', [3, 5, 7, 11])
+def test_conv_building_blocks(k):
+    from mmnas_amd import ops
+    rs = np.random.RandomState(k)
+    B, S, d = 3, 9, 64
+    x = rnd(rs, B, S, d)
+    w, b = rnd(rs, d, d, k) / math.sqrt(d * k), 0.1 * rnd(rs, d)
+    wd, bd = rnd(rs, d, 1, k), 0.1 * rnd(rs, d)
+    gy = rnd(rs, B, S, d)
+    for dense in (True, False):
+        xd = g(x).requires_grad_(True)
+        W = g(w if dense else wd).requires_grad_(True)
+        Bb = g(b if dense else bd).requires_grad_(True)
+        y = ops.conv_seq(xd, W, Bb) if dense else ops.depthwise_conv_seq(xd, W, Bb)
+        y.backward(g(gy))
+        xt = torch.from_numpy(x).double().requires_grad_(True)
+        Wt = torch.from_numpy(w if dense else wd).double().requires_grad_(True)
+        Bt = torch.from_numpy(b if dense else bd).double().requires_grad_(True)
+        r = torch.nn.functional.conv1d(xt.transpose(1, 2), Wt, Bt, padding=k // 2, groups=1 if dense else d).transpose(1, 2)
+        r.backward(torch.from_numpy(gy).double())
+        assert rel_err(y.detach().cpu().numpy(), r.detach().numpy()) < 1e-5
+        assert rel_err(xd.grad.cpu().numpy(), xt.grad.numpy()) < 1e-4
+        assert rel_err(W.grad.cpu().numpy(), Wt.grad.numpy()) < 1e-4
+        assert rel_err(Bb.grad.cpu().numpy(), Bt.grad.numpy()) < 1e-4
+
+
+def test_pack_adam_sumsq():
+    import ctypes as C
+    import mmnas_amd._lib as L
+    rs = np.random.RandomState(1)
+    n = 10007
+    p0, g0 = rnd(rs, n), rnd(rs, n) * 3
+    p, gr = g(p0), g(g0)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    ss = torch.zeros(1, device=DEV)
+    L.check(L.lib().mmnas_sumsq(L.fptr(gr), n, L.fptr(ss), L.stream()))
+    assert abs(float(ss) - float((g0.astype(np.float64) ** 2).sum())) < 1e-3 * float(ss)
+    pt = torch.from_numpy(p0.copy()).requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=1e-3, betas=(0.9, 0.98), eps=1e-9)
+    for step in (1, 2, 3):
+        L.check(L.lib().mmnas_adam_step(L.fptr(p), L.fptr(gr), L.fptr(m), L.fptr(v), n, 1e-3, 0.9, 0.98, 1e-9, 0.0,
+                                        L.fptr(ss), 1.0, step, L.stream()))
+        pt.grad = torch.from_numpy(g0.copy())
+        torch.nn.utils.clip_grad_norm_([pt], 1.0)
+        opt.step()
+    assert rel_err(p.cpu().numpy(), pt.detach().numpy()) < 1e-5
+    # pack / unpack
+    a, b = g(rnd(rs, 1000)), g(rnd(rs, 333))
+    segs = (L.Segment * 2)()
+    segs[0].ptr, segs[0].offset, segs[0].n = a.data_ptr(), 0, 1000
+    segs[1].ptr, segs[1].offset, segs[1].n = b.data_ptr(), 1000, 333
+    sd = torch.frombuffer(bytearray(bytes(segs)), dtype=torch.uint8).to(DEV)
+    stg = torch.zeros(1333, device=DEV)
+    L.check(L.lib().mmnas_pack_segments(sd.data_ptr(), 2, L.fptr(stg), 0.5, 0, L.stream()))
+    assert torch.allclose(stg[:1000], a * 0.5) and torch.allclose(stg[1000:], b * 0.5)
+    a0, b0 = a.clone(), b.clone()
+    L.check(L.lib().mmnas_pack_segments(sd.data_ptr(), 2, L.fptr(stg), 2.0, 1, L.stream()))
+    assert torch.allclose(a, a0) and torch.allclose(b, b0)

@@ -1,0 +1,176 @@
+"""Network-level parity (GPU): MixedOp, Net_Full(arch/*.json) and Net_Search weight/arch steps
+against the golden vectors of the imported reference (tests/golden/{mixed,nets}.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import cases
+from tests.util import TOL, load, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+T = torch.from_numpy
+
+
+def _loss(task, pred, target):
+    t = T(target).to(DEV)
+    if task == 'vqa':
+        return torch.nn.functional.binary_cross_entropy_with_logits(pred, t, reduction='sum')
+    if task == 'itm':
+        return torch.nn.functional.binary_cross_entropy(pred, t, reduction='sum')
+    scores, reg = pred
+    return (scores * t).sum() + 0.5 * (reg ** 2).sum()
+
+
+def _init(c):
+    return {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+            'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
+
+
+def _check_gradnorms(npz, tag, net, skip_alpha=False):
+    keys = [str(k) for k in npz[tag + 'gradnorm_keys']]
+    norms = npz[tag + 'gradnorms']
+    mine = dict(net.named_parameters())
+    assert set(keys) == set(mine.keys())  # state_dict / parameter-name compatibility
+    big = float(np.max(norms))
+    for k, n in zip(keys, norms):
+        if skip_alpha and 'alpha' in k:
+            continue
+        g = mine[k].grad
+        v = 0.0 if g is None else float(g.double().norm())
+        assert abs(v - n) <= 3e-3 * n + 1e-5 * big, (k, v, n)
+
+
+@pytest.mark.parametrize('mode', [None, 'full', 'two'])
+@pytest.mark.parametrize('kind', ['enc_safe', 'dec_safe'])
+def test_mixed_op(mode, kind):
+    from mmnas.model.mixed import MixedOp
+    npz = load('mixed.npz')
+    tag = 'mx|%s|%s|' % (mode, kind)
+    c = cases.mixed_case(mode, kind, int(npz[tag + 'seed']))
+    m = MixedOp(c['cfg'], kind)
+    m.load_state_dict({k: T(v) for k, v in c['P'].items()})
+    m = m.to(DEV).train()
+    m.active_index, m.inactive_index = list(c['act']), list(c['inact'])
+    MixedOp.MODE = mode
+    try:
+        s = T(c['s']).to(DEV).requires_grad_(True)
+        o = m(s, T(c['pre']).to(DEV), T(c['sm']).to(DEV), T(c['pm']).to(DEV), T(c['rel']).to(DEV))
+        assert rel_err(o.detach().cpu().numpy(), npz[tag + 'out']) <= TOL
+        o.backward(T(c['g']).to(DEV))
+        assert rel_err(s.grad.cpu().numpy(), npz[tag + 'ds']) <= TOL
+        if mode is not None:
+            assert rel_err(m.alpha_gate.grad.cpu().numpy(), npz[tag + 'gate_grad']) <= TOL
+            m.alpha_prob.grad = None
+            m.set_arch_param_grad()
+            assert rel_err(m.alpha_prob.grad.cpu().numpy(), npz[tag + 'prob_grad']) <= TOL
+            if mode == 'two':
+                m.alpha_prob.data.copy_(T(npz[tag + 'alpha_stepped']))
+                m.rescale_updated_arch_param()
+                assert rel_err(m.alpha_prob.data.cpu().numpy(), npz[tag + 'alpha_rescaled']) <= 1e-5
+    finally:
+        MixedOp.MODE = None
+
+
+@pytest.mark.parametrize('task,arch', [('vqa', 'mcan'), ('vqa', 'mmnas_vqa'), ('vgd', 'mmnas_vgd'), ('itm', 'mmnas_itm')])
+def test_net_full(task, arch):
+    import importlib
+    Net_Full = importlib.import_module('mmnas.model.full_%s' % task).Net_Full
+    npz = load('nets.npz')
+    tag = 'full|%s|%s|' % (task, arch)
+    c = cases.net_case(task, arch, int(npz[tag + 'seed']))
+    net = Net_Full(c['cfg'], _init(c))
+    net.load_state_dict({k: T(v) for k, v in c['P'].items()}, strict=True)
+    net = net.to(DEV).train()
+    pred = net(tuple(T(a).to(DEV) for a in c['inputs']))
+    if task == 'vgd':
+        assert rel_err(pred[0].detach().cpu().numpy(), npz[tag + 'scores']) <= TOL
+        assert rel_err(pred[1].detach().cpu().numpy(), npz[tag + 'reg']) <= TOL
+    else:
+        assert rel_err(pred.detach().cpu().numpy(), npz[tag + 'pred']) <= TOL
+    loss = _loss(task, pred, c['target'])
+    assert abs(float(loss) - float(npz[tag + 'loss'])) <= TOL * abs(float(npz[tag + 'loss']))
+    loss.backward()
+    _check_gradnorms(npz, tag, net)
+    assert rel_err(net.imgfeat_linear.bias.grad.cpu().numpy(), npz[tag + 'g:imgfeat_linear.bias']) <= 3e-3
+
+
+@pytest.mark.parametrize('task,mode', [('vqa', None), ('vqa', 'full'), ('vqa', 'two'), ('vgd', None),
+                                       ('vgd', 'full'), ('itm', None), ('itm', 'full')])
+def test_net_search_steps(task, mode):
+    import importlib
+    from mmnas.model.mixed import MixedOp
+    Net_Search = importlib.import_module('mmnas.model.hygr_%s' % task).Net_Search
+    npz = load('nets.npz')
+    tag = 'search|%s|%s|' % (task, mode)
+    seed = int(npz[tag + 'seed'])
+    c = cases.net_case(task, None, seed, search=True)
+    plan = cases.search_plan(np.random.RandomState(seed + 50000), mode)
+    flat = plan['enc'] + plan['dec']
+    net = Net_Search(c['cfg'], _init(c))
+    net.load_state_dict({k: T(v) for k, v in c['P'].items()}, strict=True)
+    net = net.to(DEV).train()
+    MixedOp.MODE = mode
+    try:
+        net.set_sampled(flat)
+        net.unused_modules_off()
+        pred = net(tuple(T(a).to(DEV) for a in c['inputs']))
+        if task == 'vgd':
+            assert rel_err(pred[0].detach().cpu().numpy(), npz[tag + 'scores']) <= TOL
+        else:
+            assert rel_err(pred.detach().cpu().numpy(), npz[tag + 'pred']) <= TOL
+        loss = _loss(task, pred, c['target'])
+        assert abs(float(loss) - float(npz[tag + 'loss'])) <= TOL * abs(float(npz[tag + 'loss']))
+        net.zero_grad()
+        loss.backward()
+        if mode is not None:
+            gg = np.stack([np.pad(m.alpha_gate.grad.cpu().numpy(), (0, 4 - m.n_choices)) for m in net.redundant_modules])
+            assert rel_err(gg, npz[tag + 'gate_grads']) <= 3e-3
+            net.set_arch_param_grad()
+            pg = np.stack([np.pad(m.alpha_prob.grad.cpu().numpy(), (0, 4 - m.n_choices)) for m in net.redundant_modules])
+            assert rel_err(pg, npz[tag + 'prob_grads']) <= 3e-3
+            if mode == 'two':
+                net.rescale_updated_arch_param()
+        net.unused_modules_back()
+        _check_gradnorms(npz, tag, net, skip_alpha=True)
+    finally:
+        MixedOp.MODE = None
+
+
+def test_supernet_sampling_and_readout():
+    """reset_binary_gates: one-hot gates, rank-consistent sampler, genotype read-out (hygr_vqa.py:168-297)."""
+    from mmnas.model.hygr_vqa import Net_Search
+    from mmnas.model import mixed
+    npz = load('nets.npz')
+    c = cases.net_case('vqa', None, int(npz['search|vqa|None|seed']), search=True)
+    net = Net_Search(c['cfg'], _init(c))
+    ia = np.stack([np.pad(p.detach().numpy(), (0, 4 - p.numel())) for p in net.alpha_prob_parameters()])
+    assert np.array_equal(ia, npz['search|vqa|init_alpha'])  # +1/-1 MCAN prior
+    net.load_state_dict({k: T(v) for k, v in c['P'].items()}, strict=True)
+    net = net.to(DEV)
+    g = net.genotype()
+    assert [n[0] for n in g['enc']] == [str(s) for s in npz['search|vqa|genotype_enc']]
+    assert [n[0] for n in g['dec']] == [str(s) for s in npz['search|vqa|genotype_dec']]
+    assert rel_err(np.stack(net.genotype_weights()['w_dec']), npz['search|vqa|w_dec']) < 1e-6
+    draws = []
+    for _ in range(2):
+        mixed.seed_arch_sampler(888)
+        net.reset_binary_gates()
+        draws.append([m.active_index[0] for m in net.redundant_modules])
+        for m in net.redundant_modules:
+            gate = m.alpha_gate.data.cpu().numpy()
+            assert gate.sum() == 1.0 and gate[m.active_index[0]] == 1.0
+            assert sorted(m.active_index + m.inactive_index) == list(range(m.n_choices))
+    assert draws[0] == draws[1]
+    # state_dict still exposes per-node alphas after they were re-homed into the flat buffers
+    sd = net.state_dict()
+    assert sd['backnone.cells_dec.0.dag.3.0.alpha_prob'].shape == (4,)
+    # sampling frequencies follow softmax(alpha)
+    m0 = net.redundant_modules[12]
+    probs = torch.softmax(m0.alpha_prob.data, 0).cpu().numpy()
+    cnt = np.zeros(4)
+    mixed.seed_arch_sampler(1)
+    for _ in range(400):
+        net.reset_binary_gates()
+        cnt[m0.active_index[0]] += 1
+    assert np.abs(cnt / 400 - probs).max() < 0.1

@@ -1,0 +1,166 @@
+"""Operator-level parity (GPU): every registry operator through the reference-style module API
+(OpsAdapter().OPS[name](__C, norm, residual)(x, y, x_mask, y_mask, rel)) against
+  (a) the golden vectors produced by the imported reference, and
+  (b) the CPU oracle on the same seeded inputs (incl. dropout via mask replay).
+Tolerance: 1e-3 relative, ||a-b||_inf / ||b||_inf, outputs and gradients (SURVEY 8d parity gate)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dropout_rng
+from oracle import mmnas_oracle as O
+from tests import oracle_runner as R
+from tests.golden import cases
+from tests.util import TOL, golden_err, has, load, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def run_hip_op(case, train=False, drop_p=0.0):
+    from mmnas_amd.utils.ops_adapter import OpsAdapter
+    cfg = case['cfg']
+    cfg.DROPOUT_R = drop_p
+    op = OpsAdapter().OPS[case['name']](cfg, norm=cfg.OPS_NORM, residual=cfg.OPS_RESIDUAL)
+    if case['P']:
+        missing = op.load_state_dict({k: torch.from_numpy(v) for k, v in case['P'].items()}, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+    op = op.to(DEV)
+    op.train(train)
+    x = torch.from_numpy(case['x']).to(DEV).requires_grad_(True)
+    y = torch.from_numpy(case['y']).to(DEV).requires_grad_(True)
+    rel = torch.from_numpy(case['rel']).to(DEV).requires_grad_(True)
+    out = op(x, y, torch.from_numpy(case['x_mask']).to(DEV), torch.from_numpy(case['y_mask']).to(DEV), rel)
+    assert out.is_cuda and out.dtype == torch.float32 and out.shape == x.shape
+    res = {'out': out.detach().cpu().numpy()}
+    if out.requires_grad:
+        out.backward(torch.from_numpy(case['gout']).to(DEV))
+    res['dx'] = x.grad.cpu().numpy() if x.grad is not None else np.zeros_like(case['x'])
+    if y.grad is not None:
+        res['dy'] = y.grad.cpu().numpy()
+    if rel.grad is not None:
+        res['drel'] = rel.grad.cpu().numpy()
+    for k, p in op.named_parameters():
+        res['g:' + k] = p.grad.cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+    return res
+
+
+def compare_golden(npz, tag, res):
+    checked = 0
+    for k, v in res.items():
+        key = tag + '|' + k
+        if not has(npz, key):
+            assert not np.any(v), key
+            continue
+        e = golden_err(npz, key, v)
+        assert e <= TOL, (key, e)
+        checked += 1
+    assert checked >= 2
+
+
+@pytest.mark.parametrize('name', O.ALL_OP_NAMES)
+@pytest.mark.parametrize('nr', [(True, True), (False, False)])
+def test_registry_op_vs_reference_golden(name, nr):
+    npz = load('ops.npz')
+    tag = '%s|%d%d' % (name, int(nr[0]), int(nr[1]))
+    case = cases.op_case(name, nr[0], nr[1], int(npz[tag + '|seed']))
+    compare_golden(npz, tag, run_hip_op(case))
+
+
+def _shape_tags():
+    npz = load('ops_shapes.npz')
+    return sorted({k.rsplit('|', 1)[0] for k in npz.files if k.endswith('|seed')})
+
+
+@pytest.mark.parametrize('tag', _shape_tags())
+def test_shape_variants_vs_reference_golden(tag):
+    npz = load('ops_shapes.npz')
+    name, dims = tag.split('|')
+    B, Sx, Sy, d = (int(v) for v in dims.split('_'))
+    case = cases.op_case(name, True, True, int(npz[tag + '|seed']), dict(B=B, Sx=Sx, Sy=Sy, HSIZE=d))
+    compare_golden(npz, tag, run_hip_op(case))
+
+
+def _drop_sites(case, seed, p):
+    """Mask-replay multipliers for every dropout site of the operator (same (seed, site, idx) map as the kernels)."""
+    kind, kw = O.parse_op_name(case['name'])
+    B, Sx, d = case['x'].shape
+    Sy = case['y'].shape[1]
+    M = B * Sx
+    drops = {'out': dropout_rng.scaled_mask(seed, 1, (B, Sx, d), p)}
+    if kind in ('self_att', 'rel_self_att', 'guided_att', 'uniimg_att'):
+        H = d * kw['hsize_k'] // kw['base']
+        Sk = {'guided_att': Sy, 'uniimg_att': Sx + Sy}.get(kind, Sx)
+        drops['att_map'] = dropout_rng.scaled_mask(seed, 0, (B, H, Sx, Sk), p)
+    elif kind == 'ffn':
+        drops['hid0'] = dropout_rng.scaled_mask(seed, 0, (B, Sx, d * kw['mid_k']), p)
+    elif kind == 'ffn_deep':
+        drops['hid0'] = dropout_rng.scaled_mask(seed, 0, (B, Sx, 2 * d), p)
+        drops['hid1'] = dropout_rng.scaled_mask(seed, 2, (B, Sx, 2 * d), p)
+    elif kind == 'glu' and kw['layers'] == 2:
+        drops['hid0'] = dropout_rng.scaled_mask(seed, 0, (B, Sx, 2 * d), p)
+    return drops
+
+
+@pytest.mark.parametrize('name', ['self_att_64', 'rel_self_att_64', 'guided_att_64', 'uniimg_att_64', 'feed_forward',
+                                  'feed_forward_deep', 'gated_linear_1', 'gated_linear_2', 'sep_conv_3', 'std_conv_5',
+                                  'self_att_32', 'feed_forward_2'])
+@pytest.mark.parametrize('nr', [(True, True), (False, False)])
+def test_training_mode_dropout_by_mask_replay(name, nr, monkeypatch):
+    from mmnas_amd import ops
+    seed, p = 0x0BADC0DE12345678, 0.1
+    monkeypatch.setattr(ops, 'next_seed', lambda: seed)
+    case = cases.op_case(name, nr[0], nr[1], 4321 + len(name), dict(B=3, Sx=12, Sy=5, HSIZE=128))
+    got = run_hip_op(case, train=True, drop_p=p)
+    case['cfg'].DROPOUT_R = 0.0
+    ref = R.run_oracle_op(case, drops=_drop_sites(case, seed, p), dtype=torch.float64)
+    for k in ref:
+        assert rel_err(got[k], ref[k]) <= TOL, (k, rel_err(got[k], ref[k]))
+    # the masks actually dropped something
+    ref0 = R.run_oracle_op(case, dtype=torch.float64)
+    assert rel_err(got['out'], ref0['out']) > 1e-2
+
+
+@pytest.mark.parametrize('name,dims', [
+    ('self_att_64', dict(B=64, Sx=100, Sy=14, HSIZE=512)),       # C2 decoder self-attention
+    ('rel_self_att_64', dict(B=16, Sx=100, Sy=14, HSIZE=256)),   # C3 relation attention (B reduced for the CPU oracle)
+    ('guided_att_64', dict(B=64, Sx=100, Sy=14, HSIZE=512)),
+    ('feed_forward', dict(B=64, Sx=100, Sy=14, HSIZE=512)),
+    ('self_att_64', dict(B=64, Sx=14, Sy=100, HSIZE=512)),       # encoder shape
+    ('feed_forward', dict(B=5, Sx=3, Sy=2, HSIZE=64)),           # ragged / tiny
+    ('self_att_16', dict(B=1, Sx=1, Sy=1, HSIZE=64)),            # single token
+])
+def test_full_size_vs_oracle(name, dims):
+    case = cases.op_case(name, True, True, 777, dims)
+    got = run_hip_op(case)
+    ref = R.run_oracle_op(case)
+    for k in ref:
+        assert rel_err(got[k], ref[k]) <= TOL, (k, rel_err(got[k], ref[k]))
+
+
+def test_edge_semantics():
+    """SURVEY appendix A edge cases: fully-masked rows give a uniform softmax (finite output);
+    r < 1e-6 gives a constant bias with zero gradient; eval mode ignores DROPOUT_R."""
+    from mmnas_amd import ops
+    case = cases.op_case('rel_self_att_64', True, True, 99)
+    case['x_mask'][:] = True
+    case['rel'][:] = 0.0
+    case['P']['mhatt.linear_r.bias'][:] = -1.0       # relu -> 0 -> clamp -> log(1e-6) everywhere
+    got = run_hip_op(case)
+    ref = R.run_oracle_op(case)
+    assert np.isfinite(got['out']).all()
+    assert rel_err(got['out'], ref['out']) <= TOL
+    assert not np.any(got['drel']) and not np.any(got['g:mhatt.linear_r.weight'])
+    case2 = cases.op_case('feed_forward', True, True, 5)
+    a = run_hip_op(case2, train=False, drop_p=0.5)
+    b = run_hip_op(case2, train=False, drop_p=0.0)
+    assert np.array_equal(a['out'], b['out'])
+
+
+def test_cpu_tensor_is_refused():
+    from mmnas_amd import _lib as L
+    from mmnas_amd.utils.ops_adapter import OpsAdapter
+    cfg = cases.small_cfg()
+    op = OpsAdapter().OPS['feed_forward'](cfg, True, True)
+    with pytest.raises(L.MMNasHipError):
+        op(torch.zeros(2, 3, cfg.HSIZE))
