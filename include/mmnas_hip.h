@@ -103,14 +103,19 @@ int mmnas_gemm(const mmnas_gemm_desc* d, void* stream);
  *         If ddrop != NULL it receives dx * dropout(seed, site, idx=row*d+col) (the gradient
  *         that flows into the operator core through the output dropout, modules.py:261).
  *         If dcol != NULL, dcol[d] += column sums of ddrop (bias gradient of the last linear).
- * d % 4 == 0, d <= 4096.
+ *         ws: NULL -> the column reductions use float atomics; otherwise a scratch buffer of
+ *         mmnas_layernorm_bwd_ws_floats(M, d) floats -> per-workgroup partial rows + a second
+ *         pass (no atomics on 3*d hot addresses, bitwise reproducible).
+ * d % 4 == 0, d <= 2048.
  * ------------------------------------------------------------------------------------------ */
 int mmnas_layernorm_fwd(const float* x, const float* a, const float* b, float* y,
                         int M, int d, float eps, void* stream);
 int mmnas_layernorm_bwd(const float* x, const float* a, const float* dy, float* dx,
-                        float* da, float* db, float* ddrop, float* dcol,
+                        float* da, float* db, float* ddrop, float* dcol, float* ws,
                         float drop_p, uint64_t seed, uint32_t site,
                         int M, int d, float eps, void* stream);
+
+size_t mmnas_layernorm_bwd_ws_floats(int M, int d);  /* host only */
 
 /* out[N] += column sums of x[M,N] (bias gradients). */
 int mmnas_colsum(const float* x, float* out, int M, int N, int ldx, void* stream);
@@ -137,7 +142,7 @@ int mmnas_glu_bwd(const float* h, const float* dy, float* dh, int M, int C, int 
  * key-major ([B,H,Sk,Sq]) so the attention core reads it coalesced along the query lanes.
  * bwd: dpre = dbiasT / r where r > 1e-6, else 0;  drel[b,q,k,:] = sum_h dpre*Wr[h,:] (overwritten
  * or, with accumulate_drel != 0, added to); dWr [H,R], dbr [H] accumulated with atomics.
- * R % 4 == 0, R <= 256, H <= 32.
+ * R in {16,32,64,128,256}, H <= 32.
  * ------------------------------------------------------------------------------------------ */
 int mmnas_rel_bias_fwd(const float* rel, const float* Wr, const float* br, float* biasT,
                        int B, int Sq, int Sk, int R, int H, void* stream);
@@ -149,8 +154,8 @@ int mmnas_rel_bias_bwd(const float* rel, const float* Wr, const float* br, const
  * Attention core: MHAtt.att (modules.py:191-199) for all (batch, head) pairs.
  *   Z = Q K^T / sqrt(dh) (+ biasT) ; Z[mask] = -1e9 ; P = softmax(Z) ; A = dropout(P) ; O = A V
  * Q [B*Sq, ldq], K,V [B*Sk, ldk/ldv], head h occupies columns [h*dh, (h+1)*dh).
- * O [B*Sq, ldo] same column convention; lse [B,H,Sq] = log-sum-exp of each score row (saved
- * for backward instead of the map).  dropout idx = ((b*H+h)*Sq+q)*Sk+k.
+* O [B*Sq, ldo] same column convention; lse [B,H,Sq,2] = (row max, 1/row sum) of each score row
+ * (saved for backward instead of the map).  dropout idx = ((b*H+h)*Sq+q)*Sk+k.
  * Limits: dh in {16,32,64,128,256}; Sk <= 256.
  * bwd recomputes P from (Q,K,lse): dQ,dK,dV (same layouts as Q,K,V) are overwritten;
  * dbiasT [B,H,Sk,Sq] (nullable) receives dZ.
@@ -161,8 +166,8 @@ typedef struct mmnas_mha_desc {
   const float* Q; const float* K; const float* V;
   const uint8_t* mask;     /* [B,Sk] or NULL */
   const float* biasT;      /* [B,H,Sk,Sq] or NULL */
-  float* O;                /* fwd: out.  bwd: unused (may be NULL) */
-  float* lse;              /* fwd: out.  bwd: in */
+  float* O;                /* fwd: out.  bwd: in (forward output, for delta = rowsum(dO*O)) */
+  float* lse;              /* row statistics [B,H,Sq,2] = (row max, 1/row sum): fwd out, bwd in */
   float drop_p; uint32_t drop_site; uint64_t drop_seed;
   /* backward only */
   const float* dO;         /* [B*Sq, ldo] */
@@ -282,6 +287,17 @@ int mmnas_adam_step(float* p, const float* g, float* m, float* v, size_t n, floa
                     int step, void* stream);
 /* out[0] += sum of squares of g[0..n) (for clip_grad_norm_). */
 int mmnas_sumsq(const float* g, size_t n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement aid (bench.py roofline): while enabled, every kernel launch of the classes below is
+ * bracketed by HIP events recorded on the stream it is launched on and tagged with its ALGORITHMIC
+ * flops / bytes; mmnas_prof_collect() synchronises the events, sums per class and resets.
+ * ------------------------------------------------------------------------------------------ */
+enum { MMNAS_K_GEMM = 0, MMNAS_K_MHA_FWD = 1, MMNAS_K_MHA_BWD = 2, MMNAS_K_REL_FWD = 3, MMNAS_K_REL_BWD = 4,
+       MMNAS_K_ROWOPS = 5, MMNAS_K_COUNT = 6 };
+typedef struct mmnas_prof_stat { double ms, flops, bytes; long launches; } mmnas_prof_stat;
+int mmnas_prof_enable(int on);
+int mmnas_prof_collect(mmnas_prof_stat* stats /* [MMNAS_K_COUNT] */);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,13 @@ class MlpOp(C.Structure):
                 ('dln_a', _fp), ('dln_b', _fp)]
 
 
+class ProfStat(C.Structure):
+    _fields_ = [('ms', C.c_double), ('flops', C.c_double), ('bytes', C.c_double), ('launches', C.c_long)]
+
+
+K_NAMES = ['gemm', 'mha_fwd', 'mha_bwd', 'rel_fwd', 'rel_bwd', 'rowops']
+
+
 class Segment(C.Structure):
     _fields_ = [('ptr', _fp), ('offset', C.c_uint64), ('n', C.c_uint64)]
 
@@ -74,7 +81,8 @@ SYMBOLS = {
     'mmnas_dropout_mask': (_i, [_fp, _sz, _f, _u64, _u32, _fp]),
     'mmnas_gemm': (_i, [C.POINTER(GemmDesc), _fp]),
     'mmnas_layernorm_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _fp]),
-    'mmnas_layernorm_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _u64, _u32, _i, _i, _f, _fp]),
+    'mmnas_layernorm_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _u64, _u32, _i, _i, _f, _fp]),
+    'mmnas_layernorm_bwd_ws_floats': (_sz, [_i, _i]),
     'mmnas_colsum': (_i, [_fp, _fp, _i, _i, _i, _fp]),
     'mmnas_eltwise_fwd': (_i, [_i, _fp, _fp, _sz, _fp]),
     'mmnas_eltwise_bwd': (_i, [_i, _fp, _fp, _fp, _sz, _fp]),
@@ -98,6 +106,8 @@ SYMBOLS = {
     'mmnas_pack_segments': (_i, [_fp, _i, _fp, _f, _i, _fp]),
     'mmnas_adam_step': (_i, [_fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _fp, _f, _i, _fp]),
     'mmnas_sumsq': (_i, [_fp, _sz, _fp, _fp]),
+    'mmnas_prof_enable': (_i, [_i]),
+    'mmnas_prof_collect': (_i, [C.POINTER(ProfStat)]),
 }
 
 _lib = None

@@ -97,14 +97,24 @@ __global__ void __launch_bounds__(64 * NW) mha_fwd_kernel(const MhaK p) {
   const bool qok = qi < Sq;
   const size_t bh = (size_t)b * p.H + h;
   float m = -INFINITY;
+  const bool has_bias = p.biasT != nullptr;  // wave-uniform: hoisted so the bias loads issue as a batch
+  const int qic = qok ? qi : Sq - 1;
 #pragma unroll
-  for (int kc = 0; kc < NKC; ++kc)
+  for (int kc = 0; kc < NKC; ++kc) {
+    float bias[16];
+    if (has_bias) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = min(32 * kc + acc_row(r, hh), Sk - 1);
+        bias[r] = p.biasT[(bh * Sk + key) * Sq + qic];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = 32 * kc + acc_row(r, hh);
       float v = acc[kc][r] * p.scale;
+      if (has_bias) v += bias[r];
       if (key < Sk) {
-        if (p.biasT && qok) v += p.biasT[(bh * Sk + key) * Sq + qi];
         if (sMask[key] != 0.f) v = -1e9f;
       } else {
         v = -INFINITY;
@@ -112,6 +122,7 @@ __global__ void __launch_bounds__(64 * NW) mha_fwd_kernel(const MhaK p) {
       acc[kc][r] = v;
       m = fmaxf(m, v);
     }
+  }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   float sum = 0.f;
 #pragma unroll
@@ -258,24 +269,32 @@ __global__ void __launch_bounds__(64 * NW) mha_bwd_q_kernel(const MhaK p) {
       }
     }
     // dZ^T for this key block (in place of acc)
+    const bool has_bias = p.biasT != nullptr, has_mask = p.mask != nullptr, has_drop = p.drop.thresh != 0;
+    const bool put_dbias = p.dbiasT != nullptr && oc == 0;
+    const int qic = qok ? qi : Sq - 1;
 #pragma unroll
-    for (int kc = 0; kc < NKC; ++kc)
+    for (int kc = 0; kc < NKC; ++kc) {
+      float bias[16], mk[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {  // batched, branch-free operand fetch (clamped indices)
+        const int key = min(kb + 32 * kc + acc_row(r, hh), Sk - 1);
+        bias[r] = has_bias ? p.biasT[(bh * Sk + key) * Sq + qic] : 0.f;
+        mk[r] = has_mask ? (float)p.mask[(size_t)b * Sk + key] : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kb + 32 * kc + acc_row(r, hh);
-        float dz = 0.f;
-        if (key < Sk && qok) {
-          float v = acc[kc][r] * p.scale;
-          if (p.biasT) v += p.biasT[(bh * Sk + key) * Sq + qi];
-          const bool masked = p.mask && p.mask[(size_t)b * Sk + key];
-          if (masked) v = -1e9f;
-          const float pr = expf(v - m) * inv;
-          const float dm = p.drop.thresh ? drop_mult(p.drop, (uint32_t)((bh * Sq + qi) * Sk + key)) : 1.f;
-          dz = masked ? 0.f : pr * (dacc[kc][r] * dm - del);
-          if (p.dbiasT && oc == 0) p.dbiasT[(bh * Sk + key) * Sq + qi] = dz;
-        }
+        const bool ok = key < Sk && qok;
+        const bool masked = mk[r] != 0.f;
+        float v = acc[kc][r] * p.scale + bias[r];
+        if (masked) v = -1e9f;
+        const float pr = expf(v - m) * inv;
+        const float dm = has_drop ? drop_mult(p.drop, (uint32_t)((bh * Sq + qi) * Sk + key)) : 1.f;
+        const float dz = (ok && !masked) ? pr * (dacc[kc][r] * dm - del) : 0.f;
+        if (put_dbias && ok) p.dbiasT[(bh * Sk + key) * Sq + qi] = dz;
         acc[kc][r] = dz * p.scale;
       }
+    }
     if (p.nch > 1) {
       __syncthreads();
       load_tile<KB, DHC, NT>(Ks, p.K + (size_t)(b * Sk + kb) * p.ldk + h * p.dh + oc * DHC, Sk - kb, p.ldk, tid);
@@ -371,21 +390,26 @@ __global__ void __launch_bounds__(64 * NW) mha_bwd_kv_kernel(const MhaK p) {
       }
     }
     // A and dZ for (query = register row, key = lane)
+    {
+      const bool has_bias = p.biasT != nullptr, has_drop = p.drop.thresh != 0;
+      const int keyc = kok ? key : Sk - 1;
+      float bias[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ql = acc_row(r, hh), q = qc + ql;
-      float a = 0.f, dz = 0.f;
-      if (q < Sq && kok) {
-        float v = acc[r] * p.scale;
-        if (p.biasT) v += p.biasT[(bh * Sk + key) * Sq + q];
+      for (int r = 0; r < 16; ++r) {  // batched, branch-free bias fetch (clamped indices)
+        const int q = min(qc + acc_row(r, hh), Sq - 1);
+        bias[r] = has_bias ? p.biasT[(bh * Sk + keyc) * Sq + q] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = acc_row(r, hh), q = qc + ql;
+        const bool ok = q < Sq && kok;
+        float v = acc[r] * p.scale + bias[r];
         if (masked) v = -1e9f;
         const float pr = expf(v - sM[ql]) * sInv[ql];
-        const float dm = p.drop.thresh ? drop_mult(p.drop, (uint32_t)((bh * Sq + q) * Sk + key)) : 1.f;
-        a = pr * dm;
-        dz = masked ? 0.f : pr * (dacc[r] * dm - sDel[ql]) * p.scale;
+        const float dm = has_drop ? drop_mult(p.drop, (uint32_t)((bh * Sq + q) * Sk + key)) : 1.f;
+        acc[r] = ok ? pr * dm : 0.f;
+        dacc[r] = (ok && !masked) ? pr * (dacc[r] * dm - sDel[ql]) * p.scale : 0.f;
       }
-      acc[r] = a;
-      dacc[r] = dz;
     }
     if (p.nch > 1) {
       __syncthreads();
@@ -494,6 +518,9 @@ extern "C" int mmnas_mha_core_fwd(const mmnas_mha_desc* d, void* stream) {
   int rc = fill(d, k, false);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  const double bhqk = (double)k.B * k.H * k.Sq * k.Sk;
+  ProfScope ps(MMNAS_K_MHA_FWD, 4.0 * bhqk * k.dh,
+               4.0 * ((double)k.B * k.H * k.dh * (2.0 * k.Sq + 2.0 * k.Sk) + (k.biasT ? bhqk : 0.0)), st);
   if (k.dh >= 64) { k.nch = k.dh / 64; launch_fwd<64>(k, st); }
   else if (k.dh == 32) { k.nch = 1; launch_fwd<32>(k, st); }
   else { k.nch = 1; launch_fwd<16>(k, st); }
@@ -505,6 +532,9 @@ extern "C" int mmnas_mha_core_bwd(const mmnas_mha_desc* d, void* stream) {
   int rc = fill(d, k, true);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  const double bhqk = (double)k.B * k.H * k.Sq * k.Sk;
+  ProfScope ps(MMNAS_K_MHA_BWD, 10.0 * bhqk * k.dh,
+               4.0 * ((double)k.B * k.H * k.dh * (4.0 * k.Sq + 4.0 * k.Sk) + (k.biasT ? 2.0 * bhqk : 0.0)), st);
   {
     const long n = (long)k.B * k.Sq * k.H;
     int blocks = (int)((n + 255) / 256);

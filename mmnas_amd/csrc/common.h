@@ -36,6 +36,15 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// RAII timing scope: when profiling is enabled (mmnas_prof_enable) a HIP event is recorded on the
+// launch stream before and after the enclosed launches, tagged with the algorithmic work.
+struct ProfScope {
+  ProfScope(int kind, double flops, double bytes, hipStream_t st);
+  ~ProfScope();
+  long idx_;
+  hipStream_t st_;
+};
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace mmnas

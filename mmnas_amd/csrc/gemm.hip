@@ -8,6 +8,11 @@
 //     per wave) for problems that would not fill 256 CUs with 128^2 tiles.
 //   * operands are staged global -> registers -> LDS (16-B vector loads issued one K-tile ahead,
 //     written to the other LDS buffer after the MFMA block: one barrier per K-tile).
+//   * FAST path (every shape of the VQA/VGD/ITM workloads): operand loads are bounds-checked
+//     buffer loads (buffer_load_dwordx4 through a per-operand descriptor): rows beyond M/N get an
+//     out-of-range offset and read as zero, so the K loop has no branches and its 8 loads issue
+//     back to back.  Shapes with K % 32 != 0, unaligned bases or leading dimensions take the
+//     generic path (guarded scalar loads) -- same tiles, same epilogue.
 //   * K-contiguous operands sit in LDS as [row][36] (pad 4: ds_read_b128 fragment reads are
 //     conflict-free because 36/4 = 9 is odd); row-contiguous operands (B of NN, A and B of TN) sit
 //     as [k][rows] and are read with conflict-free ds_read_b32.  The reduction index inside an
@@ -33,7 +38,7 @@ struct GemmK {
   int ngroups, nseg, N, K;
   int lda, ldb, ldc, ldres, ldgate;
   int relu, split_k, k_per_split, tiles_n;
-  int avec, bvec;  // 16-byte vector loads legal for the A / B operand (else guarded scalar loads)
+  int avec, bvec;  // generic path: 16-byte vector loads legal for the A / B operand
   float alpha, gate_scale;
   DropCfg drop;
   GemmGroupK g[3];
@@ -42,7 +47,16 @@ struct GemmK {
 constexpr int BK = 32;
 constexpr int LDK = 36;
 
-template <int BM, int BN, bool AKC, bool BKC>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+  float4 f;
+  f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
+  return f;
+}
+
+template <int BM, int BN, bool AKC, bool BKC, bool FAST>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmK p) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int A_SZ = BM * LDK, B_SZ = BN * LDK;  // >= BK*BM for the [k][row] form
@@ -86,11 +100,56 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmK p) {
 
   float4 ra[NA], rb[NB];
 
+  // FAST path: per-thread byte offsets of its loads inside the operand (k0 = 0), ~0u when the row is
+  // outside the matrix (the buffer range check then returns zeros)
+  unsigned offa[NA], offb[NB];
+  unsigned stepa = 0, stepb = 0;  // bytes per K-tile
+  unsigned bytesa = 0, bytesb = 0;
+  if (FAST) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int f = tid + 256 * i;
+      if (AKC) {
+        const int row = f >> 3, kq = f & 7, gr = m0 + row;
+        offa[i] = gr < Mg ? (unsigned)(gr * p.lda + kbeg + 4 * kq) * 4u : ~0u;
+      } else {
+        const int k = f / (BM / 4), rq = f - k * (BM / 4), gr = m0 + 4 * rq;
+        offa[i] = gr < Mg ? (unsigned)((kbeg + k) * p.lda + gr) * 4u : ~0u;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int f = tid + 256 * i;
+      if (BKC) {
+        const int row = f >> 3, kq = f & 7, gr = n0 + row;
+        offb[i] = gr < p.N ? (unsigned)(gr * p.ldb + kbeg + 4 * kq) * 4u : ~0u;
+      } else {
+        const int k = f / (BN / 4), rq = f - k * (BN / 4), gr = n0 + 4 * rq;
+        offb[i] = gr < p.N ? (unsigned)((kbeg + k) * p.ldb + gr) * 4u : ~0u;
+      }
+    }
+    stepa = AKC ? BK * 4u : (unsigned)p.lda * BK * 4u;
+    stepb = BKC ? BK * 4u : (unsigned)p.ldb * BK * 4u;
+    bytesa = (unsigned)(AKC ? Mg : p.K) * (unsigned)p.lda * 4u;
+    bytesb = (unsigned)(BKC ? p.N : p.K) * (unsigned)p.ldb * 4u;
+  }
+
   auto gload = [&](int t) {
     const int seg = t / ntk;
-    const int k0 = kbeg + (t - seg * ntk) * BK;
+    const int kt = t - seg * ntk;
     const float* __restrict__ Ap = G.A[seg];
     const float* __restrict__ Bp = G.B[seg];
+    if (FAST) {
+      const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, bytesa, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, bytesb, 0x00020000);
+      const unsigned ka = (unsigned)kt * stepa, kb = (unsigned)kt * stepb;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) ra[i] = buf_load4(ra_src, offa[i] == ~0u ? ~0u : offa[i] + ka);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) rb[i] = buf_load4(rb_src, offb[i] == ~0u ? ~0u : offb[i] + kb);
+      return;
+    }
+    const int k0 = kbeg + kt * BK;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int f = tid + 256 * i;
@@ -232,47 +291,69 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmK p) {
   }
 
   // ---- epilogue ----
+  // All conditions on kernel arguments are wave-uniform and hoisted out of the element loops; the
+  // residual / gate operands of a 32x32 sub-tile are fetched as one batch of 16 independent loads
+  // (clamped row index instead of a branch) before any arithmetic, so their latency overlaps.
   const bool atomic = p.split_k > 1;
+  const bool has_res = G.residual != nullptr, has_gate = G.gate != nullptr;
+  const bool has_drop = p.drop.thresh != 0, has_relu = p.relu != 0;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn * WN + j * 32 + l31;
-      if (col >= p.N) continue;
-      const float bv = G.bias ? G.bias[col] : 0.f;
+      const bool cok = col < p.N;
+      const int colc = cok ? col : p.N - 1;
+      const int rbase = m0 + wm * WM + i * 32 + 4 * hh;
+      if (atomic) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (cok && row < Mg) atomicAdd(G.C + (size_t)row * p.ldc + col, acc[i][j][r] * p.alpha);
+        }
+        continue;
+      }
+      float resv[16], gatev[16];
+      if (has_res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(rbase + (r & 3) + 8 * (r >> 2), Mg - 1);
+          resv[r] = G.residual[(size_t)row * p.ldres + colc];
+        }
+      }
+      if (has_gate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(rbase + (r & 3) + 8 * (r >> 2), Mg - 1);
+          gatev[r] = G.gate[(size_t)row * p.ldgate + colc];
+        }
+      }
+      const float bv = G.bias ? G.bias[colc] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WM + i * 32 + acc_row(r, hh);
-        if (row >= Mg) continue;
-        float v = acc[i][j][r] * p.alpha;
-        if (atomic) {
-          atomicAdd(G.C + (size_t)row * p.ldc + col, v);
-          continue;
-        }
-        v += bv;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.drop.thresh) v *= drop_mult(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)col);
-        if (G.gate) v = (G.gate[(size_t)row * p.ldgate + col] > 0.f) ? v * p.gate_scale : 0.f;
-        if (G.residual) v += G.residual[(size_t)row * p.ldres + col];
-        G.C[(size_t)row * p.ldc + col] = v;
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        float v = acc[i][j][r] * p.alpha + bv;
+        if (has_relu) v = fmaxf(v, 0.f);
+        if (has_drop) v *= drop_mult(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)col);
+        if (has_gate) v = gatev[r] > 0.f ? v * p.gate_scale : 0.f;
+        if (has_res) v += resv[r];
+        if (cok && row < Mg) G.C[(size_t)row * p.ldc + col] = v;
       }
     }
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool FAST>
 static int launch(const GemmK& k, int layout, int maxM, hipStream_t st) {
   const int tiles_m = cdiv(maxM, BM);
   dim3 grid(tiles_m * k.tiles_n, 1, k.ngroups * k.split_k), block(256);
   switch (layout) {
-    case MMNAS_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), grid, block, 0, st, k); break;
-    case MMNAS_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false>), grid, block, 0, st, k); break;
-    default: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false>), grid, block, 0, st, k); break;
+    case MMNAS_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, FAST>), grid, block, 0, st, k); break;
+    case MMNAS_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, FAST>), grid, block, 0, st, k); break;
+    default: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, FAST>), grid, block, 0, st, k); break;
   }
   return check_launch("gemm");
 }
-
-static int g_force_tile = -1;
 
 }  // namespace mmnas
 
@@ -287,6 +368,7 @@ extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
   const bool tn = d->layout == MMNAS_GEMM_TN;
   int split = d->split_k < 1 ? 1 : d->split_k;
   MMNAS_REQUIRE(split == 1 || tn, MMNAS_E_ARG, "mmnas_gemm: split_k only for the TN layout");
+
   GemmK k;
   k.ngroups = d->ngroups; k.nseg = d->nseg; k.N = d->N; k.K = d->K;
   k.lda = d->lda; k.ldb = d->ldb; k.ldc = d->ldc; k.ldres = d->ldres; k.ldgate = d->ldgate;
@@ -298,6 +380,7 @@ extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
   int avec = (d->lda % 4 == 0) && (akc ? d->K % 4 == 0 : 1);
   int bvec = (d->ldb % 4 == 0) && (bkc ? d->K % 4 == 0 : d->N % 4 == 0);
   int maxM = 0;
+  double maxbytes = 0;
   for (int g = 0; g < d->ngroups; ++g) {
     const mmnas_gemm_group& s = d->g[g];
     if (!akc && s.M % 4 != 0) avec = 0;
@@ -312,25 +395,43 @@ extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
       }
     }
     if (s.M > maxM) maxM = s.M;
+    const double ab = 4.0 * (akc ? (double)(s.M + 128) : (double)d->K) * d->lda;
+    if (ab > maxbytes) maxbytes = ab;
   }
+  const double bb = 4.0 * (bkc ? (double)(d->N + 128) : (double)d->K) * d->ldb;
+  if (bb > maxbytes) maxbytes = bb;
   k.avec = avec; k.bvec = bvec;
-  // tile choice: 128^2 when it yields enough workgroups for 256 CUs, else 64^2
+  // tile choice (measured, tools/gemm_bench.py): 64^2 tiles win on every shape of the VQA workloads
+  // (M = 6400, N,K <= 2048: 75-115 TF/s vs 69-108 with 128^2) because they give 4x the workgroups
+  // to balance over 256 CUs; 128^2 (half the LDS/L2 traffic per flop) only pays once there are
+  // >= 4 full waves of them (4096^3: 129-134 TF/s vs 117-125)
   const long t128 = (long)cdiv(maxM, 128) * cdiv(d->N, 128) * d->ngroups;
-  bool big = t128 * (tn ? split : 1) >= 160;
+  bool big = t128 * (tn ? split : 1) >= 1024;
   {  // tuning / test knob: MMNAS_GEMM_TILE=64|128 forces the tile shape
     const char* e = getenv("MMNAS_GEMM_TILE");
-    g_force_tile = e ? atoi(e) : 0;
+    const int force = e ? atoi(e) : 0;
+    if (force == 128) big = true;
+    if (force == 64) big = false;
   }
-  if (g_force_tile == 128) big = true;
-  if (g_force_tile == 64) big = false;
   // K slices are multiples of the K tile so every slice starts on a tile boundary
   const int kps = ((cdiv(d->K, split) + BK - 1) / BK) * BK;
   split = cdiv(d->K, kps);
   k.split_k = split; k.k_per_split = kps;
   if (split > 1)
     MMNAS_REQUIRE(!d->relu && d->drop_p == 0.f, MMNAS_E_ARG, "mmnas_gemm: no relu/dropout epilogue with split_k");
+  // branch-free buffer-load path: aligned vector loads, K a multiple of the K tile, 32-bit byte offsets
+  bool fast = avec && bvec && (d->K % BK == 0) && maxbytes < 4.0e9;
+  if (getenv("MMNAS_GEMM_GENERIC")) fast = false;
   hipStream_t st = (hipStream_t)stream;
-  if (big) { k.tiles_n = cdiv(d->N, 128); return launch<128, 128>(k, d->layout, maxM, st); }
+  double sumM = 0;
+  for (int g = 0; g < d->ngroups; ++g) sumM += d->g[g].M;
+  // algorithmic work: 2*M*N*K flops per product; minimum traffic = operands once + result once
+  ProfScope ps(MMNAS_K_GEMM, 2.0 * sumM * d->N * d->K * d->nseg,
+               4.0 * (sumM * d->K * d->nseg + (double)d->N * d->K * d->nseg * d->ngroups + sumM * d->N), st);
+  if (big) {
+    k.tiles_n = cdiv(d->N, 128);
+    return fast ? launch<128, 128, true>(k, d->layout, maxM, st) : launch<128, 128, false>(k, d->layout, maxM, st);
+  }
   k.tiles_n = cdiv(d->N, 64);
-  return launch<64, 64>(k, d->layout, maxM, st);
+  return fast ? launch<64, 64, true>(k, d->layout, maxM, st) : launch<64, 64, false>(k, d->layout, maxM, st);
 }

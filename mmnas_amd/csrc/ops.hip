@@ -24,12 +24,13 @@ struct Carver {
 
 static int auto_split(int M, int N, int groups, int K) {
   // weight-gradient GEMMs have few output tiles and a long reduction: cut K so ~2 workgroups/CU exist
-  const long t128 = (long)cdiv(M, 128) * cdiv(N, 128) * groups;
-  const long t64 = (long)cdiv(M, 64) * cdiv(N, 64) * groups;
-  const long tiles = t128 >= 24 ? t128 : t64;
-  int s = (int)((512 + tiles - 1) / tiles);
-  const int maxs = K / 64 > 0 ? K / 64 : 1;
+  // measured (tools/gemm_bench.py): ~1024 workgroups of 64^2 tiles (4 per CU) is the sweet spot,
+  // with at least 4 K-tiles of 32 per slice
+  const long tiles = (long)cdiv(M, 64) * cdiv(N, 64) * groups;
+  int s = (int)((1024 + tiles - 1) / tiles);
+  const int maxs = K / 128 > 0 ? K / 128 : 1;
   if (s > maxs) s = maxs;
+  if (s > 32) s = 32;
   if (s < 1) s = 1;
   return s;
 }
@@ -43,7 +44,7 @@ static void gemm_init(mmnas_gemm_desc& g, int layout, int N, int K, int lda, int
 struct AttLayout {
   size_t Mq, Mk;
   float *Q, *K, *V, *att, *stats, *z, *biasT;       // save
-  float *dz, *dt, *datt, *dQ, *dK, *dV, *delta, *dbiasT;  // backward scratch
+  float *dz, *dt, *datt, *dQ, *dK, *dV, *delta, *dbiasT, *lnws;  // backward scratch
   size_t save_bytes, ws_bwd_bytes;
 };
 
@@ -66,6 +67,7 @@ static AttLayout att_layout(const mmnas_att_op* op) {
   L.dQ = w.take(L.Mq * op->di); L.dK = w.take(L.Mk * op->di); L.dV = w.take(L.Mk * op->di);
   L.delta = w.take((size_t)op->B * op->H * op->Sq);
   L.dbiasT = rel ? w.take((size_t)op->B * op->H * op->Sk * op->Sq) : nullptr;
+  L.lnws = norm ? w.take(mmnas_layernorm_bwd_ws_floats((int)L.Mq, op->d)) : nullptr;
   L.ws_bwd_bytes = w.off;
   return L;
 }
@@ -162,7 +164,7 @@ extern "C" int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream) {
   const float* dt = op->dy;   // gradient wrt core
   if (norm) {
     if ((rc = mmnas_layernorm_bwd(L.z, op->ln_a, op->dy, L.dz, op->dln_a, op->dln_b, drop ? L.dt : nullptr, nullptr,
-                                  drop ? op->drop_p : 0.f, op->seed, 1, Mq, d, op->eps, stream)))
+                                  L.lnws, drop ? op->drop_p : 0.f, op->seed, 1, Mq, d, op->eps, stream)))
       return rc;
     dz = L.dz; dt = drop ? L.dt : L.dz;
   } else if (drop) {
@@ -250,7 +252,7 @@ namespace mmnas {
 struct MlpLayout {
   float* h[3];      // h[i] = input of layer i (h[0] = x, not stored); saved for i >= 1
   float* z;
-  float *dz, *dt, *dp[2];
+  float *dz, *dt, *dp[2], *lnws;
   size_t save_bytes, ws_bwd_bytes;
 };
 
@@ -271,6 +273,7 @@ static MlpLayout mlp_layout(const mmnas_mlp_op* op) {
   L.dt = drop ? w.take(M * op->dims[0]) : nullptr;
   L.dp[0] = w.take(M * maxh);
   L.dp[1] = op->nl > 2 ? w.take(M * maxh) : nullptr;
+  L.lnws = norm ? w.take(mmnas_layernorm_bwd_ws_floats(op->M, op->dims[0])) : nullptr;
   L.ws_bwd_bytes = w.off;
   return L;
 }
@@ -353,7 +356,7 @@ extern "C" int mmnas_mlp_op_bwd(const mmnas_mlp_op* op, void* stream) {
     // separate dt buffer exists
     float* dcol = (drop && op->db[nl - 1]) ? op->db[nl - 1] : nullptr;
     if ((rc = mmnas_layernorm_bwd(L.z, op->ln_a, op->dy, L.dz, op->dln_a, op->dln_b, drop ? L.dt : nullptr, dcol,
-                                  drop ? op->drop_p : 0.f, op->seed, 1, M, d, op->eps, stream)))
+                                  L.lnws, drop ? op->drop_p : 0.f, op->seed, 1, M, d, op->eps, stream)))
       return rc;
     dz = L.dz; dt = drop ? L.dt : L.dz;
     last_bias_done = dcol != nullptr;

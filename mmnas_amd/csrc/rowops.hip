@@ -58,7 +58,8 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ dy, float* __restrict__ dx,
                                                      float* __restrict__ da, float* __restrict__ db,
                                                      float* __restrict__ ddrop, float* __restrict__ dcol,
-                                                     DropCfg drop, int M, int d, float eps) {
+                                                     float* __restrict__ part, DropCfg drop, int M, int d,
+                                                     float eps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 acc_a[NV], acc_b[NV], acc_c[NV];
 #pragma unroll
@@ -147,12 +148,36 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ x
         const int o = lane * 4 + j;
         const float sa = (red[0][0][o] + red[0][1][o]) + (red[0][2][o] + red[0][3][o]);
         const float sb = (red[1][0][o] + red[1][1][o]) + (red[1][2][o] + red[1][3][o]);
-        if (da) atomicAdd(da + c + j, sa);
-        if (db) atomicAdd(db + c + j, sb);
-        if (dcol) atomicAdd(dcol + c + j, (red[2][0][o] + red[2][1][o]) + (red[2][2][o] + red[2][3][o]));
+        const float sc = (red[2][0][o] + red[2][1][o]) + (red[2][2][o] + red[2][3][o]);
+        if (part) {  // per-block partial rows, summed by ln_bwd_reduce_kernel (no atomics, deterministic)
+          float* pr = part + (size_t)blockIdx.x * 3 * d + c + j;
+          pr[0] = sa; pr[d] = sb; pr[2 * d] = sc;
+        } else {
+          if (da) atomicAdd(da + c + j, sa);
+          if (db) atomicAdd(db + c + j, sb);
+          if (dcol) atomicAdd(dcol + c + j, sc);
+        }
       }
     }
   }
+}
+
+// out_w[c] += sum over blocks of part[block][w][c]; grid (ceil(d/64), 3), block 256 = 64 columns x 4 slices
+__global__ void __launch_bounds__(256) ln_bwd_reduce_kernel(const float* __restrict__ part, int nblocks, int d,
+                                                            float* __restrict__ da, float* __restrict__ db,
+                                                            float* __restrict__ dcol) {
+  const int w = blockIdx.y;
+  float* out = w == 0 ? da : (w == 1 ? db : dcol);
+  if (!out) return;
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (c < d)
+    for (int b = g; b < nblocks; b += 4) s += part[((size_t)b * 3 + w) * d + c];
+  __shared__ float red[4][64];
+  red[g][cl] = s;
+  __syncthreads();
+  if (g == 0 && c < d) out[c] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 // ---------------------------------------------------------------- column sums
@@ -256,6 +281,7 @@ extern "C" int mmnas_layernorm_fwd(const float* x, const float* a, const float* 
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(cdiv(M, 4)), block(256);
   const int nv = cdiv(d, 256);
+  ProfScope ps(MMNAS_K_ROWOPS, 8.0 * M * d, 8.0 * M * d, st);
   if (nv <= 1) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, st, x, a, b, y, M, d, eps);
   else if (nv <= 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, st, x, a, b, y, M, d, eps);
   else if (nv <= 4) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, st, x, a, b, y, M, d, eps);
@@ -263,22 +289,30 @@ extern "C" int mmnas_layernorm_fwd(const float* x, const float* a, const float* 
   return check_launch("layernorm_fwd");
 }
 
+static int ln_bwd_blocks(int M) {
+  int nb = cdiv(M, 4);
+  return nb > 256 ? 256 : nb;
+}
+
+extern "C" size_t mmnas_layernorm_bwd_ws_floats(int M, int d) { return (size_t)ln_bwd_blocks(M) * 3 * d; }
+
 extern "C" int mmnas_layernorm_bwd(const float* x, const float* a, const float* dy, float* dx, float* da,
-                                   float* db, float* ddrop, float* dcol, float drop_p, uint64_t seed,
+                                   float* db, float* ddrop, float* dcol, float* ws, float drop_p, uint64_t seed,
                                    uint32_t site, int M, int d, float eps, void* stream) {
   MMNAS_REQUIRE(x && a && dy && dx, MMNAS_E_ARG, "layernorm_bwd: null pointer");
   MMNAS_REQUIRE(M > 0 && d >= 4 && d % 4 == 0 && d <= 2048, MMNAS_E_SHAPE,
                 "layernorm_bwd: M=%d d=%d (need d %% 4 == 0, 4 <= d <= 2048)", M, d);
   MMNAS_REQUIRE(dcol == nullptr || ddrop != nullptr, MMNAS_E_ARG, "layernorm_bwd: dcol needs ddrop");
   hipStream_t st = (hipStream_t)stream;
-  int nb = cdiv(M, 4);
-  if (nb > 512) nb = 512;
+  const int nb = ln_bwd_blocks(M);
   dim3 grid(nb), block(256);
   const DropCfg dc = make_drop(drop_p, seed, site);
   const int nv = cdiv(d, 256);
-#define LNB(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, 0, st, x, a, dy, dx, da, db, ddrop, dcol, dc, M, d, eps)
+  ProfScope ps(MMNAS_K_ROWOPS, 16.0 * M * d, 4.0 * M * d * (ddrop ? 4.0 : 3.0), st);
+#define LNB(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, 0, st, x, a, dy, dx, da, db, ddrop, dcol, ws, dc, M, d, eps)
   if (nv <= 1) LNB(1); else if (nv <= 2) LNB(2); else if (nv <= 4) LNB(4); else LNB(8);
 #undef LNB
+  if (ws) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(d, 64), 3), dim3(256), 0, st, ws, nb, d, da, db, dcol);
   return check_launch("layernorm_bwd");
 }
 

@@ -3,6 +3,8 @@
 // gradient exchange, fused Adam and sum-of-squares for the optimizer step.
 #include <stdarg.h>
 #include <string.h>
+#include <mutex>
+#include <vector>
 #include "common.h"
 
 namespace mmnas {
@@ -23,6 +25,41 @@ int check_launch(const char* what) {
     return MMNAS_E_LAUNCH;
   }
   return MMNAS_OK;
+}
+
+// ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline) ----
+namespace prof {
+struct Rec { hipEvent_t a, b; int kind; double flops, bytes; };
+static std::mutex mu;
+static bool enabled = false;
+static std::vector<Rec> recs;
+static std::vector<hipEvent_t> pool;
+static size_t pool_next = 0;
+
+static hipEvent_t get_event() {
+  if (pool_next == pool.size()) {
+    hipEvent_t e;
+    hipEventCreate(&e);
+    pool.push_back(e);
+  }
+  return pool[pool_next++];
+}
+}  // namespace prof
+
+ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t st) : idx_(-1), st_(st) {
+  if (!prof::enabled) return;
+  std::lock_guard<std::mutex> g(prof::mu);
+  prof::Rec r;
+  r.a = prof::get_event(); r.b = prof::get_event(); r.kind = kind; r.flops = flops; r.bytes = bytes;
+  hipEventRecord(r.a, st);
+  idx_ = (long)prof::recs.size();
+  prof::recs.push_back(r);
+}
+
+ProfScope::~ProfScope() {
+  if (idx_ < 0) return;
+  std::lock_guard<std::mutex> g(prof::mu);
+  hipEventRecord(prof::recs[idx_].b, st_);
 }
 
 __global__ void dropout_mask_kernel(float* out, size_t n, DropCfg c) {
@@ -77,6 +114,30 @@ __global__ void sumsq_kernel(const float* g, size_t n, float* out) {
 }  // namespace mmnas
 
 using namespace mmnas;
+
+extern "C" int mmnas_prof_enable(int on) {
+  std::lock_guard<std::mutex> g(prof::mu);
+  prof::enabled = on != 0;
+  prof::recs.clear();
+  prof::pool_next = 0;
+  return MMNAS_OK;
+}
+
+extern "C" int mmnas_prof_collect(mmnas_prof_stat* stats) {
+  MMNAS_REQUIRE(stats, MMNAS_E_ARG, "prof_collect: null output");
+  std::lock_guard<std::mutex> g(prof::mu);
+  for (int k = 0; k < MMNAS_K_COUNT; ++k) { stats[k].ms = 0; stats[k].flops = 0; stats[k].bytes = 0; stats[k].launches = 0; }
+  for (const prof::Rec& r : prof::recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    mmnas_prof_stat& s = stats[r.kind];
+    s.ms += ms; s.flops += r.flops; s.bytes += r.bytes; s.launches += 1;
+  }
+  prof::recs.clear();
+  prof::pool_next = 0;
+  return MMNAS_OK;
+}
 
 extern "C" int mmnas_abi_version(void) { return MMNAS_ABI_VERSION; }
 extern "C" const char* mmnas_last_error(void) { return g_err; }

@@ -278,10 +278,8 @@ def gemm(layout, groups, N, K, lda, ldb, ldc, nseg=1, relu=False, split_k=1, alp
 
 
 def _wgrad_split(M, N, K):
-    tiles = max(1, ((M + 127) // 128) * ((N + 127) // 128))
-    if tiles < 24:
-        tiles = max(1, ((M + 63) // 64) * ((N + 63) // 64))
-    return max(1, min((512 + tiles - 1) // tiles, max(K // 64, 1)))
+    tiles = max(1, ((M + 63) // 64) * ((N + 63) // 64))
+    return max(1, min((1024 + tiles - 1) // tiles, max(K // 128, 1), 32))
 
 
 class LinearFn(torch.autograd.Function):
@@ -346,8 +344,10 @@ class LayerNormFn(torch.autograd.Function):
         M = x.numel() // d
         dx = torch.empty_like(x)
         dab = torch.zeros(2, d, dtype=torch.float32, device=x.device)
+        ws = torch.empty(L.lib().mmnas_layernorm_bwd_ws_floats(M, d), dtype=torch.float32, device=x.device)
         L.check(L.lib().mmnas_layernorm_bwd(L.fptr(x), L.fptr(a), L.fptr(dy), L.fptr(dx), L.fptr(dab[0]),
-                                            L.fptr(dab[1]), None, None, 0.0, 0, 0, M, d, ctx.eps, L.stream()))
+                                            L.fptr(dab[1]), None, None, L.fptr(ws), 0.0, 0, 0, M, d, ctx.eps,
+                                            L.stream()))
         return dx, dab[0], dab[1], None
 
 

@@ -139,7 +139,13 @@ def layer_norm_backward(x, a_2, dy, eps=1e-6):
 
 
 def _drop(t, drops, site):
-    if drops is None or site not in drops or drops[site] is None:
+    """drops: None (identity) | dict site -> multiplier tensor (mask replay) | float p (nn.Dropout with
+    torch's own RNG, as the reference's modules do -- used for the timed CPU baseline)."""
+    if drops is None:
+        return t
+    if isinstance(drops, float):
+        return F.dropout(t, drops, training=True) if drops > 0 else t
+    if site not in drops or drops[site] is None:
         return t
     return t * drops[site].reshape(t.shape)
 
@@ -395,7 +401,7 @@ def net_forward(task, P, cfg, inputs, genotype=None, search=None, drops_for=None
         y = run_cell('dec', l, y, x, y_mask, x_mask, y_rel)
 
     G = cfg.ATTFLAT_GLIMPSES
-    xo = att_flat(_sub(P, 'attflat_x.'), x, x_mask, G)
+    xo = att_flat(_sub(P, 'attflat_x.'), x, x_mask, G, drops_for('attflat_x.') if drops_for else None)
     if task == 'vgd':  # full_vgd.py:105-114
         xo = xo.unsqueeze(1)
         yo = _linear(y, P['attfc_y.weight'], P['attfc_y.bias'])
@@ -404,7 +410,7 @@ def net_forward(task, P, cfg, inputs, genotype=None, search=None, drops_for=None
         if cfg.SCORES_LOSS == 'kld':
             scores = torch.log_softmax(scores, dim=-1)
         return scores, _linear(xy, P['proj_reg.weight'], P['proj_reg.bias'])
-    yo = att_flat(_sub(P, 'attflat_y.'), y, y_mask, G)
+    yo = att_flat(_sub(P, 'attflat_y.'), y, y_mask, G, drops_for('attflat_y.') if drops_for else None)
     xy = layer_norm(xo + yo, P['proj_norm.a_2'], P['proj_norm.b_2'])
     out = _linear(xy, P['proj.weight'], P['proj.bias'])
     if task == 'itm':  # full_itm.py:105-112
