@@ -30,7 +30,7 @@ static int auto_split(int M, int N, int groups, int K) {
   int s = (int)((1024 + tiles - 1) / tiles);
   const int maxs = K / 128 > 0 ? K / 128 : 1;
   if (s > maxs) s = maxs;
-  if (s > 32) s = 32;
+  if (s > 1024) s = 1024;
   if (s < 1) s = 1;
   return s;
 }

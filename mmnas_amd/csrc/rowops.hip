@@ -162,39 +162,62 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ x
   }
 }
 
-// out_w[c] += sum over blocks of part[block][w][c]; grid (ceil(d/64), 3), block 256 = 64 columns x 4 slices
-__global__ void __launch_bounds__(256) ln_bwd_reduce_kernel(const float* __restrict__ part, int nblocks, int d,
-                                                            float* __restrict__ da, float* __restrict__ db,
-                                                            float* __restrict__ dcol) {
+// out_w[c] += sum over blocks of part[block][w][c]; grid (ceil(d/16), 3), block 1024 = 16 columns x 64
+// block-slices: every partial row is touched by one lane group, 4 independent loads in flight per thread
+__global__ void __launch_bounds__(1024) ln_bwd_reduce_kernel(const float* __restrict__ part, int nblocks, int d,
+                                                             float* __restrict__ da, float* __restrict__ db,
+                                                             float* __restrict__ dcol) {
   const int w = blockIdx.y;
   float* out = w == 0 ? da : (w == 1 ? db : dcol);
   if (!out) return;
-  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  float s = 0.f;
-  if (c < d)
-    for (int b = g; b < nblocks; b += 4) s += part[((size_t)b * 3 + w) * d + c];
-  __shared__ float red[4][64];
-  red[g][cl] = s;
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;  // g in [0,64)
+  const int c = blockIdx.x * 16 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < d) {
+    int b = g;
+    for (; b + 192 < nblocks; b += 256) {
+      s0 += part[((size_t)b * 3 + w) * d + c];
+      s1 += part[((size_t)(b + 64) * 3 + w) * d + c];
+      s2 += part[((size_t)(b + 128) * 3 + w) * d + c];
+      s3 += part[((size_t)(b + 192) * 3 + w) * d + c];
+    }
+    for (; b < nblocks; b += 64) s0 += part[((size_t)b * 3 + w) * d + c];
+  }
+  __shared__ float red[64][17];
+  red[g][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (g == 0 && c < d) out[c] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+  if (g == 0 && c < d) {
+    float t = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) t += red[i][cl];
+    out[c] += t;
+  }
 }
 
 // ---------------------------------------------------------------- column sums
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                      int M, int N, int ldx, int rows_per_block) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= N) return;
+  // block = 64 columns x 4 row-slices; 8 independent loads in flight per thread, LDS reduce of the
+  // 4 slices, one atomic per column per block
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
-  float s0 = 0.f, s1 = 0.f;
-  int r = r0;
-  for (; r + 1 < r1; r += 2) {
-    s0 += x[(size_t)r * ldx + col];
-    s1 += x[(size_t)(r + 1) * ldx + col];
+  float s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = 0.f;
+  if (col < N) {
+    int r = r0 + g;
+    for (; r + 28 < r1; r += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += x[(size_t)(r + 4 * u) * ldx + col];
+    }
+    for (; r < r1; r += 4) s[0] += x[(size_t)r * ldx + col];
   }
-  if (r < r1) s0 += x[(size_t)r * ldx + col];
-  atomicAdd(out + col, s0 + s1);
+  __shared__ float red[4][64];
+  red[g][cl] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (g == 0 && col < N) atomicAdd(out + col, (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
 }
 
 // ---------------------------------------------------------------- element-wise
@@ -312,16 +335,19 @@ extern "C" int mmnas_layernorm_bwd(const float* x, const float* a, const float* 
 #define LNB(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, 0, st, x, a, dy, dx, da, db, ddrop, dcol, ws, dc, M, d, eps)
   if (nv <= 1) LNB(1); else if (nv <= 2) LNB(2); else if (nv <= 4) LNB(4); else LNB(8);
 #undef LNB
-  if (ws) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(d, 64), 3), dim3(256), 0, st, ws, nb, d, da, db, dcol);
+  if (ws) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(d, 16), 3), dim3(1024), 0, st, ws, nb, d, da, db, dcol);
   return check_launch("layernorm_bwd");
 }
 
 extern "C" int mmnas_colsum(const float* x, float* out, int M, int N, int ldx, void* stream) {
   MMNAS_REQUIRE(x && out && M > 0 && N > 0 && ldx >= N, MMNAS_E_ARG, "colsum: bad arguments");
   int splits = cdiv(M, 64);
-  if (splits > 128) splits = 128;
+  const int colblocks = cdiv(N, 64);
+  const int want = cdiv(1024, colblocks);   // ~4 workgroups per CU in total
+  if (splits > want) splits = want;
+  if (splits < 1) splits = 1;
   const int rpb = cdiv(M, splits);
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, x, out, M,
+  hipLaunchKernelGGL(colsum_kernel, dim3(colblocks, cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, x, out, M,
                      N, ldx, rpb);
   return check_launch("colsum");
 }

@@ -26,8 +26,13 @@ _PRIOR = {'enc': ['self_att_64', 'feed_forward'] * 6,
 
 class _Cell(nn.Module):
     def forward(self, s, pre=None, s_mask=None, pre_mask=None, rel_embed=None):
+        # the reference writes sum(op(...) for op in node) (hygr_vqa.py:25): 0 + t is exact, so the
+        # single-operator node skips that extra element-wise kernel
         for node in self.dag:
-            s = sum(op(s, pre, s_mask, pre_mask, rel_embed) for op in node)
+            outs = [op(s, pre, s_mask, pre_mask, rel_embed) for op in node]
+            s = outs[0]
+            for o in outs[1:]:
+                s = s + o
         return s
 
 

@@ -279,7 +279,7 @@ def gemm(layout, groups, N, K, lda, ldb, ldc, nseg=1, relu=False, split_k=1, alp
 
 def _wgrad_split(M, N, K):
     tiles = max(1, ((M + 63) // 64) * ((N + 63) // 64))
-    return max(1, min((1024 + tiles - 1) // tiles, max(K // 128, 1), 32))
+    return max(1, min((1024 + tiles - 1) // tiles, max(K // 128, 1), 1024))
 
 
 class LinearFn(torch.autograd.Function):
@@ -307,8 +307,10 @@ class LinearFn(torch.autograd.Function):
         N = W.shape[0]
         if ctx.relu:
             dy = dy * (y > 0)
-        dx = torch.empty_like(x)
-        gemm(L.GEMM_NN, [dict(M=M, A=[dy], B=[W], C=dx)], K, N, N, K, K)
+        dx = None
+        if ctx.needs_input_grad[0]:   # e.g. the relation/region feature inputs of the stem need none
+            dx = torch.empty_like(x)
+            gemm(L.GEMM_NN, [dict(M=M, A=[dy], B=[W], C=dx)], K, N, N, K, K)
         dW = torch.zeros_like(W)
         gemm(L.GEMM_TN, [dict(M=N, A=[dy], B=[x], C=dW)], K, M, N, K, K, split_k=_wgrad_split(N, K, M))
         db = None

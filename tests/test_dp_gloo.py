@@ -1,0 +1,130 @@
+"""Data-parallel gradient exchange (mmnas_amd/dp.py) on 2 CPU processes over gloo: the same code
+path that runs over RCCL on the GPUs, minus the HIP pack kernel (CPU tensors use the host copy)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.golden import cases
+
+WORLD = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(fn, port):
+    mp.spawn(_entry, args=(fn, port), nprocs=WORLD, join=True)
+
+
+def _entry(rank, fn, port):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        globals()[fn](rank)
+    finally:
+        dist.destroy_process_group()
+
+
+def _w_grad_reducer(rank):
+    from mmnas_amd import dp
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 300), torch.nn.ReLU(), torch.nn.Linear(300, 40),
+                              torch.nn.Linear(40, 7))
+    dp.broadcast_parameters(net)
+    red = dp.GradReducer(list(net.parameters()), bucket_mb=0.02)   # several buckets
+    assert len(red.buckets) >= 2
+    x = torch.randn(5, 16, generator=torch.Generator().manual_seed(10 + rank))
+    ref = torch.nn.Sequential(torch.nn.Linear(16, 300), torch.nn.ReLU(), torch.nn.Linear(300, 40), torch.nn.Linear(40, 7))
+    ref.load_state_dict(net.state_dict())
+    for _ in range(2):   # two steps: buffers are re-armed
+        red.begin_step()
+        net(x).pow(2).sum().backward()
+        red.finish()
+    # expected: mean over ranks of the per-rank gradients
+    grads = []
+    for r in range(WORLD):
+        xr = torch.randn(5, 16, generator=torch.Generator().manual_seed(10 + r))
+        ref.zero_grad()
+        ref(xr).pow(2).sum().backward()
+        grads.append([p.grad.clone() for p in ref.parameters()])
+    for i, p in enumerate(net.parameters()):
+        want = sum(g[i] for g in grads) / WORLD
+        assert torch.allclose(p.grad, want, rtol=1e-5, atol=1e-6), i
+        assert p.grad.data_ptr() == red.fg.views[i].data_ptr()   # gradients live in the flat buffer
+
+
+def _w_supernet_reducer(rank):
+    from mmnas_amd import dp
+    from mmnas.model import mixed
+    from mmnas.model.hygr_vqa import Net_Search
+    from mmnas.model.mixed import MixedOp
+    c = cases.net_case('vqa', None, 3, search=True, HSIZE=64)
+    init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+            'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
+    torch.manual_seed(100 + rank)            # different initial weights per rank ...
+    net = Net_Search(c['cfg'], init)
+    dp.broadcast_parameters(net)             # ... made identical, as DDP's constructor does
+    w0 = net.imgfeat_linear.weight.detach().clone()
+    t = w0.clone()
+    dist.broadcast(t, 0)
+    assert torch.equal(t, w0)
+    red = dp.SupernetReducer(net)
+    MixedOp.MODE = None
+    mixed.seed_arch_sampler(888)             # same seed on every rank -> same sampled architecture
+    net.reset_binary_gates()
+    assert dp.check_same_architecture(net)
+    red.begin_weight_step()
+    sampled, unsampled = [], []
+    for m in net.redundant_modules:
+        for i, op in enumerate(m.candidate_ops):
+            (sampled if i in m.active_index else unsampled).extend(op.parameters())
+    assert all(p.grad is None for p in unsampled)          # "avoid over-regularization", mixed.py:160-163
+    live = list(red.shared) + sampled
+    assert all(p.grad is not None for p in live)
+    for k, p in enumerate(live):                            # stand-in for backward: rank-dependent grads
+        p.grad.fill_(float(rank + 1) * (1 + k % 5))
+    red.finish_weight_step()
+    for k, p in enumerate(live):
+        assert torch.allclose(p.grad, torch.full_like(p.grad, 1.5 * (1 + k % 5))), k
+    assert all(p.grad is None for p in unsampled)
+    # arch step: only the alpha_gate gradients travel
+    for m in net.redundant_modules:
+        m.alpha_gate.grad = torch.full((m.n_choices,), float(rank))
+    red.reduce_alpha_gate_grads()
+    for m in net.redundant_modules:
+        assert torch.allclose(m.alpha_gate.grad, torch.full((m.n_choices,), 0.5))
+    # a rank that sampled differently is detected
+    if rank == 1:
+        m = net.redundant_modules[0]
+        m.set_active([1 - m.active_index[0]], m.active_index)
+    assert not dp.check_same_architecture(net)
+
+
+def test_grad_reducer_buckets_overlap_and_average():
+    _run('_w_grad_reducer', _free_port())
+
+
+def test_supernet_reducer_sampled_segments_and_alpha():
+    _run('_w_supernet_reducer', _free_port())
+
+
+def test_single_process_is_a_noop():
+    from mmnas_amd import dp
+    net = torch.nn.Linear(4, 3)
+    red = dp.GradReducer(list(net.parameters()))
+    red.begin_step()
+    net(torch.ones(2, 4)).sum().backward()
+    red.finish()
+    assert net.weight.grad is not None and torch.allclose(net.weight.grad, torch.full((3, 4), 2.0))

@@ -1,0 +1,49 @@
+"""Turn a rocprofv3 --kernel-trace --stats output directory into the committed summary under profiles/.
+
+    python tools/summarize_prof.py gpurun_out/prof2 profiles/r01_train_vqa 7 "command line that was profiled"
+
+Writes <out>_kernel_stats.csv (verbatim copy of rocprofv3's per-kernel stats) and <out>.md (top
+kernels per step, GEMM durations grouped by launch geometry)."""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+
+def main():
+    src, out, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    cmd = sys.argv[4] if len(sys.argv) > 4 else ''
+    stats = glob.glob(os.path.join(src, '**', '*_kernel_stats.csv'), recursive=True)[0]
+    trace = glob.glob(os.path.join(src, '**', '*_kernel_trace.csv'), recursive=True)[0]
+    shutil.copy(stats, out + '_kernel_stats.csv')
+    rows = list(csv.DictReader(open(stats)))
+    tot = sum(float(r['TotalDurationNs']) for r in rows)
+    lines = ['# rocprofv3 --kernel-trace --stats summary', '', '`%s`' % cmd, '',
+             'steps profiled (warm-up included): %d; device-busy time %.2f ms/step' % (steps, tot / steps / 1e6), '',
+             '| ms/step | launches/step | avg us | % | kernel |', '|---|---|---|---|---|']
+    for r in rows[:25]:
+        name = r['Name'].replace('void ', '').replace('|', '/')[:110]
+        lines.append('| %.3f | %.1f | %.1f | %.1f | `%s` |' % (float(r['TotalDurationNs']) / steps / 1e6, int(r['Calls']) / steps,
+                                                              float(r['AverageNs']) / 1e3, float(r['Percentage']), name))
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        n = r['Kernel_Name']
+        if 'gemm_kernel' not in n:
+            continue
+        key = (n.split('gemm_kernel')[1].split('(')[0], int(r['Grid_Size_X']) // 256, int(r['Grid_Size_Z']))
+        agg[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    gt = sum(sum(v) for v in agg.values())
+    lines += ['', '## gemm_kernel by launch geometry (%.2f ms/step, %.1f launches/step, average %.1f us)'
+              % (gt / steps / 1e3, sum(len(v) for v in agg.values()) / steps, gt / max(1, sum(len(v) for v in agg.values()))), '',
+              '| template <BM,BN,A k-contig,B k-contig,fast> | workgroups | grid.z | launches/step | avg us | ms/step |',
+              '|---|---|---|---|---|---|']
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:16]:
+        lines.append('| `%s` | %d | %d | %.1f | %.1f | %.2f |' % (k[0], k[1], k[2], len(v) / steps, sum(v) / len(v), sum(v) / steps / 1e3))
+    open(out + '.md', 'w').write('\n'.join(lines) + '\n')
+    print('\n'.join(lines[:14]))
+
+
+if __name__ == '__main__':
+    main()
