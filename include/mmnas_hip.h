@@ -42,7 +42,8 @@ enum {
   MMNAS_F_MASK = 4,      /* key-padding mask present */
   MMNAS_F_REL = 8,       /* relation bias (RelMHAtt, modules.py:231-235) */
   MMNAS_F_SELF = 16,     /* query and key/value source are the same tensor */
-  MMNAS_F_TRAIN = 32     /* dropout active */
+  MMNAS_F_TRAIN = 32,    /* dropout active */
+  MMNAS_F_RELRAW = 64    /* with MMNAS_F_REL: `rel` is the RAW [B,Sq,Sk,C] tensor + (Wy, by) -- lazy handle */
 };
 
 int mmnas_abi_version(void);
@@ -151,6 +152,26 @@ int mmnas_rel_bias_bwd(const float* rel, const float* Wr, const float* br, const
                        int B, int Sq, int Sk, int R, int H, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Lazy relation handle: the same bias straight from the RAW relation tensor raw[B,Sq,Sk,C]
+ * (C = 4 box-geometry channels, hygr_vqa.py:111 / full_vqa.py:103; C = 3 for token relations),
+ * fusing the stem's  rel = relu(raw Wy^T + by)  (linear_y_rel, [R,C] / [R]) with linear_r:
+ *   biasT[b,h,k,q] = log(max(relu(relu(raw Wy^T + by) . Wr[h,:] + br[h]), 1e-6))
+ * The [B,S,S,R] tensor, its gradient and their accumulation never exist.  bwd ACCUMULATES
+ * dWy [R,C], dby [R], dWr [H,R], dbr [H] (no input gradient: raw is data); ws holds
+ * mmnas_rel_fused_bwd_ws_floats(B,Sq,Sk) floats.  Supported: R = 64, C in {3,4}, H <= 32
+ * (mmnas_rel_fused_supported); otherwise materialise rel and use mmnas_rel_bias_*.
+ * ------------------------------------------------------------------------------------------ */
+int mmnas_rel_fused_supported(int C, int R, int H);
+int mmnas_rel_fused_fwd(const float* raw, const float* Wy, const float* by, const float* Wr,
+                        const float* br, float* biasT, int B, int Sq, int Sk, int C, int R, int H,
+                        void* stream);
+size_t mmnas_rel_fused_bwd_ws_floats(int B, int Sq, int Sk);  /* host only */
+int mmnas_rel_fused_bwd(const float* raw, const float* Wy, const float* by, const float* Wr,
+                        const float* br, const float* dbiasT, float* dWy, float* dby, float* dWr,
+                        float* dbr, float* ws, int B, int Sq, int Sk, int C, int R, int H,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Attention core: MHAtt.att (modules.py:191-199) for all (batch, head) pairs.
  *   Z = Q K^T / sqrt(dh) (+ biasT) ; Z[mask] = -1e9 ; P = softmax(Z) ; A = dropout(P) ; O = A V
  * Q [B*Sq, ldq], K,V [B*Sk, ldk/ldv], head h occupies columns [h*dh, (h+1)*dh).
@@ -210,6 +231,10 @@ typedef struct mmnas_att_op {
   float* drel;             /* [B,Sq,Sk,R] overwritten, or NULL to skip */
   float* dWq; float* dWk; float* dWv; float* dWm;      /* accumulated (+=) */
   float* dWr; float* dbr; float* dln_a; float* dln_b;  /* accumulated (+=) */
+  /* lazy relation handle (MMNAS_F_RELRAW): rel is raw[B,Sq,Sk,C]; linear_y_rel parameters + grads */
+  int C;
+  const float* Wy; const float* by;                    /* [R,C], [R] */
+  float* dWy; float* dby;                              /* accumulated (+=) */
 } mmnas_att_op;
 
 typedef struct mmnas_plan {

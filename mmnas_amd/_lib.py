@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libmmnas_hip.so')
 
-F_NORM, F_RESIDUAL, F_MASK, F_REL, F_SELF, F_TRAIN = 1, 2, 4, 8, 16, 32
+F_NORM, F_RESIDUAL, F_MASK, F_REL, F_SELF, F_TRAIN, F_RELRAW = 1, 2, 4, 8, 16, 32, 64
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 
 _fp = C.c_void_p  # device pointers travel as void*
@@ -47,7 +47,8 @@ class AttOp(C.Structure):
                 ('ln_a', _fp), ('ln_b', _fp), ('y', _fp), ('save', _fp), ('ws', _fp),
                 ('dy', _fp), ('dxq', _fp), ('dxkv', _fp), ('drel', _fp),
                 ('dWq', _fp), ('dWk', _fp), ('dWv', _fp), ('dWm', _fp), ('dWr', _fp), ('dbr', _fp),
-                ('dln_a', _fp), ('dln_b', _fp)]
+                ('dln_a', _fp), ('dln_b', _fp),
+                ('C', C.c_int), ('Wy', _fp), ('by', _fp), ('dWy', _fp), ('dby', _fp)]
 
 
 class Plan(C.Structure):
@@ -91,6 +92,10 @@ SYMBOLS = {
     'mmnas_glu_bwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _f, _u64, _u32, _fp]),
     'mmnas_rel_bias_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp]),
     'mmnas_rel_bias_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
+    'mmnas_rel_fused_supported': (_i, [_i, _i, _i]),
+    'mmnas_rel_fused_fwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
+    'mmnas_rel_fused_bwd_ws_floats': (_sz, [_i, _i, _i]),
+    'mmnas_rel_fused_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     'mmnas_mha_core_fwd': (_i, [C.POINTER(MhaDesc), _fp]),
     'mmnas_mha_core_bwd': (_i, [C.POINTER(MhaDesc), _fp]),
     'mmnas_att_op_plan': (_i, [C.POINTER(AttOp), C.POINTER(Plan)]),

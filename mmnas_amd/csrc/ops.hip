@@ -44,7 +44,7 @@ static void gemm_init(mmnas_gemm_desc& g, int layout, int N, int K, int lda, int
 struct AttLayout {
   size_t Mq, Mk;
   float *Q, *K, *V, *att, *stats, *z, *biasT;       // save
-  float *dz, *dt, *datt, *dQ, *dK, *dV, *delta, *dbiasT, *lnws;  // backward scratch
+  float *dz, *dt, *datt, *dQ, *dK, *dV, *delta, *dbiasT, *lnws, *relws;  // backward scratch
   size_t save_bytes, ws_bwd_bytes;
 };
 
@@ -68,6 +68,7 @@ static AttLayout att_layout(const mmnas_att_op* op) {
   L.delta = w.take((size_t)op->B * op->H * op->Sq);
   L.dbiasT = rel ? w.take((size_t)op->B * op->H * op->Sk * op->Sq) : nullptr;
   L.lnws = norm ? w.take(mmnas_layernorm_bwd_ws_floats((int)L.Mq, op->d)) : nullptr;
+  L.relws = (rel && (op->flags & MMNAS_F_RELRAW)) ? w.take(mmnas_rel_fused_bwd_ws_floats(op->B, op->Sq, op->Sk)) : nullptr;
   L.ws_bwd_bytes = w.off;
   return L;
 }
@@ -122,8 +123,16 @@ extern "C" int mmnas_att_op_fwd(const mmnas_att_op* op, void* stream) {
   g.g[2].M = (int)L.Mk; g.g[2].A[0] = op->xkv; g.g[2].B[0] = op->Wv; g.g[2].C = L.V;
   if ((rc = mmnas_gemm(&g, stream))) return rc;
 
-  if (rel && (rc = mmnas_rel_bias_fwd(op->rel, op->Wr, op->br, L.biasT, op->B, op->Sq, op->Sk, op->R, op->H, stream)))
-    return rc;
+  if (rel) {
+    if (fl & MMNAS_F_RELRAW) {  // lazy handle: bias straight from the raw [B,Sq,Sk,C] relations
+      MMNAS_REQUIRE(op->Wy && op->by, MMNAS_E_ARG, "att_op_fwd: RELRAW without Wy/by");
+      rc = mmnas_rel_fused_fwd(op->rel, op->Wy, op->by, op->Wr, op->br, L.biasT, op->B, op->Sq, op->Sk, op->C, op->R,
+                               op->H, stream);
+    } else {
+      rc = mmnas_rel_bias_fwd(op->rel, op->Wr, op->br, L.biasT, op->B, op->Sq, op->Sk, op->R, op->H, stream);
+    }
+    if (rc) return rc;
+  }
 
   mmnas_mha_desc m;
   memset(&m, 0, sizeof(m));
@@ -240,6 +249,11 @@ extern "C" int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream) {
   }
 
   // 7. relation bias
+  if (rel && (fl & MMNAS_F_RELRAW)) {
+    MMNAS_REQUIRE(op->Wy && op->by && op->dWy && op->dby, MMNAS_E_ARG, "att_op_bwd: RELRAW gradients missing");
+    return mmnas_rel_fused_bwd(op->rel, op->Wy, op->by, op->Wr, op->br, L.dbiasT, op->dWy, op->dby, op->dWr, op->dbr,
+                               L.relws, op->B, op->Sq, op->Sk, op->C, op->R, op->H, stream);
+  }
   if (rel)
     return mmnas_rel_bias_bwd(op->rel, op->Wr, op->br, L.dbiasT, op->drel, op->dWr, op->dbr, 0, op->B, op->Sq,
                               op->Sk, op->R, op->H, stream);

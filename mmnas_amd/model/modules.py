@@ -13,11 +13,34 @@ from .. import ops
 
 __all__ = ['FC', 'MLP', 'LayerNorm', 'AttFlat', 'Identity', 'Zero', 'GELU', 'ReLU', 'LeakyReLU',
            'GatedLinear', 'GLU', 'MHAtt', 'RelMHAtt', 'SelfAtt', 'RelSelfAtt', 'GuidedAtt', 'FeedForward',
-           'FeedForward_deep', 'UniimgAtt', 'SepConv', 'StdConv']
+           'FeedForward_deep', 'UniimgAtt', 'SepConv', 'StdConv', 'RelHandle']
 
 
 def _seed(mod, p):
     return ops.next_seed() if (mod.training and p > 0) else 0
+
+
+class RelHandle:
+    """Lazy relation embedding.  The reference materialises
+    ``rel = relu(linear_y_rel(raw))`` as a [B,S,S,64] tensor in the stem (hygr_vqa.py:111,
+    full_vqa.py:103) -- 164 MB per batch, read by every RelSelfAtt and written again as a gradient.
+    The nets pass this handle through the cells instead (``rel_embed`` argument, consumed only by
+    RelSelfAtt): the relation-bias kernel recomputes the embedding in registers from the 4-channel raw
+    tensor and reduces linear_y_rel's gradient in-kernel.  ``materialize()`` gives the plain tensor for
+    any consumer that wants one; a plain tensor is still accepted everywhere a handle is."""
+
+    def __init__(self, raw, weight, bias):
+        self.raw, self.weight, self.bias = raw, weight, bias
+        self._dense = None
+
+    def fusable(self, heads):
+        from .. import _lib as L
+        return bool(L.lib().mmnas_rel_fused_supported(self.weight.shape[1], self.weight.shape[0], heads))
+
+    def materialize(self):
+        if self._dense is None:
+            self._dense = ops.linear(self.raw, self.weight, self.bias, relu=True)
+        return self._dense
 
 
 class FC(nn.Module):
@@ -187,13 +210,19 @@ class MHAtt(nn.Module):
 
     def run(self, xq, xkv, mask, rel, ln, norm, residual, training):
         lr = getattr(self, 'linear_r', None)
+        wy = by = None
+        if lr is not None and isinstance(rel, RelHandle):
+            if rel.fusable(lr.weight.shape[0]):
+                rel, wy, by = rel.raw, rel.weight, rel.bias      # bias computed in-kernel from the raw tensor
+            else:
+                rel = rel.materialize()
         return ops.attention_op(
             xq, xkv, mask, rel if lr is not None else None,
             self.linear_q.weight, self.linear_k.weight, self.linear_v.weight, self.linear_merge.weight,
             lr.weight if lr is not None else None, lr.bias if lr is not None else None,
             ln.a_2 if norm else None, ln.b_2 if norm else None,
             dh=self.HBASE, norm=norm, residual=residual, drop_p=self.drop_p, training=training,
-            eps=ln.eps if norm else 1e-6)
+            eps=ln.eps if norm else 1e-6, rel_Wy=wy, rel_by=by)
 
     def forward(self, v, k, q, mask=None):
         if v is not k:

@@ -7,6 +7,8 @@ interchangeable.
 Stem and head: embedding + LSTM stay on torch (MIOpen); every Linear (imgfeat_linear, the relation
 embeddings, AttFlat, the projections) and every LayerNorm run on the HIP GEMM / LayerNorm kernels.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -15,9 +17,10 @@ import torch.nn.functional as F
 from .. import ops
 from ..utils.ops_adapter import OpsAdapter
 from .mixed import MixedOp, sample_indices
-from .modules import AttFlat, LayerNorm
+from .modules import AttFlat, LayerNorm, RelHandle
 
 OPS_ADAPTER = OpsAdapter()
+LAZY_REL = os.environ.get('MMNAS_LAZY_REL', '1') != '0'   # 0: materialise rel embeddings as the reference does
 
 # MCAN-style prior the supernet's alphas start from (hygr_vqa.py:138-156)
 _PRIOR = {'enc': ['self_att_64', 'feed_forward'] * 6,
@@ -136,9 +139,16 @@ class _Net(nn.Module):
             bb = ops.linear(bbox_feat, self.bboxfeat_linear.weight, self.bboxfeat_linear.bias)
             frcn_feat = torch.cat((frcn_feat, bb), dim=-1)
         y_in = ops.linear(frcn_feat, self.imgfeat_linear.weight, self.imgfeat_linear.bias)
-        if hasattr(self, 'linear_x_rel'):
-            x_rel_embed = ops.linear(x_rel_embed, self.linear_x_rel.weight, self.linear_x_rel.bias, relu=True)
-        y_rel_embed = ops.linear(y_rel_embed, self.linear_y_rel.weight, self.linear_y_rel.bias, relu=True)
+        # relation embeddings relu(linear_*_rel(raw)) (hygr_vqa.py:110-111): passed down as lazy handles
+        # -- the [B,S,S,64] tensors are only materialised if an operator asks for a plain tensor
+        if LAZY_REL:
+            if hasattr(self, 'linear_x_rel'):
+                x_rel_embed = RelHandle(x_rel_embed, self.linear_x_rel.weight, self.linear_x_rel.bias)
+            y_rel_embed = RelHandle(y_rel_embed, self.linear_y_rel.weight, self.linear_y_rel.bias)
+        else:
+            if hasattr(self, 'linear_x_rel'):
+                x_rel_embed = ops.linear(x_rel_embed, self.linear_x_rel.weight, self.linear_x_rel.bias, relu=True)
+            y_rel_embed = ops.linear(y_rel_embed, self.linear_y_rel.weight, self.linear_y_rel.bias, relu=True)
         x_out, y_out = self.backnone(x_in, y_in, x_mask, y_mask, x_rel_embed, y_rel_embed)
         x_out = self.attflat_x(x_out, x_mask)
         if self.TASK == 'vgd':  # per-object scores + box regression (full_vgd.py:105-114)

@@ -66,7 +66,7 @@ class AttentionOp(torch.autograd.Function):
     """SelfAtt / RelSelfAtt / GuidedAtt / UniimgAtt forward+backward (modules.py:248-325,403-428)."""
 
     @staticmethod
-    def forward(ctx, xq, xkv, mask, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, ln_b, dh, norm, residual, drop_p,
+    def forward(ctx, xq, xkv, mask, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, ln_b, Wy, by, dh, norm, residual, drop_p,
                 training, seed, eps):
         lib = L.lib()
         self_att = xkv is None or xkv is xq
@@ -83,18 +83,20 @@ class AttentionOp(torch.autograd.Function):
         m8 = _mask_u8(mask, B, Sk)
         if m8 is not None:
             flags |= L.F_MASK
+        lazy = rel is not None and Wy is not None   # lazy relation handle: rel is the RAW [B,Sq,Sk,C] tensor
         if rel is not None:
             rel = _f32c(rel)
-            if rel.shape != (B, Sq, Sk, Wr.shape[1]):
-                raise L.MMNasHipError('rel_embed shape %s, expected %s' % (tuple(rel.shape), (B, Sq, Sk, Wr.shape[1])))
-            flags |= L.F_REL
+            want = (B, Sq, Sk, Wy.shape[1] if lazy else Wr.shape[1])
+            if tuple(rel.shape) != want:
+                raise L.MMNasHipError('rel_embed shape %s, expected %s' % (tuple(rel.shape), want))
+            flags |= L.F_REL | (L.F_RELRAW if lazy else 0)
         if training and drop_p > 0:
             flags |= L.F_TRAIN
         op = L.AttOp()
         op.B, op.Sq, op.Sk, op.d, op.di, op.H, op.dh = B, Sq, Sk, d, di, H, dh
         op.R = Wr.shape[1] if rel is not None else 0
         op.flags, op.drop_p, op.eps, op.seed = flags, float(drop_p), float(eps), int(seed)
-        key = ('att', B, Sq, Sk, d, di, H, op.R, flags)
+        key = ('att', B, Sq, Sk, d, di, H, op.R, flags)  # flags carry RELRAW, which changes the scratch size
         plan = _plan_cache.get(key)
         if plan is None:
             p = L.Plan()
@@ -109,6 +111,9 @@ class AttentionOp(torch.autograd.Function):
         if rel is not None:
             Wr, br = _f32c(Wr), _f32c(br)
             op.Wr, op.br = L.fptr(Wr), L.fptr(br)
+        if lazy:
+            Wy, by = _f32c(Wy), _f32c(by)
+            op.C, op.Wy, op.by = Wy.shape[1], L.fptr(Wy), L.fptr(by)
         if norm:
             ln_a, ln_b = _f32c(ln_a), _f32c(ln_b)
             op.ln_a, op.ln_b = L.fptr(ln_a), L.fptr(ln_b)
@@ -118,16 +123,18 @@ class AttentionOp(torch.autograd.Function):
         ctx.plan = plan
         ctx.self_att = self_att
         ctx.has_rel = rel is not None
+        ctx.lazy = lazy
         ctx.norm = norm
         ctx.keep = (xq, xkv, m8, rel, Wq, Wk, Wv, Wm, Wr if rel is not None else None,
-                    br if rel is not None else None, ln_a if norm else None, save)
+                    br if rel is not None else None, ln_a if norm else None, save,
+                    Wy if lazy else None, by if lazy else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = L.lib()
         op = ctx.op
-        xq, xkv, m8, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, save = ctx.keep
+        xq, xkv, m8, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, save, Wy, by = ctx.keep
         dev = xq.device
         dy = _f32c(dy)
         d, di = op.d, op.di
@@ -136,37 +143,45 @@ class AttentionOp(torch.autograd.Function):
             sizes += [Wr.numel(), br.numel()]
         if ctx.norm:
             sizes += [d, d]
+        if ctx.lazy:
+            sizes += [Wy.numel(), by.numel()]
         flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
         parts = list(torch.split(flat, sizes))
         dWq, dWk, dWv, dWm = (parts[0].view(di, d), parts[1].view(di, d), parts[2].view(di, d), parts[3].view(d, di))
         i = 4
-        dWr = dbr = dla = dlb = None
+        dWr = dbr = dla = dlb = dWy = dby = None
         if ctx.has_rel:
             dWr, dbr = parts[i].view_as(Wr), parts[i + 1]
             i += 2
         if ctx.norm:
             dla, dlb = parts[i], parts[i + 1]
+            i += 2
+        if ctx.lazy:
+            dWy, dby = parts[i].view_as(Wy), parts[i + 1]
         dxq = torch.empty_like(xq)
         dxkv = None if ctx.self_att else torch.empty_like(xkv)
-        want_drel = ctx.has_rel and ctx.needs_input_grad[3]
+        want_drel = ctx.has_rel and not ctx.lazy and ctx.needs_input_grad[3]
         drel = torch.empty_like(rel) if want_drel else None
         ws = _bytes(ctx.plan[1], dev)
         op.dy, op.dxq, op.dxkv, op.drel = L.fptr(dy), L.fptr(dxq), L.fptr(dxkv), L.fptr(drel)
         op.dWq, op.dWk, op.dWv, op.dWm = L.fptr(dWq), L.fptr(dWk), L.fptr(dWv), L.fptr(dWm)
         op.dWr, op.dbr, op.dln_a, op.dln_b = L.fptr(dWr), L.fptr(dbr), L.fptr(dla), L.fptr(dlb)
+        op.dWy, op.dby = L.fptr(dWy), L.fptr(dby)
         op.ws = L.ptr(ws)
         L.check(lib.mmnas_att_op_bwd(C.byref(op), L.stream()))
         ctx.keep = None
-        return (dxq, dxkv, None, drel, dWq, dWk, dWv, dWm, dWr, dbr, dla, dlb,
+        return (dxq, dxkv, None, drel, dWq, dWk, dWv, dWm, dWr, dbr, dla, dlb, dWy, dby,
                 None, None, None, None, None, None, None)
 
 
 def attention_op(xq, xkv, mask, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, ln_b, *, dh, norm, residual, drop_p,
-                 training, eps=1e-6, seed=None):
+                 training, eps=1e-6, seed=None, rel_Wy=None, rel_by=None):
+    """rel is the [B,Sq,Sk,R] relation embedding, or -- with rel_Wy/rel_by (linear_y_rel) given -- the RAW
+    [B,Sq,Sk,C] relation tensor of a lazy RelHandle."""
     if seed is None:
         seed = next_seed() if (training and drop_p > 0) else 0
-    return AttentionOp.apply(xq, xkv, mask, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, ln_b, dh, norm, residual,
-                             float(drop_p), bool(training), seed, eps)
+    return AttentionOp.apply(xq, xkv, mask, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, ln_b, rel_Wy, rel_by, dh, norm,
+                             residual, float(drop_p), bool(training), seed, eps)
 
 
 # ------------------------------------------------------------------------------------------

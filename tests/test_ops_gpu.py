@@ -149,6 +149,51 @@ def test_full_size_vs_oracle(name, dims):
         assert frac <= 1e-4 and l2 <= 1e-4, (k, float(e.max()), frac, l2)
 
 
+@pytest.mark.parametrize('dims', [dict(B=3, Sx=7, Sy=5, HSIZE=128), dict(B=4, Sx=100, Sy=14, HSIZE=512)])
+def test_rel_self_att_with_lazy_handle(dims):
+    """RelSelfAtt fed a RelHandle (raw relations + linear_y_rel) == the reference chain
+    relu(linear_y_rel(raw)) -> RelSelfAtt, including the gradient reaching linear_y_rel."""
+    from mmnas_amd.model.modules import RelHandle
+    from mmnas_amd.utils.ops_adapter import OpsAdapter
+    case = cases.op_case('rel_self_att_64', True, True, 2024, dims)
+    rs = np.random.RandomState(7)
+    B, S = dims['B'], dims['Sx']
+    raw = rs.standard_normal((B, S, S, 4)).astype(np.float32)
+    raw[:, S - 2:] = 0
+    raw[:, :, S - 2:] = 0
+    Wy = (rs.standard_normal((64, 4)) / 2).astype(np.float32)
+    by = (0.1 * rs.standard_normal(64)).astype(np.float32)
+    cfg = case['cfg']
+    op = OpsAdapter().OPS['rel_self_att_64'](cfg, norm=True, residual=True)
+    op.load_state_dict({k: torch.from_numpy(v) for k, v in case['P'].items()})
+    op = op.to(DEV).train()
+    x = torch.from_numpy(case['x']).to(DEV).requires_grad_(True)
+    Wyd = torch.from_numpy(Wy).to(DEV).requires_grad_(True)
+    byd = torch.from_numpy(by).to(DEV).requires_grad_(True)
+    h = RelHandle(torch.from_numpy(raw).to(DEV), Wyd, byd)
+    out = op(x, None, torch.from_numpy(case['x_mask']).to(DEV), None, h)
+    out.backward(torch.from_numpy(case['gout']).to(DEV))
+    assert h._dense is None                      # the [B,S,S,64] tensor was never built
+    # oracle: materialised chain in fp64
+    P = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in case['P'].items()}
+    xt = torch.from_numpy(case['x']).double().requires_grad_(True)
+    Wyt = torch.from_numpy(Wy).double().requires_grad_(True)
+    byt = torch.from_numpy(by).double().requires_grad_(True)
+    rel = torch.relu(torch.from_numpy(raw).double() @ Wyt.t() + byt)
+    ref = O.op_forward('rel_self_att_64', P, cfg, xt, None, torch.from_numpy(case['x_mask']), None, rel)
+    (ref * torch.from_numpy(case['gout']).double()).sum().backward()
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) <= TOL
+    assert rel_err(x.grad.cpu().numpy(), xt.grad.numpy()) <= TOL
+    assert rel_err(Wyd.grad.cpu().numpy(), Wyt.grad.numpy()) <= 3e-3
+    assert rel_err(byd.grad.cpu().numpy(), byt.grad.numpy()) <= 3e-3
+    for k, p in op.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), P[k].grad.numpy()) <= 3e-3, k
+    # a plain tensor is still accepted, and a handle can be materialised for any other consumer
+    dense = h.materialize()
+    out2 = op(x.detach(), None, torch.from_numpy(case['x_mask']).to(DEV), None, dense)
+    assert rel_err(out2.detach().cpu().numpy(), ref.detach().numpy()) <= TOL
+
+
 def test_edge_semantics():
     """SURVEY appendix A edge cases: fully-masked rows give a uniform softmax (finite output);
     r < 1e-6 gives a constant bias with zero gradient; eval mode ignores DROPOUT_R."""
