@@ -152,6 +152,8 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not bracket kernels with HIP events')
+    ap.add_argument('--with-optim', action='store_true',
+                    help='also run gradient clipping + the fused Adam step inside the timed step (not part of the fwd+bwd metric)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -197,6 +199,13 @@ def main():
         reducer = dp.SupernetReducer(net)
         MixedOp.MODE = None
 
+    optim = None
+    if args.with_optim:   # train_vqa.py:174-183 / search_vqa.py:135-146: Adam(0.9, 0.98, eps 1e-9), clip 1.0
+        from mmnas_amd.optim import FlatAdam, WarmupOptimizer
+        optim = WarmupOptimizer(1.2e-4 if args.workload == 'train_vqa' else 4e-4,
+                                FlatAdam(reducer.fg.params, betas=(0.9, 0.98), eps=1e-9, grads=reducer.fg),
+                                epoch_steps=1000, warmup=True, max_norm=1.0)
+
     flops_acc = [0.0]
 
     def step():
@@ -205,6 +214,8 @@ def main():
             loss = loss_fn(net(inputs), target)
             loss.backward()
             reducer.finish()
+            if optim is not None:
+                optim.step()
             flops_acc[0] += step_flops(cfg, names_enc, names_dec, B, Sx, Sy, ANS)
         else:
             net.reset_binary_gates()
@@ -212,6 +223,8 @@ def main():
             loss = loss_fn(net(inputs), target)
             loss.backward()
             reducer.finish_weight_step()
+            if optim is not None:
+                optim.step()
             ne = [m.Used_OPS[m.active_index[0]] for m in net.redundant_modules[:12]]
             nd = [m.Used_OPS[m.active_index[0]] for m in net.redundant_modules[12:]]
             flops_acc[0] += step_flops(cfg, ne, nd, B, Sx, Sy, ANS)
@@ -259,7 +272,8 @@ def main():
             'config': {'workload': {'train_vqa': 'arch/mmnas_vqa.json Net_Full fwd+loss+bwd, HSIZE 512, B=64/GPU, 100x2048 regions + 14 tokens, dropout 0.1 (BASELINE configs[1])',
                                     'search_vqa': 'Net_Search supernet weight step (sample+fwd+loss+bwd), HSIZE 256, B=64/GPU (BASELINE configs[2])'}[args.workload],
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
-                       'grad_allreduce': 'rccl' if world > 1 else 'none'},
+                       'grad_allreduce': 'rccl' if world > 1 else 'none',
+                       'optimizer_in_step': bool(args.with_optim)},
             'samples_per_s': world * args.steps * B / elapsed,
             'algorithmic_tflops_per_gpu': flops_acc[0] / elapsed / 1e12,
             'final_loss': final_loss,

@@ -32,16 +32,57 @@ struct MhaK {
 };
 
 // rows x DHC floats from global (row stride ld) into LDS [rows][DHC+4]; rows >= nvalid are zero
+// Two phases so that every 16-byte load of a tile (or of several tiles) is in flight before the first
+// LDS write waits for one: the one-loop form compiled to a load -> vmcnt(0) -> ds_write chain per
+// iteration, i.e. 16-24 serialized memory round trips per workgroup.  Rows beyond nvalid read row 0
+// (always valid) and are zeroed by a select, so there is no branch around a load.
+template <int ROWS, int DHC, int NT>
+struct TileRegs { float4 v[(ROWS * (DHC / 4) + NT - 1) / NT]; };
+
+template <int ROWS, int DHC, int NT>
+__device__ __forceinline__ void tile_fetch(TileRegs<ROWS, DHC, NT>& t, const float* __restrict__ src, int nvalid,
+                                           int ld, int tid) {
+  constexpr int F4 = DHC / 4, N = (ROWS * F4 + NT - 1) / NT;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int f = tid + i * NT;
+    const int r = f / F4, c4 = f - r * F4;
+    const bool ok = (ROWS * F4 % NT == 0 || f < ROWS * F4) && r < nvalid;
+    const float4 x = *reinterpret_cast<const float4*>(src + (size_t)(ok ? r : 0) * ld + 4 * c4);
+    t.v[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+template <int ROWS, int DHC, int NT>
+__device__ __forceinline__ void tile_store(const TileRegs<ROWS, DHC, NT>& t, float* __restrict__ dst, int tid) {
+  constexpr int F4 = DHC / 4, LD = DHC + 4, N = (ROWS * F4 + NT - 1) / NT;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int f = tid + i * NT;
+    const int r = f / F4, c4 = f - r * F4;
+    if (ROWS * F4 % NT == 0 || f < ROWS * F4) *reinterpret_cast<float4*>(dst + r * LD + 4 * c4) = t.v[i];
+  }
+}
+
 template <int ROWS, int DHC, int NT>
 __device__ __forceinline__ void load_tile(float* __restrict__ dst, const float* __restrict__ src, int nvalid,
                                           int ld, int tid) {
-  constexpr int F4 = DHC / 4, LD = DHC + 4;
-  for (int f = tid; f < ROWS * F4; f += NT) {
-    const int r = f / F4, c4 = f - r * F4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < nvalid) v = *reinterpret_cast<const float4*>(src + (size_t)r * ld + 4 * c4);
-    *reinterpret_cast<float4*>(dst + r * LD + 4 * c4) = v;
-  }
+  TileRegs<ROWS, DHC, NT> t;
+  tile_fetch<ROWS, DHC, NT>(t, src, nvalid, ld, tid);
+  tile_store<ROWS, DHC, NT>(t, dst, tid);
+}
+
+// two tiles: all loads of both in flight before any LDS write
+template <int RA, int RB, int DHC, int NT>
+__device__ __forceinline__ void load_tiles2(float* __restrict__ da, const float* __restrict__ sa, int na, int lda,
+                                            float* __restrict__ db, const float* __restrict__ sb, int nb, int ldb,
+                                            int tid) {
+  TileRegs<RA, DHC, NT> ta;
+  TileRegs<RB, DHC, NT> tb;
+  tile_fetch<RA, DHC, NT>(ta, sa, na, lda, tid);
+  tile_fetch<RB, DHC, NT>(tb, sb, nb, ldb, tid);
+  tile_store<RA, DHC, NT>(ta, da, tid);
+  tile_store<RB, DHC, NT>(tb, db, tid);
 }
 
 #define MFMA4(ACC, AF, BF)            \
@@ -76,8 +117,8 @@ __global__ void __launch_bounds__(64 * NW) mha_fwd_kernel(const MhaK p) {
   // ---- S^T = K Q^T over the head-dim chunks ----
   for (int c = 0; c < p.nch; ++c) {
     if (c) __syncthreads();
-    load_tile<32 * NW, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + q0) * p.ldq + h * p.dh + c * DHC, Sq - q0, p.ldq, tid);
-    load_tile<32 * NKC, DHC, NT>(KVs, p.K + (size_t)(b * Sk) * p.ldk + h * p.dh + c * DHC, Sk, p.ldk, tid);
+    load_tiles2<32 * NW, 32 * NKC, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + q0) * p.ldq + h * p.dh + c * DHC, Sq - q0, p.ldq,
+                                            KVs, p.K + (size_t)(b * Sk) * p.ldk + h * p.dh + c * DHC, Sk, p.ldk, tid);
     __syncthreads();
     if (active) {
 #pragma unroll
@@ -247,10 +288,10 @@ __global__ void __launch_bounds__(64 * NW) mha_bwd_q_kernel(const MhaK p) {
     for (int c = 0; c < p.nch; ++c) {
       __syncthreads();
       const int co = h * p.dh + c * DHC;
-      load_tile<32 * NW, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + q0) * p.ldq + co, Sq - q0, p.ldq, tid);
-      load_tile<32 * NW, DHC, NT>(Gs, p.dO + (size_t)(b * Sq + q0) * p.ldo + co, Sq - q0, p.ldo, tid);
-      load_tile<KB, DHC, NT>(Ks, p.K + (size_t)(b * Sk + kb) * p.ldk + co, Sk - kb, p.ldk, tid);
-      load_tile<KB, DHC, NT>(Vs, p.V + (size_t)(b * Sk + kb) * p.ldv + co, Sk - kb, p.ldv, tid);
+      load_tiles2<32 * NW, 32 * NW, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + q0) * p.ldq + co, Sq - q0, p.ldq,
+                                             Gs, p.dO + (size_t)(b * Sq + q0) * p.ldo + co, Sq - q0, p.ldo, tid);
+      load_tiles2<KB, KB, DHC, NT>(Ks, p.K + (size_t)(b * Sk + kb) * p.ldk + co, Sk - kb, p.ldk,
+                                   Vs, p.V + (size_t)(b * Sk + kb) * p.ldv + co, Sk - kb, p.ldv, tid);
       __syncthreads();
       if (active) {
 #pragma unroll
@@ -362,11 +403,11 @@ __global__ void __launch_bounds__(64 * NW) mha_bwd_kv_kernel(const MhaK p) {
     for (int c = 0; c < p.nch; ++c) {
       __syncthreads();
       const int co = h * p.dh + c * DHC;
-      load_tile<32, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + qc) * p.ldq + co, Sq - qc, p.ldq, tid);
-      load_tile<32, DHC, NT>(Gs, p.dO + (size_t)(b * Sq + qc) * p.ldo + co, Sq - qc, p.ldo, tid);
+      load_tiles2<32, 32, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + qc) * p.ldq + co, Sq - qc, p.ldq,
+                                   Gs, p.dO + (size_t)(b * Sq + qc) * p.ldo + co, Sq - qc, p.ldo, tid);
       if (p.nch > 1 || qc == 0) {
-        load_tile<32 * NW, DHC, NT>(Ks, p.K + (size_t)(b * Sk + k0) * p.ldk + co, Sk - k0, p.ldk, tid);
-        load_tile<32 * NW, DHC, NT>(Vs, p.V + (size_t)(b * Sk + k0) * p.ldv + co, Sk - k0, p.ldv, tid);
+        load_tiles2<32 * NW, 32 * NW, DHC, NT>(Ks, p.K + (size_t)(b * Sk + k0) * p.ldk + co, Sk - k0, p.ldk,
+                                               Vs, p.V + (size_t)(b * Sk + k0) * p.ldv + co, Sk - k0, p.ldv, tid);
       }
       if (c == 0 && tid < 32) {
         const int q = qc + tid;
@@ -414,8 +455,8 @@ __global__ void __launch_bounds__(64 * NW) mha_bwd_kv_kernel(const MhaK p) {
     if (p.nch > 1) {
       __syncthreads();
       const int co = h * p.dh + oc * DHC;
-      load_tile<32, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + qc) * p.ldq + co, Sq - qc, p.ldq, tid);
-      load_tile<32, DHC, NT>(Gs, p.dO + (size_t)(b * Sq + qc) * p.ldo + co, Sq - qc, p.ldo, tid);
+      load_tiles2<32, 32, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + qc) * p.ldq + co, Sq - qc, p.ldq,
+                                   Gs, p.dO + (size_t)(b * Sq + qc) * p.ldo + co, Sq - qc, p.ldo, tid);
       __syncthreads();
     }
     if (active) {
@@ -479,14 +520,22 @@ static int fill(const mmnas_mha_desc* d, MhaK& k, bool bwd) {
   return MMNAS_OK;
 }
 
+static int mha_nw() {
+  const char* e = getenv("MMNAS_MHA_NW");
+  return (e && atoi(e) == 2) ? 2 : 4;   // measured: 4-wave groups are 7-15 % faster (K/V tiles loaded half as often)
+}
+
 template <int DHC>
 static void launch_fwd(const MhaK& k, hipStream_t st) {
   const int nkc = cdiv(k.Sk, 32);
 #define FWD(NKC, NW) hipLaunchKernelGGL((mha_fwd_kernel<DHC, NKC, NW>), dim3(cdiv(k.Sq, 32 * NW), k.H, k.B), \
                                         dim3(64 * NW), 0, st, k)
+  // waves per workgroup: 2 (64 queries) keeps the LDS image small enough for 2-3 workgroups per CU,
+  // which hides the tile loads of one behind the MFMAs of another (MMNAS_MHA_NW=4 restores 128-query groups)
+  const int nwmax = mha_nw();
   if (k.Sq <= 32) {
     if (nkc <= 1) FWD(1, 1); else if (nkc <= 2) FWD(2, 1); else if (nkc <= 4) FWD(4, 1); else FWD(8, 1);
-  } else if (k.Sq <= 64) {
+  } else if (k.Sq <= 64 || nwmax == 2) {
     if (nkc <= 1) FWD(1, 2); else if (nkc <= 2) FWD(2, 2); else if (nkc <= 4) FWD(4, 2); else FWD(8, 2);
   } else {
     if (nkc <= 1) FWD(1, 4); else if (nkc <= 2) FWD(2, 4); else if (nkc <= 4) FWD(4, 4); else FWD(8, 4);
@@ -499,13 +548,14 @@ static void launch_bwd(const MhaK& k, hipStream_t st) {
   const int nkc = cdiv(k.Sk, 32);
 #define BQ(NKC, NW) hipLaunchKernelGGL((mha_bwd_q_kernel<DHC, NKC, NW>), dim3(cdiv(k.Sq, 32 * NW), k.H * k.nch, k.B), \
                                        dim3(64 * NW), 0, st, k)
+  const int nwmax = mha_nw();
   if (k.Sq <= 32) { if (nkc <= 1) BQ(1, 1); else BQ(2, 1); }
-  else if (k.Sq <= 64) { if (nkc <= 1) BQ(1, 2); else BQ(2, 2); }
+  else if (k.Sq <= 64 || nwmax == 2) { if (nkc <= 1) BQ(1, 2); else BQ(2, 2); }
   else { if (nkc <= 1) BQ(1, 4); else BQ(2, 4); }
 #undef BQ
 #define BKV(NW) hipLaunchKernelGGL((mha_bwd_kv_kernel<DHC, NW>), dim3(cdiv(k.Sk, 32 * NW), k.H * k.nch, k.B), \
                                    dim3(64 * NW), 0, st, k)
-  if (nkc <= 1) BKV(1); else if (nkc <= 2) BKV(2); else BKV(4);
+  if (nkc <= 1) BKV(1); else if (nkc <= 2 || nwmax == 2) BKV(2); else BKV(4);
 #undef BKV
 }
 

@@ -37,7 +37,7 @@ struct GemmGroupK {
 struct GemmK {
   int ngroups, nseg, N, K;
   int lda, ldb, ldc, ldres, ldgate;
-  int relu, split_k, k_per_split, tiles_n;
+  int relu, split_k, k_per_split, tiles_n, ntiles;
   int avec, bvec;  // generic path: 16-byte vector loads legal for the A / B operand
   float alpha, gate_scale;
   DropCfg drop;
@@ -70,15 +70,18 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmK p) {
   const int wm = wave >> 1, wn = wave & 1;
 
   // ---- which problem / tile ----
-  const int z = blockIdx.z;
-  const int grp = z / p.split_k, split = z - grp * p.split_k;
+  const int grp = blockIdx.z;
   const GemmGroupK& G = p.g[grp];
   const int Mg = G.M;
-  int tile;
-  {  // XCD-aware bijective remap (blocks b and b+8 share an XCD)
+  int tile, split;
+  {  // XCD-aware bijective remap (blocks b and b+8 share an XCD) over the (K-slice, tile) space, slice
+     // major: an XCD owns a contiguous run of tiles of as few K-slices as possible, so with split-K
+     // each XCD's L2 streams only its own slices of A and B instead of all of both (8x fabric re-reads)
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, in = bid >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
+    split = v / p.ntiles;
+    tile = v - split * p.ntiles;
   }
   const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -344,9 +347,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmK p) {
 }
 
 template <int BM, int BN, bool FAST>
-static int launch(const GemmK& k, int layout, int maxM, hipStream_t st) {
+static int launch(GemmK& k, int layout, int maxM, hipStream_t st) {
   const int tiles_m = cdiv(maxM, BM);
-  dim3 grid(tiles_m * k.tiles_n, 1, k.ngroups * k.split_k), block(256);
+  k.ntiles = tiles_m * k.tiles_n;
+  dim3 grid(k.ntiles * k.split_k, 1, k.ngroups), block(256);
   switch (layout) {
     case MMNAS_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, FAST>), grid, block, 0, st, k); break;
     case MMNAS_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, FAST>), grid, block, 0, st, k); break;

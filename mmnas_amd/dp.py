@@ -32,6 +32,19 @@ def _align(n, a=64):
     return (n + a - 1) // a * a
 
 
+class _Sink:
+    """Handle a parameter carries (`p._mmnas_sink`) while its gradient lives in a flat buffer: the HIP
+    backward kernels accumulate straight into `view` (mmnas_amd.ops._grad_bufs) and call `done()`."""
+    __slots__ = ('view', 'index', 'callback')
+
+    def __init__(self, view, index, callback):
+        self.view, self.index, self.callback = view, index, callback
+
+    def done(self):
+        if self.callback is not None:
+            self.callback(self.index)
+
+
 class FlatGrads:
     """Flat gradient storage: `views[i]` is the gradient view of `params[i]` inside `flat`."""
 
@@ -60,6 +73,18 @@ class FlatGrads:
 
     def zero(self):
         self.flat.zero_()
+
+    def enable_sinks(self, callback=None):
+        """Let the operators' backward kernels write parameter gradients directly into the views
+        (no per-operator zero-fill, no autograd accumulate kernel).  `callback(i)` fires when the
+        gradient of params[i] has been enqueued."""
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
+            p._mmnas_sink = _Sink(v, i, callback)
+
+    def disable_sinks(self):
+        for p in self.params:
+            if hasattr(p, '_mmnas_sink'):
+                del p._mmnas_sink
 
 
 class GradReducer:
@@ -95,14 +120,19 @@ class GradReducer:
         self.comm_stream = torch.cuda.Stream() if (self.is_cuda and self.world > 1) else None
         if self.world > 1:
             for i, p in enumerate(self.fg.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                p.register_post_accumulate_grad_hook(self._make_hook(i))   # gradients produced by torch autograd
+        if self.is_cuda:
+            self.fg.enable_sinks(self._arrived if self.world > 1 else None)  # gradients written by the HIP kernels
+
+    def _arrived(self, i):
+        b = self.bucket_of[i]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
 
     def _make_hook(self, i):
         def hook(_p):
-            b = self.bucket_of[i]
-            self._pending[b] -= 1
-            if self._pending[b] == 0:
-                self._launch(b)
+            self._arrived(i)
         return hook
 
     def _launch(self, b):
@@ -122,12 +152,10 @@ class GradReducer:
 
     def begin_step(self):
         """Call before forward: zero the gradient buffer and arm the buckets."""
-        if self.world == 1:
-            for p in self.fg.params:     # single GPU: nothing to exchange, let autograd own the grads
-                p.grad = None
-            return
         self.fg.zero()
         self.fg.attach()
+        if self.world == 1:
+            return
         self._pending = [len(idxs) for (_, _, idxs) in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._works = []
@@ -170,6 +198,8 @@ class SupernetReducer:
         self.is_cuda = self.fg.flat.is_cuda
         self.staging = None
         self._active = None
+        if self.is_cuda:
+            self.fg.enable_sinks(None)   # HIP backward kernels add straight into the flat buffer
 
     def _segments(self, params):
         """Merge the flat ranges of `params` into maximal contiguous (offset, n) runs."""
@@ -185,10 +215,6 @@ class SupernetReducer:
     def begin_weight_step(self):
         """After reset_binary_gates(): zero the buffer, give gradient views to the stem/head and the
         sampled candidates only (unsampled candidates keep grad=None, mixed.py:160-163)."""
-        if self.world == 1:
-            for p in self.fg.params:
-                p.grad = None
-            return
         active = list(self.shared)
         for m, node in zip(self.net.redundant_modules, self.per_op):
             for i in m.active_index:

@@ -37,6 +37,33 @@ def next_seed():
 _plan_cache = {}
 
 
+def _grad_bufs(params, dev):
+    """Buffers the backward kernels accumulate parameter gradients into, one per entry of `params`
+    (None entries stay None).  A parameter whose `.grad` is a view of a flat gradient buffer
+    (dp.FlatGrads.enable_sinks) gets that view -- the kernels then add straight into the buffer that
+    is all-reduced / fed to the fused optimizer, and autograd receives None for it (no zero-fill, no
+    accumulate kernel).  Everything else comes out of ONE freshly zeroed allocation.
+    Returns (bufs, rets, sinks): what to hand to the kernel, what to return to autograd, sinks to notify."""
+    bufs, rets, sinks, fresh = [], [], [], []
+    for t in params:
+        if t is None:
+            bufs.append(None); rets.append(None)
+            continue
+        s = getattr(t, '_mmnas_sink', None)
+        if s is not None and t.grad is s.view:
+            bufs.append(s.view); rets.append(None); sinks.append(s)
+        else:
+            bufs.append(t); rets.append(t); fresh.append(len(bufs) - 1)
+    if fresh:
+        sizes = [bufs[i].numel() for i in fresh]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        for i, part in zip(fresh, torch.split(flat, sizes)):
+            g = part.view(bufs[i].shape)
+            bufs[i] = g
+            rets[i] = g
+    return bufs, rets, sinks
+
+
 def _bytes(n, dev):
     return torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)
 
@@ -125,6 +152,7 @@ class AttentionOp(torch.autograd.Function):
         ctx.has_rel = rel is not None
         ctx.lazy = lazy
         ctx.norm = norm
+        ctx.ln_b_param = ln_b if norm else None
         ctx.keep = (xq, xkv, m8, rel, Wq, Wk, Wv, Wm, Wr if rel is not None else None,
                     br if rel is not None else None, ln_a if norm else None, save,
                     Wy if lazy else None, by if lazy else None)
@@ -137,27 +165,14 @@ class AttentionOp(torch.autograd.Function):
         xq, xkv, m8, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, save, Wy, by = ctx.keep
         dev = xq.device
         dy = _f32c(dy)
-        d, di = op.d, op.di
-        sizes = [di * d, di * d, di * d, d * di]
-        if ctx.has_rel:
-            sizes += [Wr.numel(), br.numel()]
-        if ctx.norm:
-            sizes += [d, d]
+        # Wy/by (linear_y_rel) are shared by every relation operator of a net: they always take the
+        # ordinary autograd accumulation path, never a sink
+        bufs, rets, sinks = _grad_bufs([Wq, Wk, Wv, Wm, Wr, br, ln_a, ctx.ln_b_param], dev)
+        dWq, dWk, dWv, dWm, dWr, dbr, dla, dlb = bufs
+        dWy = dby = None
         if ctx.lazy:
-            sizes += [Wy.numel(), by.numel()]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-        parts = list(torch.split(flat, sizes))
-        dWq, dWk, dWv, dWm = (parts[0].view(di, d), parts[1].view(di, d), parts[2].view(di, d), parts[3].view(d, di))
-        i = 4
-        dWr = dbr = dla = dlb = dWy = dby = None
-        if ctx.has_rel:
-            dWr, dbr = parts[i].view_as(Wr), parts[i + 1]
-            i += 2
-        if ctx.norm:
-            dla, dlb = parts[i], parts[i + 1]
-            i += 2
-        if ctx.lazy:
-            dWy, dby = parts[i].view_as(Wy), parts[i + 1]
+            fy = torch.zeros(Wy.numel() + by.numel(), dtype=torch.float32, device=dev)
+            dWy, dby = fy[:Wy.numel()].view_as(Wy), fy[Wy.numel():]
         dxq = torch.empty_like(xq)
         dxkv = None if ctx.self_att else torch.empty_like(xkv)
         want_drel = ctx.has_rel and not ctx.lazy and ctx.needs_input_grad[3]
@@ -170,8 +185,9 @@ class AttentionOp(torch.autograd.Function):
         op.ws = L.ptr(ws)
         L.check(lib.mmnas_att_op_bwd(C.byref(op), L.stream()))
         ctx.keep = None
-        return (dxq, dxkv, None, drel, dWq, dWk, dWv, dWm, dWr, dbr, dla, dlb, dWy, dby,
-                None, None, None, None, None, None, None)
+        for sk in sinks:
+            sk.done()
+        return (dxq, dxkv, None, drel) + tuple(rets) + (dWy, dby, None, None, None, None, None, None, None)
 
 
 def attention_op(xq, xkv, mask, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, ln_b, *, dh, norm, residual, drop_p,
@@ -227,6 +243,7 @@ class MlpOp(torch.autograd.Function):
             op.ln_a, op.ln_b = L.fptr(ln_a), L.fptr(ln_b)
         L.check(lib.mmnas_mlp_op_fwd(C.byref(op), L.stream()))
         ctx.op, ctx.plan, ctx.nl, ctx.norm = op, plan, nl, norm
+        ctx.ln_b_param = ln_b if norm else None
         ctx.keep = (x, Ws, bs, ln_a if norm else None, save)
         return y
 
@@ -238,16 +255,9 @@ class MlpOp(torch.autograd.Function):
         dev = x.device
         dy = _f32c(dy)
         nl = ctx.nl
-        sizes = [w.numel() for w in Ws] + [(b.numel() if b is not None else 0) for b in bs]
-        if ctx.norm:
-            sizes += [op.dims[0], op.dims[0]]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-        parts = list(torch.split(flat, sizes))
-        dWs = [parts[i].view_as(Ws[i]) for i in range(nl)]
-        dbs = [(parts[nl + i] if bs[i] is not None else None) for i in range(nl)]
-        dla = dlb = None
-        if ctx.norm:
-            dla, dlb = parts[2 * nl], parts[2 * nl + 1]
+        bufs, rets, sinks = _grad_bufs(list(Ws) + list(bs) + [ln_a, ctx.ln_b_param], dev)
+        dWs, dbs = bufs[:nl], bufs[nl:2 * nl]
+        dla, dlb = bufs[2 * nl], bufs[2 * nl + 1]
         dx = torch.empty_like(x)
         ws = _bytes(ctx.plan[1], dev)
         op.dy, op.dx, op.ws = L.fptr(dy), L.fptr(dx), L.ptr(ws)
@@ -257,7 +267,9 @@ class MlpOp(torch.autograd.Function):
         op.dln_a, op.dln_b = L.fptr(dla), L.fptr(dlb)
         L.check(lib.mmnas_mlp_op_bwd(C.byref(op), L.stream()))
         ctx.keep = None
-        return (dx, dla, dlb, None, None, None, None, None, None) + tuple(dWs) + tuple(dbs)
+        for sk in sinks:
+            sk.done()
+        return (dx, rets[2 * nl], rets[2 * nl + 1], None, None, None, None, None, None) + tuple(rets[:2 * nl])
 
 
 def mlp_op(x, weights, biases, ln_a, ln_b, *, norm, residual, drop_p, training, eps=1e-6, seed=None):

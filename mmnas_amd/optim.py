@@ -1,0 +1,128 @@
+"""Fused optimizer step for the bilevel loop: gradient clipping + Adam over flat
+fp32 buffers, replacing `clip_grad_norm_` + `torch.optim.Adam` over ~230 small tensors
+(search_vqa.py:296-300, train_vqa.py:308-311) and the reference's `WarmupOptimizer`
+(mmnas/utils/optimizer.py).
+
+Semantics kept from the reference stack:
+  * torch.optim.Adam arithmetic (bias correction with a PER-PARAMETER step count: a candidate operator
+    that was not sampled has grad None, is skipped and its moments do not decay -- the reason
+    `MixedOp.binarize` clears the candidates' grads, mixed.py:160-163);
+  * clip_grad_norm_ over the parameters that have a gradient: total norm in one device scalar, the
+    scale min(1, max_norm / (norm + 1e-6)) applied inside the Adam kernel (no host round trip);
+  * WarmupOptimizer's schedule: lr = base * {1/4, 2/4, 3/4, 1} over the first three epochs, `decay()`.
+"""
+import torch
+
+from . import _lib as L
+from .dp import FlatGrads
+
+
+class FlatAdam:
+    def __init__(self, params, lr=0.0, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.0, grads=None):
+        self.fg = grads if grads is not None else FlatGrads(list(params))
+        self.params = self.fg.params
+        dev = self.fg.flat.device
+        if not self.fg.flat.is_cuda:
+            raise L.MMNasHipError('FlatAdam runs on the MI355X only (no CPU fallback)')
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        # re-home the parameters into one flat buffer with the gradient buffer's layout
+        self.flat_p = torch.zeros(self.fg.total, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.fg.offsets):
+            view = self.flat_p[o:o + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+        self.m = torch.zeros_like(self.flat_p)
+        self.v = torch.zeros_like(self.flat_p)
+        self.steps = [0] * len(self.params)
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.param_groups = [{'lr': lr, 'params': self.params}]   # WarmupOptimizer writes param_groups[i]['lr']
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None
+
+    def _live_runs(self):
+        """Maximal runs of consecutive parameters that have a gradient and share a step count."""
+        runs = []
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is None:
+                continue
+            view = self.fg.views[i]
+            if g.data_ptr() != view.data_ptr():     # gradient produced outside the flat buffer: bring it in
+                view.copy_(g)
+                p.grad = view
+            o, n = self.fg.offsets[i], p.numel()
+            end = o + ((n + 63) // 64) * 64
+            if runs and runs[-1][1] == o and runs[-1][2] == self.steps[i]:
+                runs[-1][1] = end
+                runs[-1][3].append(i)
+            else:
+                runs.append([o, end, self.steps[i], [i]])
+        return runs
+
+    @torch.no_grad()
+    def step(self, max_norm=None):
+        lib = L.lib()
+        st = L.stream()
+        lr = self.param_groups[0]['lr']
+        runs = self._live_runs()
+        if not runs:
+            return
+        sumsq_ptr = None
+        if max_norm is not None and max_norm > 0:
+            self._sumsq.zero_()
+            for o, e, _, idx in runs:
+                # padding between parameters is zero in the gradient buffer, so whole runs can be summed
+                L.check(lib.mmnas_sumsq(L.fptr(self.fg.flat[o:e]), e - o, L.fptr(self._sumsq), st))
+            sumsq_ptr = L.fptr(self._sumsq)
+        for o, e, k, idx in runs:
+            L.check(lib.mmnas_adam_step(L.fptr(self.flat_p[o:e]), L.fptr(self.fg.flat[o:e]), L.fptr(self.m[o:e]),
+                                        L.fptr(self.v[o:e]), e - o, lr, self.betas[0], self.betas[1], self.eps,
+                                        self.weight_decay, sumsq_ptr, float(max_norm or 0.0), k + 1, st))
+            for i in idx:
+                self.steps[i] += 1
+
+    def grad_norm(self):
+        """Total gradient norm of the last clipped step (device -> host; diagnostics only)."""
+        return float(self._sumsq.sqrt())
+
+
+class WarmupOptimizer:
+    """mmnas/utils/optimizer.py restated: lr warm-up over three epochs, decay(), set_start_step()."""
+
+    def __init__(self, lr_base, optimizer, epoch_steps, warmup, max_norm=None):
+        self.optimizer = optimizer
+        self._step = 0
+        self.lr_base = lr_base
+        self._rate = 0
+        self.epoch_steps = epoch_steps
+        self.warmup = warmup
+        self.max_norm = max_norm
+
+    def rate(self, step=None):
+        step = self._step if step is None else step
+        if self.warmup:
+            for k in (1, 2, 3):
+                if step <= int(self.epoch_steps * k):
+                    return self.lr_base * k / 4.0
+        return self.lr_base
+
+    def step(self):
+        self._step += 1
+        self._rate = self.rate()
+        for g in self.optimizer.param_groups:
+            g['lr'] = self._rate
+        if isinstance(self.optimizer, FlatAdam):
+            self.optimizer.step(max_norm=self.max_norm)
+        else:
+            self.optimizer.step()
+
+    def zero_grad(self):
+        self.optimizer.zero_grad()
+
+    def decay(self, decay_r):
+        self.lr_base *= decay_r
+
+    def set_start_step(self, step):
+        self._step = step
