@@ -551,7 +551,14 @@ static void launch_bwd(const MhaK& k, hipStream_t st) {
   const int nwmax = mha_nw();
   if (k.Sq <= 32) { if (nkc <= 1) BQ(1, 1); else BQ(2, 1); }
   else if (k.Sq <= 64 || nwmax == 2) { if (nkc <= 1) BQ(1, 2); else BQ(2, 2); }
-  else { if (nkc <= 1) BQ(1, 4); else BQ(2, 4); }
+  else {
+    // 65..128 keys: one 128-key block (Q/dO/K/V tiles loaded once, 139 KB LDS) instead of two 64-key
+    // blocks that reload Q and dO; MMNAS_MHA_BQ4=0 restores the two-block form
+    static const bool one_block = !(getenv("MMNAS_MHA_BQ4") && atoi(getenv("MMNAS_MHA_BQ4")) == 0);
+    if (nkc <= 1) BQ(1, 4);
+    else if (nkc <= 2 || nkc > 4 || !one_block || DHC != 64) BQ(2, 4);
+    else BQ(4, 4);
+  }
 #undef BQ
 #define BKV(NW) hipLaunchKernelGGL((mha_bwd_kv_kernel<DHC, NW>), dim3(cdiv(k.Sk, 32 * NW), k.H * k.nch, k.B), \
                                    dim3(64 * NW), 0, st, k)
