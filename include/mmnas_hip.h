@@ -68,8 +68,12 @@ int mmnas_dropout_mask(float* out, size_t n, float p, uint64_t seed, uint32_t si
  *   layout MMNAS_GEMM_TN : A[K,M] (lda), B[K,N] (ldb)        dW = dy^T x      (weight gradient)
  *   epilogue, in this order: + bias[N]; relu; * dropout(seed, site, idx = row*N+col);
  *                            * (gate[row*ldgate+col] > 0 ? gate_scale : 0); + residual[row*ldres+col]
- *   split_k > 1 (TN only): K is cut into split_k slices whose partial products are added to C
- *   with float atomics -- C must hold the value to accumulate onto (zeros for a plain product).
+ *   accumulate != 0: the result is ADDED onto the values C holds (weight gradients accumulating into
+ *   a flat gradient buffer); not combinable with relu / dropout.
+ *   Scheduling is internal (stream-K: output tiles are cut along K where that balances the 256 CUs;
+ *   partial tiles meet in a per-stream workspace the library allocates on first use, 64 MiB, and are
+ *   summed in a fixed order -- results are bitwise reproducible, no float atomics).  split_k is kept
+ *   for source compatibility: a value > 1 only implies accumulate.
  * ------------------------------------------------------------------------------------------ */
 enum { MMNAS_GEMM_NT = 0, MMNAS_GEMM_NN = 1, MMNAS_GEMM_TN = 2 };
 
@@ -88,6 +92,7 @@ typedef struct mmnas_gemm_desc {
   int N, K;
   int lda, ldb, ldc, ldres, ldgate;
   int relu, split_k;
+  int accumulate, reserved;
   float alpha, gate_scale;
   float drop_p;           /* 0 = no dropout */
   uint32_t drop_site;
@@ -96,6 +101,10 @@ typedef struct mmnas_gemm_desc {
 } mmnas_gemm_desc;
 
 int mmnas_gemm(const mmnas_gemm_desc* d, void* stream);
+
+/* Scheduling knobs of mmnas_gemm (MMNAS_GEMM_TILE, _SK, _WGS, _MIN_UNITS, _GENERIC: tuning and tests only) are
+ * read from the environment on the first call; this re-reads them. */
+int mmnas_gemm_reload_tuning(void);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm with Bessel-corrected std and eps added to the std (modules.py:52-56).

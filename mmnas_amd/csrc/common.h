@@ -39,11 +39,13 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // RAII timing scope: when profiling is enabled (mmnas_prof_enable) a HIP event is recorded on the
 // launch stream before and after the enclosed launches, tagged with the algorithmic work.
 struct ProfScope {
-  ProfScope(int kind, double flops, double bytes, hipStream_t st);
+  ProfScope(int kind, double flops, double bytes, hipStream_t st, const char* tag = nullptr);
   ~ProfScope();
   long idx_;
   hipStream_t st_;
 };
+
+bool prof_enabled();
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -18,14 +18,28 @@
 //     as [k][rows] and are read with conflict-free ds_read_b32.  The reduction index inside an
 //     8-wide K group is permuted identically for A and B (lane half hh takes k = 8s+4hh+t), which
 //     is legal because both operands see the same permutation.
-//   * blockIdx.x -> tile mapping is XCD-aware: the 8 XCDs (private 4 MiB L2 each) get contiguous
-//     runs of tiles, so an XCD re-reads only its own A row-panels and the (small) weight matrix.
+//   * scheduling is stream-K: the (output tile, K-tile) pairs of the whole (grouped) problem form one
+//     linear sequence of U work units, tile-major; workgroup v computes units [v*P, (v+1)*P).  The
+//     workloads' shapes never fill 256 CUs evenly with whole tiles (M = 6400 -> 50 row tiles, 800
+//     tiles of 64^2 on 1024 slots, ...), so tiles are cut along K where the balance needs it.  A
+//     workgroup that computed only part of a tile's reduction stores its partial accumulators to a
+//     workspace slot and bumps the tile's arrival counter; the LAST arriver sums the partials of all
+//     contributors in contributor order (bitwise reproducible, no float atomics, nobody waits) and
+//     runs the epilogue.  Weight gradients (TN, reduction over the 6400 rows) use the same mechanism
+//     instead of split-K atomics.
+//   * workgroup -> unit-range mapping is XCD-aware: the 8 XCDs (private 4 MiB L2 each) get contiguous
+//     runs of units, so an XCD re-reads only its own A row-panels and the (small) weight matrix.
+#include <string.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "common.h"
 
 namespace mmnas {
 
 struct GemmGroupK {
   int M;
+  int tile0;  // first linear tile of this group
   const float* A[3];
   const float* B[3];
   float* C;
@@ -37,12 +51,23 @@ struct GemmGroupK {
 struct GemmK {
   int ngroups, nseg, N, K;
   int lda, ldb, ldc, ldres, ldgate;
-  int relu, split_k, k_per_split, tiles_n, ntiles;
-  int avec, bvec;  // generic path: 16-byte vector loads legal for the A / B operand
+  int relu, accumulate;
+  int tiles_n, ntiles;  // tiles along N; tiles of all groups
+  int ntk, T;           // K-tiles per segment; K-tiles per output tile (= ntk * nseg)
+  int mode;             // MODE_TILE: workgroup v computes tile v.  MODE_SPLIT: "C +=" split-K, workgroup v adds the
+                        // piece (slice v / ntiles, tile v % ntiles) of P K-tiles.  MODE_STREAM: workgroup v computes
+                        // the work units [v*P, (v+1)*P) of the tile-major (tile, K-tile) sequence of U units
+  int P;                // K-tiles per piece / work units per workgroup
+  int U;                // work units in total (= ntiles * T; stream-K needs it below 2^31)
+  float* ws;            // partial-tile slots: 2 per workgroup, BM*BN floats each
+  int* cnt;             // per-tile arrival counters (zero between launches)
+  int avec, bvec;       // generic path: 16-byte vector loads legal for the A / B operand
   float alpha, gate_scale;
   DropCfg drop;
   GemmGroupK g[3];
 };
+
+enum { MODE_TILE = 0, MODE_SPLIT = 1, MODE_STREAM = 2 };
 
 constexpr int BK = 32;
 constexpr int LDK = 36;
@@ -56,301 +81,473 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigne
   return f;
 }
 
+// Partial tiles travel between workgroups that may sit on different XCDs (each XCD has its own L2):
+// device-scope relaxed atomic accesses (sc1: write-through stores, L2-missing loads) move just these bytes
+// coherently -- a release/acquire FENCE would write back / invalidate the whole L2 (measured: +200 us).
+typedef unsigned long long u64;
+__device__ __forceinline__ void st_agent(u64* ptr, float a, float b) {
+  __hip_atomic_store(ptr, ((u64)__float_as_uint(b) << 32) | __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 ld_agent(const u64* ptr) {
+  return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int BM, int BN, bool AKC, bool BKC, bool FAST>
-__global__ void __launch_bounds__(256) gemm_kernel(const GemmK p) {
+__global__ void __launch_bounds__(256, BM == 128 ? 2 : 4) gemm_kernel(const GemmK p) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int A_SZ = BM * LDK, B_SZ = BN * LDK;  // >= BK*BM for the [k][row] form
   constexpr int NA = BM / 32, NB = BN / 32;        // float4 loads per thread per tile
   __shared__ __attribute__((aligned(16))) float As[2 * A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[2 * B_SZ];
+  __shared__ int s_old;
+
+  // The kernel arguments (~400 B = 7 cache lines) live in host-visible memory: the first touch of each line
+  // is a ~1 us round trip, and the compiler reads them in dependent steps (mode -> sizes -> group -> pointers).
+  // Touch every line up front so the misses overlap (measured: -3.5 us per launch).
+  {
+    const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    unsigned t0, t1, t2, t3, t4, t5, t6;
+    asm volatile(
+        "s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %7, 0x40\n\ts_load_dword %2, %7, 0x80\n\t"
+        "s_load_dword %3, %7, 0xc0\n\ts_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\t"
+        "s_load_dword %6, %7, 0x180\n\ts_waitcnt lgkmcnt(0)"
+        : "=s"(t0), "=s"(t1), "=s"(t2), "=s"(t3), "=s"(t4), "=s"(t5), "=s"(t6)
+        : "s"(ka)
+        : "memory");
+  }
+  static_assert(sizeof(GemmK) > 0x140 && sizeof(GemmK) <= 0x1c0, "update the kernel-argument warm-up loads");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // ---- which problem / tile ----
-  const int grp = blockIdx.z;
-  const GemmGroupK& G = p.g[grp];
-  const int Mg = G.M;
-  int tile, split;
-  {  // XCD-aware bijective remap (blocks b and b+8 share an XCD) over the (K-slice, tile) space, slice
-     // major: an XCD owns a contiguous run of tiles of as few K-slices as possible, so with split-K
-     // each XCD's L2 streams only its own slices of A and B instead of all of both (8x fabric re-reads)
+  // ---- this workgroup's run of work units (XCD-aware bijective remap: blocks b and b+8 share an XCD,
+  //      so an XCD owns a contiguous run of units = neighbouring tiles / K-slices of few tiles) ----
+  int v;
+  {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, in = bid >> 3;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
-    split = v / p.ntiles;
-    tile = v - split * p.ntiles;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
   }
-  const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  if (m0 >= Mg) return;  // uniform for the whole workgroup
+  int u = 0, uend = 1;  // MODE_TILE / MODE_SPLIT: a single piece
+  if (p.mode == MODE_STREAM) { u = v * p.P; uend = min(p.U, u + p.P); }
 
-  const int kbeg = split * p.k_per_split;
-  const int kend = min(p.K, kbeg + p.k_per_split);
-  const int ntk = (kend - kbeg + BK - 1) / BK;
-  const int T = ntk * p.nseg;
-  if (T <= 0) return;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  float4 ra[NA], rb[NB];
-
-  // FAST path: per-thread byte offsets of its loads inside the operand (k0 = 0), ~0u when the row is
-  // outside the matrix (the buffer range check then returns zeros)
-  unsigned offa[NA], offb[NB];
-  unsigned stepa = 0, stepb = 0;  // bytes per K-tile
-  unsigned bytesa = 0, bytesb = 0;
-  if (FAST) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int f = tid + 256 * i;
-      if (AKC) {
-        const int row = f >> 3, kq = f & 7, gr = m0 + row;
-        offa[i] = gr < Mg ? (unsigned)(gr * p.lda + kbeg + 4 * kq) * 4u : ~0u;
-      } else {
-        const int k = f / (BM / 4), rq = f - k * (BM / 4), gr = m0 + 4 * rq;
-        offa[i] = gr < Mg ? (unsigned)((kbeg + k) * p.lda + gr) * 4u : ~0u;
-      }
+  while (u < uend) {
+    int tile, q0, nq;
+    if (p.mode == MODE_TILE) {
+      tile = v; q0 = 0; nq = p.T;
+      u = uend;
+    } else if (p.mode == MODE_SPLIT) {  // slice-major: neighbouring workgroups (one XCD) add into different tiles
+      const int sl = v / p.ntiles;       // and stream the same K-slice of both operands through its L2
+      tile = v - sl * p.ntiles;
+      q0 = sl * p.P;
+      nq = min(p.P, p.T - q0);
+      u = uend;
+      if (nq <= 0) break;
+    } else {
+      tile = u / p.T;
+      q0 = u - tile * p.T;  // first K-tile of the piece
+      nq = min(p.T - q0, uend - u);
+      u += nq;
     }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int f = tid + 256 * i;
-      if (BKC) {
-        const int row = f >> 3, kq = f & 7, gr = n0 + row;
-        offb[i] = gr < p.N ? (unsigned)(gr * p.ldb + kbeg + 4 * kq) * 4u : ~0u;
-      } else {
-        const int k = f / (BN / 4), rq = f - k * (BN / 4), gr = n0 + 4 * rq;
-        offb[i] = gr < p.N ? (unsigned)((kbeg + k) * p.ldb + gr) * 4u : ~0u;
-      }
-    }
-    stepa = AKC ? BK * 4u : (unsigned)p.lda * BK * 4u;
-    stepb = BKC ? BK * 4u : (unsigned)p.ldb * BK * 4u;
-    bytesa = (unsigned)(AKC ? Mg : p.K) * (unsigned)p.lda * 4u;
-    bytesb = (unsigned)(BKC ? p.N : p.K) * (unsigned)p.ldb * 4u;
-  }
+    int grp = 0;
+    if (p.ngroups > 1 && tile >= p.g[1].tile0) grp = 1;
+    if (p.ngroups > 2 && tile >= p.g[2].tile0) grp = 2;
+    const GemmGroupK& G = p.g[grp];
+    const int Mg = G.M;
+    const int tl = tile - G.tile0;
+    // group fields into registers once per tile (re-reading them through the kernel-argument pointer inside
+    // the epilogue made the compiler reload the pointer and drain vmcnt before every store / atomic)
+    float* __restrict__ const Cp = G.C;
+    const float* __restrict__ const biasp = G.bias;
+    const float* __restrict__ const resp = G.residual;
+    const float* __restrict__ const gatep = G.gate;
+    const float* const Aseg[3] = {G.A[0], G.A[1], G.A[2]};
+    const float* const Bseg[3] = {G.B[0], G.B[1], G.B[2]};
+    const int tile_m = tl / p.tiles_n, tile_n = tl - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  auto gload = [&](int t) {
-    const int seg = t / ntk;
-    const int kt = t - seg * ntk;
-    const float* __restrict__ Ap = G.A[seg];
-    const float* __restrict__ Bp = G.B[seg];
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[NA], rb[NB];
+
+    // FAST path: per-thread byte offsets of its loads inside the operand (k = 0), ~0u when the row is
+    // outside the matrix (the buffer range check then returns zeros)
+    unsigned offa[NA], offb[NB];
+    unsigned stepa = 0, stepb = 0;  // bytes per K-tile
+    unsigned bytesa = 0, bytesb = 0;
     if (FAST) {
-      const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, bytesa, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, bytesb, 0x00020000);
-      const unsigned ka = (unsigned)kt * stepa, kb = (unsigned)kt * stepb;
 #pragma unroll
-      for (int i = 0; i < NA; ++i) ra[i] = buf_load4(ra_src, offa[i] == ~0u ? ~0u : offa[i] + ka);
-#pragma unroll
-      for (int i = 0; i < NB; ++i) rb[i] = buf_load4(rb_src, offb[i] == ~0u ? ~0u : offb[i] + kb);
-      return;
-    }
-    const int k0 = kbeg + kt * BK;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int f = tid + 256 * i;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (AKC) {
-        const int row = f >> 3, kq = f & 7;
-        const int gr = m0 + row, gk = k0 + 4 * kq;
-        if (gr < Mg && gk < kend) {
-          const float* src = Ap + (size_t)gr * p.lda + gk;
-          if (p.avec) v = *reinterpret_cast<const float4*>(src);
-          else {
-            v.x = src[0];
-            if (gk + 1 < kend) v.y = src[1];
-            if (gk + 2 < kend) v.z = src[2];
-            if (gk + 3 < kend) v.w = src[3];
-          }
-        }
-      } else {
-        const int k = f / (BM / 4), rq = f - k * (BM / 4);
-        const int gk = k0 + k, gr = m0 + 4 * rq;
-        if (gk < kend && gr < Mg) {
-          const float* src = Ap + (size_t)gk * p.lda + gr;
-          if (p.avec) v = *reinterpret_cast<const float4*>(src);
-          else {
-            v.x = src[0];
-            if (gr + 1 < Mg) v.y = src[1];
-            if (gr + 2 < Mg) v.z = src[2];
-            if (gr + 3 < Mg) v.w = src[3];
-          }
-        }
-      }
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int f = tid + 256 * i;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (BKC) {
-        const int row = f >> 3, kq = f & 7;
-        const int gr = n0 + row, gk = k0 + 4 * kq;
-        if (gr < p.N && gk < kend) {
-          const float* src = Bp + (size_t)gr * p.ldb + gk;
-          if (p.bvec) v = *reinterpret_cast<const float4*>(src);
-          else {
-            v.x = src[0];
-            if (gk + 1 < kend) v.y = src[1];
-            if (gk + 2 < kend) v.z = src[2];
-            if (gk + 3 < kend) v.w = src[3];
-          }
-        }
-      } else {
-        const int k = f / (BN / 4), rq = f - k * (BN / 4);
-        const int gk = k0 + k, gr = n0 + 4 * rq;
-        if (gk < kend && gr < p.N) {
-          const float* src = Bp + (size_t)gk * p.ldb + gr;
-          if (p.bvec) v = *reinterpret_cast<const float4*>(src);
-          else {
-            v.x = src[0];
-            if (gr + 1 < p.N) v.y = src[1];
-            if (gr + 2 < p.N) v.z = src[2];
-            if (gr + 3 < p.N) v.w = src[3];
-          }
-        }
-      }
-      rb[i] = v;
-    }
-  };
-
-  auto lstore = [&](int buf) {
-    float* a = As + buf * A_SZ;
-    float* b = Bs + buf * B_SZ;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int f = tid + 256 * i;
-      if (AKC) {
-        const int row = f >> 3, kq = f & 7;
-        *reinterpret_cast<float4*>(a + row * LDK + 4 * kq) = ra[i];
-      } else {
-        const int k = f / (BM / 4), rq = f - k * (BM / 4);
-        *reinterpret_cast<float4*>(a + k * BM + 4 * rq) = ra[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int f = tid + 256 * i;
-      if (BKC) {
-        const int row = f >> 3, kq = f & 7;
-        *reinterpret_cast<float4*>(b + row * LDK + 4 * kq) = rb[i];
-      } else {
-        const int k = f / (BN / 4), rq = f - k * (BN / 4);
-        *reinterpret_cast<float4*>(b + k * BN + 4 * rq) = rb[i];
-      }
-    }
-  };
-
-  gload(0);
-  lstore(0);
-  __syncthreads();
-
-  for (int t = 0; t < T; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < T) gload(t + 1);  // in flight during the MFMA block
-    const float* a = As + buf * A_SZ;
-    const float* b = Bs + buf * B_SZ;
-#pragma unroll
-    for (int s = 0; s < BK / 8; ++s) {
-      float af[TM][4], bf[TN][4];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * WM + i * 32 + l31;
+      for (int i = 0; i < NA; ++i) {
+        const int f = tid + 256 * i;
         if (AKC) {
-          const float4 v = *reinterpret_cast<const float4*>(a + row * LDK + 8 * s + 4 * hh);
-          af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+          const int row = f >> 3, kq = f & 7, gr = m0 + row;
+          offa[i] = gr < Mg ? (unsigned)(gr * p.lda + 4 * kq) * 4u : ~0u;
         } else {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) af[i][u] = a[(8 * s + 4 * hh + u) * BM + row];
+          const int k = f / (BM / 4), rq = f - k * (BM / 4), gr = m0 + 4 * rq;
+          offa[i] = gr < Mg ? (unsigned)(k * p.lda + gr) * 4u : ~0u;
         }
       }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = wn * WN + j * 32 + l31;
+      for (int i = 0; i < NB; ++i) {
+        const int f = tid + 256 * i;
         if (BKC) {
-          const float4 v = *reinterpret_cast<const float4*>(b + col * LDK + 8 * s + 4 * hh);
-          bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+          const int row = f >> 3, kq = f & 7, gr = n0 + row;
+          offb[i] = gr < p.N ? (unsigned)(gr * p.ldb + 4 * kq) * 4u : ~0u;
         } else {
+          const int k = f / (BN / 4), rq = f - k * (BN / 4), gr = n0 + 4 * rq;
+          offb[i] = gr < p.N ? (unsigned)(k * p.ldb + gr) * 4u : ~0u;
+        }
+      }
+      stepa = AKC ? BK * 4u : (unsigned)p.lda * BK * 4u;
+      stepb = BKC ? BK * 4u : (unsigned)p.ldb * BK * 4u;
+      bytesa = (unsigned)(AKC ? Mg : p.K) * (unsigned)p.lda * 4u;
+      bytesb = (unsigned)(BKC ? p.N : p.K) * (unsigned)p.ldb * 4u;
+    }
+
+    auto gload = [&](int q) {  // unit q of the tile: segment q / ntk, K-tile q % ntk
+      const int seg = q / p.ntk;
+      const int kt = q - seg * p.ntk;
+      const float* __restrict__ Ap = seg == 0 ? Aseg[0] : (seg == 1 ? Aseg[1] : Aseg[2]);
+      const float* __restrict__ Bp = seg == 0 ? Bseg[0] : (seg == 1 ? Bseg[1] : Bseg[2]);
+      if (FAST) {
+        const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, bytesa, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, bytesb, 0x00020000);
+        const unsigned ka = (unsigned)kt * stepa, kb = (unsigned)kt * stepb;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) bf[j][u] = b[(8 * s + 4 * hh + u) * BN + col];
+        for (int i = 0; i < NA; ++i) ra[i] = buf_load4(ra_src, offa[i] == ~0u ? ~0u : offa[i] + ka);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = buf_load4(rb_src, offb[i] == ~0u ? ~0u : offb[i] + kb);
+        return;
+      }
+      const int k0 = kt * BK, kend = p.K;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int f = tid + 256 * i;
+        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (AKC) {
+          const int row = f >> 3, kq = f & 7;
+          const int gr = m0 + row, gk = k0 + 4 * kq;
+          if (gr < Mg && gk < kend) {
+            const float* src = Ap + (size_t)gr * p.lda + gk;
+            if (p.avec) v4 = *reinterpret_cast<const float4*>(src);
+            else {
+              v4.x = src[0];
+              if (gk + 1 < kend) v4.y = src[1];
+              if (gk + 2 < kend) v4.z = src[2];
+              if (gk + 3 < kend) v4.w = src[3];
+            }
+          }
+        } else {
+          const int k = f / (BM / 4), rq = f - k * (BM / 4);
+          const int gk = k0 + k, gr = m0 + 4 * rq;
+          if (gk < kend && gr < Mg) {
+            const float* src = Ap + (size_t)gk * p.lda + gr;
+            if (p.avec) v4 = *reinterpret_cast<const float4*>(src);
+            else {
+              v4.x = src[0];
+              if (gr + 1 < Mg) v4.y = src[1];
+              if (gr + 2 < Mg) v4.z = src[2];
+              if (gr + 3 < Mg) v4.w = src[3];
+            }
+          }
+        }
+        ra[i] = v4;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int f = tid + 256 * i;
+        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (BKC) {
+          const int row = f >> 3, kq = f & 7;
+          const int gr = n0 + row, gk = k0 + 4 * kq;
+          if (gr < p.N && gk < kend) {
+            const float* src = Bp + (size_t)gr * p.ldb + gk;
+            if (p.bvec) v4 = *reinterpret_cast<const float4*>(src);
+            else {
+              v4.x = src[0];
+              if (gk + 1 < kend) v4.y = src[1];
+              if (gk + 2 < kend) v4.z = src[2];
+              if (gk + 3 < kend) v4.w = src[3];
+            }
+          }
+        } else {
+          const int k = f / (BN / 4), rq = f - k * (BN / 4);
+          const int gk = k0 + k, gr = n0 + 4 * rq;
+          if (gk < kend && gr < p.N) {
+            const float* src = Bp + (size_t)gk * p.ldb + gr;
+            if (p.bvec) v4 = *reinterpret_cast<const float4*>(src);
+            else {
+              v4.x = src[0];
+              if (gr + 1 < p.N) v4.y = src[1];
+              if (gr + 2 < p.N) v4.z = src[2];
+              if (gr + 3 < p.N) v4.w = src[3];
+            }
+          }
+        }
+        rb[i] = v4;
+      }
+    };
+
+    auto lstore = [&](int buf) {
+      float* a = As + buf * A_SZ;
+      float* b = Bs + buf * B_SZ;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int f = tid + 256 * i;
+        if (AKC) {
+          const int row = f >> 3, kq = f & 7;
+          *reinterpret_cast<float4*>(a + row * LDK + 4 * kq) = ra[i];
+        } else {
+          const int k = f / (BM / 4), rq = f - k * (BM / 4);
+          *reinterpret_cast<float4*>(a + k * BM + 4 * rq) = ra[i];
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int i = 0; i < NB; ++i) {
+        const int f = tid + 256 * i;
+        if (BKC) {
+          const int row = f >> 3, kq = f & 7;
+          *reinterpret_cast<float4*>(b + row * LDK + 4 * kq) = rb[i];
+        } else {
+          const int k = f / (BN / 4), rq = f - k * (BN / 4);
+          *reinterpret_cast<float4*>(b + k * BN + 4 * rq) = rb[i];
+        }
+      }
+    };
+
+    gload(q0);
+    lstore(0);
+    __syncthreads();
+
+    for (int t = 0; t < nq; ++t) {
+      const int buf = t & 1;
+      if (t + 1 < nq) gload(q0 + t + 1);  // in flight during the MFMA block
+      const float* a = As + buf * A_SZ;
+      const float* b = Bs + buf * B_SZ;
+#pragma unroll
+      for (int s = 0; s < BK / 8; ++s) {
+        float af[TM][4], bf[TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = wm * WM + i * 32 + l31;
+          if (AKC) {
+            const float4 v4 = *reinterpret_cast<const float4*>(a + row * LDK + 8 * s + 4 * hh);
+            af[i][0] = v4.x; af[i][1] = v4.y; af[i][2] = v4.z; af[i][3] = v4.w;
+          } else {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) af[i][w] = a[(8 * s + 4 * hh + w) * BM + row];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = wn * WN + j * 32 + l31;
+          if (BKC) {
+            const float4 v4 = *reinterpret_cast<const float4*>(b + col * LDK + 8 * s + 4 * hh);
+            bf[j][0] = v4.x; bf[j][1] = v4.y; bf[j][2] = v4.z; bf[j][3] = v4.w;
+          } else {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) bf[j][w] = b[(8 * s + 4 * hh + w) * BN + col];
+          }
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[i][w], bf[j][w], acc[i][j]);
+      }
+      if (t + 1 < nq) lstore(buf ^ 1);
+      __syncthreads();
+    }
+
+    // ---- partial tile: hand the accumulators over; the last contributor to arrive finishes the tile ----
+    const bool atomic_out = nq != p.T && p.accumulate;  // "C +=" results: a partial tile simply adds its share
+    if (nq != p.T && !atomic_out) {
+      const int t0 = tile * p.T;
+      const int v_lo = t0 / p.P, v_hi = (t0 + p.T - 1) / p.P;  // contributors, inclusive
+      // a workgroup has at most two partial tiles: the one it starts inside (slot 2v) and the one it
+      // ends inside (slot 2v+1)
+      // slot image: [register pair][thread] of 8-byte words -- every store / load instruction covers 512
+      // contiguous bytes
+      u64* slot = reinterpret_cast<u64*>(p.ws) + (size_t)(2 * v + (q0 == 0 ? 1 : 0)) * (BM * BN / 2) + tid;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int c = 0; c < 8; ++c) st_agent(slot + ((i * TN + j) * 8 + c) * 256, acc[i][j][2 * c], acc[i][j][2 * c + 1]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every lane's partial has been written through ...
+      __syncthreads();                                    // ... before the workgroup announces its arrival
+      if (tid == 0) s_old = __hip_atomic_fetch_add(p.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const bool last = s_old == v_hi - v_lo;
+      __syncthreads();  // s_old is rewritten by the next partial tile
+      if (!last) continue;
+      if (tid == 0) __hip_atomic_store(p.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 1
+      for (int c = v_lo; c <= v_hi; ++c) {
+        const bool head = c * p.P > t0;  // contributor c starts inside this tile
+        const u64* src = reinterpret_cast<const u64*>(p.ws) + (size_t)(2 * c + (head ? 0 : 1)) * (BM * BN / 2) + tid;
+        u64 part[TM * TN * 8];  // the whole partial in flight at once: the loads miss L2 by design (~2 us each)
+#pragma unroll
+        for (int e = 0; e < TM * TN * 8; ++e) part[e] = ld_agent(src + e * 256);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[i][u], bf[j][u], acc[i][j]);
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+              const u64 w = part[(i * TN + j) * 8 + c8];
+              acc[i][j][2 * c8] += __uint_as_float((unsigned)w);
+              acc[i][j][2 * c8 + 1] += __uint_as_float((unsigned)(w >> 32));
+            }
+      }
     }
-    if (t + 1 < T) lstore(buf ^ 1);
-    __syncthreads();
-  }
 
-  // ---- epilogue ----
-  // All conditions on kernel arguments are wave-uniform and hoisted out of the element loops; the
-  // residual / gate operands of a 32x32 sub-tile are fetched as one batch of 16 independent loads
-  // (clamped row index instead of a branch) before any arithmetic, so their latency overlaps.
-  const bool atomic = p.split_k > 1;
-  const bool has_res = G.residual != nullptr, has_gate = G.gate != nullptr;
-  const bool has_drop = p.drop.thresh != 0, has_relu = p.relu != 0;
+    // ---- epilogue ----
+    // All conditions on kernel arguments are wave-uniform and hoisted out of the element loops; the
+    // residual / gate / accumulate operands of a 32x32 sub-tile are fetched as one batch of 16
+    // independent loads (clamped row index instead of a branch) before any arithmetic.
+    const bool has_res = resp != nullptr, has_gate = gatep != nullptr, has_acc = p.accumulate != 0;
+    const bool has_drop = p.drop.thresh != 0, has_relu = p.relu != 0;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * WN + j * 32 + l31;
-      const bool cok = col < p.N;
-      const int colc = cok ? col : p.N - 1;
-      const int rbase = m0 + wm * WM + i * 32 + 4 * hh;
-      if (atomic) {
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WN + j * 32 + l31;
+        const bool cok = col < p.N;
+        const int colc = cok ? col : p.N - 1;
+        const int rbase = m0 + wm * WM + i * 32 + 4 * hh;
+        if (atomic_out) {
+          // "C +=" piece: plain adds.  (Kept free of anything that waits on memory: a bias load here made the
+          // compiler drain vmcnt -- i.e. all earlier atomics -- first.)  Bias / residual ride on the piece that
+          // holds the tile's first K-tile, a path the operators never take.
+          if (q0 == 0 && (biasp != nullptr || has_res)) {
+            const float bv0 = biasp ? biasp[colc] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = rbase + (r & 3) + 8 * (r >> 2);
+              if (cok && row < Mg)
+                atomicAdd(Cp + (size_t)row * p.ldc + col,
+                          acc[i][j][r] * p.alpha + bv0 + (has_res ? resp[(size_t)row * p.ldres + col] : 0.f));
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = rbase + (r & 3) + 8 * (r >> 2);
+              if (cok && row < Mg) atomicAdd(Cp + (size_t)row * p.ldc + col, acc[i][j][r] * p.alpha);
+            }
+          }
+          continue;
+        }
+        float resv[16], gatev[16], oldv[16];
+        if (has_res) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = min(rbase + (r & 3) + 8 * (r >> 2), Mg - 1);
+            resv[r] = resp[(size_t)row * p.ldres + colc];
+          }
+        }
+        if (has_gate) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = min(rbase + (r & 3) + 8 * (r >> 2), Mg - 1);
+            gatev[r] = gatep[(size_t)row * p.ldgate + colc];
+          }
+        }
+        if (has_acc) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = min(rbase + (r & 3) + 8 * (r >> 2), Mg - 1);
+            oldv[r] = Cp[(size_t)row * p.ldc + colc];
+          }
+        }
+        const float bv = biasp ? biasp[colc] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rbase + (r & 3) + 8 * (r >> 2);
-          if (cok && row < Mg) atomicAdd(G.C + (size_t)row * p.ldc + col, acc[i][j][r] * p.alpha);
+          float val = acc[i][j][r] * p.alpha + bv;
+          if (has_relu) val = fmaxf(val, 0.f);
+          if (has_drop) val *= drop_mult(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)col);
+          if (has_gate) val = gatev[r] > 0.f ? val * p.gate_scale : 0.f;
+          if (has_res) val += resv[r];
+          if (has_acc) val += oldv[r];
+          if (cok && row < Mg) Cp[(size_t)row * p.ldc + col] = val;
         }
-        continue;
-      }
-      float resv[16], gatev[16];
-      if (has_res) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = min(rbase + (r & 3) + 8 * (r >> 2), Mg - 1);
-          resv[r] = G.residual[(size_t)row * p.ldres + colc];
-        }
-      }
-      if (has_gate) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = min(rbase + (r & 3) + 8 * (r >> 2), Mg - 1);
-          gatev[r] = G.gate[(size_t)row * p.ldgate + colc];
-        }
-      }
-      const float bv = G.bias ? G.bias[colc] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rbase + (r & 3) + 8 * (r >> 2);
-        float v = acc[i][j][r] * p.alpha + bv;
-        if (has_relu) v = fmaxf(v, 0.f);
-        if (has_drop) v *= drop_mult(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)col);
-        if (has_gate) v = gatev[r] > 0.f ? v * p.gate_scale : 0.f;
-        if (has_res) v += resv[r];
-        if (cok && row < Mg) G.C[(size_t)row * p.ldc + col] = v;
       }
     }
   }
 }
 
+// ---- stream-K workspace: partial-tile slots + arrival counters, one per stream (launches on one stream
+//      are ordered, so they can share it; two streams must not) ----
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e && e[0] ? atoi(e) : dflt;
+}
+
+// Tuning / test knobs, read from the environment once (mmnas_gemm_reload_tuning() re-reads them):
+//   MMNAS_GEMM_TILE=64|128 force the tile shape      MMNAS_GEMM_GENERIC=1 force the guarded-load path
+//   MMNAS_GEMM_SK=0|1|2    stream-K / split-K never, automatic, always
+//   MMNAS_GEMM_WGS=n       co-resident workgroup budget (default 1024 for 64^2 tiles, 512 for 128^2)
+//   MMNAS_GEMM_MIN_UNITS=n fewest K-tiles a workgroup is given (default 4)
+struct Tuning { int tile, generic, sk, wgs, min_units; bool loaded; };
+static Tuning g_tune = {0, 0, 1, 0, 4, false};
+static void load_tuning() {
+  g_tune.tile = env_int("MMNAS_GEMM_TILE", 0);
+  g_tune.generic = getenv("MMNAS_GEMM_GENERIC") != nullptr;
+  g_tune.sk = env_int("MMNAS_GEMM_SK", 1);
+  g_tune.wgs = env_int("MMNAS_GEMM_WGS", 0);
+  g_tune.min_units = env_int("MMNAS_GEMM_MIN_UNITS", 4);
+  if (g_tune.min_units < 1) g_tune.min_units = 1;
+  g_tune.loaded = true;
+}
+
+constexpr int MAX_WGS = 1024;                                  // 256 CUs x 4 workgroups of 64^2 tiles
+constexpr size_t WS_SLOT_FLOATS = (size_t)2 * 512 * 128 * 128;  // 2 slots x 512 workgroups x 128^2 (= 2 x 1024 x 64^2 x 2)
+constexpr int MAX_CNT_TILES = 1 << 16;
+
+struct SkWorkspace { float* ws; int* cnt; };
+static std::mutex g_ws_mu;
+static std::map<std::pair<int, hipStream_t>, SkWorkspace> g_ws;
+
+static int get_workspace(hipStream_t st, SkWorkspace* out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("gemm: hipGetDevice failed"); return MMNAS_E_LAUNCH; }
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  auto key = std::make_pair(dev, st);
+  auto it = g_ws.find(key);
+  if (it == g_ws.end()) {
+    SkWorkspace w{nullptr, nullptr};
+    if (hipMalloc((void**)&w.ws, WS_SLOT_FLOATS * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&w.cnt, MAX_CNT_TILES * sizeof(int)) != hipSuccess ||
+        hipMemset(w.cnt, 0, MAX_CNT_TILES * sizeof(int)) != hipSuccess) {
+      set_error("gemm: cannot allocate the stream-K workspace (%zu MiB)", WS_SLOT_FLOATS * sizeof(float) >> 20);
+      return MMNAS_E_LAUNCH;
+    }
+    it = g_ws.emplace(key, w).first;
+  }
+  *out = it->second;
+  return MMNAS_OK;
+}
+
 template <int BM, int BN, bool FAST>
-static int launch(GemmK& k, int layout, int maxM, hipStream_t st) {
-  const int tiles_m = cdiv(maxM, BM);
-  k.ntiles = tiles_m * k.tiles_n;
-  dim3 grid(k.ntiles * k.split_k, 1, k.ngroups), block(256);
+static int launch(GemmK& k, int layout, int nwg, hipStream_t st) {
+  dim3 grid(nwg), block(256);
   switch (layout) {
     case MMNAS_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, FAST>), grid, block, 0, st, k); break;
     case MMNAS_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, FAST>), grid, block, 0, st, k); break;
@@ -363,28 +560,39 @@ static int launch(GemmK& k, int layout, int maxM, hipStream_t st) {
 
 using namespace mmnas;
 
+extern "C" int mmnas_gemm_reload_tuning(void) {
+  load_tuning();
+  return MMNAS_OK;
+}
+
 extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
+  if (!g_tune.loaded) load_tuning();
   MMNAS_REQUIRE(d != nullptr, MMNAS_E_ARG, "mmnas_gemm: null descriptor");
   MMNAS_REQUIRE(d->ngroups >= 1 && d->ngroups <= 3 && d->nseg >= 1 && d->nseg <= 3, MMNAS_E_ARG,
                 "mmnas_gemm: ngroups=%d nseg=%d out of range", d->ngroups, d->nseg);
   MMNAS_REQUIRE(d->layout >= 0 && d->layout <= 2, MMNAS_E_ARG, "mmnas_gemm: bad layout %d", d->layout);
   MMNAS_REQUIRE(d->N > 0 && d->K > 0, MMNAS_E_SHAPE, "mmnas_gemm: N=%d K=%d", d->N, d->K);
   const bool tn = d->layout == MMNAS_GEMM_TN;
-  int split = d->split_k < 1 ? 1 : d->split_k;
-  MMNAS_REQUIRE(split == 1 || tn, MMNAS_E_ARG, "mmnas_gemm: split_k only for the TN layout");
+  // split_k > 1 is the historical way to ask for "add onto C" (the split itself is now chosen here)
+  const bool accumulate = d->accumulate != 0 || d->split_k > 1;
+  if (accumulate) {
+    MMNAS_REQUIRE(!d->relu && d->drop_p == 0.f, MMNAS_E_ARG, "mmnas_gemm: no relu/dropout epilogue when accumulating onto C");
+    for (int g = 0; g < d->ngroups; ++g)
+      MMNAS_REQUIRE(!d->g[g].gate, MMNAS_E_ARG, "mmnas_gemm: no gate epilogue when accumulating onto C");
+  }
 
   GemmK k;
+  memset(&k, 0, sizeof(k));
   k.ngroups = d->ngroups; k.nseg = d->nseg; k.N = d->N; k.K = d->K;
   k.lda = d->lda; k.ldb = d->ldb; k.ldc = d->ldc; k.ldres = d->ldres; k.ldgate = d->ldgate;
-  k.relu = d->relu; k.alpha = d->alpha; k.gate_scale = d->gate_scale;
+  k.relu = d->relu; k.accumulate = accumulate; k.alpha = d->alpha; k.gate_scale = d->gate_scale;
   k.drop = make_drop(d->drop_p, d->drop_seed, d->drop_site);
   // vector (16-byte) operand loads need aligned bases, leading dims and extents; otherwise the
   // kernel falls back to guarded scalar loads (odd shapes such as the 3129-way answer projection)
   const bool akc = d->layout != MMNAS_GEMM_TN, bkc = d->layout == MMNAS_GEMM_NT;
   int avec = (d->lda % 4 == 0) && (akc ? d->K % 4 == 0 : 1);
   int bvec = (d->ldb % 4 == 0) && (bkc ? d->K % 4 == 0 : d->N % 4 == 0);
-  int maxM = 0;
-  double maxbytes = 0;
+  double maxbytes = 0, sumM = 0;
   for (int g = 0; g < d->ngroups; ++g) {
     const mmnas_gemm_group& s = d->g[g];
     if (!akc && s.M % 4 != 0) avec = 0;
@@ -398,44 +606,95 @@ extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
         if (((uintptr_t)s.B[i] & 15) != 0) bvec = 0;
       }
     }
-    if (s.M > maxM) maxM = s.M;
+    sumM += s.M;
     const double ab = 4.0 * (akc ? (double)(s.M + 128) : (double)d->K) * d->lda;
     if (ab > maxbytes) maxbytes = ab;
   }
   const double bb = 4.0 * (bkc ? (double)(d->N + 128) : (double)d->K) * d->ldb;
   if (bb > maxbytes) maxbytes = bb;
   k.avec = avec; k.bvec = bvec;
-  // tile choice (measured, tools/gemm_bench.py): 64^2 tiles win on every shape of the VQA workloads
-  // (M = 6400, N,K <= 2048: 75-115 TF/s vs 69-108 with 128^2) because they give 4x the workgroups
-  // to balance over 256 CUs; 128^2 (half the LDS/L2 traffic per flop) only pays once there are
-  // >= 4 full waves of them (4096^3: 129-134 TF/s vs 117-125)
-  const long t128 = (long)cdiv(maxM, 128) * cdiv(d->N, 128) * d->ngroups;
-  bool big = t128 * (tn ? split : 1) >= 1024;
-  {  // tuning / test knob: MMNAS_GEMM_TILE=64|128 forces the tile shape
-    const char* e = getenv("MMNAS_GEMM_TILE");
-    const int force = e ? atoi(e) : 0;
-    if (force == 128) big = true;
-    if (force == 64) big = false;
-  }
-  // K slices are multiples of the K tile so every slice starts on a tile boundary
-  const int kps = ((cdiv(d->K, split) + BK - 1) / BK) * BK;
-  split = cdiv(d->K, kps);
-  k.split_k = split; k.k_per_split = kps;
-  if (split > 1)
-    MMNAS_REQUIRE(!d->relu && d->drop_p == 0.f, MMNAS_E_ARG, "mmnas_gemm: no relu/dropout epilogue with split_k");
   // branch-free buffer-load path: aligned vector loads, K a multiple of the K tile, 32-bit byte offsets
   bool fast = avec && bvec && (d->K % BK == 0) && maxbytes < 4.0e9;
-  if (getenv("MMNAS_GEMM_GENERIC")) fast = false;
-  hipStream_t st = (hipStream_t)stream;
-  double sumM = 0;
-  for (int g = 0; g < d->ngroups; ++g) sumM += d->g[g].M;
-  // algorithmic work: 2*M*N*K flops per product; minimum traffic = operands once + result once
-  ProfScope ps(MMNAS_K_GEMM, 2.0 * sumM * d->N * d->K * d->nseg,
-               4.0 * (sumM * d->K * d->nseg + (double)d->N * d->K * d->nseg * d->ngroups + sumM * d->N), st);
-  if (big) {
-    k.tiles_n = cdiv(d->N, 128);
-    return fast ? launch<128, 128, true>(k, d->layout, maxM, st) : launch<128, 128, false>(k, d->layout, maxM, st);
+  if (g_tune.generic) fast = false;
+  k.ntk = cdiv(d->K, BK);
+  k.T = k.ntk * d->nseg;
+
+  // ---- schedule: tile shape, K-slices S, units per workgroup P ----
+  // Measured on the VQA shapes (tools/gemm_bench.py, profiles/):
+  //   * 128^2 tiles move half the LDS / L2 bytes per flop of 64^2 ones (123-134 vs 96-119 TF/s) but only pay
+  //     once there are >= 4 full waves of them; below that 64^2 tiles, 4 workgroups per CU.
+  //   * whole tiles, one per workgroup (P = T), whenever they fill the CUs evenly: the dispatcher balances
+  //     them dynamically and a finishing workgroup's epilogue overlaps its successor's prologue.
+  //   * stream-K (P not a multiple of T) when whole tiles would leave the CUs unevenly loaded and there is
+  //     enough reduction per tile to amortise the hand-over of partial tiles (~5 us exposed at the end):
+  //     the M = 896 (question-side) products, and K >= 1536 products on M = 6400.
+  //   * "C +=" products (weight gradients: few tiles, reduction over the 6400 rows): plain split-K, the
+  //     pieces added with float atomics, dealt out slice-major (an XCD's workgroups add into different
+  //     tiles and stream the same K-slice of both operands through its L2).
+  auto ntiles_for = [&](int bt) {
+    long n = 0;
+    for (int g = 0; g < d->ngroups; ++g) n += (long)cdiv(d->g[g].M, bt) * cdiv(d->N, bt);
+    return n;
+  };
+  const int min_units = g_tune.min_units;
+  bool big = ntiles_for(128) >= 2048;
+  if (g_tune.tile == 128) big = true;
+  if (g_tune.tile == 64) big = false;
+  const int bt = big ? 128 : 64;
+  k.tiles_n = cdiv(d->N, bt);
+  long t0 = 0;
+  for (int g = 0; g < d->ngroups; ++g) { k.g[g].tile0 = (int)t0; t0 += (long)cdiv(d->g[g].M, bt) * k.tiles_n; }
+  MMNAS_REQUIRE(t0 < (1l << 30), MMNAS_E_SHAPE, "mmnas_gemm: too many output tiles");
+  k.ntiles = (int)t0;
+  // co-resident workgroups: 256 CUs x 2 (128^2 tiles: 72 KB LDS each) or x 4
+  const int slots = g_tune.wgs > 0 ? (g_tune.wgs < MAX_WGS ? g_tune.wgs : MAX_WGS) : (big ? 512 : 1024);
+  // how evenly whole tiles load the 256 CUs: mean / max tiles per CU (the dispatcher balances dynamically)
+  const double per_cu = (double)k.ntiles / 256.0;
+  const double dp_eff = per_cu / (double)(long)(per_cu + 0.999999);
+  const long long U = (long long)k.ntiles * k.T;
+  int sk = g_tune.sk;  // 0 never, 1 auto, 2 always
+  k.mode = MODE_TILE;
+  k.P = k.T;
+  int nwg = k.ntiles;
+  if (accumulate && sk != 0) {
+    // split-K with atomics: enough (slice, tile) pieces to fill the co-resident slots, >= min_units K-tiles each
+    int want = (slots + k.ntiles - 1) / k.ntiles;
+    if (want > k.T / min_units) want = k.T / min_units;
+    if (want > 1) {
+      k.P = (k.T + want - 1) / want;
+      const int S = (k.T + k.P - 1) / k.P;
+      MMNAS_REQUIRE((long long)S * k.ntiles < (1ll << 30), MMNAS_E_SHAPE, "mmnas_gemm: too many split-K pieces");
+      k.mode = MODE_SPLIT;
+      nwg = S * k.ntiles;
+    }
+  } else if (!accumulate && sk != 0 && U < (1ll << 30) && k.ntiles <= MAX_CNT_TILES && k.T >= 2 * min_units &&
+             (sk == 2 || (!big && ((dp_eff < 0.6 && k.T >= 16) || (dp_eff < 0.9 && k.T >= 48))))) {
+    long long G = U / min_units;
+    if (G > slots) G = slots;
+    if (G < 1) G = 1;
+    const long long P = (U + G - 1) / G;
+    if (P < k.T) {  // (a whole tile or more each: launch whole tiles instead)
+      k.mode = MODE_STREAM;
+      k.P = (int)P;
+      k.U = (int)U;
+      nwg = (int)((U + P - 1) / P);
+    }
   }
-  k.tiles_n = cdiv(d->N, 64);
-  return fast ? launch<64, 64, true>(k, d->layout, maxM, st) : launch<64, 64, false>(k, d->layout, maxM, st);
+  hipStream_t st = (hipStream_t)stream;
+  if (k.mode == MODE_STREAM) {
+    SkWorkspace w;
+    const int rc = get_workspace(st, &w);
+    if (rc) return rc;
+    k.ws = w.ws; k.cnt = w.cnt;
+  }
+  // algorithmic work: 2*M*N*K flops per product; minimum traffic = operands once + result once
+  char tag[96] = "";
+  if (prof_enabled())
+    snprintf(tag, sizeof(tag), "%s M=%d/%d/%d N=%d K=%d seg=%d t%d wg=%d P=%d/%d %s%s", tn ? "TN" : (bkc ? "NT" : "NN"),
+             d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0, d->ngroups > 2 ? d->g[2].M : 0, d->N, d->K, d->nseg, bt, nwg, k.P, k.T,
+             k.mode == MODE_TILE ? "tile" : (k.mode == MODE_SPLIT ? "split" : "stream"), fast ? "" : " generic");
+  ProfScope ps(MMNAS_K_GEMM, 2.0 * sumM * d->N * d->K * d->nseg,
+               4.0 * (sumM * d->K * d->nseg + (double)d->N * d->K * d->nseg * d->ngroups + sumM * d->N), st, tag);
+  if (big) return fast ? launch<128, 128, true>(k, d->layout, nwg, st) : launch<128, 128, false>(k, d->layout, nwg, st);
+  return fast ? launch<64, 64, true>(k, d->layout, nwg, st) : launch<64, 64, false>(k, d->layout, nwg, st);
 }

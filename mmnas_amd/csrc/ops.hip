@@ -22,19 +22,6 @@ struct Carver {
   float* take(size_t nfloats) { float* r = (float*)(base + off); off += al(nfloats * sizeof(float)); return r; }
 };
 
-static int auto_split(int M, int N, int groups, int K) {
-  // weight-gradient GEMMs have few output tiles and a long reduction: cut K so ~2 workgroups/CU exist
-  // measured (tools/gemm_bench.py): ~1024 workgroups of 64^2 tiles (4 per CU) is the sweet spot,
-  // with at least 4 K-tiles of 32 per slice
-  const long tiles = (long)cdiv(M, 64) * cdiv(N, 64) * groups;
-  int s = (int)((1024 + tiles - 1) / tiles);
-  const int maxs = K / 128 > 0 ? K / 128 : 1;
-  if (s > maxs) s = maxs;
-  if (s > 1024) s = 1024;
-  if (s < 1) s = 1;
-  return s;
-}
-
 static void gemm_init(mmnas_gemm_desc& g, int layout, int N, int K, int lda, int ldb, int ldc) {
   memset(&g, 0, sizeof(g));
   g.layout = layout; g.ngroups = 1; g.nseg = 1; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -189,7 +176,7 @@ extern "C" int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream) {
   // 3. dWm += dt^T att           [d,di], reduction over the Mq rows
   gemm_init(g, MMNAS_GEMM_TN, di, Mq, d, di, di);
   g.g[0].M = d; g.g[0].A[0] = dt; g.g[0].B[0] = L.att; g.g[0].C = op->dWm;
-  g.split_k = auto_split(d, di, 1, Mq);
+  g.accumulate = 1;
   if ((rc = mmnas_gemm(&g, stream))) return rc;
 
   // 4. attention core backward
@@ -210,18 +197,18 @@ extern "C" int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream) {
     g.g[0].M = di; g.g[0].A[0] = L.dQ; g.g[0].B[0] = op->xq;  g.g[0].C = op->dWq;
     g.g[1].M = di; g.g[1].A[0] = L.dK; g.g[1].B[0] = op->xkv; g.g[1].C = op->dWk;
     g.g[2].M = di; g.g[2].A[0] = L.dV; g.g[2].B[0] = op->xkv; g.g[2].C = op->dWv;
-    g.split_k = auto_split(di, d, 3, Mq);
+    g.accumulate = 1;
     if ((rc = mmnas_gemm(&g, stream))) return rc;
   } else {
     gemm_init(g, MMNAS_GEMM_TN, d, Mq, di, d, d);
     g.g[0].M = di; g.g[0].A[0] = L.dQ; g.g[0].B[0] = op->xq; g.g[0].C = op->dWq;
-    g.split_k = auto_split(di, d, 1, Mq);
+    g.accumulate = 1;
     if ((rc = mmnas_gemm(&g, stream))) return rc;
     gemm_init(g, MMNAS_GEMM_TN, d, Mk, di, d, d);
     g.ngroups = 2;
     g.g[0].M = di; g.g[0].A[0] = L.dK; g.g[0].B[0] = op->xkv; g.g[0].C = op->dWk;
     g.g[1].M = di; g.g[1].A[0] = L.dV; g.g[1].B[0] = op->xkv; g.g[1].C = op->dWv;
-    g.split_k = auto_split(di, d, 2, Mk);
+    g.accumulate = 1;
     if ((rc = mmnas_gemm(&g, stream))) return rc;
   }
 
@@ -391,7 +378,7 @@ extern "C" int mmnas_mlp_op_bwd(const mmnas_mlp_op* op, void* stream) {
     // weight gradient: dW_i[nout,nin] += dpre^T hin
     gemm_init(g, MMNAS_GEMM_TN, nin, M, nout, nin, nin);
     g.g[0].M = nout; g.g[0].A[0] = dpre; g.g[0].B[0] = hin; g.g[0].C = op->dW[i];
-    g.split_k = auto_split(nout, nin, 1, M);
+    g.accumulate = 1;
     if ((rc = mmnas_gemm(&g, stream))) return rc;
     // data gradient
     gemm_init(g, MMNAS_GEMM_NN, nin, nout, nout, nin, nin);

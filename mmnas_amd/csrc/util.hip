@@ -29,7 +29,7 @@ int check_launch(const char* what) {
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline) ----
 namespace prof {
-struct Rec { hipEvent_t a, b; int kind; double flops, bytes; };
+struct Rec { hipEvent_t a, b; int kind; double flops, bytes; char tag[96]; };
 static std::mutex mu;
 static bool enabled = false;
 static std::vector<Rec> recs;
@@ -46,11 +46,15 @@ static hipEvent_t get_event() {
 }
 }  // namespace prof
 
-ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t st) : idx_(-1), st_(st) {
+bool prof_enabled() { return prof::enabled; }
+
+ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t st, const char* tag) : idx_(-1), st_(st) {
   if (!prof::enabled) return;
   std::lock_guard<std::mutex> g(prof::mu);
   prof::Rec r;
   r.a = prof::get_event(); r.b = prof::get_event(); r.kind = kind; r.flops = flops; r.bytes = bytes;
+  r.tag[0] = 0;
+  if (tag) { strncpy(r.tag, tag, sizeof(r.tag) - 1); r.tag[sizeof(r.tag) - 1] = 0; }
   hipEventRecord(r.a, st);
   idx_ = (long)prof::recs.size();
   prof::recs.push_back(r);
@@ -127,13 +131,18 @@ extern "C" int mmnas_prof_collect(mmnas_prof_stat* stats) {
   MMNAS_REQUIRE(stats, MMNAS_E_ARG, "prof_collect: null output");
   std::lock_guard<std::mutex> g(prof::mu);
   for (int k = 0; k < MMNAS_K_COUNT; ++k) { stats[k].ms = 0; stats[k].flops = 0; stats[k].bytes = 0; stats[k].launches = 0; }
+  // tuning aid: MMNAS_PROF_DUMP=<file> appends one "kind,tag,ms,flops,bytes" row per bracketed launch
+  const char* dump = getenv("MMNAS_PROF_DUMP");
+  FILE* df = dump && dump[0] ? fopen(dump, "a") : nullptr;
   for (const prof::Rec& r : prof::recs) {
     if (hipEventSynchronize(r.b) != hipSuccess) continue;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    if (df) fprintf(df, "%d,%s,%.6f,%.0f,%.0f\n", r.kind, r.tag, ms, r.flops, r.bytes);
     mmnas_prof_stat& s = stats[r.kind];
     s.ms += ms; s.flops += r.flops; s.bytes += r.bytes; s.launches += 1;
   }
+  if (df) fclose(df);
   prof::recs.clear();
   prof::pool_next = 0;
   return MMNAS_OK;

@@ -283,12 +283,13 @@ def mlp_op(x, weights, biases, ln_a, ln_b, *, norm, residual, drop_p, training, 
 # building blocks for the registry-only operators (GLU, convs, activations) and for LayerNorm
 # ------------------------------------------------------------------------------------------
 def gemm(layout, groups, N, K, lda, ldb, ldc, nseg=1, relu=False, split_k=1, alpha=1.0, drop=None,
-         gate_scale=1.0, ldres=0, ldgate=0):
+         gate_scale=1.0, ldres=0, ldgate=0, accumulate=False):
     """Thin wrapper over mmnas_gemm.  groups: list of dict(M, A=[..], B=[..], C, bias, residual, gate)."""
     g = L.GemmDesc()
     g.layout, g.ngroups, g.nseg, g.N, g.K = layout, len(groups), nseg, N, K
     g.lda, g.ldb, g.ldc, g.ldres, g.ldgate = lda, ldb, ldc, ldres, ldgate
     g.relu, g.split_k, g.alpha, g.gate_scale = int(relu), split_k, alpha, gate_scale
+    g.accumulate = int(accumulate)
     if drop is not None:
         g.drop_p, g.drop_seed, g.drop_site = drop
     for i, grp in enumerate(groups):
@@ -302,11 +303,6 @@ def gemm(layout, groups, N, K, lda, ldb, ldc, nseg=1, relu=False, split_k=1, alp
         gg.residual = L.fptr(grp.get('residual'))
         gg.gate = L.fptr(grp.get('gate'))
     L.check(L.lib().mmnas_gemm(C.byref(g), L.stream()))
-
-
-def _wgrad_split(M, N, K):
-    tiles = max(1, ((M + 63) // 64) * ((N + 63) // 64))
-    return max(1, min((1024 + tiles - 1) // tiles, max(K // 128, 1), 1024))
 
 
 class LinearFn(torch.autograd.Function):
@@ -338,8 +334,8 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:   # e.g. the relation/region feature inputs of the stem need none
             dx = torch.empty_like(x)
             gemm(L.GEMM_NN, [dict(M=M, A=[dy], B=[W], C=dx)], K, N, N, K, K)
-        dW = torch.zeros_like(W)
-        gemm(L.GEMM_TN, [dict(M=N, A=[dy], B=[x], C=dW)], K, M, N, K, K, split_k=_wgrad_split(N, K, M))
+        dW = torch.empty_like(W)
+        gemm(L.GEMM_TN, [dict(M=N, A=[dy], B=[x], C=dW)], K, M, N, K, K)
         db = None
         if ctx.has_bias:
             db = torch.zeros(N, dtype=torch.float32, device=x.device)

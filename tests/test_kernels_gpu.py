@@ -39,11 +39,37 @@ def test_dropout_mask_matches_numpy_restatement():
 
 
 # ----------------------------------------------------------------------------- GEMM
+@pytest.fixture
+def gemm_tuning():
+    """Set MMNAS_GEMM_* scheduling knobs for one test (the library caches them: reload after every change)."""
+    import os
+    import mmnas_amd._lib as L
+    saved = {}
+
+    def set_knobs(**kw):
+        for k, v in kw.items():
+            name = 'MMNAS_GEMM_' + k.upper()
+            saved.setdefault(name, os.environ.get(name))
+            if v is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = str(v)
+        L.lib().mmnas_gemm_reload_tuning()
+
+    yield set_knobs
+    for name, v in saved.items():
+        if v is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = v
+    L.lib().mmnas_gemm_reload_tuning()
+
+
 @pytest.mark.parametrize('layout', ['NT', 'NN', 'TN'])
 @pytest.mark.parametrize('M,N,K', [(896, 512, 512), (300, 192, 160), (64, 64, 32), (21, 3129, 1024),
                                    (130, 1, 64), (257, 130, 100), (6400, 256, 256)])
 @pytest.mark.parametrize('tile', [0, 64, 128])
-def test_gemm_layouts(layout, M, N, K, tile, monkeypatch):
+def test_gemm_layouts(layout, M, N, K, tile, gemm_tuning):
     from mmnas_amd import ops
     import mmnas_amd._lib as L
     if tile and (M * N > 400000):
@@ -63,10 +89,7 @@ def test_gemm_layouts(layout, M, N, K, tile, monkeypatch):
         lda, ldb = M, N
     Ad, Bd = g(A), g(B)
     Cd = torch.zeros(M, N, device=DEV)
-    if tile:
-        monkeypatch.setenv('MMNAS_GEMM_TILE', str(tile))  # read by mmnas_gemm on every call
-    else:
-        monkeypatch.delenv('MMNAS_GEMM_TILE', raising=False)
+    gemm_tuning(tile=tile or None)
     split = 1
     if layout == 'TN' and K >= 256:
         split = 3
@@ -117,10 +140,65 @@ def test_gemm_split_k_accumulates_onto_c():
     rs = np.random.RandomState(6)
     K, M, N = 6400, 256, 256
     A, B, C0 = rnd(rs, K, M), rnd(rs, K, N), rnd(rs, M, N)
-    C = g(C0)
-    ops.gemm(L.GEMM_TN, [dict(M=M, A=[g(A)], B=[g(B)], C=C)], N, K, M, N, N, split_k=16)
     ref = torch.from_numpy(C0).double() + torch.from_numpy(A).double().t() @ torch.from_numpy(B).double()
+    for kw in (dict(split_k=16), dict(accumulate=True)):     # split_k > 1 is the legacy spelling of accumulate
+        C = g(C0)
+        ops.gemm(L.GEMM_TN, [dict(M=M, A=[g(A)], B=[g(B)], C=C)], N, K, M, N, N, **kw)
+        assert rel_err(C.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('tile', [64, 128])
+@pytest.mark.parametrize('wgs,min_units', [(7, 1), (33, 1), (256, 2), (1024, 1), (0, 4)])
+def test_gemm_stream_k_partial_tiles(gemm_tuning, tile, wgs, min_units):
+    """Stream-K schedule: output tiles cut along K at arbitrary unit boundaries (forced through the tuning
+    knobs), grouped problems with different M, several K-segments, every epilogue term.  The result must
+    not depend on the cut, and must be bitwise identical from launch to launch (fixed summation order)."""
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    from oracle import dropout_rng
+    gemm_tuning(tile=tile, sk=2, min_units=min_units, wgs=wgs or None)
+    rs = np.random.RandomState(100 + tile + wgs)
+    td = lambda a: torch.from_numpy(a).double()
+    # NT, three groups, two K segments, bias + residual
+    Ms, N, K = [300, 77, 130], 200, 160
+    A = [[rnd(rs, m, K) for _ in range(2)] for m in Ms]
+    B = [[rnd(rs, N, K) for _ in range(2)] for _ in Ms]
+    bias = [rnd(rs, N) for _ in Ms]
+    res = [rnd(rs, m, N) for m in Ms]
+    outs = []
+    for rep in range(3):
+        Cs = [torch.full((m, N), float('nan'), device=DEV) for m in Ms]
+        groups = [dict(M=m, A=[g(x) for x in a], B=[g(x) for x in b], C=c, bias=g(bi), residual=g(r))
+                  for m, a, b, c, bi, r in zip(Ms, A, B, Cs, bias, res)]
+        ops.gemm(L.GEMM_NT, groups, N, K, K, K, N, nseg=2, ldres=N)
+        outs.append([c.cpu().numpy() for c in Cs])
+    for i in range(len(Ms)):
+        ref = sum(td(a) @ td(b).t() for a, b in zip(A[i], B[i])) + td(bias[i]) + td(res[i])
+        assert rel_err(outs[0][i], ref.numpy()) < 1e-5
+        assert np.array_equal(outs[0][i], outs[1][i]) and np.array_equal(outs[0][i], outs[2][i])
+    # NN with relu + dropout epilogue on a cut tile
+    M, N, K = 333, 96, 512
+    a, b = rnd(rs, M, K), rnd(rs, K, N)
+    seed, site, p = 987654321, 3, 0.3
+    C = torch.empty(M, N, device=DEV)
+    ops.gemm(L.GEMM_NN, [dict(M=M, A=[g(a)], B=[g(b)], C=C)], N, K, K, N, N, relu=True, drop=(p, seed, site))
+    ref = torch.relu(td(a) @ td(b)) * td(dropout_rng.scaled_mask(seed, site, (M, N), p))
     assert rel_err(C.cpu().numpy(), ref.numpy()) < 1e-5
+    # TN weight gradient accumulating onto C, long reduction, two groups
+    K, Ms, N = 1888, [96, 160], 72
+    A = [rnd(rs, K, m) for m in Ms]
+    B = [rnd(rs, K, N) for _ in Ms]
+    C0 = [rnd(rs, m, N) for m in Ms]
+    for m, x, y, c0 in zip(Ms, A, B, C0):
+        c = g(c0)
+        ops.gemm(L.GEMM_TN, [dict(M=m, A=[g(x)], B=[g(y)], C=c)], N, K, m, N, N, accumulate=True)
+        assert rel_err(c.cpu().numpy(), (td(c0) + td(x).t() @ td(y)).numpy()) < 1e-5
+    # odd K (generic guarded path) cut along K
+    M, N, K = 150, 130, 203
+    a, b = rnd(rs, M, K), rnd(rs, N, K)
+    C = torch.empty(M, N, device=DEV)
+    ops.gemm(L.GEMM_NT, [dict(M=M, A=[g(a)], B=[g(b)], C=C)], N, K, K, K, N)
+    assert rel_err(C.cpu().numpy(), (td(a) @ td(b).t()).numpy()) < 1e-5
 
 
 # ----------------------------------------------------------------------------- LayerNorm & friends

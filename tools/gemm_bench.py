@@ -33,18 +33,20 @@ def run(layout, Ms, N, K, nseg=1, split=1, iters=30):
     res = {}
     for tile in (64, 128):
         os.environ['MMNAS_GEMM_TILE'] = str(tile)
+        L.lib().mmnas_gemm_reload_tuning()
         for _ in range(3):
-            ops.gemm(lay, groups, N, K, lda, ldb, N, nseg=nseg, split_k=split)
+            ops.gemm(lay, groups, N, K, lda, ldb, N, nseg=nseg, accumulate=(layout == 'TN'))
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            ops.gemm(lay, groups, N, K, lda, ldb, N, nseg=nseg, split_k=split)
+            ops.gemm(lay, groups, N, K, lda, ldb, N, nseg=nseg, accumulate=(layout == 'TN'))
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / iters
         res[tile] = (flops / us / 1e6, us)
     os.environ.pop('MMNAS_GEMM_TILE', None)
+    L.lib().mmnas_gemm_reload_tuning()
     print('%-3s M=%-16s N=%-5d K=%-5d nseg=%d split=%-3d | t64: %6.1f TF %7.1f us | t128: %6.1f TF %7.1f us'
           % (layout, Ms, N, K, nseg, split, res[64][0], res[64][1], res[128][0], res[128][1]), flush=True)
 
