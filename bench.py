@@ -12,8 +12,9 @@ GPU:
 For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs its own batch
 (weak scaling) and the parameter gradients are averaged with RCCL all-reduce inside the step.
 Rank 0 prints ONE JSON line.  `roofline` is the fp32-MFMA GEMM kernel class (the dominant kernel:
->80 % of device time), measured with HIP events on the launch stream inside the timed region
-(mmnas_prof_*); `cpu_baseline` is the CPU oracle (a port of the reference step) timed on this
+~65 % of device time), measured with HIP events on the launch stream (mmnas_prof_*: start/stop events
+carried by each kernel's dispatch) over a repeat of the timed steps right after the timed region --
+the events cost ~9 % of a step, so they stay out of the throughput measurement; `cpu_baseline` is the CPU oracle (a port of the reference step) timed on this
 box's host cores on the same workload (rank 0, N = 1 only).
 """
 import argparse
@@ -240,20 +241,30 @@ def main():
     barrier()
     flops_acc[0] = 0.0
     prof_on = not args.no_prof
-    if prof_on:
-        L.check(lib.mmnas_prof_enable(1))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    timed_flops = flops_acc[0]
+    # Roofline pass: the same step repeated right after the timed region with every library launch carrying a
+    # start/stop HIP event (on the launch stream).  It is kept out of the timed region because the events
+    # themselves cost ~9 % of the step (a completion signal per dispatch); launches, shapes and data are identical.
     stats = None
+    prof_steps = min(args.steps, 10)
     if prof_on:
+        L.check(lib.mmnas_prof_enable(1))
+        tp = time.perf_counter()
+        for _ in range(prof_steps):
+            step()
+        barrier()
+        prof_elapsed = time.perf_counter() - tp
         arr = (L.ProfStat * len(L.K_NAMES))()
         L.check(lib.mmnas_prof_collect(arr))
         L.check(lib.mmnas_prof_enable(0))
         stats = {n: dict(ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes, launches=arr[i].launches)
                  for i, n in enumerate(L.K_NAMES)}
+    flops_acc[0] = timed_flops
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -285,11 +296,11 @@ def main():
                                'achieved': ach, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': ach / PEAK_MFMA_F32_TFLOPS, 'traffic': None,
                                'avg_launch_us': 1e3 * gm['ms'] / max(gm['launches'], 1),
-                               'launches_per_step': gm['launches'] / args.steps,
-                               'share_of_step_time': gm['ms'] * 1e-3 / elapsed}
+                               'launches_per_step': gm['launches'] / prof_steps,
+                               'share_of_step_time': gm['ms'] * 1e-3 / prof_elapsed}
             tot_ms = sum(s['ms'] for s in stats.values())
             out['kernel_classes'] = {
-                n: {'ms_per_step': s['ms'] / args.steps, 'launches_per_step': s['launches'] / args.steps,
+                n: {'ms_per_step': s['ms'] / prof_steps, 'launches_per_step': s['launches'] / prof_steps,
                     'tflops': (s['flops'] / (s['ms'] * 1e-3) / 1e12) if s['ms'] > 0 else 0.0,
                     'algorithmic_gbs': (s['bytes'] / (s['ms'] * 1e-3) / 1e9) if s['ms'] > 0 else 0.0}
                 for n, s in stats.items()}
@@ -298,7 +309,9 @@ def main():
                 out['hbm_kernel'] = {'kernel': 'rel_bias_bwd_kernel', 'bound': 'hbm',
                                      'achieved': rb['bytes'] / (rb['ms'] * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS,
                                      'unit': 'GB/s', 'frac': rb['bytes'] / (rb['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS}
-            out['instrumented_ms_per_step'] = tot_ms / args.steps
+            out['roofline_pass'] = {'steps': prof_steps, 'ms_per_step': 1000.0 * prof_elapsed / prof_steps,
+                                    'kernel_ms_per_step': tot_ms / prof_steps,
+                                    'note': 'same step repeated after the timed region with per-launch HIP events'}
         if world == 1 and not args.no_cpu_baseline:
             plan = None
             if args.workload == 'search_vqa':

@@ -528,7 +528,7 @@ static int mha_nw() {
 template <int DHC>
 static void launch_fwd(const MhaK& k, hipStream_t st) {
   const int nkc = cdiv(k.Sk, 32);
-#define FWD(NKC, NW) hipLaunchKernelGGL((mha_fwd_kernel<DHC, NKC, NW>), dim3(cdiv(k.Sq, 32 * NW), k.H, k.B), \
+#define FWD(NKC, NW) MMNAS_LAUNCH((mha_fwd_kernel<DHC, NKC, NW>), dim3(cdiv(k.Sq, 32 * NW), k.H, k.B), \
                                         dim3(64 * NW), 0, st, k)
   // waves per workgroup: 2 (64 queries) keeps the LDS image small enough for 2-3 workgroups per CU,
   // which hides the tile loads of one behind the MFMAs of another (MMNAS_MHA_NW=4 restores 128-query groups)
@@ -546,7 +546,7 @@ static void launch_fwd(const MhaK& k, hipStream_t st) {
 template <int DHC>
 static void launch_bwd(const MhaK& k, hipStream_t st) {
   const int nkc = cdiv(k.Sk, 32);
-#define BQ(NKC, NW) hipLaunchKernelGGL((mha_bwd_q_kernel<DHC, NKC, NW>), dim3(cdiv(k.Sq, 32 * NW), k.H * k.nch, k.B), \
+#define BQ(NKC, NW) MMNAS_LAUNCH((mha_bwd_q_kernel<DHC, NKC, NW>), dim3(cdiv(k.Sq, 32 * NW), k.H * k.nch, k.B), \
                                        dim3(64 * NW), 0, st, k)
   const int nwmax = mha_nw();
   if (k.Sq <= 32) { if (nkc <= 1) BQ(1, 1); else BQ(2, 1); }
@@ -560,7 +560,7 @@ static void launch_bwd(const MhaK& k, hipStream_t st) {
     else BQ(4, 4);
   }
 #undef BQ
-#define BKV(NW) hipLaunchKernelGGL((mha_bwd_kv_kernel<DHC, NW>), dim3(cdiv(k.Sk, 32 * NW), k.H * k.nch, k.B), \
+#define BKV(NW) MMNAS_LAUNCH((mha_bwd_kv_kernel<DHC, NW>), dim3(cdiv(k.Sk, 32 * NW), k.H * k.nch, k.B), \
                                    dim3(64 * NW), 0, st, k)
   if (nkc <= 1) BKV(1); else if (nkc <= 2 || nwmax == 2) BKV(2); else BKV(4);
 #undef BKV
@@ -596,7 +596,7 @@ extern "C" int mmnas_mha_core_bwd(const mmnas_mha_desc* d, void* stream) {
     const long n = (long)k.B * k.Sq * k.H;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(mha_delta_kernel, dim3(blocks), dim3(256), 0, st, k.dO, (const float*)d->O, k.delta, k.B, k.H,
+    MMNAS_LAUNCH(mha_delta_kernel, dim3(blocks), dim3(256), 0, st, k.dO, (const float*)d->O, k.delta, k.B, k.H,
                        k.Sq, k.dh, k.ldo);
   }
   if (k.dh >= 64) { k.nch = k.dh / 64; launch_bwd<64>(k, st); }

@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels (wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/mmnas_hip.h"
@@ -36,14 +37,28 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// RAII timing scope: when profiling is enabled (mmnas_prof_enable) a HIP event is recorded on the
-// launch stream before and after the enclosed launches, tagged with the algorithmic work.
+// RAII timing scope: when profiling is enabled (mmnas_prof_enable) the kernel launches enclosed by the scope
+// carry a start / stop HIP event in their own dispatch packets (hipExtLaunchKernelGGL through MMNAS_LAUNCH:
+// device timestamps of the first kernel's begin and the last kernel's end on the launch stream, without
+// the barrier packets a separate hipEventRecord costs -- bracketing with hipEventRecord slowed the
+// training step by 12 %), tagged with the algorithmic work.
 struct ProfScope {
   ProfScope(int kind, double flops, double bytes, hipStream_t st, const char* tag = nullptr);
   ~ProfScope();
   long idx_;
   hipStream_t st_;
 };
+
+struct ProfEvents { hipEvent_t start, stop; };
+ProfEvents prof_launch_events();  // events for the next launch of the active scope ({null, null}: none)
+
+// Every kernel launch of the library goes through this.
+#define MMNAS_LAUNCH(kernel, grid, block, shmem, stream, ...)                                            \
+  do {                                                                                                   \
+    const ::mmnas::ProfEvents pe_ = ::mmnas::prof_launch_events();                                       \
+    if (pe_.stop) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, pe_.start, pe_.stop, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                            \
+  } while (0)
 
 bool prof_enabled();
 

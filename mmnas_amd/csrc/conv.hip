@@ -125,7 +125,7 @@ extern "C" int mmnas_im2col_seq(const float* x, float* col, int B, int S, int d,
   int rc = conv_check("im2col_seq", B, S, d, k);
   if (rc) return rc;
   MMNAS_REQUIRE(d % 4 == 0, MMNAS_E_SHAPE, "im2col_seq: d=%d %% 4", d);
-  hipLaunchKernelGGL(im2col_kernel, dim3(nblocks((size_t)B * S * k * d / 4)), dim3(256), 0, (hipStream_t)stream, x, col,
+  MMNAS_LAUNCH(im2col_kernel, dim3(nblocks((size_t)B * S * k * d / 4)), dim3(256), 0, (hipStream_t)stream, x, col,
                      B, S, d, k);
   return check_launch("im2col_seq");
 }
@@ -135,7 +135,7 @@ extern "C" int mmnas_col2im_seq(const float* dcol, float* dx, int B, int S, int 
   int rc = conv_check("col2im_seq", B, S, d, k);
   if (rc) return rc;
   MMNAS_REQUIRE(d % 4 == 0, MMNAS_E_SHAPE, "col2im_seq: d=%d %% 4", d);
-  hipLaunchKernelGGL(col2im_kernel, dim3(nblocks((size_t)B * S * d / 4)), dim3(256), 0, (hipStream_t)stream, dcol, dx,
+  MMNAS_LAUNCH(col2im_kernel, dim3(nblocks((size_t)B * S * d / 4)), dim3(256), 0, (hipStream_t)stream, dcol, dx,
                      B, S, d, k);
   return check_launch("col2im_seq");
 }
@@ -145,7 +145,7 @@ extern "C" int mmnas_dwconv_seq_fwd(const float* x, const float* w, const float*
   MMNAS_REQUIRE(x && w && y, MMNAS_E_ARG, "dwconv_seq_fwd: null pointer");
   int rc = conv_check("dwconv_seq_fwd", B, S, d, k);
   if (rc) return rc;
-  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(nblocks((size_t)B * S * d)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+  MMNAS_LAUNCH(dwconv_fwd_kernel, dim3(nblocks((size_t)B * S * d)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                      y, B, S, d, k);
   return check_launch("dwconv_seq_fwd");
 }
@@ -156,12 +156,12 @@ extern "C" int mmnas_dwconv_seq_bwd(const float* x, const float* w, const float*
   int rc = conv_check("dwconv_seq_bwd", B, S, d, k);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(dwconv_bwd_x_kernel, dim3(nblocks((size_t)B * S * d)), dim3(256), 0, st, dy, w, dx, B, S, d, k);
+  MMNAS_LAUNCH(dwconv_bwd_x_kernel, dim3(nblocks((size_t)B * S * d)), dim3(256), 0, st, dy, w, dx, B, S, d, k);
   const long M = (long)B * S;
   int splits = (int)((M + 63) / 64);
   if (splits > 256) splits = 256;
   const int rpb = (int)((M + splits - 1) / splits);
-  hipLaunchKernelGGL(dwconv_bwd_w_kernel<11>, dim3(cdiv(d, 256), cdiv(M, rpb)), dim3(256), 0, st, x, dy, dw, db, B, S, d,
+  MMNAS_LAUNCH(dwconv_bwd_w_kernel<11>, dim3(cdiv(d, 256), cdiv(M, rpb)), dim3(256), 0, st, x, dy, dw, db, B, S, d,
                      k, rpb);
   return check_launch("dwconv_seq_bwd");
 }

@@ -549,9 +549,9 @@ template <int BM, int BN, bool FAST>
 static int launch(GemmK& k, int layout, int nwg, hipStream_t st) {
   dim3 grid(nwg), block(256);
   switch (layout) {
-    case MMNAS_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, FAST>), grid, block, 0, st, k); break;
-    case MMNAS_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, FAST>), grid, block, 0, st, k); break;
-    default: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, FAST>), grid, block, 0, st, k); break;
+    case MMNAS_GEMM_NT: MMNAS_LAUNCH((gemm_kernel<BM, BN, true, true, FAST>), grid, block, 0, st, k); break;
+    case MMNAS_GEMM_NN: MMNAS_LAUNCH((gemm_kernel<BM, BN, true, false, FAST>), grid, block, 0, st, k); break;
+    default: MMNAS_LAUNCH((gemm_kernel<BM, BN, false, false, FAST>), grid, block, 0, st, k); break;
   }
   return check_launch("gemm");
 }

@@ -180,7 +180,7 @@ extern "C" int mmnas_rel_bias_fwd(const float* rel, const float* Wr, const float
   const int blocks = (int)(need < 4096 ? (need ? need : 1) : 4096);
   // algorithmic traffic: rel read once + bias written once
   ProfScope ps(MMNAS_K_REL_FWD, 2.0 * nrows * R * H, 4.0 * ((double)nrows * R + (double)nrows * H), st);
-#define FWDK(LPR, HM, ...) hipLaunchKernelGGL((rel_bias_fwd_kernel<LPR, HM>), dim3(blocks), dim3(256), 0, st, __VA_ARGS__)
+#define FWDK(LPR, HM, ...) MMNAS_LAUNCH((rel_bias_fwd_kernel<LPR, HM>), dim3(blocks), dim3(256), 0, st, __VA_ARGS__)
   REL_DISPATCH(FWDK, rel, Wr, br, biasT, B, Sq, Sk, H);
 #undef FWDK
   return check_launch("rel_bias_fwd");
@@ -199,7 +199,7 @@ extern "C" int mmnas_rel_bias_bwd(const float* rel, const float* Wr, const float
   // algorithmic traffic: rel read once, d_rel written once, dbias read once
   ProfScope ps(MMNAS_K_REL_BWD, 6.0 * nrows * R * H,
                4.0 * ((double)nrows * R * (drel ? 2.0 : 1.0) + (double)nrows * H), st);
-#define BWDK(LPR, HM, ...) hipLaunchKernelGGL((rel_bias_bwd_kernel<LPR, HM>), dim3(blocks), dim3(256), 0, st, __VA_ARGS__)
+#define BWDK(LPR, HM, ...) MMNAS_LAUNCH((rel_bias_bwd_kernel<LPR, HM>), dim3(blocks), dim3(256), 0, st, __VA_ARGS__)
   REL_DISPATCH(BWDK, rel, Wr, br, dbiasT, drel, dWr, dbr, accumulate_drel, B, Sq, Sk, H);
 #undef BWDK
   return check_launch("rel_bias_bwd");

@@ -243,8 +243,8 @@ extern "C" int mmnas_rel_fused_fwd(const float* raw, const float* Wy, const floa
   hipStream_t st = (hipStream_t)stream;
   const double n = (double)B * Sq * Sk;
   ProfScope ps(MMNAS_K_REL_FWD, 2.0 * n * (RF_R * (C + 1) + (double)H * RF_R), 4.0 * n * (C + H), st);
-  if (C == 4) hipLaunchKernelGGL(rel_fused_fwd_kernel<4>, dim3((unsigned)nbatch), dim3(256), 0, st, k, Wy, by, Wr, br);
-  else hipLaunchKernelGGL(rel_fused_fwd_kernel<3>, dim3((unsigned)nbatch), dim3(256), 0, st, k, Wy, by, Wr, br);
+  if (C == 4) MMNAS_LAUNCH(rel_fused_fwd_kernel<4>, dim3((unsigned)nbatch), dim3(256), 0, st, k, Wy, by, Wr, br);
+  else MMNAS_LAUNCH(rel_fused_fwd_kernel<3>, dim3((unsigned)nbatch), dim3(256), 0, st, k, Wy, by, Wr, br);
   return check_launch("rel_fused_fwd");
 }
 
@@ -269,13 +269,13 @@ extern "C" int mmnas_rel_fused_bwd(const float* raw, const float* Wy, const floa
   const double n = (double)B * Sq * Sk;
   ProfScope ps(MMNAS_K_REL_BWD, 2.0 * n * (RF_R * (C + 1) + 3.0 * H * RF_R + RF_R * (C + 1)), 4.0 * n * (C + H), st);
   if (H <= 8) {
-    if (C == 4) hipLaunchKernelGGL((rel_fused_bwd_kernel<4, 8>), dim3(grid), dim3(256), 0, st, k, nbatch, Wy, by, Wr, br);
-    else hipLaunchKernelGGL((rel_fused_bwd_kernel<3, 8>), dim3(grid), dim3(256), 0, st, k, nbatch, Wy, by, Wr, br);
+    if (C == 4) MMNAS_LAUNCH((rel_fused_bwd_kernel<4, 8>), dim3(grid), dim3(256), 0, st, k, nbatch, Wy, by, Wr, br);
+    else MMNAS_LAUNCH((rel_fused_bwd_kernel<3, 8>), dim3(grid), dim3(256), 0, st, k, nbatch, Wy, by, Wr, br);
   } else {
-    if (C == 4) hipLaunchKernelGGL((rel_fused_bwd_kernel<4, 32>), dim3(grid), dim3(256), 0, st, k, nbatch, Wy, by, Wr, br);
-    else hipLaunchKernelGGL((rel_fused_bwd_kernel<3, 32>), dim3(grid), dim3(256), 0, st, k, nbatch, Wy, by, Wr, br);
+    if (C == 4) MMNAS_LAUNCH((rel_fused_bwd_kernel<4, 32>), dim3(grid), dim3(256), 0, st, k, nbatch, Wy, by, Wr, br);
+    else MMNAS_LAUNCH((rel_fused_bwd_kernel<3, 32>), dim3(grid), dim3(256), 0, st, k, nbatch, Wy, by, Wr, br);
   }
-  hipLaunchKernelGGL(rel_fused_reduce_kernel, dim3(cdiv(RF_ROW, 64)), dim3(256), 0, st, ws, grid * 2, C, H, dWr, dbr, dWy,
+  MMNAS_LAUNCH(rel_fused_reduce_kernel, dim3(cdiv(RF_ROW, 64)), dim3(256), 0, st, ws, grid * 2, C, H, dWr, dbr, dWy,
                      dby);
   return check_launch("rel_fused_bwd");
 }

@@ -305,10 +305,10 @@ extern "C" int mmnas_layernorm_fwd(const float* x, const float* a, const float* 
   dim3 grid(cdiv(M, 4)), block(256);
   const int nv = cdiv(d, 256);
   ProfScope ps(MMNAS_K_ROWOPS, 8.0 * M * d, 8.0 * M * d, st);
-  if (nv <= 1) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, st, x, a, b, y, M, d, eps);
-  else if (nv <= 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, st, x, a, b, y, M, d, eps);
-  else if (nv <= 4) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, st, x, a, b, y, M, d, eps);
-  else hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, st, x, a, b, y, M, d, eps);
+  if (nv <= 1) MMNAS_LAUNCH(ln_fwd_kernel<1>, grid, block, 0, st, x, a, b, y, M, d, eps);
+  else if (nv <= 2) MMNAS_LAUNCH(ln_fwd_kernel<2>, grid, block, 0, st, x, a, b, y, M, d, eps);
+  else if (nv <= 4) MMNAS_LAUNCH(ln_fwd_kernel<4>, grid, block, 0, st, x, a, b, y, M, d, eps);
+  else MMNAS_LAUNCH(ln_fwd_kernel<8>, grid, block, 0, st, x, a, b, y, M, d, eps);
   return check_launch("layernorm_fwd");
 }
 
@@ -332,10 +332,10 @@ extern "C" int mmnas_layernorm_bwd(const float* x, const float* a, const float* 
   const DropCfg dc = make_drop(drop_p, seed, site);
   const int nv = cdiv(d, 256);
   ProfScope ps(MMNAS_K_ROWOPS, 16.0 * M * d, 4.0 * M * d * (ddrop ? 4.0 : 3.0), st);
-#define LNB(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, 0, st, x, a, dy, dx, da, db, ddrop, dcol, ws, dc, M, d, eps)
+#define LNB(NV) MMNAS_LAUNCH(ln_bwd_kernel<NV>, grid, block, 0, st, x, a, dy, dx, da, db, ddrop, dcol, ws, dc, M, d, eps)
   if (nv <= 1) LNB(1); else if (nv <= 2) LNB(2); else if (nv <= 4) LNB(4); else LNB(8);
 #undef LNB
-  if (ws) hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(d, 16), 3), dim3(1024), 0, st, ws, nb, d, da, db, dcol);
+  if (ws) MMNAS_LAUNCH(ln_bwd_reduce_kernel, dim3(cdiv(d, 16), 3), dim3(1024), 0, st, ws, nb, d, da, db, dcol);
   return check_launch("layernorm_bwd");
 }
 
@@ -347,7 +347,7 @@ extern "C" int mmnas_colsum(const float* x, float* out, int M, int N, int ldx, v
   if (splits > want) splits = want;
   if (splits < 1) splits = 1;
   const int rpb = cdiv(M, splits);
-  hipLaunchKernelGGL(colsum_kernel, dim3(colblocks, cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, x, out, M,
+  MMNAS_LAUNCH(colsum_kernel, dim3(colblocks, cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, x, out, M,
                      N, ldx, rpb);
   return check_launch("colsum");
 }
@@ -355,34 +355,34 @@ extern "C" int mmnas_colsum(const float* x, float* out, int M, int N, int ldx, v
 extern "C" int mmnas_eltwise_fwd(int kind, const float* x, float* y, size_t n, void* stream) {
   MMNAS_REQUIRE(kind >= 0 && kind <= 3 && x && y, MMNAS_E_ARG, "eltwise_fwd: bad arguments");
   if (n == 0) return MMNAS_OK;
-  hipLaunchKernelGGL(eltwise_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, kind, x, y, n);
+  MMNAS_LAUNCH(eltwise_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, kind, x, y, n);
   return check_launch("eltwise_fwd");
 }
 extern "C" int mmnas_eltwise_bwd(int kind, const float* x, const float* dy, float* dx, size_t n, void* stream) {
   MMNAS_REQUIRE(kind >= 0 && kind <= 3 && x && dy && dx, MMNAS_E_ARG, "eltwise_bwd: bad arguments");
   if (n == 0) return MMNAS_OK;
-  hipLaunchKernelGGL(eltwise_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, kind, x, dy, dx, n);
+  MMNAS_LAUNCH(eltwise_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, kind, x, dy, dx, n);
   return check_launch("eltwise_bwd");
 }
 extern "C" int mmnas_drop_add(const float* x, const float* res, float* y, size_t n, float drop_p, uint64_t seed,
                               uint32_t site, void* stream) {
   MMNAS_REQUIRE(x && y && n < (1ull << 32), MMNAS_E_ARG, "drop_add: bad arguments");
   if (n == 0) return MMNAS_OK;
-  hipLaunchKernelGGL(drop_add_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, res, y, n,
+  MMNAS_LAUNCH(drop_add_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, res, y, n,
                      make_drop(drop_p, seed, site));
   return check_launch("drop_add");
 }
 extern "C" int mmnas_glu_fwd(const float* h, float* y, int M, int C, int relu, float drop_p, uint64_t seed,
                              uint32_t site, void* stream) {
   MMNAS_REQUIRE(h && y && M > 0 && C > 0, MMNAS_E_ARG, "glu_fwd: bad arguments");
-  hipLaunchKernelGGL(glu_fwd_kernel, dim3(blocks_for((size_t)M * C)), dim3(256), 0, (hipStream_t)stream, h, y, M, C,
+  MMNAS_LAUNCH(glu_fwd_kernel, dim3(blocks_for((size_t)M * C)), dim3(256), 0, (hipStream_t)stream, h, y, M, C,
                      relu, make_drop(drop_p, seed, site));
   return check_launch("glu_fwd");
 }
 extern "C" int mmnas_glu_bwd(const float* h, const float* dy, float* dh, int M, int C, int relu, float drop_p,
                              uint64_t seed, uint32_t site, void* stream) {
   MMNAS_REQUIRE(h && dy && dh && M > 0 && C > 0, MMNAS_E_ARG, "glu_bwd: bad arguments");
-  hipLaunchKernelGGL(glu_bwd_kernel, dim3(blocks_for((size_t)M * C)), dim3(256), 0, (hipStream_t)stream, h, dy, dh, M,
+  MMNAS_LAUNCH(glu_bwd_kernel, dim3(blocks_for((size_t)M * C)), dim3(256), 0, (hipStream_t)stream, h, dy, dh, M,
                      C, relu, make_drop(drop_p, seed, site));
   return check_launch("glu_bwd");
 }

@@ -48,22 +48,40 @@ static hipEvent_t get_event() {
 
 bool prof_enabled() { return prof::enabled; }
 
+struct ActiveScope { long idx; bool started; };
+static thread_local ActiveScope g_active = {-1, false};
+
 ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t st, const char* tag) : idx_(-1), st_(st) {
-  if (!prof::enabled) return;
+  if (!prof::enabled || g_active.idx >= 0) return;  // (scopes do not nest: the outer one keeps the launches)
   std::lock_guard<std::mutex> g(prof::mu);
   prof::Rec r;
   r.a = prof::get_event(); r.b = prof::get_event(); r.kind = kind; r.flops = flops; r.bytes = bytes;
   r.tag[0] = 0;
   if (tag) { strncpy(r.tag, tag, sizeof(r.tag) - 1); r.tag[sizeof(r.tag) - 1] = 0; }
-  hipEventRecord(r.a, st);
   idx_ = (long)prof::recs.size();
   prof::recs.push_back(r);
+  g_active.idx = idx_;
+  g_active.started = false;
 }
 
 ProfScope::~ProfScope() {
   if (idx_ < 0) return;
+  if (!g_active.started) {  // no kernel was launched inside the scope: drop the record
+    std::lock_guard<std::mutex> g(prof::mu);
+    prof::recs[idx_].kind = -1;
+  }
+  g_active.idx = -1;
+}
+
+ProfEvents prof_launch_events() {
+  ProfEvents e = {nullptr, nullptr};
+  if (g_active.idx < 0) return e;
   std::lock_guard<std::mutex> g(prof::mu);
-  hipEventRecord(prof::recs[idx_].b, st_);
+  const prof::Rec& r = prof::recs[g_active.idx];
+  e.start = g_active.started ? nullptr : r.a;
+  e.stop = r.b;
+  g_active.started = true;
+  return e;
 }
 
 __global__ void dropout_mask_kernel(float* out, size_t n, DropCfg c) {
@@ -135,6 +153,7 @@ extern "C" int mmnas_prof_collect(mmnas_prof_stat* stats) {
   const char* dump = getenv("MMNAS_PROF_DUMP");
   FILE* df = dump && dump[0] ? fopen(dump, "a") : nullptr;
   for (const prof::Rec& r : prof::recs) {
+    if (r.kind < 0) continue;
     if (hipEventSynchronize(r.b) != hipSuccess) continue;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
@@ -156,7 +175,7 @@ extern "C" int mmnas_dropout_mask(float* out, size_t n, float p, uint64_t seed, 
   if (n == 0) return MMNAS_OK;
   MMNAS_REQUIRE(n < (1ull << 32), MMNAS_E_SHAPE, "mmnas_dropout_mask: n too large");
   const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-  hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, n,
+  MMNAS_LAUNCH(dropout_mask_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, n,
                      make_drop(p, seed, site));
   return check_launch("dropout_mask");
 }
@@ -165,7 +184,7 @@ extern "C" int mmnas_pack_segments(const mmnas_segment* segs, int nseg, float* s
                                    int direction, void* stream) {
   if (nseg <= 0) return MMNAS_OK;
   MMNAS_REQUIRE(segs && staging, MMNAS_E_ARG, "mmnas_pack_segments: null pointer");
-  hipLaunchKernelGGL(pack_kernel, dim3(64, nseg), dim3(256), 0, (hipStream_t)stream, segs, staging, scale, direction);
+  MMNAS_LAUNCH(pack_kernel, dim3(64, nseg), dim3(256), 0, (hipStream_t)stream, segs, staging, scale, direction);
   return check_launch("pack_segments");
 }
 
@@ -177,7 +196,7 @@ extern "C" int mmnas_adam_step(float* p, const float* g, float* m, float* v, siz
   const float c1 = 1.f - powf(beta1, (float)step);
   const float c2 = sqrtf(1.f - powf(beta2, (float)step));
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+  MMNAS_LAUNCH(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
                      beta2, eps, weight_decay, sumsq, max_norm, c1, c2);
   return check_launch("adam_step");
 }
@@ -186,6 +205,6 @@ extern "C" int mmnas_sumsq(const float* g, size_t n, float* out, void* stream) {
   if (n == 0) return MMNAS_OK;
   MMNAS_REQUIRE(g && out, MMNAS_E_ARG, "mmnas_sumsq: null pointer");
   const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  MMNAS_LAUNCH(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
   return check_launch("sumsq");
 }
