@@ -75,108 +75,277 @@ __global__ void __launch_bounds__(256) rel_fused_fwd_kernel(const RelFusedK p, c
   }
 }
 
-// workspace row layout per (workgroup, element-half): [ dWr: HP x R | dWy_ext: R x CP | dbr: HP ]
+// workspace row layout per workgroup: [ dWr: HP x R | dWy_ext: R x CP | dbr: HP ]
 constexpr int RF_ROW = RF_HP * RF_R + RF_R * RF_CP + RF_HP;
+constexpr int RF_LDH = RF_R + 4;   // LDS row stride of the hid / dhid image (16-byte aligned rows, odd in 16-byte units)
 
-// LDS image of hid/dhid: [element][64] with the column rotated by the element index -- unpadded (so two
-// workgroups fit in a CU's 160 KB) yet conflict-free both for the per-thread row writes (lane = element)
-// and for the MFMA operand reads (lane = column)
-__device__ __forceinline__ int rf_sw(int e, int j) { return e * RF_R + ((j + e) & (RF_R - 1)); }
-
-template <int C, int HP>   // HP = heads padded: 8 (H <= 8, 80 KB LDS -> 2 workgroups/CU) or 32
-__global__ void __launch_bounds__(256) rel_fused_bwd_kernel(const RelFusedK p, long nbatch, const float* __restrict__ Wy,
-                                                            const float* __restrict__ by, const float* __restrict__ Wr,
-                                                            const float* __restrict__ br) {
-  __shared__ float sHid[256 * RF_R];         // hid, then dhid, of the 256 elements of a batch
-  __shared__ float sDpre[256 * HP];          // dpre[e][h], zero beyond H
-  __shared__ float sRaw[256 * RF_CP];        // raw[e][c], 1 at c = C, zero beyond
+// Backward, one 32-element tile per wave at a time, everything on the fp32 MFMA (32x32x2), chained through the
+// accumulator layout so no intermediate leaves the registers until the two parameter-gradient contractions:
+//   1. hid^T[j,e]  = relu(Wy_ext[j,:] . raw_ext[e,:])        A = Wy|by (constant per lane), B = the lane's raw row
+//   2. r[h,e]      = Wr[h,:] . hid[:,e]                       B = the hid accumulators themselves (k runs in
+//                                                               accumulator order; A = Wr gathered in that order)
+//   3. dpre[h,e]   = dbias / r  (r >= 1e-6)                   lane (e, half) owns heads 8g + 4*half + 0..3
+//   4. dhid^T[j,e] = relu'(hid) * Wr[:,j] . dpre[:,e]         B = dpre registers, A = Wr^T (constant per lane)
+//   5. dWr[h,j] += sum_e dpre[h,e] hid[j,e],  dWy_ext[j,c] += sum_e dhid[j,e] raw_ext[e,c]: the reduction index e
+//      sits on the lanes of both operands, so hid / dhid / dpre / raw go through a wave-private LDS image
+//      ([e][.] rows, no workgroup barrier anywhere) and come back with e as the MFMA k index.
+// The previous version kept hid[64] and dhid[64] per thread in VGPRs (1 wave per SIMD) and streamed the
+// weights through ~1300 scalar loads per element: 285 us per launch, latency-bound.
+template <int C, int NG>   // NG = groups of 8 heads (H <= 8 * NG)
+__global__ void __launch_bounds__(256, NG == 1 ? 2 : 1)
+rel_fused_bwd_kernel(const RelFusedK p, long ntiles, int tiles_per_b, const float* __restrict__ Wy,
+                     const float* __restrict__ by, const float* __restrict__ Wr, const float* __restrict__ br) {
+  constexpr int DP = 8 * NG;
+  __shared__ __attribute__((aligned(16))) float sHidAll[4][32 * RF_LDH];
+  __shared__ __attribute__((aligned(16))) float sDpreAll[4][32 * DP];
+  __shared__ __attribute__((aligned(16))) float sRawAll[4][32 * RF_CP];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-  const int jt = w & 1, eh = w >> 1;         // this wave's 32-column tile and 128-element half
-  for (int i = tid; i < 256 * HP; i += 256) sDpre[i] = 0.f;
-  f32x16 accWr, accWy;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { accWr[r] = 0.f; accWy[r] = 0.f; }
-  float accbr = 0.f;                          // wave 0: lane l31 = head, hh = element parity
-  const bool arow = l31 < HP;                 // A-operand rows beyond the padded heads are zero
-  const int hcl = arow ? l31 : 0;
+  float* sHid = sHidAll[w];
+  float* sDpre = sDpreAll[w];
+  float* sRaw = sRawAll[w];
+  const int H = p.H;
 
-  for (long batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
-    int b, q, k;
-    const bool ok = rf_coords(p, batch, tid, b, q, k);
-    float rawv[C], hid[RF_R];
-    rf_hidden<C>(p, Wy, by, ok, b, q, k, rawv, hid);
-    __syncthreads();                          // previous batch's MFMA reads are done
+  // ---- per-lane constant MFMA operands ----
+  float wyA[2][4];       // step 1, A[i = j][k = c]
 #pragma unroll
-    for (int j = 0; j < RF_R; ++j) sHid[rf_sw(tid, j)] = ok ? hid[j] : 0.f;
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int c = 0; c < RF_CP; ++c) sRaw[tid * RF_CP + c] = !ok ? 0.f : (c < C ? rawv[c < C ? c : 0] : (c == C ? 1.f : 0.f));
-    float dh[RF_R];
-#pragma unroll
-    for (int j = 0; j < RF_R; ++j) dh[j] = 0.f;
-    for (int h = 0; h < p.H; ++h) {
-      float r = br[h];
-      const float* wr = Wr + h * RF_R;
-      // unconditional (clamped) load, issued before the 64-FMA dot so its latency is covered
-      const float db = p.dbiasT[(((size_t)b * p.H + h) * p.Sk + (ok ? k : 0)) * p.Sq + (ok ? q : 0)];
-#pragma unroll
-      for (int j = 0; j < RF_R; ++j) r += wr[j] * hid[j];
-      const float dpre = (ok && r >= 1e-6f) ? db / r : 0.f;
-      sDpre[tid * HP + h] = dpre;
-#pragma unroll
-      for (int j = 0; j < RF_R; ++j) dh[j] += dpre * wr[j];
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int j = 32 * t + l31, c = 2 * s4 + hh;
+      wyA[t][s4] = c < C ? Wy[j * C + c] : (c == C ? by[j] : 0.f);
     }
-    __syncthreads();
-    // dWr[h][j] += sum_e dpre[e][h] * hid[e][j]   (A = dpre^T, B = hid); operands fetched 8 steps ahead
+  // step 2, A[i = h][k = j in accumulator order]: 32 values per lane, identical for the 4 waves -> one LDS image
+  // [step][lane] (keeps 32 VGPRs free: with them in registers the kernel spilled)
+  __shared__ float sWrA[32 * 64];
+  if (w == 0) {
 #pragma unroll
-    for (int t0 = 0; t0 < 64; t0 += 8) {
-      float av[8], bv[8];
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = 128 * eh + 2 * (t0 + u) + hh;
-        av[u] = sDpre[e * HP + hcl];
-        bv[u] = sHid[rf_sw(e, 32 * jt + l31)];
+      for (int r = 0; r < 16; ++r)
+        sWrA[(16 * t + r) * 64 + lane] = l31 < H ? Wr[l31 * RF_R + 32 * t + acc_row(r, hh)] : 0.f;
+  }
+  __syncthreads();
+  float wrT[2][NG][4];   // step 4, A[i = j][k = h]
+  float brv[NG][4];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = 8 * g + r + 4 * hh;
+      brv[g][r] = h < H ? br[h] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) wrT[t][g][r] = h < H ? Wr[h * RF_R + 32 * t + l31] : 0.f;
+    }
+
+  f32x16 accWr[2], accWy[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accWr[t][r] = 0.f; accWy[t][r] = 0.f; }
+  float accbr[NG][4];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) accbr[g][r] = 0.f;
+
+  const long SS = (long)p.Sq * p.Sk;
+  const long nwaves = (long)gridDim.x * 4;
+  // loads of one tile: the lane's raw row (gathered, 16 B) and its heads' dbias; issued one tile ahead
+  float ext[RF_CP], db[NG][4];
+  auto tile_load = [&](long tile, float* ex, float (*dbv)[4]) {
+    // element of this lane: b, flattened f = k * Sq + q (dbiasT is contiguous in f)
+    const int b = (int)(tile / tiles_per_b);
+    const long f = (tile - (long)b * tiles_per_b) * 32 + l31;
+    const bool ok = tile < ntiles && f < SS;
+    const long fc = ok ? f : 0;
+    const int bc = ok ? b : 0;
+    const int k = (int)(fc / p.Sq), q = (int)(fc - (long)k * p.Sq);
+    const float* src = p.raw + (((size_t)bc * p.Sq + q) * p.Sk + k) * C;
+#pragma unroll
+    for (int c = 0; c < RF_CP; ++c) ex[c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) ex[c] = ok ? src[c] : 0.f;   // (address clamped above: the load itself is unconditional)
+    ex[C] = ok ? 1.f : 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int h = 8 * g + r + 4 * hh;
+        const float v = p.dbiasT[((size_t)bc * H + (h < H ? h : 0)) * SS + fc];
+        dbv[g][r] = (ok && h < H) ? v : 0.f;
+      }
+  };
+  long tile = (long)blockIdx.x * 4 + w;
+  tile_load(tile, ext, db);
+  for (; tile < ntiles; tile += nwaves) {
+    float ext_n[RF_CP], db_n[NG][4];
+    tile_load(tile + nwaves, ext_n, db_n);   // in flight during this tile's MFMA chain
+    // 1. hidden layer (transposed: rows j, columns e)
+    f32x16 hid[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hid[t][r] = 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) hid[t] = mfma32(wyA[t][s4], hh ? ext[2 * s4 + 1] : ext[2 * s4], hid[t]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hid[t][r] = fmaxf(hid[t][r], 0.f);
+    }
+    // 2. r[h, e]
+    f32x16 rr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rr[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rr = mfma32(sWrA[(16 * t + r) * 64 + lane], hid[t][r], rr);
+    // 3. d(log max(r, 1e-6)) / dr
+    float dpre[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float rv = rr[4 * g + r] + brv[g][r];
+        dpre[g][r] = rv >= 1e-6f ? db[g][r] / rv : 0.f;
+        accbr[g][r] += dpre[g][r];
+      }
+    // 4. gradient of the hidden layer, gated by relu'
+    f32x16 dh[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dh[t][r] = 0.f;
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh[t] = mfma32(wrT[t][g][r], dpre[g][r], dh[t]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dh[t][r] = hid[t][r] > 0.f ? dh[t][r] : 0.f;
+    }
+    // 5. transposes through the wave's LDS image.  LDS operations of one wave execute in order; the waits only
+    //    keep the compiler from moving a read above the write it depends on.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        *reinterpret_cast<float4*>(sHid + l31 * RF_LDH + 32 * t + 8 * u + 4 * hh) =
+            make_float4(hid[t][4 * u], hid[t][4 * u + 1], hid[t][4 * u + 2], hid[t][4 * u + 3]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      *reinterpret_cast<float4*>(sDpre + l31 * DP + 8 * g + 4 * hh) = make_float4(dpre[g][0], dpre[g][1], dpre[g][2], dpre[g][3]);
+    if (hh == 0) {
+      *reinterpret_cast<float4*>(sRaw + l31 * RF_CP) = make_float4(ext[0], ext[1], ext[2], ext[3]);
+      *reinterpret_cast<float4*>(sRaw + l31 * RF_CP + 4) = make_float4(ext[4], ext[5], ext[6], ext[7]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // 5a. dWr[h, j] += sum_e dpre[h, e] hid[j, e]
+    const int hcl = l31 < DP ? l31 : 0;
+#pragma unroll
+    for (int s0 = 0; s0 < 16; s0 += 4) {
+      float av[4], b0[4], b1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = 2 * (s0 + u) + hh;
+        av[u] = sDpre[e * DP + hcl];
+        b0[u] = sHid[e * RF_LDH + l31];
+        b1[u] = sHid[e * RF_LDH + 32 + l31];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) accWr = mfma32(arow ? av[u] : 0.f, bv[u], accWr);
+      for (int u = 0; u < 4; ++u) {
+        const float a = l31 < DP ? av[u] : 0.f;
+        accWr[0] = mfma32(a, b0[u], accWr[0]);
+        accWr[1] = mfma32(a, b1[u], accWr[1]);
+      }
     }
-    if (w == 0 && arow) {
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll 8
-      for (int e = hh; e < 256; e += 4) { s0 += sDpre[e * HP + l31]; s1 += sDpre[(e + 2) * HP + l31]; }
-      accbr += s0 + s1;
-    }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < RF_R; ++j) sHid[rf_sw(tid, j)] = (ok && hid[j] > 0.f) ? dh[j] : 0.f;   // relu' gate
-    __syncthreads();
-    // dWy_ext[j][c] += sum_e dhid[e][j] * rawext[e][c]   (A = dhid^T, B = raw | 1)
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        *reinterpret_cast<float4*>(sHid + l31 * RF_LDH + 32 * t + 8 * u + 4 * hh) =
+            make_float4(dh[t][4 * u], dh[t][4 * u + 1], dh[t][4 * u + 2], dh[t][4 * u + 3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // 5b. dWy_ext[j, c] += sum_e dhid[j, e] raw_ext[e, c]   (column C of raw_ext is 1: dby)
     const int ccl = l31 < RF_CP ? l31 : 0;
 #pragma unroll
-    for (int t0 = 0; t0 < 64; t0 += 8) {
-      float av[8], bv[8];
+    for (int s0 = 0; s0 < 16; s0 += 4) {
+      float a0[4], a1[4], bv[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = 128 * eh + 2 * (t0 + u) + hh;
-        av[u] = sHid[rf_sw(e, 32 * jt + l31)];
+      for (int u = 0; u < 4; ++u) {
+        const int e = 2 * (s0 + u) + hh;
+        a0[u] = sHid[e * RF_LDH + l31];
+        a1[u] = sHid[e * RF_LDH + 32 + l31];
         bv[u] = sRaw[e * RF_CP + ccl];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) accWy = mfma32(av[u], l31 < RF_CP ? bv[u] : 0.f, accWy);
+      for (int u = 0; u < 4; ++u) {
+        const float bb = l31 < RF_CP ? bv[u] : 0.f;
+        accWy[0] = mfma32(a0[u], bb, accWy[0]);
+        accWy[1] = mfma32(a1[u], bb, accWy[1]);
+      }
     }
-  }
-  // partial row of this (workgroup, element-half): waves with the same eh fill disjoint column tiles
-  float* row = p.part + ((size_t)blockIdx.x * 2 + eh) * RF_ROW;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = acc_row(r, hh);
-    row[i * RF_R + 32 * jt + l31] = accWr[r];                       // dWr[h = i][j]
-    if (l31 < RF_CP) row[RF_HP * RF_R + (32 * jt + i) * RF_CP + l31] = accWy[r];   // dWy_ext[j][c]
+    for (int c = 0; c < RF_CP; ++c) ext[c] = ext_n[c];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) db[g][r] = db_n[g][r];
   }
-  if (w == 0) {
-    accbr += __shfl_xor(accbr, 32, 64);
-    if (hh == 0) row[RF_HP * RF_R + RF_R * RF_CP + l31] = arow ? accbr : 0.f;
+
+  // ---- the workgroup's partial row: the 4 waves add their accumulators in wave order through LDS (fixed order:
+  //      reproducible), the last one writes the row ----
+  __syncthreads();                    // every wave is done with its LDS image
+  float* srow = &sHidAll[0][0];       // 4 * 32 * RF_LDH floats >= RF_ROW
+  static_assert(4 * 32 * RF_LDH >= RF_ROW, "partial row does not fit the hid images");
+  float* grow = p.part + (size_t)blockIdx.x * RF_ROW;
+  float brsum[NG][4];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = accbr[g][r];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      brsum[g][r] = v;
+    }
+  for (int turn = 0; turn < 4; ++turn) {
+    if (w == turn) {
+      const bool first = turn == 0, last = turn == 3;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = acc_row(r, hh);
+          const int o1 = i * RF_R + 32 * t + l31;                               // dWr[h = i][j]
+          const float v1 = accWr[t][r] + (first ? 0.f : srow[o1]);
+          if (last) grow[o1] = v1; else srow[o1] = v1;
+          if (l31 < RF_CP) {
+            const int o2 = RF_HP * RF_R + (32 * t + i) * RF_CP + l31;           // dWy_ext[j][c]
+            const float v2 = accWy[t][r] + (first ? 0.f : srow[o2]);
+            if (last) grow[o2] = v2; else srow[o2] = v2;
+          }
+        }
+      // dbr: lane (l31 == 0, half) carries heads 8g + 4*half + r; the other slots of the 32-head block are zero
+      if (hh == 0) {
+        const int o3 = RF_HP * RF_R + RF_R * RF_CP + l31;
+        const float v3 = first ? 0.f : srow[o3];
+        if (last) grow[o3] = v3; else srow[o3] = v3;
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (l31 == 0) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o3 = RF_HP * RF_R + RF_R * RF_CP + 8 * g + r + 4 * hh;
+            const float v3 = brsum[g][r] + (first ? 0.f : srow[o3]);
+            if (last) grow[o3] = v3; else srow[o3] = v3;
+          }
+      }
+    }
+    __syncthreads();
   }
-  if (w == 2 && hh == 0) row[RF_HP * RF_R + RF_R * RF_CP + l31] = 0.f;    // eh = 1 rows carry no dbr
 }
 
 // sum the partial rows and add into the parameter gradients (single writer per output: plain +=)
@@ -223,7 +392,11 @@ static int rf_check(const char* who, int B, int Sq, int Sk, int C, int R, int H)
   return MMNAS_OK;
 }
 
-static int rf_grid(long nbatch) { return (int)(nbatch < 512 ? nbatch : 512); }   // persistent: <= 2 per CU
+static long rf_tiles_per_b(int Sq, int Sk) { return ((long)Sq * Sk + 31) / 32; }
+static int rf_grid(long ntiles) {   // persistent: <= 2 workgroups (8 waves) per CU, one 32-element tile per wave at a time
+  const long wgs = (ntiles + 3) / 4;
+  return (int)(wgs < 512 ? wgs : 512);
+}
 
 }  // namespace mmnas
 
@@ -249,8 +422,7 @@ extern "C" int mmnas_rel_fused_fwd(const float* raw, const float* Wy, const floa
 }
 
 extern "C" size_t mmnas_rel_fused_bwd_ws_floats(int B, int Sq, int Sk) {
-  const long nbatch = (long)B * cdiv(Sq, 64) * cdiv(Sk, 4);
-  return (size_t)rf_grid(nbatch) * 2 * RF_ROW;
+  return (size_t)rf_grid((long)B * rf_tiles_per_b(Sq, Sk)) * RF_ROW;
 }
 
 extern "C" int mmnas_rel_fused_bwd(const float* raw, const float* Wy, const float* by, const float* Wr, const float* br,
@@ -263,19 +435,17 @@ extern "C" int mmnas_rel_fused_bwd(const float* raw, const float* Wy, const floa
   RelFusedK k;
   k.raw = raw; k.Wy = Wy; k.by = by; k.Wr = Wr; k.br = br; k.biasT = nullptr; k.dbiasT = dbiasT; k.part = ws;
   k.B = B; k.Sq = Sq; k.Sk = Sk; k.C = C; k.H = H; k.nbq = cdiv(Sq, 64); k.nbk = cdiv(Sk, 4);
-  const long nbatch = (long)B * k.nbq * k.nbk;
-  const int grid = rf_grid(nbatch);
+  const int tpb = (int)rf_tiles_per_b(Sq, Sk);
+  const long ntiles = (long)B * tpb;
+  const int grid = rf_grid(ntiles);
   hipStream_t st = (hipStream_t)stream;
   const double n = (double)B * Sq * Sk;
   ProfScope ps(MMNAS_K_REL_BWD, 2.0 * n * (RF_R * (C + 1) + 3.0 * H * RF_R + RF_R * (C + 1)), 4.0 * n * (C + H), st);
-  if (H <= 8) {
-    if (C == 4) MMNAS_LAUNCH((rel_fused_bwd_kernel<4, 8>), dim3(grid), dim3(256), 0, st, k, nbatch, Wy, by, Wr, br);
-    else MMNAS_LAUNCH((rel_fused_bwd_kernel<3, 8>), dim3(grid), dim3(256), 0, st, k, nbatch, Wy, by, Wr, br);
-  } else {
-    if (C == 4) MMNAS_LAUNCH((rel_fused_bwd_kernel<4, 32>), dim3(grid), dim3(256), 0, st, k, nbatch, Wy, by, Wr, br);
-    else MMNAS_LAUNCH((rel_fused_bwd_kernel<3, 32>), dim3(grid), dim3(256), 0, st, k, nbatch, Wy, by, Wr, br);
-  }
-  MMNAS_LAUNCH(rel_fused_reduce_kernel, dim3(cdiv(RF_ROW, 64)), dim3(256), 0, st, ws, grid * 2, C, H, dWr, dbr, dWy,
-                     dby);
+#define RF_BWD(CC, NGG) MMNAS_LAUNCH((rel_fused_bwd_kernel<CC, NGG>), dim3(grid), dim3(256), 0, st, k, ntiles, tpb, Wy, by, Wr, br)
+  if (H <= 8) { if (C == 4) RF_BWD(4, 1); else RF_BWD(3, 1); }
+  else if (H <= 16) { if (C == 4) RF_BWD(4, 2); else RF_BWD(3, 2); }
+  else { if (C == 4) RF_BWD(4, 4); else RF_BWD(3, 4); }
+#undef RF_BWD
+  MMNAS_LAUNCH(rel_fused_reduce_kernel, dim3(cdiv(RF_ROW, 64)), dim3(256), 0, st, ws, grid, C, H, dWr, dbr, dWy, dby);
   return check_launch("rel_fused_bwd");
 }
