@@ -35,6 +35,27 @@ PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(workload):
+    """HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r01_traffic_<workload>.json, made by
+    tools/pmc_traffic.py from two `rocprofv3 --pmc` runs of this benchmark: FETCH_SIZE and WRITE_SIZE cannot share a
+    pass; traffic = 2*FETCH + WRITE, the gfx950 correction of MI355X_MICROARCH.md).  None when the file is absent."""
+    path = os.path.join(REPO, 'profiles', 'r01_traffic_%s.json' % workload)
+    if not os.path.exists(path):
+        return None, None
+    d = json.load(open(path))
+    n = tot = fetch = write = 0.0
+    for k, v in d.items():
+        if 'gemm_kernel' in k:
+            n += v['launches']
+            tot += v['launches'] * v['traffic_bytes_per_launch']
+            fetch += v['launches'] * v['fetch_kb_per_launch'] * 1024.0
+            write += v['launches'] * v['write_kb_per_launch'] * 1024.0
+    if n == 0:
+        return None, None
+    return tot / n, {'source': os.path.relpath(path, REPO), 'fetch_size_bytes_per_launch': fetch / n,
+                     'write_size_bytes_per_launch': write / n, 'formula': '2*FETCH_SIZE + WRITE_SIZE (gfx950)'}
+
+
 def make_cfg(workload):
     from types import SimpleNamespace
     c = dict(DROPOUT_R=0.1, REL_SIZE=64, OPS_NORM=True, OPS_RESIDUAL=True, LAYERS=1,
@@ -292,9 +313,11 @@ def main():
         if stats:
             gm = stats['gemm']
             ach = gm['flops'] / (gm['ms'] * 1e-3) / 1e12 if gm['ms'] > 0 else 0.0
+            traffic, traffic_detail = pmc_traffic(args.workload)
             out['roofline'] = {'kernel': 'gemm_kernel<BM,BN> (fp32 MFMA 32x32x2, NT/NN/TN, grouped)', 'bound': 'mfma',
                                'achieved': ach, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / PEAK_MFMA_F32_TFLOPS, 'traffic': None,
+                               'frac': ach / PEAK_MFMA_F32_TFLOPS, 'traffic': traffic, 'traffic_pmc': traffic_detail,
+                               'algorithmic_bytes_per_launch': gm['bytes'] / max(gm['launches'], 1),
                                'avg_launch_us': 1e3 * gm['ms'] / max(gm['launches'], 1),
                                'launches_per_step': gm['launches'] / prof_steps,
                                'share_of_step_time': gm['ms'] * 1e-3 / prof_elapsed}

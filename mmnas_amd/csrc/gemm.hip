@@ -53,6 +53,8 @@ struct GemmK {
   int lda, ldb, ldc, ldres, ldgate;
   int relu, accumulate;
   int tiles_n, ntiles;  // tiles along N; tiles of all groups
+  int xcd_remap;        // 0: workgroup v = blockIdx.x (tuning experiments)
+  int gm;               // tile order inside a group: blocks of gm row-panels walked column by column (L2 reuse)
   int ntk, T;           // K-tiles per segment; K-tiles per output tile (= ntk * nseg)
   int mode;             // MODE_TILE: workgroup v computes tile v.  MODE_SPLIT: "C +=" split-K, workgroup v adds the
                         // piece (slice v / ntiles, tile v % ntiles) of P K-tiles.  MODE_STREAM: workgroup v computes
@@ -68,6 +70,8 @@ struct GemmK {
 };
 
 enum { MODE_TILE = 0, MODE_SPLIT = 1, MODE_STREAM = 2 };
+
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
 constexpr int BK = 32;
 constexpr int LDK = 36;
@@ -129,6 +133,7 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 4) gemm_kernel(const Gemm
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, in = bid >> 3;
     v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
+    if (!p.xcd_remap) v = bid;
   }
   int u = 0, uend = 1;  // MODE_TILE / MODE_SPLIT: a single piece
   if (p.mode == MODE_STREAM) { u = v * p.P; uend = min(p.U, u + p.P); }
@@ -165,7 +170,19 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 4) gemm_kernel(const Gemm
     const float* __restrict__ const gatep = G.gate;
     const float* const Aseg[3] = {G.A[0], G.A[1], G.A[2]};
     const float* const Bseg[3] = {G.B[0], G.B[1], G.B[2]};
-    const int tile_m = tl / p.tiles_n, tile_n = tl - tile_m * p.tiles_n;
+    // Tiles of a problem are numbered in blocks of gm row-panels x all column tiles, column by column inside a
+    // block: the workgroups resident on an XCD at one time (consecutive numbers) then share gm A-panels and only
+    // (resident / gm) B-panels, instead of one A-panel per tiles_n workgroups and ALL of B (N = 2048: the whole
+    // 4 MB weight matrix fell out of the 4 MB L2 between row-panels -- 7x the algorithmic fabric reads).
+    int tile_m, tile_n;
+    {
+      const int tiles_m = cdiv_dev(Mg, BM);
+      const int per_block = p.gm * p.tiles_n;
+      const int blk = tl / per_block, in = tl - blk * per_block;
+      const int rows = min(p.gm, tiles_m - blk * p.gm);   // the last block may be shorter
+      tile_n = in / rows;
+      tile_m = blk * p.gm + (in - tile_n * rows);
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     f32x16 acc[TM][TN];
@@ -505,8 +522,8 @@ static int env_int(const char* name, int dflt) {
 //   MMNAS_GEMM_SK=0|1|2    stream-K / split-K never, automatic, always
 //   MMNAS_GEMM_WGS=n       co-resident workgroup budget (default 1024 for 64^2 tiles, 512 for 128^2)
 //   MMNAS_GEMM_MIN_UNITS=n fewest K-tiles a workgroup is given (default 4)
-struct Tuning { int tile, generic, sk, wgs, min_units; bool loaded; };
-static Tuning g_tune = {0, 0, 1, 0, 4, false};
+struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd; bool loaded; };
+static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, false};
 static void load_tuning() {
   g_tune.tile = env_int("MMNAS_GEMM_TILE", 0);
   g_tune.generic = getenv("MMNAS_GEMM_GENERIC") != nullptr;
@@ -514,6 +531,8 @@ static void load_tuning() {
   g_tune.wgs = env_int("MMNAS_GEMM_WGS", 0);
   g_tune.min_units = env_int("MMNAS_GEMM_MIN_UNITS", 4);
   if (g_tune.min_units < 1) g_tune.min_units = 1;
+  g_tune.gm = env_int("MMNAS_GEMM_GM", 0);
+  g_tune.xcd = env_int("MMNAS_GEMM_XCD", 1);
   g_tune.loaded = true;
 }
 
@@ -646,6 +665,8 @@ extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
   for (int g = 0; g < d->ngroups; ++g) { k.g[g].tile0 = (int)t0; t0 += (long)cdiv(d->g[g].M, bt) * k.tiles_n; }
   MMNAS_REQUIRE(t0 < (1l << 30), MMNAS_E_SHAPE, "mmnas_gemm: too many output tiles");
   k.ntiles = (int)t0;
+  k.gm = g_tune.gm > 0 ? g_tune.gm : 8;
+  k.xcd_remap = g_tune.xcd;
   // co-resident workgroups: 256 CUs x 2 (128^2 tiles: 72 KB LDS each) or x 4
   const int slots = g_tune.wgs > 0 ? (g_tune.wgs < MAX_WGS ? g_tune.wgs : MAX_WGS) : (big ? 512 : 1024);
   // how evenly whole tiles load the 256 CUs: mean / max tiles per CU (the dispatcher balances dynamically)

@@ -27,6 +27,14 @@ def go(layout, M, N, K, tile, reps=10, acc=False):
 
 
 if __name__ == '__main__':
+    if os.environ.get('GEMM_PMC_SWEEP'):   # fabric traffic vs tile order / XCD mapping on one shape
+        for xcd in (1, 0):
+            for gm in (1, 8, 16):
+                os.environ['MMNAS_GEMM_XCD'] = str(xcd)
+                os.environ['MMNAS_GEMM_GM'] = str(gm)
+                go('NT', 6400, 2048, 512, 64, reps=4)
+                go('NT', 6400, 512, 512, 64, reps=4)
+        sys.exit(0)
     for tile in (64, 128):
         go('NT', 8192, 2048, 2048, tile)
         go('NT', 6400, 2048, 512, tile)
