@@ -95,7 +95,7 @@ __device__ __forceinline__ void load_tiles2(float* __restrict__ da, const float*
 // forward: grid (ceil(Sq / (32 NW)), H, B), block 64 NW.  NKC = key chunks of 32 (all keys).
 // ------------------------------------------------------------------------------------------
 template <int DHC, int NKC, int NW>
-__global__ void __launch_bounds__(64 * NW) mha_fwd_kernel(const MhaK p) {
+__global__ void __launch_bounds__(64 * NW, (NKC <= 4 && NW == 4) ? 2 : 1) mha_fwd_kernel(const MhaK p) {
   constexpr int LD = DHC + 4, NT = 64 * NW, JC = DHC >= 32 ? DHC / 32 : 1;
   __shared__ __attribute__((aligned(16))) float Qs[32 * NW * LD];
   __shared__ __attribute__((aligned(16))) float KVs[32 * NKC * LD];
@@ -254,10 +254,12 @@ __global__ void mha_delta_kernel(const float* __restrict__ dO, const float* __re
 // grid (ceil(Sq / (32 NW)), H * nch, B); keys swept in blocks of 32 NKC.
 // ------------------------------------------------------------------------------------------
 template <int DHC, int NKC, int NW>
-__global__ void __launch_bounds__(64 * NW) mha_bwd_q_kernel(const MhaK p) {
-  constexpr int LD = DHC + 4, NT = 64 * NW, JC = DHC >= 32 ? DHC / 32 : 1, KB = 32 * NKC;
-  __shared__ __attribute__((aligned(16))) float Qs[32 * NW * LD];
-  __shared__ __attribute__((aligned(16))) float Gs[32 * NW * LD];   // dO
+__global__ void __launch_bounds__(64 * NW, (NKC <= 2 && NW == 4) ? 2 : 1) mha_bwd_q_kernel(const MhaK p) {
+  constexpr int LD = DHC + 4, NT = 64 * NW, JC = DHC >= 32 ? DHC / 32 : 1, KB = 32 * NKC, NS = DHC / 8;
+  // Only the key / value blocks go through LDS (shared by the waves).  The Q and dO operands of a wave are the
+  // rows of its own 32 queries: each lane reads its fragments (4 consecutive floats of its row per k-step)
+  // straight from global into registers, once for all key blocks.  Staging them through LDS as well cost
+  // 70 KB per workgroup and, with the registers of the staging copies, held the kernel at one wave per SIMD.
   __shared__ __attribute__((aligned(16))) float Ks[KB * LD];
   __shared__ __attribute__((aligned(16))) float Vs[KB * LD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
@@ -273,6 +275,22 @@ __global__ void __launch_bounds__(64 * NW) mha_bwd_q_kernel(const MhaK p) {
     inv = p.stats[(bh * Sq + qi) * 2 + 1];
     del = p.delta[bh * Sq + qi];
   }
+  float4 qfr[NS], gfr[NS];   // B operands of S^T = K Q^T and dA^T = V dO^T for head-dim chunk c
+  auto load_frags = [&](int c) {
+    const int co = h * p.dh + c * DHC + 4 * hh;
+    const size_t row = (size_t)b * Sq + (qok ? qi : Sq - 1);   // clamped: no branch around the loads
+    const float* qrow = p.Q + row * p.ldq + co;
+    const float* grow = p.dO + row * p.ldo + co;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      qfr[s] = *reinterpret_cast<const float4*>(qrow + 8 * s);
+      gfr[s] = *reinterpret_cast<const float4*>(grow + 8 * s);
+    }
+    if (!qok) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { qfr[s] = make_float4(0.f, 0.f, 0.f, 0.f); gfr[s] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+  };
   f32x16 dq[JC];
 #pragma unroll
   for (int jc = 0; jc < JC; ++jc)
@@ -288,17 +306,16 @@ __global__ void __launch_bounds__(64 * NW) mha_bwd_q_kernel(const MhaK p) {
     for (int c = 0; c < p.nch; ++c) {
       __syncthreads();
       const int co = h * p.dh + c * DHC;
-      load_tiles2<32 * NW, 32 * NW, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + q0) * p.ldq + co, Sq - q0, p.ldq,
-                                             Gs, p.dO + (size_t)(b * Sq + q0) * p.ldo + co, Sq - q0, p.ldo, tid);
+      if (p.nch > 1 || kb == 0) load_frags(c);
       load_tiles2<KB, KB, DHC, NT>(Ks, p.K + (size_t)(b * Sk + kb) * p.ldk + co, Sk - kb, p.ldk,
                                    Vs, p.V + (size_t)(b * Sk + kb) * p.ldv + co, Sk - kb, p.ldv, tid);
       __syncthreads();
       if (active) {
 #pragma unroll
-        for (int s = 0; s < DHC / 8; ++s) {
+        for (int s = 0; s < NS; ++s) {
           const int fo = 8 * s + 4 * hh;
-          const float4 qf = *reinterpret_cast<const float4*>(Qs + (32 * w + l31) * LD + fo);
-          const float4 gf = *reinterpret_cast<const float4*>(Gs + (32 * w + l31) * LD + fo);
+          const float4 qf = qfr[s];
+          const float4 gf = gfr[s];
 #pragma unroll
           for (int kc = 0; kc < NKC; ++kc) {
             const float4 kf = *reinterpret_cast<const float4*>(Ks + (32 * kc + l31) * LD + fo);
@@ -375,12 +392,12 @@ __global__ void __launch_bounds__(64 * NW) mha_bwd_q_kernel(const MhaK p) {
 // queries swept 32 at a time.
 // ------------------------------------------------------------------------------------------
 template <int DHC, int NW>
-__global__ void __launch_bounds__(64 * NW) mha_bwd_kv_kernel(const MhaK p) {
-  constexpr int LD = DHC + 4, NT = 64 * NW, JC = DHC >= 32 ? DHC / 32 : 1;
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) mha_bwd_kv_kernel(const MhaK p) {
+  constexpr int LD = DHC + 4, NT = 64 * NW, JC = DHC >= 32 ? DHC / 32 : 1, NS = DHC / 8;
+  // Q / dO blocks (shared by the waves) go through LDS; a wave's own K and V rows are read straight from global
+  // into register fragments (see mha_bwd_q_kernel).
   __shared__ __attribute__((aligned(16))) float Qs[32 * LD];
   __shared__ __attribute__((aligned(16))) float Gs[32 * LD];
-  __shared__ __attribute__((aligned(16))) float Ks[32 * NW * LD];
-  __shared__ __attribute__((aligned(16))) float Vs[32 * NW * LD];
   __shared__ float sM[32], sInv[32], sDel[32];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y % p.H, oc = blockIdx.y / p.H, k0 = blockIdx.x * 32 * NW;
@@ -395,6 +412,22 @@ __global__ void __launch_bounds__(64 * NW) mha_bwd_kv_kernel(const MhaK p) {
   for (int jc = 0; jc < JC; ++jc)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[jc][r] = 0.f; dv[jc][r] = 0.f; }
+  float4 kfr[NS], vfr[NS];
+  auto load_frags = [&](int c) {
+    const int co = h * p.dh + c * DHC + 4 * hh;
+    const size_t row = (size_t)b * Sk + (kok ? key : Sk - 1);   // clamped: no branch around the loads
+    const float* krow = p.K + row * p.ldk + co;
+    const float* vrow = p.V + row * p.ldv + co;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      kfr[s] = *reinterpret_cast<const float4*>(krow + 8 * s);
+      vfr[s] = *reinterpret_cast<const float4*>(vrow + 8 * s);
+    }
+    if (!kok) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { kfr[s] = make_float4(0.f, 0.f, 0.f, 0.f); vfr[s] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+  };
 
   for (int qc = 0; qc < Sq; qc += 32) {
     f32x16 acc, dacc;
@@ -405,10 +438,7 @@ __global__ void __launch_bounds__(64 * NW) mha_bwd_kv_kernel(const MhaK p) {
       const int co = h * p.dh + c * DHC;
       load_tiles2<32, 32, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + qc) * p.ldq + co, Sq - qc, p.ldq,
                                    Gs, p.dO + (size_t)(b * Sq + qc) * p.ldo + co, Sq - qc, p.ldo, tid);
-      if (p.nch > 1 || qc == 0) {
-        load_tiles2<32 * NW, 32 * NW, DHC, NT>(Ks, p.K + (size_t)(b * Sk + k0) * p.ldk + co, Sk - k0, p.ldk,
-                                               Vs, p.V + (size_t)(b * Sk + k0) * p.ldv + co, Sk - k0, p.ldv, tid);
-      }
+      if (p.nch > 1 || qc == 0) load_frags(c);
       if (c == 0 && tid < 32) {
         const int q = qc + tid;
         const bool ok = q < Sq;
@@ -419,12 +449,12 @@ __global__ void __launch_bounds__(64 * NW) mha_bwd_kv_kernel(const MhaK p) {
       __syncthreads();
       if (active) {
 #pragma unroll
-        for (int s = 0; s < DHC / 8; ++s) {
+        for (int s = 0; s < NS; ++s) {
           const int fo = 8 * s + 4 * hh;
           const float4 qf = *reinterpret_cast<const float4*>(Qs + l31 * LD + fo);
           const float4 gf = *reinterpret_cast<const float4*>(Gs + l31 * LD + fo);
-          const float4 kf = *reinterpret_cast<const float4*>(Ks + (32 * w + l31) * LD + fo);
-          const float4 vf = *reinterpret_cast<const float4*>(Vs + (32 * w + l31) * LD + fo);
+          const float4 kf = kfr[s];
+          const float4 vf = vfr[s];
           MFMA4(acc, qf, kf)    // S[query][key]
           MFMA4(dacc, gf, vf)   // dA[query][key]
         }
@@ -554,10 +584,7 @@ static void launch_bwd(const MhaK& k, hipStream_t st) {
   else {
     // 65..128 keys: one 128-key block (Q/dO/K/V tiles loaded once, 139 KB LDS) instead of two 64-key
     // blocks that reload Q and dO; MMNAS_MHA_BQ4=0 restores the two-block form
-    static const bool one_block = !(getenv("MMNAS_MHA_BQ4") && atoi(getenv("MMNAS_MHA_BQ4")) == 0);
-    if (nkc <= 1) BQ(1, 4);
-    else if (nkc <= 2 || nkc > 4 || !one_block || DHC != 64) BQ(2, 4);
-    else BQ(4, 4);
+    if (nkc <= 1) BQ(1, 4); else BQ(2, 4);   // 64-key blocks: 35 KB LDS, <= 256 VGPRs -> two workgroups per CU
   }
 #undef BQ
 #define BKV(NW) MMNAS_LAUNCH((mha_bwd_kv_kernel<DHC, NW>), dim3(cdiv(k.Sk, 32 * NW), k.H * k.nch, k.B), \

@@ -73,8 +73,18 @@ enum { MODE_TILE = 0, MODE_SPLIT = 1, MODE_STREAM = 2 };
 
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
-constexpr int BK = 32;
-constexpr int LDK = 36;
+#ifndef MMNAS_OCC64
+#define MMNAS_OCC64 4
+#endif
+#ifndef MMNAS_OCC128
+#define MMNAS_OCC128 2
+#endif
+#ifndef MMNAS_BK
+#define MMNAS_BK 32
+#endif
+constexpr int BK = MMNAS_BK;   // K-tile depth
+constexpr int LDK = BK + 4;    // LDS row stride of a K-contiguous operand
+constexpr int KQ = BK / 4;     // float4 chunks per K-contiguous row
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -97,10 +107,10 @@ __device__ __forceinline__ u64 ld_agent(const u64* ptr) {
 }
 
 template <int BM, int BN, bool AKC, bool BKC, bool FAST>
-__global__ void __launch_bounds__(256, BM == 128 ? 2 : 4) gemm_kernel(const GemmK p) {
+__global__ void __launch_bounds__(256, BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64) gemm_kernel(const GemmK p) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int A_SZ = BM * LDK, B_SZ = BN * LDK;  // >= BK*BM for the [k][row] form
-  constexpr int NA = BM / 32, NB = BN / 32;        // float4 loads per thread per tile
+  constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;   // float4 loads per thread per tile
   __shared__ __attribute__((aligned(16))) float As[2 * A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[2 * B_SZ];
   __shared__ int s_old;
@@ -205,7 +215,7 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 4) gemm_kernel(const Gemm
       for (int i = 0; i < NA; ++i) {
         const int f = tid + 256 * i;
         if (AKC) {
-          const int row = f >> 3, kq = f & 7, gr = m0 + row;
+          const int row = f / KQ, kq = f % KQ, gr = m0 + row;
           offa[i] = gr < Mg ? (unsigned)(gr * p.lda + 4 * kq) * 4u : ~0u;
         } else {
           const int k = f / (BM / 4), rq = f - k * (BM / 4), gr = m0 + 4 * rq;
@@ -216,7 +226,7 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 4) gemm_kernel(const Gemm
       for (int i = 0; i < NB; ++i) {
         const int f = tid + 256 * i;
         if (BKC) {
-          const int row = f >> 3, kq = f & 7, gr = n0 + row;
+          const int row = f / KQ, kq = f % KQ, gr = n0 + row;
           offb[i] = gr < p.N ? (unsigned)(gr * p.ldb + 4 * kq) * 4u : ~0u;
         } else {
           const int k = f / (BN / 4), rq = f - k * (BN / 4), gr = n0 + 4 * rq;
@@ -250,7 +260,7 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 4) gemm_kernel(const Gemm
         const int f = tid + 256 * i;
         float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (AKC) {
-          const int row = f >> 3, kq = f & 7;
+          const int row = f / KQ, kq = f % KQ;
           const int gr = m0 + row, gk = k0 + 4 * kq;
           if (gr < Mg && gk < kend) {
             const float* src = Ap + (size_t)gr * p.lda + gk;
@@ -283,7 +293,7 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 4) gemm_kernel(const Gemm
         const int f = tid + 256 * i;
         float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (BKC) {
-          const int row = f >> 3, kq = f & 7;
+          const int row = f / KQ, kq = f % KQ;
           const int gr = n0 + row, gk = k0 + 4 * kq;
           if (gr < p.N && gk < kend) {
             const float* src = Bp + (size_t)gr * p.ldb + gk;
@@ -320,7 +330,7 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 4) gemm_kernel(const Gemm
       for (int i = 0; i < NA; ++i) {
         const int f = tid + 256 * i;
         if (AKC) {
-          const int row = f >> 3, kq = f & 7;
+          const int row = f / KQ, kq = f % KQ;
           *reinterpret_cast<float4*>(a + row * LDK + 4 * kq) = ra[i];
         } else {
           const int k = f / (BM / 4), rq = f - k * (BM / 4);
@@ -331,7 +341,7 @@ __global__ void __launch_bounds__(256, BM == 128 ? 2 : 4) gemm_kernel(const Gemm
       for (int i = 0; i < NB; ++i) {
         const int f = tid + 256 * i;
         if (BKC) {
-          const int row = f >> 3, kq = f & 7;
+          const int row = f / KQ, kq = f % KQ;
           *reinterpret_cast<float4*>(b + row * LDK + 4 * kq) = rb[i];
         } else {
           const int k = f / (BN / 4), rq = f - k * (BN / 4);
