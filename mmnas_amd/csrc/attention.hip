@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(64 * NW, (NKC <= 2 && NW == 4) ? 2 : 1) mha_bw
   if (qok) {
     m = p.stats[(bh * Sq + qi) * 2];
     inv = p.stats[(bh * Sq + qi) * 2 + 1];
-    del = p.delta[bh * Sq + qi];
+    if (p.nch > 1) del = p.delta[bh * Sq + qi];   // (one head-dim chunk: computed below from the fragments)
   }
   float4 qfr[NS], gfr[NS];   // B operands of S^T = K Q^T and dA^T = V dO^T for head-dim chunk c
   auto load_frags = [&](int c) {
@@ -291,6 +291,21 @@ __global__ void __launch_bounds__(64 * NW, (NKC <= 2 && NW == 4) ? 2 : 1) mha_bw
       for (int s = 0; s < NS; ++s) { qfr[s] = make_float4(0.f, 0.f, 0.f, 0.f); gfr[s] = make_float4(0.f, 0.f, 0.f, 0.f); }
     }
   };
+  if (p.nch == 1) {
+    // delta[b,h,q] = sum_j dO[q,j] O[q,j] (= sum_k dA[q,k] A[q,k]) from this lane's half row, the other half-wave
+    // holds the other half; written for the dK/dV kernel that follows on the stream (replaces a separate launch)
+    load_frags(0);
+    const float* orow = p.O + ((size_t)b * Sq + (qok ? qi : Sq - 1)) * p.ldo + h * p.dh + 4 * hh;
+    float part = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float4 o4 = *reinterpret_cast<const float4*>(orow + 8 * s);
+      part += (gfr[s].x * o4.x + gfr[s].y * o4.y) + (gfr[s].z * o4.z + gfr[s].w * o4.w);
+    }
+    part += __shfl_xor(part, 32, 64);
+    del = qok ? part : 0.f;
+    if (qok && hh == 0) p.delta[bh * Sq + qi] = del;
+  }
   f32x16 dq[JC];
 #pragma unroll
   for (int jc = 0; jc < JC; ++jc)
@@ -306,7 +321,7 @@ __global__ void __launch_bounds__(64 * NW, (NKC <= 2 && NW == 4) ? 2 : 1) mha_bw
     for (int c = 0; c < p.nch; ++c) {
       __syncthreads();
       const int co = h * p.dh + c * DHC;
-      if (p.nch > 1 || kb == 0) load_frags(c);
+      if (p.nch > 1) load_frags(c);
       load_tiles2<KB, KB, DHC, NT>(Ks, p.K + (size_t)(b * Sk + kb) * p.ldk + co, Sk - kb, p.ldk,
                                    Vs, p.V + (size_t)(b * Sk + kb) * p.ldv + co, Sk - kb, p.ldv, tid);
       __syncthreads();
@@ -391,15 +406,28 @@ __global__ void __launch_bounds__(64 * NW, (NKC <= 2 && NW == 4) ? 2 : 1) mha_bw
 // backward, key-owner: dK, dV (head-dim chunk oc).  grid (ceil(Sk / (32 NW)), H * nch, B);
 // queries swept 32 at a time.
 // ------------------------------------------------------------------------------------------
-template <int DHC, int NW>
-__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) mha_bwd_kv_kernel(const MhaK p) {
+// QS > 1 (few keys, many queries -- guided attention over 14 words): QS groups of NW waves own the SAME keys and
+// split the query blocks among them (the single-wave form walked the 4 query blocks one after the other,
+// 41 us of pure latency); their dK / dV partials are added in group order through LDS at the end.
+template <int DHC, int NW, int QS>
+__global__ void __launch_bounds__(64 * NW * QS, (NW == 4 && QS == 1) ? 2 : 1) mha_bwd_kv_kernel(const MhaK p) {
   constexpr int LD = DHC + 4, NT = 64 * NW, JC = DHC >= 32 ? DHC / 32 : 1, NS = DHC / 8;
   // Q / dO blocks (shared by the waves) go through LDS; a wave's own K and V rows are read straight from global
   // into register fragments (see mha_bwd_q_kernel).
-  __shared__ __attribute__((aligned(16))) float Qs[32 * LD];
-  __shared__ __attribute__((aligned(16))) float Gs[32 * LD];
-  __shared__ float sM[32], sInv[32], sDel[32];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  constexpr int PER = NW * JC * 2 * 16 * 64;   // floats of one group's dK / dV partials (QS > 1)
+  constexpr int TILES = 2 * QS * 32 * LD, SMEM = TILES > (QS - 1) * PER ? TILES : (QS - 1) * PER;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+  float* QsAll = smem;
+  float* GsAll = smem + QS * 32 * LD;
+  __shared__ float sMAll[QS * 32], sInvAll[QS * 32], sDelAll[QS * 32];
+  const int qs = threadIdx.x / NT;            // query-split group of this wave
+  const int tid = threadIdx.x - qs * NT;      // thread index inside the group
+  float* Qs = QsAll + qs * 32 * LD;
+  float* Gs = GsAll + qs * 32 * LD;
+  float* sM = sMAll + qs * 32;
+  float* sInv = sInvAll + qs * 32;
+  float* sDel = sDelAll + qs * 32;
+  const int lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y % p.H, oc = blockIdx.y / p.H, k0 = blockIdx.x * 32 * NW;
   const int Sq = p.Sq, Sk = p.Sk;
   const bool active = k0 + 32 * w < Sk;
@@ -429,16 +457,20 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) mha_bwd_kv_kernel(co
     }
   };
 
-  for (int qc = 0; qc < Sq; qc += 32) {
+  // every group runs the same number of rounds (the barriers are workgroup-wide); a group whose block lies beyond
+  // Sq works on zero tiles
+  for (int qc0 = 0; qc0 < Sq; qc0 += 32 * QS) {
+    const int qc = qc0 + 32 * qs;
     f32x16 acc, dacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; dacc[r] = 0.f; }
     for (int c = 0; c < p.nch; ++c) {
       __syncthreads();
       const int co = h * p.dh + c * DHC;
-      load_tiles2<32, 32, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + qc) * p.ldq + co, Sq - qc, p.ldq,
-                                   Gs, p.dO + (size_t)(b * Sq + qc) * p.ldo + co, Sq - qc, p.ldo, tid);
-      if (p.nch > 1 || qc == 0) load_frags(c);
+      const int qcl = qc < Sq ? qc : 0;   // (a block beyond Sq: valid addresses, zero rows)
+      load_tiles2<32, 32, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + qcl) * p.ldq + co, Sq - qc, p.ldq,
+                                   Gs, p.dO + (size_t)(b * Sq + qcl) * p.ldo + co, Sq - qc, p.ldo, tid);
+      if (p.nch > 1 || qc0 == 0) load_frags(c);
       if (c == 0 && tid < 32) {
         const int q = qc + tid;
         const bool ok = q < Sq;
@@ -485,8 +517,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) mha_bwd_kv_kernel(co
     if (p.nch > 1) {
       __syncthreads();
       const int co = h * p.dh + oc * DHC;
-      load_tiles2<32, 32, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + qc) * p.ldq + co, Sq - qc, p.ldq,
-                                   Gs, p.dO + (size_t)(b * Sq + qc) * p.ldo + co, Sq - qc, p.ldo, tid);
+      const int qcl = qc < Sq ? qc : 0;
+      load_tiles2<32, 32, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + qcl) * p.ldq + co, Sq - qc, p.ldq,
+                                   Gs, p.dO + (size_t)(b * Sq + qcl) * p.ldo + co, Sq - qc, p.ldo, tid);
       __syncthreads();
     }
     if (active) {
@@ -502,6 +535,32 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) mha_bwd_kv_kernel(co
           dk[jc] = mfma32(dacc[r], qv, dk[jc]);   // dK[key][j] += dZ[q][key] Q[q][j] / sqrt(dh)
         }
       }
+    }
+  }
+  if (QS > 1) {   // groups 1.. leave their partials in LDS (the tile images are free now); group 0 adds them in order
+    __syncthreads();
+    float* red = smem;
+    float* base = red + (qs > 0 ? (qs - 1) * PER : 0) + w * (JC * 2 * 16 * 64);
+    if (qs > 0) {
+#pragma unroll
+      for (int jc = 0; jc < JC; ++jc)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          base[((jc * 2 + 0) * 16 + r) * 64 + lane] = dk[jc][r];
+          base[((jc * 2 + 1) * 16 + r) * 64 + lane] = dv[jc][r];
+        }
+    }
+    __syncthreads();
+    if (qs > 0) return;
+    for (int g = 1; g < QS; ++g) {
+      const float* src = red + (g - 1) * PER + w * (JC * 2 * 16 * 64);
+#pragma unroll
+      for (int jc = 0; jc < JC; ++jc)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          dk[jc][r] += src[((jc * 2 + 0) * 16 + r) * 64 + lane];
+          dv[jc][r] += src[((jc * 2 + 1) * 16 + r) * 64 + lane];
+        }
     }
   }
   if (active) {
@@ -587,9 +646,10 @@ static void launch_bwd(const MhaK& k, hipStream_t st) {
     if (nkc <= 1) BQ(1, 4); else BQ(2, 4);   // 64-key blocks: 35 KB LDS, <= 256 VGPRs -> two workgroups per CU
   }
 #undef BQ
-#define BKV(NW) MMNAS_LAUNCH((mha_bwd_kv_kernel<DHC, NW>), dim3(cdiv(k.Sk, 32 * NW), k.H * k.nch, k.B), \
-                                   dim3(64 * NW), 0, st, k)
-  if (nkc <= 1) BKV(1); else if (nkc <= 2 || nwmax == 2) BKV(2); else BKV(4);
+#define BKV(NW, QS) MMNAS_LAUNCH((mha_bwd_kv_kernel<DHC, NW, QS>), dim3(cdiv(k.Sk, 32 * NW), k.H * k.nch, k.B), \
+                                       dim3(64 * NW * QS), 0, st, k)
+  if (nkc <= 1) { if (k.Sq > 32) BKV(1, 4); else BKV(1, 1); }
+  else if (nkc <= 2 || nwmax == 2) BKV(2, 1); else BKV(4, 1);
 #undef BKV
 }
 
@@ -619,7 +679,7 @@ extern "C" int mmnas_mha_core_bwd(const mmnas_mha_desc* d, void* stream) {
   const double bhqk = (double)k.B * k.H * k.Sq * k.Sk;
   ProfScope ps(MMNAS_K_MHA_BWD, 10.0 * bhqk * k.dh,
                4.0 * ((double)k.B * k.H * k.dh * (4.0 * k.Sq + 4.0 * k.Sk) + (k.biasT ? 2.0 * bhqk : 0.0)), st);
-  {
+  if (k.dh > 64) {   // several head-dim chunks: delta needs the whole row first (dh <= 64: fused into the dQ kernel)
     const long n = (long)k.B * k.Sq * k.H;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
