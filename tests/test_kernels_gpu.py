@@ -380,7 +380,10 @@ def _mha_ref(Q, K, V, mask, biasT, H, dh, dmask=None):
     (2, 2, 7, 7, 64, True, False, 0.0), (2, 8, 100, 100, 64, True, True, 0.0), (2, 8, 100, 14, 64, True, False, 0.1),
     (3, 4, 14, 14, 64, True, False, 0.0), (2, 2, 36, 50, 64, True, False, 0.0), (2, 4, 9, 9, 32, True, True, 0.0),
     (2, 8, 9, 15, 16, False, False, 0.0), (2, 2, 9, 9, 128, True, False, 0.0), (2, 1, 7, 12, 256, True, True, 0.0),
-    (1, 2, 130, 130, 64, True, False, 0.0), (2, 2, 50, 200, 64, True, True, 0.2), (2, 4, 70, 33, 32, True, False, 0.0)])
+    (1, 2, 130, 130, 64, True, False, 0.0), (2, 2, 50, 200, 64, True, True, 0.2), (2, 4, 70, 33, 32, True, False, 0.0),
+    # few keys, many queries: query-split dK/dV workgroups, all head-dim chunk widths
+    (2, 4, 100, 14, 32, True, False, 0.1), (2, 8, 100, 20, 16, True, True, 0.0), (2, 2, 40, 10, 64, False, False, 0.0),
+    (1, 2, 150, 31, 128, True, False, 0.0)])
 def test_mha_core(B, H, Sq, Sk, dh, use_mask, use_bias, p):
     import ctypes as C
     import mmnas_amd._lib as L
