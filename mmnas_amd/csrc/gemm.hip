@@ -59,6 +59,8 @@ struct GemmK {
   int mode;             // MODE_TILE: workgroup v computes tile v.  MODE_SPLIT: "C +=" split-K, workgroup v adds the
                         // piece (slice v / ntiles, tile v % ntiles) of P K-tiles.  MODE_STREAM: workgroup v computes
                         // the work units [v*P, (v+1)*P) of the tile-major (tile, K-tile) sequence of U units
+  int n_full, full_per, sk_per;  // MODE_STREAM hybrid: tiles [0, n_full) are computed whole, one per workgroup; only the
+                        // tail tiles are streamed.  Per XCD: sk_per streaming workgroups (launched first), then full_per whole tiles
   int P;                // K-tiles per piece / work units per workgroup
   int U;                // work units in total (= ntiles * T; stream-K needs it below 2^31)
   float* ws;            // partial-tile slots: 2 per workgroup, BM*BN floats each
@@ -146,12 +148,21 @@ __global__ void __launch_bounds__(256, BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64) g
     if (!p.xcd_remap) v = bid;
   }
   int u = 0, uend = 1;  // MODE_TILE / MODE_SPLIT: a single piece
-  if (p.mode == MODE_STREAM) { u = v * p.P; uend = min(p.U, u + p.P); }
+  int vs = v;           // MODE_STREAM: index among the streaming workgroups
+  int whole = -1;       // hybrid: the whole tile of this workgroup
+  if (p.mode == MODE_STREAM) {
+    if (p.n_full > 0) {  // grid = 8 * (sk_per + full_per); blockIdx % 8 labels the XCD, low indices start first
+      const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+      if (li < p.sk_per) vs = xcd * p.sk_per + li;
+      else whole = xcd * p.full_per + (li - p.sk_per);
+    }
+    if (whole < 0) { u = vs * p.P; uend = min(p.U, u + p.P); }
+  }
 
   while (u < uend) {
     int tile, q0, nq;
-    if (p.mode == MODE_TILE) {
-      tile = v; q0 = 0; nq = p.T;
+    if (p.mode == MODE_TILE || whole >= 0) {
+      tile = whole >= 0 ? whole : v; q0 = 0; nq = p.T;
       u = uend;
     } else if (p.mode == MODE_SPLIT) {  // slice-major: neighbouring workgroups (one XCD) add into different tiles
       const int sl = v / p.ntiles;       // and stream the same K-slice of both operands through its L2
@@ -161,8 +172,9 @@ __global__ void __launch_bounds__(256, BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64) g
       u = uend;
       if (nq <= 0) break;
     } else {
-      tile = u / p.T;
-      q0 = u - tile * p.T;  // first K-tile of the piece
+      const int tt = u / p.T;  // tile among the streamed (tail) tiles
+      tile = p.n_full + tt;
+      q0 = u - tt * p.T;       // first K-tile of the piece
       nq = min(p.T - q0, uend - u);
       u += nq;
     }
@@ -398,13 +410,13 @@ __global__ void __launch_bounds__(256, BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64) g
     // ---- partial tile: hand the accumulators over; the last contributor to arrive finishes the tile ----
     const bool atomic_out = nq != p.T && p.accumulate;  // "C +=" results: a partial tile simply adds its share
     if (nq != p.T && !atomic_out) {
-      const int t0 = tile * p.T;
-      const int v_lo = t0 / p.P, v_hi = (t0 + p.T - 1) / p.P;  // contributors, inclusive
+      const int t0 = (tile - p.n_full) * p.T;  // first unit of the tile in the streamed sequence
+      const int v_lo = t0 / p.P, v_hi = (t0 + p.T - 1) / p.P;  // contributors (streaming workgroup indices), inclusive
       // a workgroup has at most two partial tiles: the one it starts inside (slot 2v) and the one it
       // ends inside (slot 2v+1)
       // slot image: [register pair][thread] of 8-byte words -- every store / load instruction covers 512
       // contiguous bytes
-      u64* slot = reinterpret_cast<u64*>(p.ws) + (size_t)(2 * v + (q0 == 0 ? 1 : 0)) * (BM * BN / 2) + tid;
+      u64* slot = reinterpret_cast<u64*>(p.ws) + (size_t)(2 * vs + (q0 == 0 ? 1 : 0)) * (BM * BN / 2) + tid;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -698,6 +710,24 @@ extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
       k.mode = MODE_SPLIT;
       nwg = S * k.ntiles;
     }
+  } else if (!accumulate && sk != 0 && !big && U < (1ll << 30) && k.ntiles <= MAX_CNT_TILES && g_tune.wgs == 0 &&
+             sk == 1 && k.ntiles > 256 && k.ntiles < 1024 && k.ntiles % 256 != 0 && k.T >= 16) {
+    // Single round (every tile resident at once, 3-4 workgroups per CU) with a ragged last "layer": the first
+    // floor(ntiles / 256) * 256 tiles are computed whole; the R tail tiles are streamed by ~one extra SHORT workgroup
+    // per CU (R * T units cut into <= 256 runs), launched first.  Their hand-over through the workspace ends long
+    // before the whole tiles do, so -- unlike streaming everything -- it costs nothing, the whole tiles keep
+    // their K-phases aligned (L2 reuse of the A-panels), and every CU carries the same number of K-tiles.
+    const int n_full = (k.ntiles / 256) * 256, R = k.ntiles - n_full;
+    const long long Ut = (long long)R * k.T;
+    long long P = (Ut + 255) / 256;
+    if (P < 2) P = 2;
+    int n_sk = (int)((Ut + P - 1) / P);
+    n_sk = (n_sk + 7) / 8 * 8;
+    k.mode = MODE_STREAM;
+    k.n_full = n_full; k.full_per = n_full / 8; k.sk_per = n_sk / 8;
+    k.P = (int)P;
+    k.U = (int)Ut;
+    nwg = n_full + n_sk;
   } else if (!accumulate && sk != 0 && U < (1ll << 30) && k.ntiles <= MAX_CNT_TILES && k.T >= 2 * min_units &&
              (sk == 2 || (!big && ((dp_eff < 0.6 && k.T >= 16) || (dp_eff < 0.9 && k.T >= 48))))) {
     long long G = U / min_units;
@@ -723,7 +753,7 @@ extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
   if (prof_enabled())
     snprintf(tag, sizeof(tag), "%s M=%d/%d/%d N=%d K=%d seg=%d t%d wg=%d P=%d/%d %s%s", tn ? "TN" : (bkc ? "NT" : "NN"),
              d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0, d->ngroups > 2 ? d->g[2].M : 0, d->N, d->K, d->nseg, bt, nwg, k.P, k.T,
-             k.mode == MODE_TILE ? "tile" : (k.mode == MODE_SPLIT ? "split" : "stream"), fast ? "" : " generic");
+             k.mode == MODE_TILE ? "tile" : (k.mode == MODE_SPLIT ? "split" : (k.n_full ? "hybrid" : "stream")), fast ? "" : " generic");
   ProfScope ps(MMNAS_K_GEMM, 2.0 * sumM * d->N * d->K * d->nseg,
                4.0 * (sumM * d->K * d->nseg + (double)d->N * d->K * d->nseg * d->ngroups + sumM * d->N), st, tag);
   if (big) return fast ? launch<128, 128, true>(k, d->layout, nwg, st) : launch<128, 128, false>(k, d->layout, nwg, st);

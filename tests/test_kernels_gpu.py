@@ -201,6 +201,41 @@ def test_gemm_stream_k_partial_tiles(gemm_tuning, tile, wgs, min_units):
     assert rel_err(C.cpu().numpy(), (td(a) @ td(b).t()).numpy()) < 1e-5
 
 
+def test_gemm_hybrid_schedule_whole_tiles_plus_streamed_tail():
+    """256 < tiles < 1024 with a ragged last layer (the 6400 x 512 products: 800 tiles): the library computes
+    floor(tiles / 256) * 256 tiles whole and streams the tail through short workgroups.  Every epilogue term,
+    grouped problems (tile numbering across groups), bitwise repeatability."""
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    from oracle import dropout_rng
+    rs = np.random.RandomState(77)
+    td = lambda a: torch.from_numpy(a).double()
+    # NT 1700 x 1024 x 512: 27 x 16 = 432 tiles of 64^2, 16 K-tiles -> 256 whole + 176 streamed
+    M, N, K = 1700, 1024, 512
+    a, b, bias, res = rnd(rs, M, K), rnd(rs, N, K), rnd(rs, N), rnd(rs, M, N)
+    seed, site, p = 5551212, 2, 0.2
+    outs = []
+    for _ in range(3):
+        C = torch.full((M, N), float('nan'), device=DEV)
+        ops.gemm(L.GEMM_NT, [dict(M=M, A=[g(a)], B=[g(b)], C=C, bias=g(bias), residual=g(res))], N, K, K, K, N,
+                 relu=True, drop=(p, seed, site), ldres=N)
+        outs.append(C.cpu().numpy())
+    ref = torch.relu(td(a) @ td(b).t() + td(bias)) * td(dropout_rng.scaled_mask(seed, site, (M, N), p)) + td(res)
+    assert rel_err(outs[0], ref.numpy()) < 1e-5
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    # NN, three groups of different M (300 + 1000 + 777 rows -> 5 + 16 + 13 row tiles x 12 = 408 tiles), two K segments
+    Ms, N, K = [300, 1000, 777], 768, 256
+    A = [[rnd(rs, m, K) for _ in range(2)] for m in Ms]
+    B = [[rnd(rs, K, N) for _ in range(2)] for _ in Ms]
+    gate = [rnd(rs, m, N) for m in Ms]
+    Cs = [torch.full((m, N), float('nan'), device=DEV) for m in Ms]
+    ops.gemm(L.GEMM_NN, [dict(M=m, A=[g(x) for x in aa], B=[g(x) for x in bb], C=c, gate=g(gt))
+                         for m, aa, bb, c, gt in zip(Ms, A, B, Cs, gate)], N, K, K, N, N, nseg=2, gate_scale=1.25, ldgate=N)
+    for aa, bb, gt, c in zip(A, B, gate, Cs):
+        ref = sum(td(x) @ td(y) for x, y in zip(aa, bb)) * (td(gt) > 0).double() * 1.25
+        assert rel_err(c.cpu().numpy(), ref.numpy()) < 1e-5
+
+
 # ----------------------------------------------------------------------------- LayerNorm & friends
 @pytest.mark.parametrize('M,d', [(15, 128), (6400, 512), (64, 1024), (7, 2048), (33, 36)])
 def test_layernorm(M, d):
