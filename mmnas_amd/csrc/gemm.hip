@@ -711,7 +711,7 @@ extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
       nwg = S * k.ntiles;
     }
   } else if (!accumulate && sk != 0 && !big && U < (1ll << 30) && k.ntiles <= MAX_CNT_TILES && g_tune.wgs == 0 &&
-             sk == 1 && k.ntiles > 256 && k.ntiles < 1024 && k.ntiles % 256 != 0 && k.T >= 16) {
+             sk == 1 && k.ntiles > 256 && k.ntiles < 8192 && k.ntiles % 256 != 0 && k.T >= 16) {
     // Single round (every tile resident at once, 3-4 workgroups per CU) with a ragged last "layer": the first
     // floor(ntiles / 256) * 256 tiles are computed whole; the R tail tiles are streamed by ~one extra SHORT workgroup
     // per CU (R * T units cut into <= 256 runs), launched first.  Their hand-over through the workspace ends long
