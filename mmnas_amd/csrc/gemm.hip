@@ -701,7 +701,8 @@ extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
   int nwg = k.ntiles;
   if (accumulate && sk != 0) {
     // split-K with atomics: enough (slice, tile) pieces to fill the co-resident slots, >= min_units K-tiles each
-    int want = (slots + k.ntiles - 1) / k.ntiles;
+    int want = slots / k.ntiles;   // rounded DOWN: 192 tiles x 6 slices = 1152 pieces spill into a second, nearly empty round
+    if (want < 1) want = 1;
     if (want > k.T / min_units) want = k.T / min_units;
     if (want > 1) {
       k.P = (k.T + want - 1) / want;
