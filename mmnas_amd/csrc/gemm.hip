@@ -731,7 +731,10 @@ extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
     nwg = n_full + n_sk;
   } else if (!accumulate && sk != 0 && U < (1ll << 30) && k.ntiles <= MAX_CNT_TILES && k.T >= 2 * min_units &&
              (sk == 2 || (!big && ((dp_eff < 0.6 && k.T >= 16) || (dp_eff < 0.9 && k.T >= 48))))) {
-    long long G = U / min_units;
+    // (runs of >= 8 K-tiles when the choice is automatic: fewer contributors per tile in the hand-over, measured
+    //  5-20 % faster than 4 on the M = 896 products)
+    const int smu = sk == 2 ? min_units : 2 * min_units;
+    long long G = U / smu;
     if (G > slots) G = slots;
     if (G < 1) G = 1;
     const long long P = (U + G - 1) / G;

@@ -334,8 +334,11 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:   # e.g. the relation/region feature inputs of the stem need none
             dx = torch.empty_like(x)
             gemm(L.GEMM_NN, [dict(M=M, A=[dy], B=[W], C=dx)], K, N, N, K, K)
-        dW = torch.empty_like(W)
-        gemm(L.GEMM_TN, [dict(M=N, A=[dy], B=[x], C=dW)], K, M, N, K, K)
+        # long reductions over few output tiles (the 2048->512 region projection: 256 tiles, 6400 rows) go through
+        # the split-K path, which adds onto C
+        acc = M >= 2048
+        dW = torch.zeros_like(W) if acc else torch.empty_like(W)
+        gemm(L.GEMM_TN, [dict(M=N, A=[dy], B=[x], C=dW)], K, M, N, K, K, accumulate=acc)
         db = None
         if ctx.has_bias:
             db = torch.zeros(N, dtype=torch.float32, device=x.device)
