@@ -146,6 +146,23 @@ int mmnas_glu_bwd(const float* h, const float* dy, float* dh, int M, int C, int 
                   uint64_t seed, uint32_t site, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Stem / head helpers.
+ *   mmnas_row_is_zero: make_mask of the nets (hygr_vqa.py:121-122): mask[r] = 1 iff sum_j |f[r,j]| == 0
+ *     (one pass over f [rows, d]).
+ *   mmnas_attflat_pool_*: the pooling stage of AttFlat (modules.py:78-84) for logits [B,S,G], features x [B,S,d],
+ *     key mask [B,S] (uint8, non-zero = padded, may be NULL):
+ *       probs[b,s,g] = softmax over s of (mask ? -1e9 : logits);  pooled[b, g*d + j] = sum_s probs[b,s,g] x[b,s,j]
+ *     bwd: dlogits [B,S,G] (zero at masked positions) and dx [B,S,d] (the pooling path's share of the feature
+ *     gradient) from dpooled [B,G*d].
+ *   S <= 1024.
+ * ------------------------------------------------------------------------------------------ */
+int mmnas_row_is_zero(const float* f, uint8_t* mask, long rows, int d, void* stream);
+int mmnas_attflat_pool_fwd(const float* logits, const float* x, const uint8_t* mask, float* probs, float* pooled,
+                           int B, int S, int d, int G, void* stream);
+int mmnas_attflat_pool_bwd(const float* probs, const float* x, const uint8_t* mask, const float* dpooled,
+                           float* dlogits, float* dx, int B, int S, int d, int G, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Relation bias of RelMHAtt (modules.py:231-235):
  *   biasT[b,h,k,q] = log(max(relu(rel[b,q,k,:] . Wr[h,:] + br[h]), 1e-6))
  * rel [B,Sq,Sk,R] is read exactly once (the HBM-bound kernel of the path); the bias is written

@@ -93,6 +93,9 @@ SYMBOLS = {
     'mmnas_glu_bwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _f, _u64, _u32, _fp]),
     'mmnas_rel_bias_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp]),
     'mmnas_rel_bias_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
+    'mmnas_row_is_zero': (_i, [_fp, _fp, C.c_long, _i, _fp]),
+    'mmnas_attflat_pool_fwd': (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),
+    'mmnas_attflat_pool_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),
     'mmnas_rel_fused_supported': (_i, [_i, _i, _i]),
     'mmnas_rel_fused_fwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     'mmnas_rel_fused_bwd_ws_floats': (_sz, [_i, _i, _i]),

@@ -1,0 +1,152 @@
+// Stem / head kernels:
+//   * make_mask (hygr_vqa.py:121-122): mask[r] = (sum_j |f[r,j]| == 0), one pass over the 52 MB region-feature
+//     tensor instead of abs -> sum -> compare (two 52 MB passes plus a 52 MB temporary).
+//   * AttFlat pooling (modules.py:78-84): masked softmax of the glimpse logits over the sequence and the
+//     attention-weighted sum of the features, forward and backward, one workgroup per batch element
+//     (replaces masked_fill, softmax, mul, sum, cat and their five autograd kernels).
+#include "common.h"
+
+namespace mmnas {
+
+// one wave per row; a row is "padding" iff every element is +-0 (a NaN makes sum|f| NaN != 0: not padding)
+__global__ void __launch_bounds__(256) row_is_zero_kernel(const float* __restrict__ f, uint8_t* __restrict__ mask,
+                                                          long rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* fr = f + row * d;
+  bool nz = false;
+  if ((d & 3) == 0 && (((uintptr_t)fr) & 15) == 0) {
+    for (int c = lane * 4; c < d; c += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(fr + c);
+      nz |= !(v.x == 0.f && v.y == 0.f && v.z == 0.f && v.w == 0.f);
+    }
+  } else {
+    for (int c = lane; c < d; c += 64) nz |= !(fr[c] == 0.f);
+  }
+  const unsigned long long any = __ballot(nz);
+  if (lane == 0) mask[row] = any ? 0 : 1;
+}
+
+constexpr int AF_MAXS = 1024;   // sequence positions handled by one workgroup
+
+// probs[b,s,g] = softmax_s(logits[b,s,g] masked to -1e9);  pooled[b, g*d + j] = sum_s probs[b,s,g] x[b,s,j]
+__global__ void __launch_bounds__(256) attflat_pool_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ x,
+                                                               const uint8_t* __restrict__ mask, float* __restrict__ probs,
+                                                               float* __restrict__ pooled, int S, int d, int G) {
+  __shared__ float sp[AF_MAXS];
+  __shared__ float red[4];
+  const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* lg = logits + (size_t)b * S * G + g;
+  float m = -INFINITY;
+  for (int s = tid; s < S; s += 256) {
+    float v = lg[(size_t)s * G];
+    if (mask && mask[(size_t)b * S + s]) v = -1e9f;
+    sp[s] = v;
+    m = fmaxf(m, v);
+  }
+  m = wave_max(m);
+  if (lane == 0) red[w] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int s = tid; s < S; s += 256) {
+    const float e = expf(sp[s] - m);
+    sp[s] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[w] = sum;
+  __syncthreads();
+  const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+  for (int s = tid; s < S; s += 256) {
+    const float pr = sp[s] * inv;
+    sp[s] = pr;
+    probs[((size_t)b * S + s) * G + g] = pr;
+  }
+  __syncthreads();
+  const float* xb = x + (size_t)b * S * d;
+  for (int j = tid; j < d; j += 256) {
+    float a0 = 0.f, a1 = 0.f;
+    int s = 0;
+    for (; s + 1 < S; s += 2) {
+      a0 += sp[s] * xb[(size_t)s * d + j];
+      a1 += sp[s + 1] * xb[(size_t)(s + 1) * d + j];
+    }
+    if (s < S) a0 += sp[s] * xb[(size_t)s * d + j];
+    pooled[(size_t)b * G * d + (size_t)g * d + j] = a0 + a1;
+  }
+}
+
+// t[s,g] = x[b,s,:] . dpooled[b,g,:];  dlogits[b,s,g] = p (t - sum_s' p t);  dx[b,s,:] = sum_g p[b,s,g] dpooled[b,g,:]
+// (a masked position's logit was REPLACED by -1e9, so its gradient is zero even when a fully masked sequence gives
+//  it the probability 1/S)
+__global__ void __launch_bounds__(256) attflat_pool_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ x,
+                                                               const uint8_t* __restrict__ mask,
+                                                               const float* __restrict__ dpooled, float* __restrict__ dlogits,
+                                                               float* __restrict__ dx, int S, int d, int G) {
+  __shared__ float st[AF_MAXS];
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* xb = x + (size_t)b * S * d;
+  for (int g = 0; g < G; ++g) {
+    const float* dp = dpooled + (size_t)b * G * d + (size_t)g * d;
+    // t[s]: one wave per row, lanes over the feature dimension
+    for (int s = w; s < S; s += 4) {
+      float a = 0.f;
+      for (int j = lane; j < d; j += 64) a += xb[(size_t)s * d + j] * dp[j];
+      a = wave_sum(a);
+      if (lane == 0) st[s] = a;
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int s = tid; s < S; s += 256) dot += probs[((size_t)b * S + s) * G + g] * st[s];
+    dot = wave_sum(dot);
+    if (lane == 0) red[w] = dot;
+    __syncthreads();
+    dot = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int s = tid; s < S; s += 256) {
+      const float pr = probs[((size_t)b * S + s) * G + g];
+      const bool masked = mask && mask[(size_t)b * S + s];
+      dlogits[((size_t)b * S + s) * G + g] = masked ? 0.f : pr * (st[s] - dot);
+    }
+    __syncthreads();
+  }
+  // dx: rows over waves, lanes over features
+  for (int s = w; s < S; s += 4) {
+    for (int j = lane; j < d; j += 64) {
+      float a = 0.f;
+      for (int g = 0; g < G; ++g) a += probs[((size_t)b * S + s) * G + g] * dpooled[(size_t)b * G * d + (size_t)g * d + j];
+      dx[((size_t)b * S + s) * d + j] = a;
+    }
+  }
+}
+
+}  // namespace mmnas
+
+using namespace mmnas;
+
+extern "C" int mmnas_row_is_zero(const float* f, uint8_t* mask, long rows, int d, void* stream) {
+  MMNAS_REQUIRE(f && mask && rows > 0 && d > 0, MMNAS_E_ARG, "row_is_zero: bad arguments");
+  MMNAS_LAUNCH(row_is_zero_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, f, mask, rows, d);
+  return check_launch("row_is_zero");
+}
+
+extern "C" int mmnas_attflat_pool_fwd(const float* logits, const float* x, const uint8_t* mask, float* probs,
+                                      float* pooled, int B, int S, int d, int G, void* stream) {
+  MMNAS_REQUIRE(logits && x && probs && pooled, MMNAS_E_ARG, "attflat_pool_fwd: null pointer");
+  MMNAS_REQUIRE(B > 0 && S > 0 && S <= AF_MAXS && d > 0 && G > 0, MMNAS_E_SHAPE, "attflat_pool_fwd: B=%d S=%d d=%d G=%d (S <= %d)",
+                B, S, d, G, AF_MAXS);
+  MMNAS_LAUNCH(attflat_pool_fwd_kernel, dim3(B, G), dim3(256), 0, (hipStream_t)stream, logits, x, mask, probs, pooled, S, d, G);
+  return check_launch("attflat_pool_fwd");
+}
+
+extern "C" int mmnas_attflat_pool_bwd(const float* probs, const float* x, const uint8_t* mask, const float* dpooled,
+                                      float* dlogits, float* dx, int B, int S, int d, int G, void* stream) {
+  MMNAS_REQUIRE(probs && x && dpooled && dlogits && dx, MMNAS_E_ARG, "attflat_pool_bwd: null pointer");
+  MMNAS_REQUIRE(B > 0 && S > 0 && S <= AF_MAXS && d > 0 && G > 0, MMNAS_E_SHAPE, "attflat_pool_bwd: B=%d S=%d d=%d G=%d (S <= %d)",
+                B, S, d, G, AF_MAXS);
+  MMNAS_LAUNCH(attflat_pool_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, probs, x, mask, dpooled, dlogits, dx, S, d, G);
+  return check_launch("attflat_pool_bwd");
+}

@@ -88,8 +88,8 @@ class LayerNorm(nn.Module):
 
 
 class AttFlat(nn.Module):
-    """Attentional pooling head (modules.py:59-85).  The two GEMM stages run on the HIP GEMM;
-    the masked softmax over <= 100 positions and the weighted sum are torch device ops."""
+    """Attentional pooling head (modules.py:59-85): the two GEMM stages run on the HIP GEMM, the masked softmax
+    over the sequence and the attention-weighted sum in one pooling kernel (mmnas_attflat_pool_*)."""
 
     def __init__(self, __C):
         super().__init__()
@@ -99,11 +99,7 @@ class AttFlat(nn.Module):
         self.linear_merge = nn.Linear(__C.HSIZE * __C.ATTFLAT_GLIMPSES, __C.ATTFLAT_OUT_SIZE)
 
     def forward(self, x, x_mask=None):
-        att = self.mlp(x)
-        if x_mask is not None:
-            att = att.masked_fill(x_mask.squeeze(1).squeeze(1).unsqueeze(2), -1e9)
-        att = torch.softmax(att, dim=1)
-        pooled = torch.cat([torch.sum(att[:, :, g:g + 1] * x, dim=1) for g in range(self.glimpses)], dim=1)
+        pooled = ops.attflat_pool(self.mlp(x), x, x_mask)
         return ops.linear(pooled, self.linear_merge.weight, self.linear_merge.bias)
 
 

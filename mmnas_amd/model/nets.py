@@ -86,7 +86,10 @@ class Backbone_Full(_Backbone):
 
 
 def make_mask(feature):
-    """True where a whole feature row is zero = padding (hygr_vqa.py:121-122)."""
+    """True where a whole feature row is zero = padding (hygr_vqa.py:121-122).  Float features on the GPU (the
+    [B,100,2048] region tensor) take one pass of mmnas_row_is_zero; token indices keep the torch expression."""
+    if feature.dtype == torch.float32 and feature.is_cuda:
+        return ops.row_is_zero(feature).unsqueeze(1).unsqueeze(2)
     return (torch.sum(torch.abs(feature), dim=-1) == 0).unsqueeze(1).unsqueeze(2)
 
 

@@ -527,6 +527,50 @@ def depthwise_conv_seq(x, weight, bias):
     return DwConvFn.apply(x, weight, bias)
 
 
+class AttFlatPoolFn(torch.autograd.Function):
+    """Pooling stage of AttFlat (modules.py:78-84): masked softmax of the glimpse logits over the sequence and the
+    attention-weighted sum of the features."""
+
+    @staticmethod
+    def forward(ctx, logits, x, mask):
+        logits, x = _f32c(logits), _f32c(x)
+        B, S, d = x.shape
+        G = logits.shape[-1]
+        m8 = _mask_u8(mask, B, S)
+        probs = torch.empty(B, S, G, dtype=torch.float32, device=x.device)
+        pooled = torch.empty(B, G * d, dtype=torch.float32, device=x.device)
+        L.check(L.lib().mmnas_attflat_pool_fwd(L.fptr(logits), L.fptr(x), L.ptr(m8), L.fptr(probs), L.fptr(pooled),
+                                               B, S, d, G, L.stream()))
+        ctx.save_for_backward(probs, x, m8)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        probs, x, m8 = ctx.saved_tensors
+        dpooled = _f32c(dpooled)
+        B, S, d = x.shape
+        G = probs.shape[-1]
+        dlogits = torch.empty_like(probs)
+        dx = torch.empty_like(x)
+        L.check(L.lib().mmnas_attflat_pool_bwd(L.fptr(probs), L.fptr(x), L.ptr(m8), L.fptr(dpooled), L.fptr(dlogits), L.fptr(dx),
+                                               B, S, d, G, L.stream()))
+        return dlogits, dx, None
+
+
+def attflat_pool(logits, x, mask):
+    return AttFlatPoolFn.apply(logits, x, mask)
+
+
+def row_is_zero(feature):
+    """make_mask (hygr_vqa.py:121-122) for a float feature tensor [..., d]: True where the whole row is zero."""
+    f = _f32c(feature)
+    d = f.shape[-1]
+    rows = f.numel() // d
+    out = torch.empty(f.shape[:-1], dtype=torch.uint8, device=f.device)
+    L.check(L.lib().mmnas_row_is_zero(L.fptr(f), L.ptr(out), rows, d, L.stream()))
+    return out.view(torch.bool)
+
+
 def dropout_mask(n, p, seed, site, device):
     """Materialise the multiplier stream of one dropout site (tests / mask replay)."""
     out = torch.empty(n, dtype=torch.float32, device=device)

@@ -393,6 +393,52 @@ def test_rel_fused_lazy_handle(B, Sq, Sk, C, H):
     assert rel_err(dby.cpu().numpy(), byt.grad.numpy()) < wtol
 
 
+# ----------------------------------------------------------------------------- stem / head helpers
+@pytest.mark.parametrize('shape', [(64, 100, 2048), (3, 7, 5), (2, 9, 36), (1, 1, 4)])
+def test_row_is_zero_is_make_mask(shape):
+    """mmnas_row_is_zero == (sum |f| == 0) of hygr_vqa.py:121-122, including -0.0 rows and NaN rows."""
+    from mmnas_amd import ops
+    rs = np.random.RandomState(sum(shape))
+    f = rnd(rs, *shape)
+    f[rs.uniform(size=shape[:-1]) < 0.4] = 0.0
+    if shape[0] > 1:
+        f[0, 0] = -0.0
+        f[1, 0] = 0.0
+        f[1, 0, -1] = np.nan
+    ft = torch.from_numpy(f)
+    ref = (ft.abs().sum(-1) == 0)
+    got = ops.row_is_zero(ft.to(DEV)).cpu()
+    assert got.dtype == torch.bool and torch.equal(got, ref)
+
+
+@pytest.mark.parametrize('B,S,d,G,use_mask', [(64, 100, 512, 1, True), (3, 14, 512, 1, True), (2, 7, 36, 2, True),
+                                              (2, 300, 64, 3, False), (1, 1, 8, 1, True)])
+def test_attflat_pool(B, S, d, G, use_mask):
+    """pooling stage of AttFlat (modules.py:78-84): masked softmax over the sequence + weighted sum, fwd and bwd,
+    against the torch expression of the reference in fp64; a fully masked sequence pools uniformly."""
+    from mmnas_amd import ops
+    rs = np.random.RandomState(B * 7 + S)
+    logits, x, gp = rnd(rs, B, S, G), rnd(rs, B, S, d), rnd(rs, B, G * d)
+    mask = None
+    if use_mask:
+        mask = rs.uniform(size=(B, 1, 1, S)) < 0.3
+        mask[0] = True                      # everything padded: softmax of equal -1e9 logits is uniform
+        mask_t = torch.from_numpy(mask)
+    lt, xt = torch.from_numpy(logits).double().requires_grad_(True), torch.from_numpy(x).double().requires_grad_(True)
+    att = lt
+    if use_mask:
+        att = att.masked_fill(mask_t.squeeze(1).squeeze(1).unsqueeze(2), -1e9)
+    att = torch.softmax(att, dim=1)
+    ref = torch.cat([(att[:, :, g_:g_ + 1] * xt).sum(1) for g_ in range(G)], dim=1)
+    ref.backward(torch.from_numpy(gp).double())
+    ld, xd = g(logits).requires_grad_(True), g(x).requires_grad_(True)
+    out = ops.attflat_pool(ld, xd, mask_t.to(DEV) if use_mask else None)
+    out.backward(g(gp))
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
+    assert rel_err(xd.grad.cpu().numpy(), xt.grad.numpy()) < 1e-5
+    assert rel_err(ld.grad.cpu().numpy(), lt.grad.numpy()) < 2e-5
+
+
 # ----------------------------------------------------------------------------- attention core
 def _mha_ref(Q, K, V, mask, biasT, H, dh, dmask=None):
     B, Sq, _ = Q.shape
