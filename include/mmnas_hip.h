@@ -162,6 +162,11 @@ int mmnas_attflat_pool_fwd(const float* logits, const float* x, const uint8_t* m
 int mmnas_attflat_pool_bwd(const float* probs, const float* x, const uint8_t* mask, const float* dpooled,
                            float* dlogits, float* dx, int B, int S, int d, int G, void* stream);
 
+/* Data path: box-geometry relation features of the loaders (relation_embedding, load_data_vqa.py:224-239,
+ * load_data_vgd.py:7-33), batched: bbox [B,S,4] (x1,y1,x2,y2), nobj [B] valid boxes per sample (NULL = S)
+ * -> out [B,S,S,4] = (log max(|dcx|/w_i,1e-3), log max(|dcy|/h_i,1e-3), log(w_i/w_j), log(h_i/h_j)), zero padded. */
+int mmnas_relation_embedding(const float* bbox, const int* nobj, float* out, int B, int S, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Relation bias of RelMHAtt (modules.py:231-235):
  *   biasT[b,h,k,q] = log(max(relu(rel[b,q,k,:] . Wr[h,:] + br[h]), 1e-6))

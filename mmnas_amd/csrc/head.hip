@@ -150,3 +150,43 @@ extern "C" int mmnas_attflat_pool_bwd(const float* probs, const float* x, const 
   MMNAS_LAUNCH(attflat_pool_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, probs, x, mask, dpooled, dlogits, dx, S, d, G);
   return check_launch("attflat_pool_bwd");
 }
+
+// ------------------------------------------------------------------------------------------
+// Data path: the box-geometry relation features the reference's loaders compute per sample on
+// the CPU (relation_embedding, load_data_vqa.py:224-239 / load_data_vgd.py:7-33) and ship as a [100,100,4] tensor
+// (10 MB per batch of 64 over PCIe).  Batched on the GPU from the [B,S,4] boxes (6 KB per batch):
+//   w_i = x2-x1+1, h_i = y2-y1+1, c = box centre
+//   out[b,i,j] = ( log max(|cx_i-cx_j| / w_i, 1e-3), log max(|cy_i-cy_j| / h_i, 1e-3), log(w_i/w_j), log(h_i/h_j) )
+// for i, j < nobj[b]; zero elsewhere (the loaders zero-pad to S).
+// ------------------------------------------------------------------------------------------
+namespace mmnas {
+__global__ void __launch_bounds__(256) relation_embedding_kernel(const float* __restrict__ bbox, const int* __restrict__ nobj,
+                                                                 float* __restrict__ out, int S) {
+  const int b = blockIdx.y, i = blockIdx.x;
+  const int n = nobj ? nobj[b] : S;
+  const float* bi = bbox + ((size_t)b * S + i) * 4;
+  const float wi = (bi[2] - bi[0]) + 1.f, hi = (bi[3] - bi[1]) + 1.f;
+  const float cxi = (bi[0] + bi[2]) * 0.5f, cyi = (bi[1] + bi[3]) * 0.5f;
+  float4* o = reinterpret_cast<float4*>(out + ((size_t)b * S + i) * S * 4);
+  for (int j = threadIdx.x; j < S; j += 256) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n && j < n) {
+      const float* bj = bbox + ((size_t)b * S + j) * 4;
+      const float wj = (bj[2] - bj[0]) + 1.f, hj = (bj[3] - bj[1]) + 1.f;
+      const float cxj = (bj[0] + bj[2]) * 0.5f, cyj = (bj[1] + bj[3]) * 0.5f;
+      v.x = logf(fmaxf(fabsf((cxi - cxj) / wi), 1e-3f));
+      v.y = logf(fmaxf(fabsf((cyi - cyj) / hi), 1e-3f));
+      v.z = logf(wi / wj);
+      v.w = logf(hi / hj);
+    }
+    o[j] = v;
+  }
+}
+}  // namespace mmnas
+
+extern "C" int mmnas_relation_embedding(const float* bbox, const int* nobj, float* out, int B, int S, void* stream) {
+  MMNAS_REQUIRE(bbox && out && B > 0 && S > 0, MMNAS_E_ARG, "relation_embedding: bad arguments");
+  MMNAS_REQUIRE((((uintptr_t)out) & 15) == 0, MMNAS_E_ARG, "relation_embedding: output not 16-byte aligned");
+  MMNAS_LAUNCH(relation_embedding_kernel, dim3(S, B), dim3(256), 0, (hipStream_t)stream, bbox, nobj, out, S);
+  return check_launch("relation_embedding");
+}

@@ -571,6 +571,18 @@ def row_is_zero(feature):
     return out.view(torch.bool)
 
 
+def relation_embedding(bbox, nobj=None):
+    """Box-geometry relation features of the reference's loaders (relation_embedding, load_data_vqa.py:224-239),
+    batched on the GPU: bbox [B,S,4] float32 (x1,y1,x2,y2), nobj [B] int32 valid boxes per sample (None: all S)
+    -> [B,S,S,4], zero outside the first nobj[b] rows/columns (the loaders' zero padding)."""
+    bbox = _f32c(bbox)
+    B, S, _ = bbox.shape
+    out = torch.empty(B, S, S, 4, dtype=torch.float32, device=bbox.device)
+    n = None if nobj is None else nobj.to(device=bbox.device, dtype=torch.int32).contiguous()
+    L.check(L.lib().mmnas_relation_embedding(L.fptr(bbox), L.ptr(n), L.fptr(out), B, S, L.stream()))
+    return out
+
+
 def dropout_mask(n, p, seed, site, device):
     """Materialise the multiplier stream of one dropout site (tests / mask replay)."""
     out = torch.empty(n, dtype=torch.float32, device=device)

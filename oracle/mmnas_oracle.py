@@ -271,6 +271,21 @@ def att_flat(P, x, x_mask, glimpses, drops=None):
     return _linear(pooled, P['linear_merge.weight'], P['linear_merge.bias'])
 
 
+def relation_embedding(bbox):
+    """Loader-side relation features (load_data_vqa.py:224-239 = load_data_vgd.py:7-33 = load_data_itm.py:5-31) for one
+    sample: bbox [n,4] -> [n,n,4].  PARITY UNPINNED for this function: the loader modules cannot be imported in the
+    build container (they import en_vectors_web_lg / spacy at module level), so this restatement follows the source
+    text only and no golden vector backs it."""
+    x_min, y_min, x_max, y_max = torch.chunk(bbox, 4, dim=1)
+    cx, cy = (x_min + x_max) * 0.5, (y_min + y_max) * 0.5
+    w, h = (x_max - x_min) + 1., (y_max - y_min) + 1.
+    dx = torch.log(torch.clamp(torch.abs((cx - cx.view(1, -1)) / w), min=1e-3))
+    dy = torch.log(torch.clamp(torch.abs((cy - cy.view(1, -1)) / h), min=1e-3))
+    dw = torch.log(w / w.view(1, -1))
+    dh = torch.log(h / h.view(1, -1))
+    return torch.stack((dx, dy, dw, dh), -1)
+
+
 def make_mask(feature):
     """hygr_vqa.py:121-122 -- True where the whole feature row is zero (padding)."""
     return (feature.abs().sum(-1) == 0).unsqueeze(1).unsqueeze(2)

@@ -411,6 +411,27 @@ def test_row_is_zero_is_make_mask(shape):
     assert got.dtype == torch.bool and torch.equal(got, ref)
 
 
+def test_relation_embedding_batched():
+    """loader-side box-geometry features (load_data_vqa.py:224-239) computed batched on the GPU, zero padded
+    to S, against the per-sample restatement in the oracle (parity unpinned for this function, see oracle)."""
+    from mmnas_amd import ops
+    from oracle import mmnas_oracle as O
+    rs = np.random.RandomState(31)
+    B, S = 5, 100
+    x1, y1 = rs.uniform(0, 500, (B, S)), rs.uniform(0, 400, (B, S))
+    bw, bh = rs.uniform(1, 300, (B, S)), rs.uniform(1, 200, (B, S))
+    bbox = np.stack([x1, y1, x1 + bw, y1 + bh], -1).astype(np.float32)
+    bbox[0, 3] = bbox[0, 2]                     # identical boxes: |dcx|/w clamps at 1e-3
+    nobj = np.array([100, 37, 1, 64, 10], np.int32)
+    got = ops.relation_embedding(g(bbox), torch.from_numpy(nobj)).cpu().numpy()
+    for b in range(B):
+        n = int(nobj[b])
+        ref = np.zeros((S, S, 4), np.float32)
+        ref[:n, :n] = O.relation_embedding(torch.from_numpy(bbox[b, :n]).double()).numpy()
+        assert rel_err(got[b], ref) < 1e-4   # fp32 centre differences of ~500-pixel coordinates vs the fp64 restatement
+    assert np.array_equal(ops.relation_embedding(g(bbox)).cpu().numpy()[0], got[0])   # nobj=None: all S boxes
+
+
 @pytest.mark.parametrize('B,S,d,G,use_mask', [(64, 100, 512, 1, True), (3, 14, 512, 1, True), (2, 7, 36, 2, True),
                                               (2, 300, 64, 3, False), (1, 1, 8, 1, True)])
 def test_attflat_pool(B, S, d, G, use_mask):
