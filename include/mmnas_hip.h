@@ -167,6 +167,11 @@ int mmnas_attflat_pool_bwd(const float* probs, const float* x, const uint8_t* ma
  * -> out [B,S,S,4] = (log max(|dcx|/w_i,1e-3), log max(|dcy|/h_i,1e-3), log(w_i/w_j), log(h_i/h_j)), zero padded. */
 int mmnas_relation_embedding(const float* bbox, const int* nobj, float* out, int B, int S, void* stream);
 
+/* Supernet plumbing: out [rows, width] = one-hot rows, out[r, idx_host[r]] = 1 (idx_host is a HOST array, read at
+ * call time and passed in the kernel arguments; rows <= 128).  Writes the alpha_gate block of all MixedOps after
+ * sampling (mixed.py:131-158) without a host->device copy / stream synchronisation. */
+int mmnas_onehot_rows(float* out, int rows, int width, const int* idx_host, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Relation bias of RelMHAtt (modules.py:231-235):
  *   biasT[b,h,k,q] = log(max(relu(rel[b,q,k,:] . Wr[h,:] + br[h]), 1e-6))

@@ -190,3 +190,26 @@ extern "C" int mmnas_relation_embedding(const float* bbox, const int* nobj, floa
   MMNAS_LAUNCH(relation_embedding_kernel, dim3(S, B), dim3(256), 0, (hipStream_t)stream, bbox, nobj, out, S);
   return check_launch("relation_embedding");
 }
+
+// ------------------------------------------------------------------------------------------
+// Supernet plumbing: write the binary gates of all nodes (MixedOp.binarize, mixed.py:131-158: alpha_gate = one-hot
+// of the sampled operator) in one launch whose indices travel in the kernel arguments -- no host->device copy,
+// hence no stream synchronisation, per NAS step.
+// ------------------------------------------------------------------------------------------
+namespace mmnas {
+struct OneHotArgs { int idx[128]; };
+__global__ void onehot_rows_kernel(float* __restrict__ out, int rows, int width, OneHotArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * width) return;
+  const int r = i / width, c = i - r * width;
+  out[i] = a.idx[r] == c ? 1.f : 0.f;
+}
+}  // namespace mmnas
+
+extern "C" int mmnas_onehot_rows(float* out, int rows, int width, const int* idx_host, void* stream) {
+  MMNAS_REQUIRE(out && idx_host && rows > 0 && rows <= 128 && width > 0, MMNAS_E_ARG, "onehot_rows: rows=%d (1..128) width=%d", rows, width);
+  OneHotArgs a;
+  for (int r = 0; r < 128; ++r) a.idx[r] = r < rows ? idx_host[r] : -1;
+  MMNAS_LAUNCH(onehot_rows_kernel, dim3(cdiv((long)rows * width, 256)), dim3(256), 0, (hipStream_t)stream, out, rows, width, a);
+  return check_launch("onehot_rows");
+}

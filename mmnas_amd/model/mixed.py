@@ -58,6 +58,8 @@ class MixedOp(nn.Module):
         self.active_index = None
         self.inactive_index = None
         self._two_snapshot = None
+        self._cand_params = None
+        self.alpha_version = 0
 
     def forward(self, s, pre=None, s_mask=None, pre_mask=None, rel_embed=None):
         if MixedOp.MODE in ('full', 'two'):
@@ -105,9 +107,17 @@ class MixedOp(nn.Module):
         self.set_active(act, inact)
         self.clear_candidate_grads()
 
+    def candidate_parameters(self):
+        """All candidates' parameters (cached: walking the module tree 30 times per step cost 2 ms of host time;
+        unused_modules_off() only swaps entries of candidate_ops for None, the parameters stay the same objects)."""
+        if self._cand_params is None:
+            self._cand_params = [p for op in self.candidate_ops if op is not None for p in op.parameters()]
+            assert all(op is not None for op in self.candidate_ops), 'candidate_parameters() before unused_modules_back()'
+        return self._cand_params
+
     def clear_candidate_grads(self):
         # "avoid over-regularization" (mixed.py:160-163): unsampled candidates must not see Adam momentum
-        for p in self.candidate_ops.parameters():
+        for p in self.candidate_parameters():
             p.grad = None
 
     def set_arch_param_grad(self):
@@ -133,3 +143,4 @@ class MixedOp(nn.Module):
         new = self.alpha_prob.data[idx]
         offset = torch.logsumexp(new, 0) - torch.logsumexp(old, 0)
         self.alpha_prob.data[idx] -= offset
+        self.alpha_version += 1   # (.data writes do not bump the tensor version the sampling cache keys on)

@@ -7,6 +7,7 @@ interchangeable.
 Stem and head: embedding + LSTM stay on torch (MIOpen); every Linear (imgfeat_linear, the relation
 embeddings, AttFlat, the projections) and every LayerNorm run on the HIP GEMM / LayerNorm kernels.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -191,6 +192,7 @@ class NetSearchBase(_Net):
         self._net_weights = [(n, p) for n, p in self.named_parameters()
                              if 'alpha_prob' not in n and 'alpha_gate' not in n]
         self._flat = None
+        self._probs_cache = None
 
     # -- architecture parameters ------------------------------------------------------------
     def init_arch(self):
@@ -234,19 +236,44 @@ class NetSearchBase(_Net):
             m.alpha_prob.data = prob[i, :m.n_choices]
             m.alpha_gate.data = gate[i, :m.n_choices]
         self._flat = (prob, gate)
+        self._probs_cache = None
         return self._flat
 
+    def _probs_cpu(self, prob):
+        """softmax(alpha_prob) of every node on the host.  The alphas change only at architecture steps (one in six
+        of the bilevel loop, search_vqa.py:149-150), so the device->host copy -- a full stream synchronisation -- is
+        made only when they did: the cache keys on the parameters' version counters (in-place optimizer updates and
+        load_state_dict bump them) plus MixedOp.alpha_version for the `.data` writes of the rescale step."""
+        key = tuple((m.alpha_prob._version, m.alpha_version) for m in self.redundant_modules)
+        if self._probs_cache is None or self._probs_cache[0] != key:
+            self._probs_cache = (key, torch.softmax(prob.detach(), dim=1).cpu())
+        return self._probs_cache[1]
+
+    def invalidate_arch_cache(self):
+        """Call after writing alpha_prob through `.data` (anything that does not bump the tensor version)."""
+        self._probs_cache = None
+
     def reset_binary_gates(self):
-        """binarize() every node (hygr_vqa.py:168-173) with one device->host and one host->device copy."""
+        """binarize() every node (hygr_vqa.py:168-173): sampled on the host from the cached probabilities, the gates
+        written by one kernel that carries the indices in its arguments -- no copy in either direction, so the host
+        is free to run ahead of the GPU."""
         prob, gate = self._flat_alphas()
-        probs = torch.softmax(prob.detach(), dim=1).cpu()
-        g = torch.zeros(prob.shape)
-        for i, m in enumerate(self.redundant_modules):
+        probs = self._probs_cpu(prob)
+        mops = self.redundant_modules
+        idx = (ctypes.c_int * len(mops))()
+        for i, m in enumerate(mops):
             act, inact = sample_indices(probs[i, :m.n_choices], MixedOp.MODE)
             m.set_active(act, inact, write_gate=False)
-            g[i, act[0]] = 1.0
+            idx[i] = act[0]
             m.clear_candidate_grads()
-        gate.copy_(g)
+        if gate.is_cuda and len(mops) <= 128:
+            from .. import _lib as L
+            L.check(L.lib().mmnas_onehot_rows(L.fptr(gate), gate.shape[0], gate.shape[1], idx, L.stream()))
+        else:
+            g = torch.zeros(gate.shape)
+            for i in range(len(mops)):
+                g[i, idx[i]] = 1.0
+            gate.copy_(g)
 
     def set_sampled(self, plan):
         """Install an explicit list of (active, inactive) choices, one per node (tests, replay)."""

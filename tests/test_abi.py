@@ -167,3 +167,53 @@ def test_supernet_structure_and_prior_on_host():
     cf = cases.net_case('vqa', 'mmnas_vqa', 2)
     full = Net_Full(cf['cfg'], init)
     assert set(full.state_dict().keys()) == set(cf['P'].keys())
+
+
+def test_sampling_probability_cache_follows_the_alphas():
+    """reset_binary_gates() keeps softmax(alpha) on the host between architecture updates (no device->host copy per
+    weight step); an in-place optimizer update, a load_state_dict and the rescale step's `.data` write must each
+    refresh it (host logic only: CPU parameters)."""
+    from mmnas.model.hygr_vqa import Net_Search
+    from mmnas.model.mixed import MixedOp
+    from mmnas_amd.model import mixed
+    c = cases.net_case('vqa', None, 1, search=True)
+    init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+            'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
+    net = Net_Search(c['cfg'], init)
+    mixed.seed_arch_sampler(5)
+    net.reset_binary_gates()
+    first = net._probs_cache[1]
+    net.reset_binary_gates()
+    assert net._probs_cache[1] is first                                   # reused
+    for m in net.redundant_modules:                                       # gates are one-hot of the sampled index
+        g = m.alpha_gate.detach().numpy()
+        assert g.sum() == 1.0 and g[m.active_index[0]] == 1.0
+    # 1. in-place update through the Parameter (what torch.optim.Adam does): node 0 collapses onto its last choice
+    opt = torch.optim.SGD(list(net.alpha_prob_parameters()), lr=1.0)
+    p0 = next(iter(net.alpha_prob_parameters()))
+    p0.grad = torch.zeros_like(p0)
+    p0.grad[-1] = -50.0
+    opt.step()
+    net.reset_binary_gates()
+    assert net._probs_cache[1] is not first
+    assert net.redundant_modules[0].active_index == [p0.numel() - 1]
+    # 2. the rescale step writes through .data: MixedOp.alpha_version covers it
+    MixedOp.MODE = 'two'
+    try:
+        net.reset_binary_gates()
+        before = net._probs_cache[1]
+        for m in net.redundant_modules:
+            m.alpha_gate.grad = torch.ones_like(m.alpha_gate)
+        net.set_arch_param_grad()
+        for p in net.alpha_prob_parameters():
+            p.data.add_(0.25 * torch.arange(p.numel(), dtype=p.dtype))    # an update that bumps no version counter
+        net.rescale_updated_arch_param()
+        net.reset_binary_gates()
+        assert net._probs_cache[1] is not before
+    finally:
+        MixedOp.MODE = None
+    # 3. load_state_dict
+    before = net._probs_cache[1]
+    net.load_state_dict(net.state_dict())
+    net.reset_binary_gates()
+    assert net._probs_cache[1] is not before
