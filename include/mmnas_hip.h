@@ -12,7 +12,8 @@
  *   - plain pointers and sizes only; every pointer is DEVICE memory (HBM) unless marked host.
  *   - all tensors are dense row-major fp32; masks are uint8 (non-zero = padded key).
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Every call only enqueues
- *     work on that stream: no allocation, no synchronisation, graph-capturable.
+ *     work on that stream: no allocation (one exception: mmnas_gemm's workspace, see there), no
+ *     synchronisation, graph-capturable.
  *   - return value: 0 on success, negative MMNAS_E_* otherwise; mmnas_last_error() gives the text.
  *   - scratch/saved buffers are caller-owned; sizes come from the *_plan() functions.
  */
@@ -70,10 +71,11 @@ int mmnas_dropout_mask(float* out, size_t n, float p, uint64_t seed, uint32_t si
  *                            * (gate[row*ldgate+col] > 0 ? gate_scale : 0); + residual[row*ldres+col]
  *   accumulate != 0: the result is ADDED onto the values C holds (weight gradients accumulating into
  *   a flat gradient buffer); not combinable with relu / dropout.
- *   Scheduling is internal (stream-K: output tiles are cut along K where that balances the 256 CUs;
- *   partial tiles meet in a per-stream workspace the library allocates on first use, 64 MiB, and are
- *   summed in a fixed order -- results are bitwise reproducible, no float atomics).  split_k is kept
- *   for source compatibility: a value > 1 only implies accumulate.
+ *   Scheduling is internal.  Plain products: whole tiles, with ragged tails / under-filled launches cut
+ *   along K (stream-K); partial tiles meet in a per-stream workspace the library allocates on first use
+ *   (64 MiB -- the one allocation any call makes) and are summed in a fixed order: bitwise reproducible,
+ *   no float atomics.  Accumulating products: split-K, the pieces added with float atomics (summation order
+ *   not fixed).  split_k is kept for source compatibility: a value > 1 only implies accumulate.
  * ------------------------------------------------------------------------------------------ */
 enum { MMNAS_GEMM_NT = 0, MMNAS_GEMM_NN = 1, MMNAS_GEMM_TN = 2 };
 
@@ -337,6 +339,10 @@ int mmnas_dwconv_seq_bwd(const float* x, const float* w, const float* dy, float*
 typedef struct mmnas_segment { float* ptr; uint64_t offset; uint64_t n; } mmnas_segment;
 int mmnas_pack_segments(const mmnas_segment* segs, int nseg, float* staging, float scale,
                         int direction, void* stream);
+/* Same, with `segs` a HOST array read at call time and carried in the kernel arguments (chunks of 96 records):
+ * no host->device copy of the table, hence no stream synchronisation per step. */
+int mmnas_pack_segments_host(const mmnas_segment* segs_host, int nseg, float* staging, float scale,
+                             int direction, void* stream);
 
 /* Fused Adam over a flat fp32 parameter buffer (net_optim.step(), search_vqa.py:300 through
  * mmnas/utils/optimizer.py): torch.optim.Adam arithmetic with bias correction at `step`.

@@ -115,6 +115,7 @@ SYMBOLS = {
     'mmnas_dwconv_seq_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),
     'mmnas_dwconv_seq_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),
     'mmnas_pack_segments': (_i, [_fp, _i, _fp, _f, _i, _fp]),
+    'mmnas_pack_segments_host': (_i, [C.POINTER(Segment), _i, _fp, _f, _i, _fp]),
     'mmnas_adam_step': (_i, [_fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _fp, _f, _i, _fp]),
     'mmnas_sumsq': (_i, [_fp, _sz, _fp, _fp]),
     'mmnas_prof_enable': (_i, [_i]),

@@ -106,6 +106,24 @@ __global__ void pack_kernel(const mmnas_segment* segs, float* staging, float sca
   }
 }
 
+struct PackArgs { mmnas_segment s[96]; };
+__global__ void pack_args_kernel(PackArgs a, float* staging, float scale, int direction) {
+  const mmnas_segment s = a.s[blockIdx.y];
+  float* stg = staging + s.offset;
+  const size_t n4 = (((uintptr_t)s.ptr & 15) == 0 && ((uintptr_t)stg & 15) == 0) ? (s.n >> 2) : 0;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float4* p4 = reinterpret_cast<float4*>(s.ptr);
+  float4* s4 = reinterpret_cast<float4*>(stg);
+  for (size_t i = t0; i < n4; i += stride) {
+    if (direction == 0) { float4 v = p4[i]; v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; s4[i] = v; }
+    else { float4 v = s4[i]; v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; p4[i] = v; }
+  }
+  for (size_t i = (n4 << 2) + t0; i < s.n; i += stride) {
+    if (direction == 0) stg[i] = s.ptr[i] * scale; else s.ptr[i] = stg[i] * scale;
+  }
+}
+
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1,
                             float b2, float eps, float wd, const float* sumsq, float max_norm, float c1, float c2) {
   float gscale = 1.f;
@@ -186,6 +204,20 @@ extern "C" int mmnas_pack_segments(const mmnas_segment* segs, int nseg, float* s
   MMNAS_REQUIRE(segs && staging, MMNAS_E_ARG, "mmnas_pack_segments: null pointer");
   MMNAS_LAUNCH(pack_kernel, dim3(64, nseg), dim3(256), 0, (hipStream_t)stream, segs, staging, scale, direction);
   return check_launch("pack_segments");
+}
+
+extern "C" int mmnas_pack_segments_host(const mmnas_segment* segs_host, int nseg, float* staging, float scale,
+                                        int direction, void* stream) {
+  if (nseg <= 0) return MMNAS_OK;
+  MMNAS_REQUIRE(segs_host && staging, MMNAS_E_ARG, "mmnas_pack_segments_host: null pointer");
+  for (int base = 0; base < nseg; base += 96) {
+    const int n = nseg - base < 96 ? nseg - base : 96;
+    PackArgs a;
+    memset(&a, 0, sizeof(a));
+    memcpy(a.s, segs_host + base, (size_t)n * sizeof(mmnas_segment));
+    MMNAS_LAUNCH(pack_args_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, a, staging, scale, direction);
+  }
+  return check_launch("pack_segments_host");
 }
 
 extern "C" int mmnas_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,

@@ -249,9 +249,8 @@ class SupernetReducer:
             for k, (o, n) in enumerate(segs):
                 arr[k].ptr, arr[k].offset, arr[k].n = base + 4 * o, off, n
                 off += n
-            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.fg.flat.device, non_blocking=False)
-            L.check(L.lib().mmnas_pack_segments(dev.data_ptr(), len(segs), L.fptr(stg), 1.0, direction, L.stream()))
-            self._keep = dev
+            # the table rides in the kernel arguments: no host->device copy, no stream synchronisation per step
+            L.check(L.lib().mmnas_pack_segments_host(arr, len(segs), L.fptr(stg), 1.0, direction, L.stream()))
         else:  # CPU tensors (gloo tests): host plumbing only
             off = 0
             for o, n in segs:

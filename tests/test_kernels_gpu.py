@@ -590,3 +590,23 @@ def test_pack_adam_sumsq():
     a0, b0 = a.clone(), b.clone()
     L.check(L.lib().mmnas_pack_segments(sd.data_ptr(), 2, L.fptr(stg), 2.0, 1, L.stream()))
     assert torch.allclose(a, a0) and torch.allclose(b, b0)
+    # the host-table variant (table in the kernel arguments, chunks of 96 records): 200 ragged segments
+    sizes = [int(x) for x in rs.randint(1, 700, size=200)]
+    flat = g(rnd(rs, sum(sizes) + 64 * 200))
+    many = (L.Segment * 200)()
+    off_src = off_stg = 0
+    for i, nseg in enumerate(sizes):
+        many[i].ptr, many[i].offset, many[i].n = flat.data_ptr() + 4 * off_src, off_stg, nseg
+        off_src += nseg + 64
+        off_stg += nseg
+    stg2 = torch.zeros(off_stg, device=DEV)
+    L.check(L.lib().mmnas_pack_segments_host(many, 200, L.fptr(stg2), 1.0, 0, L.stream()))
+    exp = torch.cat([flat[o:o + nseg] for o, nseg in zip(np.cumsum([0] + [x + 64 for x in sizes[:-1]]), sizes)])
+    assert torch.equal(stg2, exp)
+    before = flat.clone()
+    L.check(L.lib().mmnas_pack_segments_host(many, 200, L.fptr(stg2 * 3.0), 1.0, 1, L.stream()))
+    o = 0
+    for nseg in sizes:
+        assert torch.equal(flat[o:o + nseg], before[o:o + nseg] * 3.0)
+        assert torch.equal(flat[o + nseg:o + nseg + 64], before[o + nseg:o + nseg + 64])     # gaps untouched
+        o += nseg + 64
