@@ -544,6 +544,7 @@ static int env_int(const char* name, int dflt) {
 //   MMNAS_GEMM_SK=0|1|2    stream-K / split-K never, automatic, always
 //   MMNAS_GEMM_WGS=n       co-resident workgroup budget (default 1024 for 64^2 tiles, 512 for 128^2)
 //   MMNAS_GEMM_MIN_UNITS=n fewest K-tiles a workgroup is given (default 4)
+//   MMNAS_GEMM_GM=n        row-panels per tile-order block (default 8)     MMNAS_GEMM_XCD=0 identity workgroup mapping
 struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd; bool loaded; };
 static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, false};
 static void load_tuning() {

@@ -38,8 +38,8 @@ static size_t pool_next = 0;
 
 static hipEvent_t get_event() {
   if (pool_next == pool.size()) {
-    hipEvent_t e;
-    hipEventCreate(&e);
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) e = nullptr;   // (a null event makes the launch carry no timestamp)
     pool.push_back(e);
   }
   return pool[pool_next++];
