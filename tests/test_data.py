@@ -1,0 +1,75 @@
+"""Data path (mmnas_amd/data.py): known-answer tests of the loader restatements (host logic, CPU) and the device
+prefetcher (pass-through on CPU; the GPU path is covered in test_data_gpu below)."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import rel_err  # noqa: F401  (also puts the repo on sys.path)
+from mmnas_amd import data
+
+
+def test_pad_rows_truncates_and_zero_pads():
+    a = np.arange(12, dtype=np.float32).reshape(4, 3)
+    p = data.pad_rows(a, 6)
+    assert p.shape == (6, 3) and np.array_equal(p[:4], a) and not p[4:].any()
+    t = data.pad_rows(a, 2)
+    assert np.array_equal(t, a[:2])
+    assert data.pad_rows(np.zeros((0, 3), np.float32), 2).shape == (2, 3)
+
+
+def test_bbox_features_known_answer():
+    # load_data_vqa.py:266-275: x over the image width (img_shape[1]), y over the height, area fraction
+    bbox = np.array([[10., 20., 110., 220.], [0., 0., 640., 480.]], np.float32)
+    f = data.bbox_features(bbox, (480, 640))
+    exp = np.array([[10 / 640, 20 / 480, 110 / 640, 220 / 480, 100 * 200 / (480 * 640)], [0, 0, 1, 1, 1]], np.float32)
+    assert f.dtype == np.float32 and np.allclose(f, exp, rtol=1e-6)
+
+
+def test_load_frcn_npz_and_collate():
+    rs = np.random.RandomState(0)
+    samples = []
+    for n in (37, 100, 120):
+        buf = io.BytesIO()
+        np.savez(buf, x=rs.standard_normal((2048, n)).astype(np.float32), bbox=rs.uniform(0, 400, (n, 4)).astype(np.float32),
+                 image_h=np.int64(480), image_w=np.int64(640))
+        buf.seek(0)
+        samples.append(data.load_frcn_npz(buf, pad_size=100))
+    s = samples[0]
+    assert s['frcn_feat'].shape == (100, 2048) and s['bbox_feat'].shape == (100, 5) and s['bbox'].shape == (100, 4)
+    assert s['nobj'] == 37 and not s['frcn_feat'][37:].any() and s['frcn_feat'][:37].any()
+    assert samples[2]['nobj'] == 100                      # more boxes than the pad size: truncated
+    b = data.collate_regions(samples)
+    assert b['frcn_feat'].shape == (3, 100, 2048) and b['nobj'].tolist() == [37, 100, 100] and b['nobj'].dtype == np.int32
+
+
+def test_prefetcher_is_a_pass_through_on_cpu():
+    batches = [({'a': np.full((2, 3), i, np.float32)}, torch.full((4,), float(i)), 'tag%d' % i) for i in range(4)]
+    out = list(data.DevicePrefetcher(batches, 'cpu'))
+    assert len(out) == 4
+    for i, (d, t, tag) in enumerate(out):
+        assert isinstance(d['a'], torch.Tensor) and float(d['a'][0, 0]) == i and float(t[0]) == i and tag == 'tag%d' % i
+    assert list(data.DevicePrefetcher([], 'cpu')) == []
+
+
+@pytest.mark.gpu
+def test_prefetcher_and_relations_on_the_gpu():
+    from oracle import mmnas_oracle as O
+    rs = np.random.RandomState(3)
+    batches = []
+    for i in range(5):
+        x1, y1 = rs.uniform(0, 300, (4, 20)), rs.uniform(0, 200, (4, 20))
+        bbox = np.stack([x1, y1, x1 + rs.uniform(1, 99, (4, 20)), y1 + rs.uniform(1, 99, (4, 20))], -1).astype(np.float32)
+        batches.append({'bbox': bbox, 'nobj': np.array([20, 3, 11, 1], np.int32), 'feat': rs.standard_normal((4, 20, 64)).astype(np.float32)})
+    seen = 0
+    for ref, got in zip(batches, data.DevicePrefetcher(batches, 'cuda')):
+        assert got['feat'].is_cuda and np.array_equal(got['feat'].cpu().numpy(), ref['feat'])
+        rel = data.relations_on_device(got['bbox'], got['nobj']).cpu().numpy()
+        for b in range(4):
+            n = int(ref['nobj'][b])
+            exp = np.zeros((20, 20, 4), np.float32)
+            exp[:n, :n] = O.relation_embedding(torch.from_numpy(ref['bbox'][b, :n]).double()).numpy()
+            assert rel_err(rel[b], exp) < 1e-4
+        seen += 1
+    assert seen == 5
