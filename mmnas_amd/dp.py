@@ -28,6 +28,11 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _has_avg(group=None):
+    """ReduceOp.AVG exists on RCCL only; gloo (CPU tests, and the two-ranks-on-one-GPU test) sums and scales."""
+    return dist.get_backend(group) == 'nccl'
+
+
 def _align(n, a=64):
     return (n + a - 1) // a * a
 
@@ -115,16 +120,25 @@ class GradReducer:
             for i in idxs:
                 self.bucket_of[i] = b
         self._pending = [0] * len(self.buckets)
+        self._seen = [True] * len(self.fg.params)   # armed by begin_step()
         self._works = []
         self._launched = [False] * len(self.buckets)
         self.comm_stream = torch.cuda.Stream() if (self.is_cuda and self.world > 1) else None
         if self.world > 1:
             for i, p in enumerate(self.fg.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))   # gradients produced by torch autograd
+                # The hook is the ONLY arrival signal.  Autograd runs a parameter's AccumulateGrad node -- and
+                # this hook -- once per backward, after every use of the parameter has run its backward, also
+                # when the operator wrote the gradient through a sink and handed autograd None.  (Counting the
+                # sinks' done() as well made every sink parameter arrive twice, so a bucket could be reduced
+                # before its last gradients were enqueued.)
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
         if self.is_cuda:
-            self.fg.enable_sinks(self._arrived if self.world > 1 else None)  # gradients written by the HIP kernels
+            self.fg.enable_sinks(None)   # HIP backward kernels add straight into the flat buffer
 
     def _arrived(self, i):
+        if self._seen[i]:
+            return
+        self._seen[i] = True
         b = self.bucket_of[i]
         self._pending[b] -= 1
         if self._pending[b] == 0:
@@ -141,14 +155,16 @@ class GradReducer:
         self._launched[b] = True
         lo, hi, _ = self.buckets[b]
         chunk = self.fg.flat[lo:hi]
+        avg = _has_avg(self.group)
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
         if self.is_cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                self._works.append((dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True), chunk, False))
-        else:  # gloo (CPU tests): no AVG
-            self._works.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk, True))
+                self._works.append((dist.all_reduce(chunk, op=op, group=self.group, async_op=True), chunk, not avg))
+        else:
+            self._works.append((dist.all_reduce(chunk, op=op, group=self.group, async_op=True), chunk, not avg))
 
     def begin_step(self):
         """Call before forward: zero the gradient buffer and arm the buckets."""
@@ -157,6 +173,7 @@ class GradReducer:
         if self.world == 1:
             return
         self._pending = [len(idxs) for (_, _, idxs) in self.buckets]
+        self._seen = [False] * len(self.fg.params)
         self._launched = [False] * len(self.buckets)
         self._works = []
 
@@ -166,12 +183,18 @@ class GradReducer:
             return
         for b in range(len(self.buckets)):
             self._launch(b)
-        for w, chunk, need_div in self._works:
-            w.wait()
-            if need_div:
-                chunk.mul_(1.0 / self.world)
         if self.is_cuda:
+            with torch.cuda.stream(self.comm_stream):   # (the scaling of a summed bucket stays on the comm stream)
+                for w, chunk, need_div in self._works:
+                    w.wait()
+                    if need_div:
+                        chunk.mul_(1.0 / self.world)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        else:
+            for w, chunk, need_div in self._works:
+                w.wait()
+                if need_div:
+                    chunk.mul_(1.0 / self.world)
         self._works = []
 
 
@@ -232,13 +255,12 @@ class SupernetReducer:
             self.staging = torch.empty(total, dtype=torch.float32, device=self.fg.flat.device)
         stg = self.staging[:total]
         self._pack(segs, stg, 0)
-        if self.is_cuda:
+        if _has_avg(self.group):
             dist.all_reduce(stg, op=dist.ReduceOp.AVG, group=self.group)
-            self._pack(segs, stg, 1)
         else:
             dist.all_reduce(stg, op=dist.ReduceOp.SUM, group=self.group)
             stg.mul_(1.0 / self.world)
-            self._pack(segs, stg, 1)
+        self._pack(segs, stg, 1)
 
     def _pack(self, segs, stg, direction):
         if self.is_cuda:
@@ -271,7 +293,7 @@ class SupernetReducer:
         for i, m in enumerate(mops):
             if m.alpha_gate.grad is not None:
                 g[i, :m.n_choices] = m.alpha_gate.grad
-        if self.is_cuda:
+        if _has_avg(self.group):
             dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
         else:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)

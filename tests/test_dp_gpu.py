@@ -1,0 +1,129 @@
+"""The data-parallel reducers on DEVICE tensors with two ranks: both processes share the one GPU of the test box and
+talk over gloo (RCCL refuses two ranks on one device), so everything except the collective's transport is the
+production path -- flat gradient buffer, HIP kernels writing into it (sinks), bucket launches from the backward
+thread, the comm stream and its events, the supernet pack/unpack kernel with the table in the kernel arguments."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+WORLD = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _entry(rank, fn, port):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        globals()[fn](rank)
+    finally:
+        dist.destroy_process_group()
+
+
+def _build_full(c):
+    from mmnas.model.full_vqa import Net_Full
+    init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+            'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
+    net = Net_Full(c['cfg'], init)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in c['P'].items()})
+    return net.cuda().train()
+
+
+def _loss(net, c):
+    inp = tuple(torch.from_numpy(a).cuda() for a in c['inputs'])
+    tgt = torch.from_numpy(c['target']).cuda()
+    return torch.nn.functional.binary_cross_entropy_with_logits(net(inp), tgt, reduction='sum')
+
+
+def _w_full(rank):
+    from mmnas_amd import dp
+    cs = [cases.net_case('vqa', 'mmnas_vqa', 500 + r, HSIZE=64, B=3, Sx=6, Sy=9) for r in range(WORLD)]
+    for c in cs:
+        c['cfg'].DROPOUT_R = 0.0
+        c['P'] = cs[0]['P']                     # same weights on both ranks, different batches
+    net = _build_full(cs[rank])
+    dp.broadcast_parameters(net)
+    red = dp.GradReducer(list(net.parameters()), bucket_mb=0.05)
+    assert len(red.buckets) >= 3 and red.comm_stream is not None
+    # expected: mean over ranks of the plain autograd gradients
+    ref = _build_full(cs[0])
+    want = None
+    for r in range(WORLD):
+        ref.zero_grad()
+        _loss(ref, cs[r]).backward()
+        g = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in ref.named_parameters()}
+        want = g if want is None else {k: want[k] + g[k] for k in g}
+    scale = max(float(v.abs().max()) for v in want.values()) / WORLD
+    for step in range(6):   # (a bucket reduced too early shows up intermittently: repeat)
+        red.begin_step()
+        _loss(net, cs[rank]).backward()
+        assert all(red._seen), 'a parameter never reported its gradient'
+        red.finish()
+        torch.cuda.synchronize()
+        bad = []
+        for k, p in net.named_parameters():
+            err = float((p.grad - want[k] / WORLD).abs().max())
+            if not err <= 1e-4 * max(float(want[k].abs().max()) / WORLD, 1e-3 * scale):
+                bad.append((step, k, err, float(want[k].abs().max()) / WORLD))
+        assert not bad, bad[:8]
+
+
+def _w_supernet(rank):
+    from mmnas_amd import dp
+    from mmnas_amd.model import mixed
+    from mmnas.model.hygr_vqa import Net_Search
+    from mmnas.model.mixed import MixedOp
+    cs = [cases.net_case('vqa', None, 700 + r, search=True, HSIZE=64, B=2) for r in range(WORLD)]
+    init = {'token_size': cs[0]['token_size'], 'ans_size': cs[0]['ans_size'],
+            'pretrained_emb': np.zeros((cs[0]['token_size'], cs[0]['cfg'].WORD_EMBED_SIZE), np.float32)}
+    cs[rank]['cfg'].DROPOUT_R = 0.0
+    torch.manual_seed(1)
+    net = Net_Search(cs[rank]['cfg'], init).cuda().train()
+    dp.broadcast_parameters(net)
+    red = dp.SupernetReducer(net)
+    mixed.seed_arch_sampler(321)                 # same samples on both ranks
+    MixedOp.MODE = None
+    net.reset_binary_gates()
+    assert dp.check_same_architecture(net)
+    red.begin_weight_step()
+    net.unused_modules_off()
+    _loss(net, cs[rank]).backward()
+    local = red.fg.flat.clone()
+    red.finish_weight_step()
+    net.unused_modules_back()
+    torch.cuda.synchronize()
+    # every rank's flat buffer must now hold the mean of the two local buffers on the exchanged (active) segments
+    both = [torch.zeros_like(local) for _ in range(WORLD)]
+    dist.all_gather(both, local)
+    mean = (both[0] + both[1]) / WORLD
+    segs = red._segments(red._active)
+    covered = 0
+    for o, n in segs:
+        assert torch.allclose(red.fg.flat[o:o + n], mean[o:o + n], rtol=1e-5, atol=1e-7)
+        covered += n
+    assert covered < red.fg.total                # unsampled candidates were not exchanged ...
+    mask = torch.ones(red.fg.total, dtype=torch.bool, device='cuda')
+    for o, n in segs:
+        mask[o:o + n] = False
+    assert torch.equal(red.fg.flat[mask], local[mask])   # ... and stay untouched
+
+
+@pytest.mark.parametrize('fn', ['_w_full', '_w_supernet'])
+def test_two_ranks_on_one_gpu(fn):
+    mp.spawn(_entry, args=(fn, _free_port()), nprocs=WORLD, join=True)
