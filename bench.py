@@ -173,10 +173,17 @@ def main():
     ap.add_argument('--workload', default='train_vqa', choices=['train_vqa', 'search_vqa'])
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gemm-split', type=int, default=0, choices=[0, 3, 6],
+                    help='EXPERIMENT, not the headline: run the GEMMs as 3 / 6 bf16-MFMA products of split operands '
+                         '(MMNAS_GEMM_SPLIT); the JSON line then says so in dtype and config')
     ap.add_argument('--no-prof', action='store_true', help='do not bracket kernels with HIP events')
     ap.add_argument('--with-optim', action='store_true',
                     help='also run gradient clipping + the fused Adam step inside the timed step (not part of the fwd+bwd metric)')
     args = ap.parse_args()
+    if args.gemm_split:
+        os.environ['MMNAS_GEMM_SPLIT'] = str(args.gemm_split)   # read when the library first schedules a GEMM
+    else:
+        os.environ.pop('MMNAS_GEMM_SPLIT', None)                 # the headline line is always the fp32-MFMA path
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -300,12 +307,13 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1000.0 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32' if not args.gemm_split else 'f32 results from bf16x%d split-operand MFMA products (experiment)' % args.gemm_split,
+            'data': 'synthetic',
             'config': {'workload': {'train_vqa': 'arch/mmnas_vqa.json Net_Full fwd+loss+bwd, HSIZE 512, B=64/GPU, 100x2048 regions + 14 tokens, dropout 0.1 (BASELINE configs[1])',
                                     'search_vqa': 'Net_Search supernet weight step (sample+fwd+loss+bwd), HSIZE 256, B=64/GPU (BASELINE configs[2])'}[args.workload],
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
                        'grad_allreduce': 'rccl' if world > 1 else 'none',
-                       'optimizer_in_step': bool(args.with_optim)},
+                       'optimizer_in_step': bool(args.with_optim), 'gemm_split': args.gemm_split},
             'samples_per_s': world * args.steps * B / elapsed,
             'algorithmic_tflops_per_gpu': flops_acc[0] / elapsed / 1e12,
             'final_loss': final_loss,
@@ -314,7 +322,11 @@ def main():
             gm = stats['gemm']
             ach = gm['flops'] / (gm['ms'] * 1e-3) / 1e12 if gm['ms'] > 0 else 0.0
             traffic, traffic_detail = pmc_traffic(args.workload)
-            out['roofline'] = {'kernel': 'gemm_kernel<BM,BN> (fp32 MFMA 32x32x2, NT/NN/TN, grouped)', 'bound': 'mfma',
+            kname = 'gemm_kernel<BM,BN> (fp32 MFMA 32x32x2, NT/NN/TN, grouped)'
+            if args.gemm_split:   # algorithmic (fp32-equivalent) flops still priced against the fp32-MFMA peak, for comparison only
+                kname = 'gemm_kernel<BM,BN,NS=%d> (%d bf16 MFMA 32x32x16 products of split operands per fp32 product; ' \
+                        'achieved = algorithmic flops, peak = the fp32 MFMA peak)' % (args.gemm_split // 3 + 1, args.gemm_split)
+            out['roofline'] = {'kernel': kname, 'bound': 'mfma',
                                'achieved': ach, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': ach / PEAK_MFMA_F32_TFLOPS, 'traffic': traffic, 'traffic_pmc': traffic_detail,
                                'algorithmic_bytes_per_launch': gm['bytes'] / max(gm['launches'], 1),

@@ -104,8 +104,9 @@ typedef struct mmnas_gemm_desc {
 
 int mmnas_gemm(const mmnas_gemm_desc* d, void* stream);
 
-/* Scheduling knobs of mmnas_gemm (MMNAS_GEMM_TILE, _SK, _WGS, _MIN_UNITS, _GENERIC: tuning and tests only) are
- * read from the environment on the first call; this re-reads them. */
+/* Scheduling knobs of mmnas_gemm (MMNAS_GEMM_TILE, _SK, _WGS, _MIN_UNITS, _GENERIC, _GM, _XCD: tuning and tests only)
+ * and the opt-in MMNAS_GEMM_SPLIT=3|6 (products as 3 / 6 bf16-MFMA products of exactly split fp32 operands, fp32
+ * accumulation; default 0 = fp32 MFMA) are read from the environment on the first call; this re-reads them. */
 int mmnas_gemm_reload_tuning(void);
 
 /* ------------------------------------------------------------------------------------------

@@ -108,10 +108,78 @@ __device__ __forceinline__ u64 ld_agent(const u64* ptr) {
   return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int BM, int BN, bool AKC, bool BKC, bool FAST>
-__global__ void __launch_bounds__(256, BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64) gemm_kernel(const GemmK p) {
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// (x0, x1) -> NS packed bf16 pairs: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); the subtractions are exact
+// (x0, x1) -> NS packed bf16 pairs written to dst[c * 16], c = 0..NS-1: h = bf16(x), m = bf16(x - h),
+// l = bf16(x - h - m); the subtractions are exact
+template <int NS>
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& w0, unsigned& w1, unsigned& w2) {
+  f32x2 r = {x0, x1};
+  const bf16x2 h = __builtin_convertvector(r, bf16x2);
+  w0 = __builtin_bit_cast(unsigned, h);
+  r -= __builtin_convertvector(h, f32x2);
+  const bf16x2 m = __builtin_convertvector(r, bf16x2);
+  w1 = __builtin_bit_cast(unsigned, m);
+  if (NS > 2) {
+    r -= __builtin_convertvector(m, f32x2);
+    w2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  }
+}
+
+// Word w (0..15: a pair of K indices) of a part of row `row` sits at this word of the part: the 16-B group index is
+// XORed with bits 4-5 of the row.  Fragment reads (one aligned group per lane, 16 consecutive rows share the XOR) stay
+// conflict-free b128 reads; the transposing stores below (a wave writes one group of 16 x 4 rows) spread over all banks.
+__device__ __forceinline__ int swz(int w, int row) { return w ^ (((row >> 4) & 3) << 2); }
+
+// One K-tile of one operand, registers -> LDS in split form: row r of the tile is NS runs of 32 bf16 (part c at
+// word c*16), K index j at position j of each run.  KC: a thread holds 4 consecutive K of one row per load;
+// otherwise loads 2j / 2j+1 hold rows k = 2kp / 2kp+1 of 4 consecutive tile rows.
+template <int BR, bool KC, int NS>
+__device__ __forceinline__ void split_store_kc(unsigned* dst, const float4 v, int f) {
+  constexpr int RSW = NS * 16 + 4;
+  const int row = f / KQ, kq = f % KQ;
+  unsigned a0, a1, a2 = 0, b0, b1, b2 = 0;
+  split_pair<NS>(v.x, v.y, a0, a1, a2);
+  split_pair<NS>(v.z, v.w, b0, b1, b2);
+  unsigned* d = dst + row * RSW + swz(2 * kq, row);
+  *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
+  *reinterpret_cast<uint2*>(d + 16) = make_uint2(a1, b1);
+  if (NS > 2) *reinterpret_cast<uint2*>(d + 32) = make_uint2(a2, b2);
+}
+template <int NS>
+__device__ __forceinline__ void split_put(unsigned* dst, float x0, float x1, int row, int kp) {
+  constexpr int RSW = NS * 16 + 4;
+  unsigned a0, a1, a2 = 0;
+  split_pair<NS>(x0, x1, a0, a1, a2);
+  unsigned* d = dst + row * RSW + swz(kp, row);
+  d[0] = a0;
+  d[16] = a1;
+  if (NS > 2) d[32] = a2;
+}
+template <int BR, int NS>
+__device__ __forceinline__ void split_store_t(unsigned* dst, const float4 e, const float4 o, int tid, int j) {
+  const int kp = tid / (BR / 4) + (1024 / BR) * j, row = 4 * (tid % (BR / 4));
+  split_put<NS>(dst, e.x, o.x, row, kp);
+  split_put<NS>(dst, e.y, o.y, row + 1, kp);
+  split_put<NS>(dst, e.z, o.z, row + 2, kp);
+  split_put<NS>(dst, e.w, o.w, row + 3, kp);
+}
+
+// NS > 0: the operands are split into NS bf16 parts while they are written to LDS and the products run on
+// v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate per instruction), fp32 accumulation as before:
+//   NS = 2: x = h + l  (16 mantissa bits kept), products hh + hl + lh            -- "bf16x3"
+//   NS = 3: x = h + m + l (all 24 bits),        products hh + hm + mh + mm + hl + lh -- "bf16x6", fp32-grade
+// (the dropped cross terms are below 2^-16 resp. 2^-24 of |a||b|).  Off unless asked for: see Tuning::split.
+template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS>
+__global__ void __launch_bounds__(256, NS == 3 ? (BM == 128 ? 1 : 3) : (BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64)) gemm_kernel(const GemmK p) {
+  static_assert(NS == 0 || (FAST && BK == 32), "the bf16-split path exists for the buffer-load path only");
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  constexpr int A_SZ = BM * LDK, B_SZ = BN * LDK;  // >= BK*BM for the [k][row] form
+  // split rows: NS parts of 32 bf16 (64 B) + 16 B pad -> 144 / 208 B, an odd number of 16-B words (conflict-free b128)
+  constexpr int RSW = NS ? NS * 16 + 4 : LDK;        // LDS row stride in 4-byte words
+  constexpr int A_SZ = BM * RSW, B_SZ = BN * RSW;  // >= BK*BM for the [k][row] form
   constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;   // float4 loads per thread per tile
   __shared__ __attribute__((aligned(16))) float As[2 * A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[2 * B_SZ];
@@ -229,6 +297,9 @@ __global__ void __launch_bounds__(256, BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64) g
         if (AKC) {
           const int row = f / KQ, kq = f % KQ, gr = m0 + row;
           offa[i] = gr < Mg ? (unsigned)(gr * p.lda + 4 * kq) * 4u : ~0u;
+        } else if (NS) {  // loads 2j / 2j+1 of a thread: rows k = 2kp, 2kp+1 of the same 4 columns (packed as bf16 pairs)
+          const int kp = tid / (BM / 4) + (1024 / BM) * (i >> 1), rq = tid % (BM / 4), gr = m0 + 4 * rq;
+          offa[i] = gr < Mg ? (unsigned)((2 * kp + (i & 1)) * p.lda + gr) * 4u : ~0u;
         } else {
           const int k = f / (BM / 4), rq = f - k * (BM / 4), gr = m0 + 4 * rq;
           offa[i] = gr < Mg ? (unsigned)(k * p.lda + gr) * 4u : ~0u;
@@ -240,6 +311,9 @@ __global__ void __launch_bounds__(256, BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64) g
         if (BKC) {
           const int row = f / KQ, kq = f % KQ, gr = n0 + row;
           offb[i] = gr < p.N ? (unsigned)(gr * p.ldb + 4 * kq) * 4u : ~0u;
+        } else if (NS) {
+          const int kp = tid / (BN / 4) + (1024 / BN) * (i >> 1), rq = tid % (BN / 4), gr = n0 + 4 * rq;
+          offb[i] = gr < p.N ? (unsigned)((2 * kp + (i & 1)) * p.ldb + gr) * 4u : ~0u;
         } else {
           const int k = f / (BN / 4), rq = f - k * (BN / 4), gr = n0 + 4 * rq;
           offb[i] = gr < p.N ? (unsigned)(k * p.ldb + gr) * 4u : ~0u;
@@ -338,6 +412,25 @@ __global__ void __launch_bounds__(256, BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64) g
     auto lstore = [&](int buf) {
       float* a = As + buf * A_SZ;
       float* b = Bs + buf * B_SZ;
+      if (NS) {
+        unsigned* ua = reinterpret_cast<unsigned*>(a);
+        unsigned* ub = reinterpret_cast<unsigned*>(b);
+        if (AKC) {
+#pragma unroll
+          for (int i = 0; i < NA; ++i) split_store_kc<BM, true, NS ? NS : 2>(ua, ra[i], tid + 256 * i);
+        } else {
+#pragma unroll
+          for (int j = 0; j < NA / 2; ++j) split_store_t<BM, NS ? NS : 2>(ua, ra[2 * j], ra[2 * j + 1], tid, j);
+        }
+        if (BKC) {
+#pragma unroll
+          for (int i = 0; i < NB; ++i) split_store_kc<BN, true, NS ? NS : 2>(ub, rb[i], tid + 256 * i);
+        } else {
+#pragma unroll
+          for (int j = 0; j < NB / 2; ++j) split_store_t<BN, NS ? NS : 2>(ub, rb[2 * j], rb[2 * j + 1], tid, j);
+        }
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const int f = tid + 256 * i;
@@ -371,6 +464,32 @@ __global__ void __launch_bounds__(256, BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64) g
       if (t + 1 < nq) gload(q0 + t + 1);  // in flight during the MFMA block
       const float* a = As + buf * A_SZ;
       const float* b = Bs + buf * B_SZ;
+      if (NS) {
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+          bf16x8 af[TM][NS ? NS : 1], bf[TN][NS ? NS : 1];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int c = 0; c < NS; ++c)
+              af[i][c] = *reinterpret_cast<const bf16x8*>(a + (wm * WM + i * 32 + l31) * RSW + c * 16 + swz(s * 8 + hh * 4, wm * WM + i * 32 + l31));
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int c = 0; c < NS; ++c)
+              bf[j][c] = *reinterpret_cast<const bf16x8*>(b + (wn * WN + j * 32 + l31) * RSW + c * 16 + swz(s * 8 + hh * 4, wn * WN + j * 32 + l31));
+          // smallest cross terms first; part c of A with part e of B is kept while c + e < NS
+#pragma unroll
+          for (int o = NS - 1; o >= 0; --o)
+#pragma unroll
+            for (int c = 0; c <= o; ++c)
+#pragma unroll
+              for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][c], bf[j][o - c], acc[i][j], 0, 0, 0);
+        }
+      } else
 #pragma unroll
       for (int s = 0; s < BK / 8; ++s) {
         float af[TM][4], bf[TN][4];
@@ -545,8 +664,9 @@ static int env_int(const char* name, int dflt) {
 //   MMNAS_GEMM_WGS=n       co-resident workgroup budget (default 1024 for 64^2 tiles, 512 for 128^2)
 //   MMNAS_GEMM_MIN_UNITS=n fewest K-tiles a workgroup is given (default 4)
 //   MMNAS_GEMM_GM=n        row-panels per tile-order block (default 8)     MMNAS_GEMM_XCD=0 identity workgroup mapping
-struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd; bool loaded; };
-static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, false};
+//   MMNAS_GEMM_SPLIT=0|3|6 products on the fp32 MFMA (default) / as 3 / 6 bf16 MFMA products of split operands
+struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split; bool loaded; };
+static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 0, false};
 static void load_tuning() {
   g_tune.tile = env_int("MMNAS_GEMM_TILE", 0);
   g_tune.generic = getenv("MMNAS_GEMM_GENERIC") != nullptr;
@@ -556,6 +676,8 @@ static void load_tuning() {
   if (g_tune.min_units < 1) g_tune.min_units = 1;
   g_tune.gm = env_int("MMNAS_GEMM_GM", 0);
   g_tune.xcd = env_int("MMNAS_GEMM_XCD", 1);
+  const int sp = env_int("MMNAS_GEMM_SPLIT", 0);
+  g_tune.split = sp == 3 ? 2 : (sp == 6 ? 3 : 0);   // number of bf16 parts per operand
   g_tune.loaded = true;
 }
 
@@ -587,13 +709,13 @@ static int get_workspace(hipStream_t st, SkWorkspace* out) {
   return MMNAS_OK;
 }
 
-template <int BM, int BN, bool FAST>
+template <int BM, int BN, bool FAST, int NS>
 static int launch(GemmK& k, int layout, int nwg, hipStream_t st) {
   dim3 grid(nwg), block(256);
   switch (layout) {
-    case MMNAS_GEMM_NT: MMNAS_LAUNCH((gemm_kernel<BM, BN, true, true, FAST>), grid, block, 0, st, k); break;
-    case MMNAS_GEMM_NN: MMNAS_LAUNCH((gemm_kernel<BM, BN, true, false, FAST>), grid, block, 0, st, k); break;
-    default: MMNAS_LAUNCH((gemm_kernel<BM, BN, false, false, FAST>), grid, block, 0, st, k); break;
+    case MMNAS_GEMM_NT: MMNAS_LAUNCH((gemm_kernel<BM, BN, true, true, FAST, NS>), grid, block, 0, st, k); break;
+    case MMNAS_GEMM_NN: MMNAS_LAUNCH((gemm_kernel<BM, BN, true, false, FAST, NS>), grid, block, 0, st, k); break;
+    default: MMNAS_LAUNCH((gemm_kernel<BM, BN, false, false, FAST, NS>), grid, block, 0, st, k); break;
   }
   return check_launch("gemm");
 }
@@ -758,9 +880,17 @@ extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
   if (prof_enabled())
     snprintf(tag, sizeof(tag), "%s M=%d/%d/%d N=%d K=%d seg=%d t%d wg=%d P=%d/%d %s%s", tn ? "TN" : (bkc ? "NT" : "NN"),
              d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0, d->ngroups > 2 ? d->g[2].M : 0, d->N, d->K, d->nseg, bt, nwg, k.P, k.T,
-             k.mode == MODE_TILE ? "tile" : (k.mode == MODE_SPLIT ? "split" : (k.n_full ? "hybrid" : "stream")), fast ? "" : " generic");
+             k.mode == MODE_TILE ? "tile" : (k.mode == MODE_SPLIT ? "split" : (k.n_full ? "hybrid" : "stream")),
+             fast ? (g_tune.split == 2 ? " bf16x3" : (g_tune.split == 3 ? " bf16x6" : "")) : " generic");
   ProfScope ps(MMNAS_K_GEMM, 2.0 * sumM * d->N * d->K * d->nseg,
                4.0 * (sumM * d->K * d->nseg + (double)d->N * d->K * d->nseg * d->ngroups + sumM * d->N), st, tag);
-  if (big) return fast ? launch<128, 128, true>(k, d->layout, nwg, st) : launch<128, 128, false>(k, d->layout, nwg, st);
-  return fast ? launch<64, 64, true>(k, d->layout, nwg, st) : launch<64, 64, false>(k, d->layout, nwg, st);
+  const int ns = fast ? g_tune.split : 0;   // (odd shapes on the guarded-load path stay on the fp32 MFMA)
+  if (big) {
+    if (ns == 2) return launch<128, 128, true, 2>(k, d->layout, nwg, st);
+    if (ns == 3) return launch<128, 128, true, 3>(k, d->layout, nwg, st);
+    return fast ? launch<128, 128, true, 0>(k, d->layout, nwg, st) : launch<128, 128, false, 0>(k, d->layout, nwg, st);
+  }
+  if (ns == 2) return launch<64, 64, true, 2>(k, d->layout, nwg, st);
+  if (ns == 3) return launch<64, 64, true, 3>(k, d->layout, nwg, st);
+  return fast ? launch<64, 64, true, 0>(k, d->layout, nwg, st) : launch<64, 64, false, 0>(k, d->layout, nwg, st);
 }

@@ -99,6 +99,60 @@ def test_gemm_layouts(layout, M, N, K, tile, gemm_tuning):
     assert err < 1e-5, err
 
 
+@pytest.mark.parametrize('layout', ['NT', 'NN', 'TN'])
+@pytest.mark.parametrize('M,N,K', [(896, 512, 512), (300, 192, 160), (64, 64, 32), (257, 132, 96), (6400, 256, 256)])
+@pytest.mark.parametrize('mode,tol', [(3, 2e-5), (6, 3e-6)])
+@pytest.mark.parametrize('tile', [0, 128])
+def test_gemm_bf16_split_modes(layout, M, N, K, mode, tol, tile, gemm_tuning):
+    """Opt-in MMNAS_GEMM_SPLIT modes: operands split into 2 / 3 bf16 parts, 3 / 6 bf16-MFMA products, fp32 accumulate.
+    Bounds (max-norm relative, against fp64): 2^-16-class for bf16x3, fp32-class for bf16x6 -- both far inside the
+    1e-3 parity tolerance.  Operand scales spread over 2^+-20 to exercise the exponent range the parts share with fp32."""
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    if tile and M * N > 400000:
+        pytest.skip('big case only with the default tile choice')
+    rs = np.random.RandomState(M + N + K + mode)
+    sa, sb = np.float32(2.0 ** rs.randint(-20, 20)), np.float32(2.0 ** rs.randint(-20, 20))
+    td = lambda a: torch.from_numpy(a).double()
+    if layout == 'NT':
+        A, B = rnd(rs, M, K) * sa, rnd(rs, N, K) * sb
+        ref, lda, ldb = td(A) @ td(B).t(), K, K
+    elif layout == 'NN':
+        A, B = rnd(rs, M, K) * sa, rnd(rs, K, N) * sb
+        ref, lda, ldb = td(A) @ td(B), K, N
+    else:
+        A, B = rnd(rs, K, M) * sa, rnd(rs, K, N) * sb
+        ref, lda, ldb = td(A).t() @ td(B), M, N
+    C = torch.zeros(M, N, device=DEV)
+    gemm_tuning(split=mode, tile=tile or None)
+    lay = {'NT': L.GEMM_NT, 'NN': L.GEMM_NN, 'TN': L.GEMM_TN}[layout]
+    ops.gemm(lay, [dict(M=M, A=[g(A)], B=[g(B)], C=C)], N, K, lda, ldb, N, accumulate=(layout == 'TN'))
+    err = rel_err(C.cpu().numpy(), ref.numpy())
+    assert err < tol, err
+
+
+@pytest.mark.parametrize('mode', [3, 6])
+def test_gemm_bf16_split_stream_k_and_epilogue(mode, gemm_tuning):
+    """Split modes under the stream-K schedule with grouped problems, K segments and the full epilogue."""
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    gemm_tuning(split=mode, sk=2, min_units=1, wgs=33)
+    rs = np.random.RandomState(mode)
+    td = lambda a: torch.from_numpy(a).double()
+    Ms, N, K = [300, 77, 130], 200, 160
+    A = [[rnd(rs, m, K) for _ in range(2)] for m in Ms]
+    B = [[rnd(rs, N, K) for _ in range(2)] for _ in Ms]
+    bias = [rnd(rs, N) for _ in Ms]
+    res = [rnd(rs, m, N) for m in Ms]
+    Cs = [torch.full((m, N), float('nan'), device=DEV) for m in Ms]
+    groups = [dict(M=m, A=[g(x) for x in a], B=[g(x) for x in b], C=c, bias=g(bi), residual=g(r))
+              for m, a, b, c, bi, r in zip(Ms, A, B, Cs, bias, res)]
+    ops.gemm(L.GEMM_NT, groups, N, K, K, K, N, nseg=2, ldres=N, relu=True)
+    for i in range(len(Ms)):
+        ref = torch.relu(sum(td(a) @ td(b).t() for a, b in zip(A[i], B[i])) + td(bias[i])) + td(res[i])
+        assert rel_err(Cs[i].cpu().numpy(), ref.numpy()) < (2e-5 if mode == 3 else 3e-6)
+
+
 def test_gemm_groups_segments_epilogue():
     from mmnas_amd import ops
     import mmnas_amd._lib as L
