@@ -189,11 +189,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # (tests only: MMNAS_BENCH_DEVICE / MMNAS_BENCH_BACKEND=gloo run several ranks on ONE GPU -- RCCL refuses that --
+    #  so the N > 1 code path can be exercised end to end on a single-GPU box; see tests/test_bench_gpu.py)
+    dev_index = int(os.environ.get('MMNAS_BENCH_DEVICE', local_rank))
+    backend = os.environ.get('MMNAS_BENCH_BACKEND', 'nccl')
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from mmnas_amd import _lib as L, dp, ops
     from mmnas_amd.model import mixed
@@ -312,7 +319,7 @@ def main():
             'config': {'workload': {'train_vqa': 'arch/mmnas_vqa.json Net_Full fwd+loss+bwd, HSIZE 512, B=64/GPU, 100x2048 regions + 14 tokens, dropout 0.1 (BASELINE configs[1])',
                                     'search_vqa': 'Net_Search supernet weight step (sample+fwd+loss+bwd), HSIZE 256, B=64/GPU (BASELINE configs[2])'}[args.workload],
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
-                       'grad_allreduce': 'rccl' if world > 1 else 'none',
+                       'grad_allreduce': ('rccl' if backend == 'nccl' else backend) if world > 1 else 'none',
                        'optimizer_in_step': bool(args.with_optim), 'gemm_split': args.gemm_split},
             'samples_per_s': world * args.steps * B / elapsed,
             'algorithmic_tflops_per_gpu': flops_acc[0] / elapsed / 1e12,

@@ -1,0 +1,54 @@
+"""bench.py end to end: the single-GPU line the driver records, and the N = 2 launch exactly as the driver starts it
+(`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`) with both ranks on the box's one GPU and
+gloo as transport (RCCL refuses two ranks on one device) -- reducers, comm stream, barrier + max-over-ranks timing."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def _check(d, world):
+    assert d['n_gpus'] == world and d['steps'] == 2 and d['warmup'] == 1
+    assert d['unit'] == 'steps/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['value'] > 0 and abs(d['value'] - world * 1000.0 / d['ms_per_step']) < 1e-6 * d['value']
+    assert d['final_loss'] == d['final_loss'] and abs(d['final_loss']) < 1e9
+    assert d['config']['global_batch'] == 64 * world and d['dtype'] == 'f32'
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and 0 < r['frac'] < 1 and r['unit'] == 'TFLOP/s' and r['achieved'] > 0
+
+
+@pytest.mark.parametrize('workload', ['train_vqa', 'search_vqa'])
+def test_bench_single_gpu(workload):
+    p = subprocess.run([sys.executable, 'bench.py', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--workload', workload],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    _check(_json_line(p.stdout), 1)
+
+
+@pytest.mark.parametrize('workload', ['train_vqa', 'search_vqa'])
+def test_bench_two_ranks_one_gpu(workload):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MMNAS_BENCH_BACKEND='gloo', MMNAS_BENCH_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port), 'bench.py', '--gpus', '2',
+                        '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--workload', workload],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    d = _json_line(p.stdout)
+    _check(d, 2)
+    assert d['config']['parallelism'] == 'dp2' and d['config']['grad_allreduce'] == 'gloo'
