@@ -104,6 +104,14 @@ typedef struct mmnas_gemm_desc {
 
 int mmnas_gemm(const mmnas_gemm_desc* d, void* stream);
 
+/* The two backward products of one linear layer -- data gradient dx = dy W (layout NN) and weight gradient
+ * dW += dy^T x (layout TN, accumulate) -- which autograd issues as two independent mm calls
+ * (torch/csrc/autograd: AddmmBackward / MmBackward of modules.py:18,38,172-175).  Results are those of two mmnas_gemm
+ * calls; when both take the 64x64 buffer-load kernel they are issued as ONE launch whose second section starts as
+ * the first one drains (saves one launch's idle start/end phases, ~10 us).  MMNAS_GEMM_PAIR=0 forces two launches.
+ * The outputs must not overlap each other or either product's inputs. */
+int mmnas_gemm_pair(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, void* stream);
+
 /* Scheduling knobs of mmnas_gemm (MMNAS_GEMM_TILE, _SK, _WGS, _MIN_UNITS, _GENERIC, _GM, _XCD: tuning and tests only)
  * and the opt-in MMNAS_GEMM_SPLIT=3|6 (products as 3 / 6 bf16-MFMA products of exactly split fp32 operands, fp32
  * accumulation; default 0 = fp32 MFMA) are read from the environment on the first call; this re-reads them. */

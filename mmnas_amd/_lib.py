@@ -81,6 +81,7 @@ SYMBOLS = {
     'mmnas_last_error': (C.c_char_p, []),
     'mmnas_dropout_mask': (_i, [_fp, _sz, _f, _u64, _u32, _fp]),
     'mmnas_gemm': (_i, [C.POINTER(GemmDesc), _fp]),
+    'mmnas_gemm_pair': (_i, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), _fp]),
     'mmnas_gemm_reload_tuning': (_i, []),
     'mmnas_layernorm_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _fp]),
     'mmnas_layernorm_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _u64, _u32, _i, _i, _f, _fp]),

@@ -173,29 +173,36 @@ __device__ __forceinline__ void split_store_t(unsigned* dst, const float4 e, con
 //   NS = 2: x = h + l  (16 mantissa bits kept), products hh + hl + lh            -- "bf16x3"
 //   NS = 3: x = h + m + l (all 24 bits),        products hh + hm + mh + mm + hl + lh -- "bf16x6", fp32-grade
 // (the dropped cross terms are below 2^-16 resp. 2^-24 of |a||b|).  Off unless asked for: see Tuning::split.
+template <int BM, int BN, int NS>
+struct GemmShape {
+  static constexpr int RSW = NS ? NS * 16 + 4 : LDK;   // LDS row stride in 4-byte words
+  static constexpr int A_SZ = BM * RSW, B_SZ = BN * RSW;  // >= BK*BM for the [k][row] form
+};
+
+// The work of workgroup `bid` of `nwg` on problem p (the kernel's own blockIdx / gridDim, or its position inside one
+// section of a two-section launch); `koff` = byte offset of p inside the kernel-argument segment.
 template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS>
-__global__ void __launch_bounds__(256, NS == 3 ? (BM == 128 ? 1 : 3) : (BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64)) gemm_kernel(const GemmK p) {
+__device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const int nwg, const int koff,
+                                          float* __restrict__ As, float* __restrict__ Bs, int& s_old) {
   static_assert(NS == 0 || (FAST && BK == 32), "the bf16-split path exists for the buffer-load path only");
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   // split rows: NS parts of 32 bf16 (64 B) + 16 B pad -> 144 / 208 B, an odd number of 16-B words (conflict-free b128)
-  constexpr int RSW = NS ? NS * 16 + 4 : LDK;        // LDS row stride in 4-byte words
-  constexpr int A_SZ = BM * RSW, B_SZ = BN * RSW;  // >= BK*BM for the [k][row] form
+  constexpr int RSW = GemmShape<BM, BN, NS>::RSW;
+  constexpr int A_SZ = GemmShape<BM, BN, NS>::A_SZ, B_SZ = GemmShape<BM, BN, NS>::B_SZ;
   constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;   // float4 loads per thread per tile
-  __shared__ __attribute__((aligned(16))) float As[2 * A_SZ];
-  __shared__ __attribute__((aligned(16))) float Bs[2 * B_SZ];
-  __shared__ int s_old;
 
   // The kernel arguments (~400 B = 7 cache lines) live in host-visible memory: the first touch of each line
   // is a ~1 us round trip, and the compiler reads them in dependent steps (mode -> sizes -> group -> pointers).
   // Touch every line up front so the misses overlap (measured: -3.5 us per launch).
   {
-    const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr() + koff;
     unsigned t0, t1, t2, t3, t4, t5, t6;
     asm volatile(
         "s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %7, 0x40\n\ts_load_dword %2, %7, 0x80\n\t"
         "s_load_dword %3, %7, 0xc0\n\ts_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\t"
         "s_load_dword %6, %7, 0x180\n\ts_waitcnt lgkmcnt(0)"
-        : "=s"(t0), "=s"(t1), "=s"(t2), "=s"(t3), "=s"(t4), "=s"(t5), "=s"(t6)
+        : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6)   // early-clobber: the loads
+                                                  // return while later ones are still being issued from %7
         : "s"(ka)
         : "memory");
   }
@@ -210,7 +217,6 @@ __global__ void __launch_bounds__(256, NS == 3 ? (BM == 128 ? 1 : 3) : (BM == 12
   //      so an XCD owns a contiguous run of units = neighbouring tiles / K-slices of few tiles) ----
   int v;
   {
-    const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, in = bid >> 3;
     v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
     if (!p.xcd_remap) v = bid;
@@ -219,8 +225,8 @@ __global__ void __launch_bounds__(256, NS == 3 ? (BM == 128 ? 1 : 3) : (BM == 12
   int vs = v;           // MODE_STREAM: index among the streaming workgroups
   int whole = -1;       // hybrid: the whole tile of this workgroup
   if (p.mode == MODE_STREAM) {
-    if (p.n_full > 0) {  // grid = 8 * (sk_per + full_per); blockIdx % 8 labels the XCD, low indices start first
-      const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    if (p.n_full > 0) {  // grid = 8 * (sk_per + full_per); bid % 8 labels the XCD, low indices start first
+      const int xcd = bid & 7, li = bid >> 3;
       if (li < p.sk_per) vs = xcd * p.sk_per + li;
       else whole = xcd * p.full_per + (li - p.sk_per);
     }
@@ -651,6 +657,35 @@ __global__ void __launch_bounds__(256, NS == 3 ? (BM == 128 ? 1 : 3) : (BM == 12
   }
 }
 
+template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS>
+__global__ void __launch_bounds__(256, NS == 3 ? (BM == 128 ? 1 : 3) : (BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64)) gemm_kernel(const GemmK p) {
+  __shared__ __attribute__((aligned(16))) float As[2 * GemmShape<BM, BN, NS>::A_SZ];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * GemmShape<BM, BN, NS>::B_SZ];
+  __shared__ int s_old;
+  gemm_body<BM, BN, AKC, BKC, FAST, NS>(p, blockIdx.x, gridDim.x, 0, As, Bs, s_old);
+}
+
+// Two independent problems in ONE launch: the data gradient (NN) and the weight gradient (TN) of a linear layer.
+// A product of the workloads' sizes is a single round of workgroups that all load, compute and store in lockstep,
+// so each launch pays its start (dispatch, kernel arguments, a 16 MB burst of first loads) and its end (the store
+// burst, write-back of the XCD L2s) with the MFMA pipes idle: ~15 us of a 40-60 us kernel.  Here the second
+// problem's workgroups are dispatched as the first problem's finish, so one of those two idle phases disappears.
+// Workgroups [0, nwg0p) belong to q0 (nwg0p = nwg0 rounded up to 8, so blockIdx % 8 keeps naming the XCD in both
+// sections), the rest to q1.
+template <int BM, int BN, int NS>
+__global__ void __launch_bounds__(256, NS == 3 ? 3 : MMNAS_OCC64) gemm_pair_kernel(const GemmK q0, const GemmK q1, const int nwg0,
+                                                                                    const int nwg0p) {
+  __shared__ __attribute__((aligned(16))) float As[2 * GemmShape<BM, BN, NS>::A_SZ];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * GemmShape<BM, BN, NS>::B_SZ];
+  __shared__ int s_old;
+  const int bid = blockIdx.x;
+  if (bid < nwg0p) {
+    if (bid < nwg0) gemm_body<BM, BN, true, false, true, NS>(q0, bid, nwg0, 0, As, Bs, s_old);
+  } else {
+    gemm_body<BM, BN, false, false, true, NS>(q1, bid - nwg0p, (int)gridDim.x - nwg0p, (int)sizeof(GemmK), As, Bs, s_old);
+  }
+}
+
 // ---- stream-K workspace: partial-tile slots + arrival counters, one per stream (launches on one stream
 //      are ordered, so they can share it; two streams must not) ----
 static int env_int(const char* name, int dflt) {
@@ -665,8 +700,9 @@ static int env_int(const char* name, int dflt) {
 //   MMNAS_GEMM_MIN_UNITS=n fewest K-tiles a workgroup is given (default 4)
 //   MMNAS_GEMM_GM=n        row-panels per tile-order block (default 8)     MMNAS_GEMM_XCD=0 identity workgroup mapping
 //   MMNAS_GEMM_SPLIT=0|3|6 products on the fp32 MFMA (default) / as 3 / 6 bf16 MFMA products of split operands
-struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split; bool loaded; };
-static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 0, false};
+//   MMNAS_GEMM_PAIR=0      mmnas_gemm_pair launches its two products separately
+struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split, pair; bool loaded; };
+static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 0, 1, false};
 static void load_tuning() {
   g_tune.tile = env_int("MMNAS_GEMM_TILE", 0);
   g_tune.generic = getenv("MMNAS_GEMM_GENERIC") != nullptr;
@@ -678,6 +714,7 @@ static void load_tuning() {
   g_tune.xcd = env_int("MMNAS_GEMM_XCD", 1);
   const int sp = env_int("MMNAS_GEMM_SPLIT", 0);
   g_tune.split = sp == 3 ? 2 : (sp == 6 ? 3 : 0);   // number of bf16 parts per operand
+  g_tune.pair = env_int("MMNAS_GEMM_PAIR", 1);
   g_tune.loaded = true;
 }
 
@@ -729,7 +766,17 @@ extern "C" int mmnas_gemm_reload_tuning(void) {
   return MMNAS_OK;
 }
 
-extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
+namespace mmnas {
+
+struct GemmPlan {
+  GemmK k;
+  int nwg, layout;
+  bool big, fast;
+  double flops, bytes;
+  char tag[96];
+};
+
+static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
   if (!g_tune.loaded) load_tuning();
   MMNAS_REQUIRE(d != nullptr, MMNAS_E_ARG, "mmnas_gemm: null descriptor");
   MMNAS_REQUIRE(d->ngroups >= 1 && d->ngroups <= 3 && d->nseg >= 1 && d->nseg <= 3, MMNAS_E_ARG,
@@ -745,7 +792,7 @@ extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
       MMNAS_REQUIRE(!d->g[g].gate, MMNAS_E_ARG, "mmnas_gemm: no gate epilogue when accumulating onto C");
   }
 
-  GemmK k;
+  GemmK& k = out.k;
   memset(&k, 0, sizeof(k));
   k.ngroups = d->ngroups; k.nseg = d->nseg; k.N = d->N; k.K = d->K;
   k.lda = d->lda; k.ldb = d->ldb; k.ldc = d->ldc; k.ldres = d->ldres; k.ldgate = d->ldgate;
@@ -868,7 +915,6 @@ extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
       nwg = (int)((U + P - 1) / P);
     }
   }
-  hipStream_t st = (hipStream_t)stream;
   if (k.mode == MODE_STREAM) {
     SkWorkspace w;
     const int rc = get_workspace(st, &w);
@@ -876,21 +922,63 @@ extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
     k.ws = w.ws; k.cnt = w.cnt;
   }
   // algorithmic work: 2*M*N*K flops per product; minimum traffic = operands once + result once
-  char tag[96] = "";
+  out.tag[0] = 0;
   if (prof_enabled())
-    snprintf(tag, sizeof(tag), "%s M=%d/%d/%d N=%d K=%d seg=%d t%d wg=%d P=%d/%d %s%s", tn ? "TN" : (bkc ? "NT" : "NN"),
+    snprintf(out.tag, sizeof(out.tag), "%s M=%d/%d/%d N=%d K=%d seg=%d t%d wg=%d P=%d/%d %s%s", tn ? "TN" : (bkc ? "NT" : "NN"),
              d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0, d->ngroups > 2 ? d->g[2].M : 0, d->N, d->K, d->nseg, bt, nwg, k.P, k.T,
              k.mode == MODE_TILE ? "tile" : (k.mode == MODE_SPLIT ? "split" : (k.n_full ? "hybrid" : "stream")),
              fast ? (g_tune.split == 2 ? " bf16x3" : (g_tune.split == 3 ? " bf16x6" : "")) : " generic");
-  ProfScope ps(MMNAS_K_GEMM, 2.0 * sumM * d->N * d->K * d->nseg,
-               4.0 * (sumM * d->K * d->nseg + (double)d->N * d->K * d->nseg * d->ngroups + sumM * d->N), st, tag);
-  const int ns = fast ? g_tune.split : 0;   // (odd shapes on the guarded-load path stay on the fp32 MFMA)
-  if (big) {
-    if (ns == 2) return launch<128, 128, true, 2>(k, d->layout, nwg, st);
-    if (ns == 3) return launch<128, 128, true, 3>(k, d->layout, nwg, st);
-    return fast ? launch<128, 128, true, 0>(k, d->layout, nwg, st) : launch<128, 128, false, 0>(k, d->layout, nwg, st);
+  out.flops = 2.0 * sumM * d->N * d->K * d->nseg;
+  out.bytes = 4.0 * (sumM * d->K * d->nseg + (double)d->N * d->K * d->nseg * d->ngroups + sumM * d->N);
+  out.nwg = nwg; out.layout = d->layout; out.big = big; out.fast = fast;
+  return MMNAS_OK;
+}
+
+static int launch_plan(GemmPlan& pl, hipStream_t st) {
+  GemmK& k = pl.k;
+  ProfScope ps(MMNAS_K_GEMM, pl.flops, pl.bytes, st, pl.tag);
+  const int ns = pl.fast ? g_tune.split : 0;   // (odd shapes on the guarded-load path stay on the fp32 MFMA)
+  if (pl.big) {
+    if (ns == 2) return launch<128, 128, true, 2>(k, pl.layout, pl.nwg, st);
+    if (ns == 3) return launch<128, 128, true, 3>(k, pl.layout, pl.nwg, st);
+    return pl.fast ? launch<128, 128, true, 0>(k, pl.layout, pl.nwg, st) : launch<128, 128, false, 0>(k, pl.layout, pl.nwg, st);
   }
-  if (ns == 2) return launch<64, 64, true, 2>(k, d->layout, nwg, st);
-  if (ns == 3) return launch<64, 64, true, 3>(k, d->layout, nwg, st);
-  return fast ? launch<64, 64, true, 0>(k, d->layout, nwg, st) : launch<64, 64, false, 0>(k, d->layout, nwg, st);
+  if (ns == 2) return launch<64, 64, true, 2>(k, pl.layout, pl.nwg, st);
+  if (ns == 3) return launch<64, 64, true, 3>(k, pl.layout, pl.nwg, st);
+  return pl.fast ? launch<64, 64, true, 0>(k, pl.layout, pl.nwg, st) : launch<64, 64, false, 0>(k, pl.layout, pl.nwg, st);
+}
+
+}  // namespace mmnas
+
+extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
+  GemmPlan pl;
+  const int rc = plan_gemm(d, (hipStream_t)stream, pl);
+  if (rc) return rc;
+  return launch_plan(pl, (hipStream_t)stream);
+}
+
+extern "C" int mmnas_gemm_pair(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GemmPlan p0, p1;
+  int rc;
+  if ((rc = plan_gemm(dgrad, st, p0))) return rc;
+  if ((rc = plan_gemm(wgrad, st, p1))) return rc;
+  // one launch when both run on the 64^2 buffer-load kernel and the second one needs no workspace of its own
+  const bool pair = g_tune.pair && p0.fast && p1.fast && !p0.big && !p1.big && p0.layout == MMNAS_GEMM_NN &&
+                    p1.layout == MMNAS_GEMM_TN && p1.k.mode != MODE_STREAM;
+  if (!pair) {
+    if ((rc = launch_plan(p0, st))) return rc;
+    return launch_plan(p1, st);
+  }
+  char tag[96] = "";
+  if (prof_enabled()) snprintf(tag, sizeof(tag), "PAIR %.44s | %.40s", p0.tag, p1.tag);
+  ProfScope ps(MMNAS_K_GEMM, p0.flops + p1.flops, p0.bytes + p1.bytes, st, tag);
+  const int nwg0p = (p0.nwg + 7) / 8 * 8;
+  dim3 grid(nwg0p + p1.nwg), block(256);
+  switch (g_tune.split) {
+    case 2: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p); break;
+    case 3: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p); break;
+    default: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 0>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p); break;
+  }
+  return check_launch("gemm_pair");
 }

@@ -168,16 +168,15 @@ extern "C" int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream) {
     dt = L.dt;
   }
 
-  mmnas_gemm_desc g;
+  mmnas_gemm_desc g, w;
   // 2. d(att) = dt Wm            [Mq,d] x [d,di]
   gemm_init(g, MMNAS_GEMM_NN, di, d, d, di, di);
   g.g[0].M = Mq; g.g[0].A[0] = dt; g.g[0].B[0] = op->Wm; g.g[0].C = L.datt;
-  if ((rc = mmnas_gemm(&g, stream))) return rc;
-  // 3. dWm += dt^T att           [d,di], reduction over the Mq rows
-  gemm_init(g, MMNAS_GEMM_TN, di, Mq, d, di, di);
-  g.g[0].M = d; g.g[0].A[0] = dt; g.g[0].B[0] = L.att; g.g[0].C = op->dWm;
-  g.accumulate = 1;
-  if ((rc = mmnas_gemm(&g, stream))) return rc;
+  // 3. dWm += dt^T att           [d,di], reduction over the Mq rows (same launch: mmnas_gemm_pair)
+  gemm_init(w, MMNAS_GEMM_TN, di, Mq, d, di, di);
+  w.g[0].M = d; w.g[0].A[0] = dt; w.g[0].B[0] = L.att; w.g[0].C = op->dWm;
+  w.accumulate = 1;
+  if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
 
   // 4. attention core backward
   mmnas_mha_desc m;
@@ -190,30 +189,14 @@ extern "C" int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream) {
   m.dO = L.datt; m.dQ = L.dQ; m.dK = L.dK; m.dV = L.dV; m.dbiasT = L.dbiasT; m.delta = L.delta;
   if ((rc = mmnas_mha_core_bwd(&m, stream))) return rc;
 
-  // 5. projection weight gradients
-  if (Mq == Mk) {
-    gemm_init(g, MMNAS_GEMM_TN, d, Mq, di, d, d);
-    g.ngroups = 3;
-    g.g[0].M = di; g.g[0].A[0] = L.dQ; g.g[0].B[0] = op->xq;  g.g[0].C = op->dWq;
-    g.g[1].M = di; g.g[1].A[0] = L.dK; g.g[1].B[0] = op->xkv; g.g[1].C = op->dWk;
-    g.g[2].M = di; g.g[2].A[0] = L.dV; g.g[2].B[0] = op->xkv; g.g[2].C = op->dWv;
-    g.accumulate = 1;
-    if ((rc = mmnas_gemm(&g, stream))) return rc;
-  } else {
-    gemm_init(g, MMNAS_GEMM_TN, d, Mq, di, d, d);
-    g.g[0].M = di; g.g[0].A[0] = L.dQ; g.g[0].B[0] = op->xq; g.g[0].C = op->dWq;
-    g.accumulate = 1;
-    if ((rc = mmnas_gemm(&g, stream))) return rc;
-    gemm_init(g, MMNAS_GEMM_TN, d, Mk, di, d, d);
-    g.ngroups = 2;
-    g.g[0].M = di; g.g[0].A[0] = L.dK; g.g[0].B[0] = op->xkv; g.g[0].C = op->dWk;
-    g.g[1].M = di; g.g[1].A[0] = L.dV; g.g[1].B[0] = op->xkv; g.g[1].C = op->dWv;
-    g.accumulate = 1;
-    if ((rc = mmnas_gemm(&g, stream))) return rc;
-  }
-
-  // 6. input gradients (+ the residual branch dz)
+  // 5. + 6. projection weight gradients and input gradients (+ the residual branch dz), pairwise in one launch
   if (self) {
+    gemm_init(w, MMNAS_GEMM_TN, d, Mq, di, d, d);
+    w.ngroups = 3;
+    w.g[0].M = di; w.g[0].A[0] = L.dQ; w.g[0].B[0] = op->xq;  w.g[0].C = op->dWq;
+    w.g[1].M = di; w.g[1].A[0] = L.dK; w.g[1].B[0] = op->xkv; w.g[1].C = op->dWk;
+    w.g[2].M = di; w.g[2].A[0] = L.dV; w.g[2].B[0] = op->xkv; w.g[2].C = op->dWv;
+    w.accumulate = 1;
     gemm_init(g, MMNAS_GEMM_NN, d, di, di, d, d);
     g.nseg = 3;
     g.g[0].M = Mq; g.g[0].C = op->dxq;
@@ -221,18 +204,26 @@ extern "C" int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream) {
     g.g[0].A[1] = L.dK; g.g[0].B[1] = op->Wk;
     g.g[0].A[2] = L.dV; g.g[0].B[2] = op->Wv;
     if (fl & MMNAS_F_RESIDUAL) { g.g[0].residual = dz; g.ldres = d; }
-    if ((rc = mmnas_gemm(&g, stream))) return rc;
+    if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
   } else {
+    gemm_init(w, MMNAS_GEMM_TN, d, Mq, di, d, d);
+    w.g[0].M = di; w.g[0].A[0] = L.dQ; w.g[0].B[0] = op->xq; w.g[0].C = op->dWq;
+    w.accumulate = 1;
     gemm_init(g, MMNAS_GEMM_NN, d, di, di, d, d);
     g.g[0].M = Mq; g.g[0].C = op->dxq; g.g[0].A[0] = L.dQ; g.g[0].B[0] = op->Wq;
     if (fl & MMNAS_F_RESIDUAL) { g.g[0].residual = dz; g.ldres = d; }
-    if ((rc = mmnas_gemm(&g, stream))) return rc;
+    if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
+    gemm_init(w, MMNAS_GEMM_TN, d, Mk, di, d, d);
+    w.ngroups = 2;
+    w.g[0].M = di; w.g[0].A[0] = L.dK; w.g[0].B[0] = op->xkv; w.g[0].C = op->dWk;
+    w.g[1].M = di; w.g[1].A[0] = L.dV; w.g[1].B[0] = op->xkv; w.g[1].C = op->dWv;
+    w.accumulate = 1;
     gemm_init(g, MMNAS_GEMM_NN, d, di, di, d, d);
     g.nseg = 2;
     g.g[0].M = Mk; g.g[0].C = op->dxkv;
     g.g[0].A[0] = L.dK; g.g[0].B[0] = op->Wk;
     g.g[0].A[1] = L.dV; g.g[0].B[1] = op->Wv;
-    if ((rc = mmnas_gemm(&g, stream))) return rc;
+    if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
   }
 
   // 7. relation bias
@@ -375,26 +366,24 @@ extern "C" int mmnas_mlp_op_bwd(const mmnas_mlp_op* op, void* stream) {
     // bias gradient
     if (op->db[i] && !(i == nl - 1 && last_bias_done))
       if ((rc = mmnas_colsum(dpre, op->db[i], M, nout, nout, stream))) return rc;
-    // weight gradient: dW_i[nout,nin] += dpre^T hin
-    gemm_init(g, MMNAS_GEMM_TN, nin, M, nout, nin, nin);
-    g.g[0].M = nout; g.g[0].A[0] = dpre; g.g[0].B[0] = hin; g.g[0].C = op->dW[i];
-    g.accumulate = 1;
-    if ((rc = mmnas_gemm(&g, stream))) return rc;
-    // data gradient
+    // weight gradient dW_i[nout,nin] += dpre^T hin and data gradient, one launch
+    mmnas_gemm_desc w;
+    gemm_init(w, MMNAS_GEMM_TN, nin, M, nout, nin, nin);
+    w.g[0].M = nout; w.g[0].A[0] = dpre; w.g[0].B[0] = hin; w.g[0].C = op->dW[i];
+    w.accumulate = 1;
     gemm_init(g, MMNAS_GEMM_NN, nin, nout, nout, nin, nin);
     g.g[0].M = M; g.g[0].A[0] = dpre; g.g[0].B[0] = op->W[i];
     if (i == 0) {
       g.g[0].C = op->dx;
       if (fl & MMNAS_F_RESIDUAL) { g.g[0].residual = dz; g.ldres = d; }
+      if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
     } else {
       float* out = L.dp[(nl - 1 - i) & 1];
       g.g[0].C = out;
       g.g[0].gate = L.h[i]; g.ldgate = nin; g.gate_scale = gate_scale;  // relu' and dropout replay from h_i
-      if ((rc = mmnas_gemm(&g, stream))) return rc;
+      if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
       dpre = out;
-      continue;
     }
-    if ((rc = mmnas_gemm(&g, stream))) return rc;
   }
   return MMNAS_OK;
 }

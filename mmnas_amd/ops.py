@@ -282,9 +282,9 @@ def mlp_op(x, weights, biases, ln_a, ln_b, *, norm, residual, drop_p, training, 
 # ------------------------------------------------------------------------------------------
 # building blocks for the registry-only operators (GLU, convs, activations) and for LayerNorm
 # ------------------------------------------------------------------------------------------
-def gemm(layout, groups, N, K, lda, ldb, ldc, nseg=1, relu=False, split_k=1, alpha=1.0, drop=None,
-         gate_scale=1.0, ldres=0, ldgate=0, accumulate=False):
-    """Thin wrapper over mmnas_gemm.  groups: list of dict(M, A=[..], B=[..], C, bias, residual, gate)."""
+def gemm_desc(layout, groups, N, K, lda, ldb, ldc, nseg=1, relu=False, split_k=1, alpha=1.0, drop=None,
+              gate_scale=1.0, ldres=0, ldgate=0, accumulate=False):
+    """mmnas_gemm_desc from Python values.  groups: list of dict(M, A=[..], B=[..], C, bias, residual, gate)."""
     g = L.GemmDesc()
     g.layout, g.ngroups, g.nseg, g.N, g.K = layout, len(groups), nseg, N, K
     g.lda, g.ldb, g.ldc, g.ldres, g.ldgate = lda, ldb, ldc, ldres, ldgate
@@ -302,7 +302,18 @@ def gemm(layout, groups, N, K, lda, ldb, ldc, nseg=1, relu=False, split_k=1, alp
         gg.bias = L.fptr(grp.get('bias'))
         gg.residual = L.fptr(grp.get('residual'))
         gg.gate = L.fptr(grp.get('gate'))
+    return g
+
+
+def gemm(*args, **kw):
+    """Thin wrapper over mmnas_gemm (arguments of gemm_desc)."""
+    g = gemm_desc(*args, **kw)
     L.check(L.lib().mmnas_gemm(C.byref(g), L.stream()))
+
+
+def gemm_pair(dgrad, wgrad):
+    """mmnas_gemm_pair: the data-gradient (NN) and weight-gradient (TN) descriptors of one linear layer, one launch."""
+    L.check(L.lib().mmnas_gemm_pair(C.byref(dgrad), C.byref(wgrad), L.stream()))
 
 
 class LinearFn(torch.autograd.Function):
@@ -330,15 +341,17 @@ class LinearFn(torch.autograd.Function):
         N = W.shape[0]
         if ctx.relu:
             dy = dy * (y > 0)
-        dx = None
-        if ctx.needs_input_grad[0]:   # e.g. the relation/region feature inputs of the stem need none
-            dx = torch.empty_like(x)
-            gemm(L.GEMM_NN, [dict(M=M, A=[dy], B=[W], C=dx)], K, N, N, K, K)
         # long reductions over few output tiles (the 2048->512 region projection: 256 tiles, 6400 rows) go through
         # the split-K path, which adds onto C
         acc = M >= 2048
         dW = torch.zeros_like(W) if acc else torch.empty_like(W)
-        gemm(L.GEMM_TN, [dict(M=N, A=[dy], B=[x], C=dW)], K, M, N, K, K, accumulate=acc)
+        wgrad = gemm_desc(L.GEMM_TN, [dict(M=N, A=[dy], B=[x], C=dW)], K, M, N, K, K, accumulate=acc)
+        dx = None
+        if ctx.needs_input_grad[0]:   # e.g. the relation/region feature inputs of the stem need none
+            dx = torch.empty_like(x)
+            gemm_pair(gemm_desc(L.GEMM_NN, [dict(M=M, A=[dy], B=[W], C=dx)], K, N, N, K, K), wgrad)
+        else:
+            L.check(L.lib().mmnas_gemm(C.byref(wgrad), L.stream()))
         db = None
         if ctx.has_bias:
             db = torch.zeros(N, dtype=torch.float32, device=x.device)

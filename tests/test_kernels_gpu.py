@@ -153,6 +153,56 @@ def test_gemm_bf16_split_stream_k_and_epilogue(mode, gemm_tuning):
         assert rel_err(Cs[i].cpu().numpy(), ref.numpy()) < (2e-5 if mode == 3 else 3e-6)
 
 
+@pytest.mark.parametrize('M,nin,nout', [(6400, 512, 512), (896, 256, 1024), (300, 132, 68), (6400, 2048, 512), (64, 32, 32)])
+@pytest.mark.parametrize('pair', [1, 0])
+@pytest.mark.parametrize('split', [0, 6])
+def test_gemm_pair_matches_two_launches(M, nin, nout, pair, split, gemm_tuning):
+    """mmnas_gemm_pair (data gradient NN + weight gradient TN of one linear layer in one launch, the second section
+    behind the first): grouped weight gradients, K segments, residual and gate epilogues on the data gradient;
+    odd shapes fall back to two launches inside the call.  Same results as the fp64 products either way."""
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    gemm_tuning(pair=pair, split=split)
+    rs = np.random.RandomState(M + nin + nout)
+    td = lambda a: torch.from_numpy(a).double()
+    dy, x, W, res = rnd(rs, M, nout), rnd(rs, M, nin), rnd(rs, nout, nin), rnd(rs, M, nin)
+    gate = (rnd(rs, M, nin) > 0).astype(np.float32)
+    dW0 = rnd(rs, nout, nin)
+    for use_gate in (False, True):
+        dx = torch.full((M, nin), float('nan'), device=DEV)
+        dW = g(dW0.copy())
+        grp = dict(M=M, A=[g(dy)], B=[g(W)], C=dx)
+        kw = {}
+        if use_gate:
+            grp['gate'] = g(gate)
+            kw = dict(ldgate=nin, gate_scale=1.25)
+        else:
+            grp['residual'] = g(res)
+            kw = dict(ldres=nin)
+        dg = ops.gemm_desc(L.GEMM_NN, [grp], nin, nout, nout, nin, nin, **kw)
+        wg = ops.gemm_desc(L.GEMM_TN, [dict(M=nout, A=[g(dy)], B=[g(x)], C=dW)], nin, M, nout, nin, nin, accumulate=True)
+        ops.gemm_pair(dg, wg)
+        ref_dx = td(dy) @ td(W)
+        ref_dx = torch.where(td(gate) > 0, ref_dx * 1.25, torch.zeros_like(ref_dx)) if use_gate else ref_dx + td(res)
+        ref_dW = td(dW0) + td(dy).t() @ td(x)
+        assert rel_err(dx.cpu().numpy(), ref_dx.numpy()) < 1e-5
+        assert rel_err(dW.cpu().numpy(), ref_dW.numpy()) < 1e-5
+    # grouped weight gradients (q, k, v) + a 3-segment data gradient, as the self-attention backward issues them
+    d3 = [rnd(rs, M, nout) for _ in range(3)]
+    W3 = [rnd(rs, nout, nin) for _ in range(3)]
+    dWs = [torch.zeros(nout, nin, device=DEV) for _ in range(3)]
+    dx = torch.empty(M, nin, device=DEV)
+    d3d, W3d, xd, resd = [g(a) for a in d3], [g(b) for b in W3], g(x), g(res)   # (descriptors hold raw pointers)
+    dg = ops.gemm_desc(L.GEMM_NN, [dict(M=M, A=d3d, B=W3d, C=dx, residual=resd)], nin, nout, nout, nin, nin, nseg=3, ldres=nin)
+    wg = ops.gemm_desc(L.GEMM_TN, [dict(M=nout, A=[a], B=[xd], C=c) for a, c in zip(d3d, dWs)], nin, M, nout, nin, nin,
+                       accumulate=True)
+    ops.gemm_pair(dg, wg)
+    ref = sum(td(a) @ td(b) for a, b in zip(d3, W3)) + td(res)
+    assert rel_err(dx.cpu().numpy(), ref.numpy()) < 1e-5
+    for a, c in zip(d3, dWs):
+        assert rel_err(c.cpu().numpy(), (td(a).t() @ td(x)).numpy()) < 1e-5
+
+
 def test_gemm_groups_segments_epilogue():
     from mmnas_amd import ops
     import mmnas_amd._lib as L
