@@ -45,7 +45,7 @@ def pmc_traffic(workload):
     d = json.load(open(path))
     n = tot = fetch = write = 0.0
     for k, v in d.items():
-        if 'gemm_kernel' in k:
+        if 'gemm_kernel' in k or 'gemm_pair_kernel' in k:
             n += v['launches']
             tot += v['launches'] * v['traffic_bytes_per_launch']
             fetch += v['launches'] * v['fetch_kb_per_launch'] * 1024.0
@@ -329,7 +329,7 @@ def main():
             gm = stats['gemm']
             ach = gm['flops'] / (gm['ms'] * 1e-3) / 1e12 if gm['ms'] > 0 else 0.0
             traffic, traffic_detail = pmc_traffic(args.workload)
-            kname = 'gemm_kernel<BM,BN> (fp32 MFMA 32x32x2, NT/NN/TN, grouped)'
+            kname = 'gemm_kernel / gemm_pair_kernel <BM,BN> (fp32 MFMA 32x32x2; NT/NN/TN, grouped; dgrad+wgrad pairs in one launch)'
             if args.gemm_split:   # algorithmic (fp32-equivalent) flops still priced against the fp32-MFMA peak, for comparison only
                 kname = 'gemm_kernel<BM,BN,NS=%d> (%d bf16 MFMA 32x32x16 products of split operands per fp32 product; ' \
                         'achieved = algorithmic flops, peak = the fp32 MFMA peak)' % (args.gemm_split // 3 + 1, args.gemm_split)

@@ -30,14 +30,16 @@ def main():
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
         n = r['Kernel_Name']
-        if 'gemm_kernel' not in n:
+        if 'gemm_kernel' not in n and 'gemm_pair_kernel' not in n:
             continue
-        key = (n.split('gemm_kernel')[1].split('(')[0], int(r['Grid_Size_X']) // 256, int(r['Grid_Size_Z']))
+        which = 'gemm_pair_kernel' if 'gemm_pair_kernel' in n else 'gemm_kernel'
+        key = (('pair' if which == 'gemm_pair_kernel' else '') + n.split(which)[1].split('(')[0], int(r['Grid_Size_X']) // 256,
+               int(r['Grid_Size_Z']))
         agg[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
     gt = sum(sum(v) for v in agg.values())
-    lines += ['', '## gemm_kernel by launch geometry (%.2f ms/step, %.1f launches/step, average %.1f us)'
+    lines += ['', '## gemm_kernel / gemm_pair_kernel by launch geometry (%.2f ms/step, %.1f launches/step, average %.1f us)'
               % (gt / steps / 1e3, sum(len(v) for v in agg.values()) / steps, gt / max(1, sum(len(v) for v in agg.values()))), '',
-              '| template <BM,BN,A k-contig,B k-contig,fast> | workgroups | grid.z | launches/step | avg us | ms/step |',
+              '| template <BM,BN,A k-contig,B k-contig,fast,split parts> (pair<BM,BN,parts>: NN + TN sections) | workgroups | grid.z | launches/step | avg us | ms/step |',
               '|---|---|---|---|---|---|']
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:16]:
         lines.append('| `%s` | %d | %d | %.1f | %.1f | %.2f |' % (k[0], k[1], k[2], len(v) / steps, sum(v) / len(v), sum(v) / steps / 1e3))
