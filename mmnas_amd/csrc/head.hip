@@ -31,69 +31,89 @@ __global__ void __launch_bounds__(256) row_is_zero_kernel(const float* __restric
 constexpr int AF_MAXS = 1024;   // sequence positions handled by one workgroup
 
 // probs[b,s,g] = softmax_s(logits[b,s,g] masked to -1e9);  pooled[b, g*d + j] = sum_s probs[b,s,g] x[b,s,j]
-__global__ void __launch_bounds__(256) attflat_pool_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ x,
-                                                               const uint8_t* __restrict__ mask, float* __restrict__ probs,
-                                                               float* __restrict__ pooled, int S, int d, int G) {
+// One workgroup of AF_THREADS per (sample, glimpse): only B*G workgroups exist (64-128 on 256 CUs), so the kernel is
+// latency-bound -- 16 waves and 4-8 independent loads per thread keep enough of the 200 KB sample in flight.
+constexpr int AF_THREADS = 1024, AF_WAVES = AF_THREADS / 64;
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();   // red may still be read from the previous reduction
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < AF_WAVES; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+  return r;
+}
+
+__global__ void __launch_bounds__(AF_THREADS) attflat_pool_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ x,
+                                                                      const uint8_t* __restrict__ mask, float* __restrict__ probs,
+                                                                      float* __restrict__ pooled, int S, int d, int G) {
   __shared__ float sp[AF_MAXS];
-  __shared__ float red[4];
-  const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  __shared__ float red[AF_WAVES];
+  __shared__ float part[AF_WAVES / 4][1024];   // partial column sums of the row groups (d <= 1024 per pass)
+  const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
   const float* lg = logits + (size_t)b * S * G + g;
   float m = -INFINITY;
-  for (int s = tid; s < S; s += 256) {
+  for (int s = tid; s < S; s += AF_THREADS) {
     float v = lg[(size_t)s * G];
     if (mask && mask[(size_t)b * S + s]) v = -1e9f;
     sp[s] = v;
     m = fmaxf(m, v);
   }
-  m = wave_max(m);
-  if (lane == 0) red[w] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  __syncthreads();
+  m = block_reduce(m, red, true);
   float sum = 0.f;
-  for (int s = tid; s < S; s += 256) {
+  for (int s = tid; s < S; s += AF_THREADS) {
     const float e = expf(sp[s] - m);
     sp[s] = e;
     sum += e;
   }
-  sum = wave_sum(sum);
-  if (lane == 0) red[w] = sum;
-  __syncthreads();
-  const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
-  for (int s = tid; s < S; s += 256) {
+  sum = block_reduce(sum, red, false);
+  const float inv = 1.0f / sum;
+  for (int s = tid; s < S; s += AF_THREADS) {
     const float pr = sp[s] * inv;
     sp[s] = pr;
     probs[((size_t)b * S + s) * G + g] = pr;
   }
   __syncthreads();
+  // pooled: 256 column threads x 4 row groups (rows s = rg mod 4), 4 independent accumulators each
   const float* xb = x + (size_t)b * S * d;
-  for (int j = tid; j < d; j += 256) {
-    float a0 = 0.f, a1 = 0.f;
-    int s = 0;
-    for (; s + 1 < S; s += 2) {
-      a0 += sp[s] * xb[(size_t)s * d + j];
-      a1 += sp[s + 1] * xb[(size_t)(s + 1) * d + j];
+  const int col = tid & 255, rg = tid >> 8;
+  for (int j0 = 0; j0 < d; j0 += 1024) {
+    for (int j = j0 + col; j < min(d, j0 + 1024); j += 256) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int s = rg;
+      for (; s + 12 < S; s += 16) {
+        a0 += sp[s] * xb[(size_t)s * d + j];
+        a1 += sp[s + 4] * xb[(size_t)(s + 4) * d + j];
+        a2 += sp[s + 8] * xb[(size_t)(s + 8) * d + j];
+        a3 += sp[s + 12] * xb[(size_t)(s + 12) * d + j];
+      }
+      for (; s < S; s += 4) a0 += sp[s] * xb[(size_t)s * d + j];
+      part[rg][j - j0] = (a0 + a1) + (a2 + a3);
     }
-    if (s < S) a0 += sp[s] * xb[(size_t)s * d + j];
-    pooled[(size_t)b * G * d + (size_t)g * d + j] = a0 + a1;
+    __syncthreads();
+    for (int j = j0 + tid; j < min(d, j0 + 1024); j += AF_THREADS)
+      pooled[(size_t)b * G * d + (size_t)g * d + j] = (part[0][j - j0] + part[1][j - j0]) + (part[2][j - j0] + part[3][j - j0]);
+    __syncthreads();
   }
 }
 
 // t[s,g] = x[b,s,:] . dpooled[b,g,:];  dlogits[b,s,g] = p (t - sum_s' p t);  dx[b,s,:] = sum_g p[b,s,g] dpooled[b,g,:]
 // (a masked position's logit was REPLACED by -1e9, so its gradient is zero even when a fully masked sequence gives
 //  it the probability 1/S)
-__global__ void __launch_bounds__(256) attflat_pool_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ x,
-                                                               const uint8_t* __restrict__ mask,
-                                                               const float* __restrict__ dpooled, float* __restrict__ dlogits,
-                                                               float* __restrict__ dx, int S, int d, int G) {
+__global__ void __launch_bounds__(AF_THREADS) attflat_pool_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ x,
+                                                                      const uint8_t* __restrict__ mask,
+                                                                      const float* __restrict__ dpooled, float* __restrict__ dlogits,
+                                                                      float* __restrict__ dx, int S, int d, int G) {
   __shared__ float st[AF_MAXS];
-  __shared__ float red[4];
+  __shared__ float red[AF_WAVES];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float* xb = x + (size_t)b * S * d;
   for (int g = 0; g < G; ++g) {
     const float* dp = dpooled + (size_t)b * G * d + (size_t)g * d;
     // t[s]: one wave per row, lanes over the feature dimension
-    for (int s = w; s < S; s += 4) {
+    for (int s = w; s < S; s += AF_WAVES) {
       float a = 0.f;
       for (int j = lane; j < d; j += 64) a += xb[(size_t)s * d + j] * dp[j];
       a = wave_sum(a);
@@ -101,12 +121,9 @@ __global__ void __launch_bounds__(256) attflat_pool_bwd_kernel(const float* __re
     }
     __syncthreads();
     float dot = 0.f;
-    for (int s = tid; s < S; s += 256) dot += probs[((size_t)b * S + s) * G + g] * st[s];
-    dot = wave_sum(dot);
-    if (lane == 0) red[w] = dot;
-    __syncthreads();
-    dot = (red[0] + red[1]) + (red[2] + red[3]);
-    for (int s = tid; s < S; s += 256) {
+    for (int s = tid; s < S; s += AF_THREADS) dot += probs[((size_t)b * S + s) * G + g] * st[s];
+    dot = block_reduce(dot, red, false);
+    for (int s = tid; s < S; s += AF_THREADS) {
       const float pr = probs[((size_t)b * S + s) * G + g];
       const bool masked = mask && mask[(size_t)b * S + s];
       dlogits[((size_t)b * S + s) * G + g] = masked ? 0.f : pr * (st[s] - dot);
@@ -114,7 +131,7 @@ __global__ void __launch_bounds__(256) attflat_pool_bwd_kernel(const float* __re
     __syncthreads();
   }
   // dx: rows over waves, lanes over features
-  for (int s = w; s < S; s += 4) {
+  for (int s = w; s < S; s += AF_WAVES) {
     for (int j = lane; j < d; j += 64) {
       float a = 0.f;
       for (int g = 0; g < G; ++g) a += probs[((size_t)b * S + s) * G + g] * dpooled[(size_t)b * G * d + (size_t)g * d + j];
@@ -138,7 +155,7 @@ extern "C" int mmnas_attflat_pool_fwd(const float* logits, const float* x, const
   MMNAS_REQUIRE(logits && x && probs && pooled, MMNAS_E_ARG, "attflat_pool_fwd: null pointer");
   MMNAS_REQUIRE(B > 0 && S > 0 && S <= AF_MAXS && d > 0 && G > 0, MMNAS_E_SHAPE, "attflat_pool_fwd: B=%d S=%d d=%d G=%d (S <= %d)",
                 B, S, d, G, AF_MAXS);
-  MMNAS_LAUNCH(attflat_pool_fwd_kernel, dim3(B, G), dim3(256), 0, (hipStream_t)stream, logits, x, mask, probs, pooled, S, d, G);
+  MMNAS_LAUNCH(attflat_pool_fwd_kernel, dim3(B, G), dim3(AF_THREADS), 0, (hipStream_t)stream, logits, x, mask, probs, pooled, S, d, G);
   return check_launch("attflat_pool_fwd");
 }
 
@@ -147,7 +164,7 @@ extern "C" int mmnas_attflat_pool_bwd(const float* probs, const float* x, const 
   MMNAS_REQUIRE(probs && x && dpooled && dlogits && dx, MMNAS_E_ARG, "attflat_pool_bwd: null pointer");
   MMNAS_REQUIRE(B > 0 && S > 0 && S <= AF_MAXS && d > 0 && G > 0, MMNAS_E_SHAPE, "attflat_pool_bwd: B=%d S=%d d=%d G=%d (S <= %d)",
                 B, S, d, G, AF_MAXS);
-  MMNAS_LAUNCH(attflat_pool_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, probs, x, mask, dpooled, dlogits, dx, S, d, G);
+  MMNAS_LAUNCH(attflat_pool_bwd_kernel, dim3(B), dim3(AF_THREADS), 0, (hipStream_t)stream, probs, x, mask, dpooled, dlogits, dx, S, d, G);
   return check_launch("attflat_pool_bwd");
 }
 
