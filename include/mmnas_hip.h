@@ -87,6 +87,8 @@ typedef struct mmnas_gemm_group {
   const float* bias;      /* [N] or NULL */
   const float* residual;  /* [M, ldres] or NULL */
   const float* gate;      /* [M, ldgate] or NULL */
+  float* colsum;          /* [N] or NULL: colsum[n] += sum_m C[m, n] of the values just stored (the bias gradient of the
+                             layer below when C is its pre-activation gradient); not with accumulate */
 } mmnas_gemm_group;
 
 typedef struct mmnas_gemm_desc {

@@ -19,7 +19,7 @@ _fp = C.c_void_p  # device pointers travel as void*
 
 class GemmGroup(C.Structure):
     _fields_ = [('M', C.c_int), ('A', _fp * 3), ('B', _fp * 3), ('C', _fp), ('bias', _fp),
-                ('residual', _fp), ('gate', _fp)]
+                ('residual', _fp), ('gate', _fp), ('colsum', _fp)]
 
 
 class GemmDesc(C.Structure):

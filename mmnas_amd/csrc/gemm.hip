@@ -46,6 +46,7 @@ struct GemmGroupK {
   const float* bias;
   const float* residual;
   const float* gate;
+  float* colsum;
 };
 
 struct GemmK {
@@ -264,6 +265,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     const float* __restrict__ const biasp = G.bias;
     const float* __restrict__ const resp = G.residual;
     const float* __restrict__ const gatep = G.gate;
+    float* __restrict__ const csp = G.colsum;
     const float* const Aseg[3] = {G.A[0], G.A[1], G.A[2]};
     const float* const Bseg[3] = {G.B[0], G.B[1], G.B[2]};
     // Tiles of a problem are numbered in blocks of gm row-panels x all column tiles, column by column inside a
@@ -641,6 +643,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
           }
         }
         const float bv = biasp ? biasp[colc] : 0.f;
+        float cs = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rbase + (r & 3) + 8 * (r >> 2);
@@ -650,7 +653,11 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
           if (has_gate) val = gatev[r] > 0.f ? val * p.gate_scale : 0.f;
           if (has_res) val += resv[r];
           if (has_acc) val += oldv[r];
-          if (cok && row < Mg) Cp[(size_t)row * p.ldc + col] = val;
+          if (cok && row < Mg) { Cp[(size_t)row * p.ldc + col] = val; cs += val; }
+        }
+        if (csp != nullptr) {   // column sums of the stored tile: the two lane halves hold the other 16 rows of a column
+          cs += __shfl_xor(cs, 32, 64);
+          if (hh == 0 && cok) atomicAdd(csp + col, cs);
         }
       }
     }
@@ -809,6 +816,8 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
     if (!akc && s.M % 4 != 0) avec = 0;
     MMNAS_REQUIRE(s.M > 0 && s.C, MMNAS_E_ARG, "mmnas_gemm: group %d M=%d C=%p", g, s.M, (void*)s.C);
     k.g[g].M = s.M; k.g[g].C = s.C; k.g[g].bias = s.bias; k.g[g].residual = s.residual; k.g[g].gate = s.gate;
+    k.g[g].colsum = s.colsum;
+    MMNAS_REQUIRE(!(s.colsum && accumulate), MMNAS_E_ARG, "mmnas_gemm: no column sums when accumulating onto C");
     for (int i = 0; i < 3; ++i) {
       k.g[g].A[i] = s.A[i]; k.g[g].B[i] = s.B[i];
       if (i < d->nseg) {

@@ -363,8 +363,9 @@ extern "C" int mmnas_mlp_op_bwd(const mmnas_mlp_op* op, void* stream) {
   for (int i = nl - 1; i >= 0; --i) {
     const float* hin = i == 0 ? op->x : L.h[i];
     const int nout = op->dims[i + 1], nin = op->dims[i];
-    // bias gradient
-    if (op->db[i] && !(i == nl - 1 && last_bias_done))
+    // bias gradient: column sums of dpre.  The last layer's ride on the LayerNorm backward when possible; a hidden
+    // layer's are accumulated by the epilogue of the data-gradient product that writes its dpre (below)
+    if (op->db[i] && i == nl - 1 && !last_bias_done)
       if ((rc = mmnas_colsum(dpre, op->db[i], M, nout, nout, stream))) return rc;
     // weight gradient dW_i[nout,nin] += dpre^T hin and data gradient, one launch
     mmnas_gemm_desc w;
@@ -381,6 +382,7 @@ extern "C" int mmnas_mlp_op_bwd(const mmnas_mlp_op* op, void* stream) {
       float* out = L.dp[(nl - 1 - i) & 1];
       g.g[0].C = out;
       g.g[0].gate = L.h[i]; g.ldgate = nin; g.gate_scale = gate_scale;  // relu' and dropout replay from h_i
+      g.g[0].colsum = op->db[i - 1];   // db_{i-1} += column sums of dpre_{i-1} (may be NULL: layer without bias)
       if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
       dpre = out;
     }

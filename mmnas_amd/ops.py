@@ -302,6 +302,7 @@ def gemm_desc(layout, groups, N, K, lda, ldb, ldc, nseg=1, relu=False, split_k=1
         gg.bias = L.fptr(grp.get('bias'))
         gg.residual = L.fptr(grp.get('residual'))
         gg.gate = L.fptr(grp.get('gate'))
+        gg.colsum = L.fptr(grp.get('colsum'))
     return g
 
 

@@ -203,6 +203,28 @@ def test_gemm_pair_matches_two_launches(M, nin, nout, pair, split, gemm_tuning):
         assert rel_err(c.cpu().numpy(), (td(a).t() @ td(x)).numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('M,N,K', [(6400, 2048, 512), (300, 132, 96), (896, 512, 512), (64, 64, 32)])
+@pytest.mark.parametrize('sk', [1, 2])
+def test_gemm_colsum_epilogue(M, N, K, sk, gemm_tuning):
+    """colsum[n] += sum_m C[m, n] of the stored values (gate epilogue applied), also on tiles cut by stream-K."""
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    gemm_tuning(sk=sk, min_units=1 if sk == 2 else None)
+    rs = np.random.RandomState(M + N)
+    td = lambda a: torch.from_numpy(a).double()
+    a, b = rnd(rs, M, K), rnd(rs, K, N)
+    gate = (rnd(rs, M, N) > 0).astype(np.float32)
+    cs0 = rnd(rs, N)
+    C = torch.empty(M, N, device=DEV)
+    cs = g(cs0.copy())
+    ad, bd, gd = g(a), g(b), g(gate)
+    ops.gemm(L.GEMM_NN, [dict(M=M, A=[ad], B=[bd], C=C, gate=gd, colsum=cs)], N, K, K, N, N, ldgate=N, gate_scale=1.5)
+    ref = torch.where(td(gate) > 0, (td(a) @ td(b)) * 1.5, torch.zeros(M, N, dtype=torch.float64))
+    assert rel_err(C.cpu().numpy(), ref.numpy()) < 1e-5
+    want = td(cs0) + ref.sum(0)
+    assert rel_err(cs.cpu().numpy(), want.numpy()) < 2e-5
+
+
 def test_gemm_groups_segments_epilogue():
     from mmnas_amd import ops
     import mmnas_amd._lib as L

@@ -15,12 +15,16 @@ import torch
 _fp = C.c_void_p
 
 
-class Group(C.Structure):
-    _fields_ = [('M', C.c_int), ('A', _fp * 3), ('B', _fp * 3), ('C', _fp), ('bias', _fp), ('residual', _fp), ('gate', _fp)]
+def group_type(current):
+    class Group(C.Structure):   # the current ABI has the colsum epilogue pointer
+        _fields_ = [('M', C.c_int), ('A', _fp * 3), ('B', _fp * 3), ('C', _fp), ('bias', _fp), ('residual', _fp), ('gate', _fp)] + \
+                   ([('colsum', _fp)] if current else [])
+    return Group
 
 
 def desc_type(with_acc):
     mid = [('accumulate', C.c_int), ('reserved', C.c_int)] if with_acc else []
+    Group = group_type(with_acc)
 
     class Desc(C.Structure):
         _fields_ = [('layout', C.c_int), ('ngroups', C.c_int), ('nseg', C.c_int), ('N', C.c_int), ('K', C.c_int),
