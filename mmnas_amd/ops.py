@@ -322,6 +322,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, b, relu):
+        ctx.params = (W, b)   # the parameter objects themselves: their gradient sinks are looked up in backward
         x, W = _f32c(x), _f32c(W)
         K = x.shape[-1]
         M = x.numel() // K
@@ -341,23 +342,22 @@ class LinearFn(torch.autograd.Function):
         M = x.numel() // K
         N = W.shape[0]
         if ctx.relu:
-            dy = dy * (y > 0)
-        # long reductions over few output tiles (the 2048->512 region projection: 256 tiles, 6400 rows) go through
-        # the split-K path, which adds onto C
-        acc = M >= 2048
-        dW = torch.zeros_like(W) if acc else torch.empty_like(W)
-        wgrad = gemm_desc(L.GEMM_TN, [dict(M=N, A=[dy], B=[x], C=dW)], K, M, N, K, K, accumulate=acc)
+            dy = torch.ops.aten.threshold_backward(dy, y, 0.0)   # dy * (y > 0), one kernel
+        # Both parameter gradients are ADDED into their buffers: the flat gradient buffer's views when the parameter
+        # has a sink (no zero-fill, no autograd accumulate kernel), one fresh zeroed allocation otherwise.
+        (dW, db), rets, sinks = _grad_bufs(ctx.params, x.device)
+        wgrad = gemm_desc(L.GEMM_TN, [dict(M=N, A=[dy], B=[x], C=dW)], K, M, N, K, K, accumulate=True)
         dx = None
         if ctx.needs_input_grad[0]:   # e.g. the relation/region feature inputs of the stem need none
             dx = torch.empty_like(x)
             gemm_pair(gemm_desc(L.GEMM_NN, [dict(M=M, A=[dy], B=[W], C=dx)], K, N, N, K, K), wgrad)
         else:
             L.check(L.lib().mmnas_gemm(C.byref(wgrad), L.stream()))
-        db = None
         if ctx.has_bias:
-            db = torch.zeros(N, dtype=torch.float32, device=x.device)
             L.check(L.lib().mmnas_colsum(L.fptr(dy), L.fptr(db), M, N, N, L.stream()))
-        return dx, dW, db, None
+        for sk in sinks:
+            sk.done()
+        return dx, rets[0], rets[1], None
 
 
 def linear(x, W, b=None, relu=False):
