@@ -165,14 +165,11 @@ class AttentionOp(torch.autograd.Function):
         xq, xkv, m8, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, save, Wy, by = ctx.keep
         dev = xq.device
         dy = _f32c(dy)
-        # Wy/by (linear_y_rel) are shared by every relation operator of a net: they always take the
-        # ordinary autograd accumulation path, never a sink
-        bufs, rets, sinks = _grad_bufs([Wq, Wk, Wv, Wm, Wr, br, ln_a, ctx.ln_b_param], dev)
-        dWq, dWk, dWv, dWm, dWr, dbr, dla, dlb = bufs
-        dWy = dby = None
-        if ctx.lazy:
-            fy = torch.zeros(Wy.numel() + by.numel(), dtype=torch.float32, device=dev)
-            dWy, dby = fy[:Wy.numel()].view_as(Wy), fy[Wy.numel():]
+        # Wy/by (linear_y_rel) are shared by every relation operator of a net; the kernels ADD their contribution, so
+        # a sink works for them too (the reducer waits for autograd's post-accumulate hook, which fires once after
+        # the last use)
+        bufs, rets, sinks = _grad_bufs([Wq, Wk, Wv, Wm, Wr, br, ln_a, ctx.ln_b_param] + ([Wy, by] if ctx.lazy else [None, None]), dev)
+        dWq, dWk, dWv, dWm, dWr, dbr, dla, dlb, dWy, dby = bufs
         dxq = torch.empty_like(xq)
         dxkv = None if ctx.self_att else torch.empty_like(xkv)
         want_drel = ctx.has_rel and not ctx.lazy and ctx.needs_input_grad[3]
@@ -187,7 +184,7 @@ class AttentionOp(torch.autograd.Function):
         ctx.keep = None
         for sk in sinks:
             sk.done()
-        return (dxq, dxkv, None, drel) + tuple(rets) + (dWy, dby, None, None, None, None, None, None, None)
+        return (dxq, dxkv, None, drel) + tuple(rets) + (None, None, None, None, None, None, None)
 
 
 def attention_op(xq, xkv, mask, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, ln_b, *, dh, norm, residual, drop_p,
