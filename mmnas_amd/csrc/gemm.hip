@@ -708,8 +708,8 @@ static int env_int(const char* name, int dflt) {
 //   MMNAS_GEMM_GM=n        row-panels per tile-order block (default 8)     MMNAS_GEMM_XCD=0 identity workgroup mapping
 //   MMNAS_GEMM_SPLIT=0|3|6 products on the fp32 MFMA (default) / as 3 / 6 bf16 MFMA products of split operands
 //   MMNAS_GEMM_PAIR=0      mmnas_gemm_pair launches its two products separately
-struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split, pair; bool loaded; };
-static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 0, 1, false};
+struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split, pair, split_slots, split_p; bool loaded; };
+static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 0, 1, 0, 24, false};
 static void load_tuning() {
   g_tune.tile = env_int("MMNAS_GEMM_TILE", 0);
   g_tune.generic = getenv("MMNAS_GEMM_GENERIC") != nullptr;
@@ -722,6 +722,9 @@ static void load_tuning() {
   const int sp = env_int("MMNAS_GEMM_SPLIT", 0);
   g_tune.split = sp == 3 ? 2 : (sp == 6 ? 3 : 0);   // number of bf16 parts per operand
   g_tune.pair = env_int("MMNAS_GEMM_PAIR", 1);
+  g_tune.split_slots = env_int("MMNAS_GEMM_SPLIT_SLOTS", 0);
+  g_tune.split_p = env_int("MMNAS_GEMM_SPLIT_P", 24);           // K-tiles per split-K piece
+  if (g_tune.split_p < 1) g_tune.split_p = 1;
   g_tune.loaded = true;
 }
 
@@ -879,8 +882,15 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
   k.P = k.T;
   int nwg = k.ntiles;
   if (accumulate && sk != 0) {
-    // split-K with atomics: enough (slice, tile) pieces to fill the co-resident slots, >= min_units K-tiles each
-    int want = slots / k.ntiles;   // rounded DOWN: 192 tiles x 6 slices = 1152 pieces spill into a second, nearly empty round
+    // split-K with atomics.  Pieces of ~split_p K-tiles (long enough to amortise a piece's operand prologue and its
+    // 16 KB of atomic adds, short enough to balance), but at least ~2 workgroups per CU in total, >= min_units K-tiles each.
+    // (MMNAS_GEMM_SPLIT_SLOTS=n restores the older rule: as many pieces as fit n co-resident slots.)
+    int want;
+    if (g_tune.split_slots > 0) want = g_tune.split_slots / k.ntiles;
+    else {
+      want = (k.T + g_tune.split_p / 2) / g_tune.split_p;
+      if ((long)want * k.ntiles < 512) want = (512 + k.ntiles - 1) / k.ntiles;
+    }
     if (want < 1) want = 1;
     if (want > k.T / min_units) want = k.T / min_units;
     if (want > 1) {
