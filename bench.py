@@ -276,11 +276,31 @@ def main():
     barrier()
     flops_acc[0] = 0.0
     prof_on = not args.no_prof
+    if os.environ.get('MMNAS_BENCH_TORCHPROF'):   # diagnostic: which ATen ops run per step (counts), with python stacks
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU], with_stack=True) as tp:
+            for _ in range(3):
+                step()
+        barrier()
+        for ev in sorted(tp.key_averages(group_by_stack_n=12), key=lambda e: -e.count):
+            if ev.key.split('::')[-1] in ('fill_', 'add_', 'add', 'copy_', 'cat', 'mul', 'zero_', 'sum', 'div', 'sub', 'where', 'gt'):
+                where = [s for s in ev.stack if 'repo' in s or 'mmnas' in s]
+                print('%-14s x%-3d %s' % (ev.key, ev.count, ' <- '.join(w.split('repo/')[-1] for w in where[:4])), file=sys.stderr)
+    prof_host = None
+    if os.environ.get('MMNAS_BENCH_CPROFILE'):   # diagnostic: python-level profile of the issuing thread (forward + loss)
+        import cProfile
+        prof_host = cProfile.Profile()
+        prof_host.enable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_enqueue = time.perf_counter() - t0   # host time to issue the steps (diagnostic: close to `elapsed` = host-bound)
     barrier()
     elapsed = time.perf_counter() - t0
+    if prof_host is not None:
+        import pstats
+        prof_host.disable()
+        pstats.Stats(prof_host, stream=sys.stderr).sort_stats('tottime').print_stats(40)
     timed_flops = flops_acc[0]
     # Roofline pass: the same step repeated right after the timed region with every library launch carrying a
     # start/stop HIP event (on the launch stream).  It is kept out of the timed region because the events
@@ -324,6 +344,7 @@ def main():
             'samples_per_s': world * args.steps * B / elapsed,
             'algorithmic_tflops_per_gpu': flops_acc[0] / elapsed / 1e12,
             'final_loss': final_loss,
+            'host_issue_ms_per_step': 1000.0 * t_enqueue / args.steps,
         }
         if stats:
             gm = stats['gemm']

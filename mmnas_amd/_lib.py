@@ -173,4 +173,6 @@ def fptr(t):
 
 
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current stream on the current device (the C calls take a hipStream_t).  The private
+    accessors cost ~0.3 us; torch.cuda.current_stream() builds a Stream object (~10 us, ~45 times a step)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())

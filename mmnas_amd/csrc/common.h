@@ -62,6 +62,22 @@ ProfEvents prof_launch_events();  // events for the next launch of the active sc
 
 bool prof_enabled();
 
+// Column reduction of per-workgroup partial rows that a kernel left behind (LayerNorm backward: part[nrows][3][d] ->
+// out[w][c] += sum_rows part[row][w][c]).  Instead of its own launch it can ride on the next mmnas_gemm_pair launch as
+// a few extra workgroups (internal: gemm_pair_aux); launch_aux_reduce() runs it stand-alone.
+struct AuxReduce {
+  const float* part;
+  int nrows, d;
+  float* out[3];   // NULL entries are skipped
+};
+int launch_aux_reduce(const AuxReduce& a, hipStream_t st);
+int gemm_pair_aux(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, const AuxReduce* aux, hipStream_t st);
+// mmnas_layernorm_bwd without the final reduction: fills *aux (part == NULL when nothing is pending)
+int layernorm_bwd_deferred(const float* x, const float* a, const float* dy, float* dx, float* da, float* db, float* ddrop,
+                           float* dcol, float* ws, float drop_p, uint64_t seed, uint32_t site, int M, int d, float eps,
+                           hipStream_t st, AuxReduce* aux);
+
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace mmnas

@@ -679,17 +679,60 @@ __global__ void __launch_bounds__(256, NS == 3 ? (BM == 128 ? 1 : 3) : (BM == 12
 // problem's workgroups are dispatched as the first problem's finish, so one of those two idle phases disappears.
 // Workgroups [0, nwg0p) belong to q0 (nwg0p = nwg0 rounded up to 8, so blockIdx % 8 keeps naming the XCD in both
 // sections), the rest to q1.
+// Pending column reduction riding on a pair launch (AuxReduce): job = (output w, block of 16 columns); 16 lanes x 16
+// row slices per workgroup.  out[w][c] += sum_rows part[row][w][c]
+struct AuxReduceK {
+  const float* part;
+  float* out[3];
+  int nrows, d, ncb, njobs;   // ncb = column blocks per output; njobs = 3 * ncb
+};
+
+__device__ __forceinline__ void aux_reduce_body(const AuxReduceK& a, int job, float* red /* >= 16*17 floats */) {
+  const int w = job / a.ncb, cb = job - w * a.ncb;
+  float* __restrict__ out = w == 0 ? a.out[0] : (w == 1 ? a.out[1] : a.out[2]);
+  if (!out) return;
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = cb * 16 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < a.d) {
+    const float* __restrict__ p = a.part + (size_t)w * a.d + c;
+    const size_t rs = (size_t)3 * a.d;
+    int b = g;
+    for (; b + 48 < a.nrows; b += 64) {
+      s0 += p[(size_t)b * rs];
+      s1 += p[(size_t)(b + 16) * rs];
+      s2 += p[(size_t)(b + 32) * rs];
+      s3 += p[(size_t)(b + 48) * rs];
+    }
+    for (; b < a.nrows; b += 16) s0 += p[(size_t)b * rs];
+  }
+  red[g * 17 + cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && c < a.d) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i * 17 + cl];
+    out[c] += t;
+  }
+}
+
 template <int BM, int BN, int NS>
 __global__ void __launch_bounds__(256, NS == 3 ? 3 : MMNAS_OCC64) gemm_pair_kernel(const GemmK q0, const GemmK q1, const int nwg0,
-                                                                                    const int nwg0p) {
+                                                                                    const int nwg0p, const AuxReduceK aux,
+                                                                                    const int naux8) {
   __shared__ __attribute__((aligned(16))) float As[2 * GemmShape<BM, BN, NS>::A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[2 * GemmShape<BM, BN, NS>::B_SZ];
   __shared__ int s_old;
-  const int bid = blockIdx.x;
+  int bid = blockIdx.x;
+  if (bid < naux8) {   // (a multiple of 8, so blockIdx % 8 keeps naming the XCD in the sections behind it)
+    if (bid < aux.njobs) aux_reduce_body(aux, bid, As);
+    return;
+  }
+  bid -= naux8;
   if (bid < nwg0p) {
     if (bid < nwg0) gemm_body<BM, BN, true, false, true, NS>(q0, bid, nwg0, 0, As, Bs, s_old);
   } else {
-    gemm_body<BM, BN, false, false, true, NS>(q1, bid - nwg0p, (int)gridDim.x - nwg0p, (int)sizeof(GemmK), As, Bs, s_old);
+    gemm_body<BM, BN, false, false, true, NS>(q1, bid - nwg0p, (int)gridDim.x - naux8 - nwg0p, (int)sizeof(GemmK), As, Bs, s_old);
   }
 }
 
@@ -976,8 +1019,8 @@ extern "C" int mmnas_gemm(const mmnas_gemm_desc* d, void* stream) {
   return launch_plan(pl, (hipStream_t)stream);
 }
 
-extern "C" int mmnas_gemm_pair(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
+namespace mmnas {
+int gemm_pair_aux(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, const AuxReduce* aux, hipStream_t st) {
   GemmPlan p0, p1;
   int rc;
   if ((rc = plan_gemm(dgrad, st, p0))) return rc;
@@ -986,18 +1029,33 @@ extern "C" int mmnas_gemm_pair(const mmnas_gemm_desc* dgrad, const mmnas_gemm_de
   const bool pair = g_tune.pair && p0.fast && p1.fast && !p0.big && !p1.big && p0.layout == MMNAS_GEMM_NN &&
                     p1.layout == MMNAS_GEMM_TN && p1.k.mode != MODE_STREAM;
   if (!pair) {
+    if (aux && (rc = launch_aux_reduce(*aux, st))) return rc;
     if ((rc = launch_plan(p0, st))) return rc;
     return launch_plan(p1, st);
   }
+  AuxReduceK ak;
+  memset(&ak, 0, sizeof(ak));
+  if (aux && aux->part && g_tune.pair != 3) {   // (MMNAS_GEMM_PAIR=3: pending reductions get their own launch)
+    ak.part = aux->part; ak.nrows = aux->nrows; ak.d = aux->d;
+    for (int i = 0; i < 3; ++i) ak.out[i] = aux->out[i];
+    ak.ncb = cdiv(aux->d, 16);
+    ak.njobs = 3 * ak.ncb;
+  } else if (aux && (rc = launch_aux_reduce(*aux, st))) return rc;
+  const int naux8 = (ak.njobs + 7) / 8 * 8;
   char tag[96] = "";
   if (prof_enabled()) snprintf(tag, sizeof(tag), "PAIR %.44s | %.40s", p0.tag, p1.tag);
   ProfScope ps(MMNAS_K_GEMM, p0.flops + p1.flops, p0.bytes + p1.bytes, st, tag);
   const int nwg0p = (p0.nwg + 7) / 8 * 8;
-  dim3 grid(nwg0p + p1.nwg), block(256);
+  dim3 grid(naux8 + nwg0p + p1.nwg), block(256);
   switch (g_tune.split) {
-    case 2: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p); break;
-    case 3: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p); break;
-    default: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 0>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p); break;
+    case 2: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8); break;
+    case 3: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8); break;
+    default: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 0>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8); break;
   }
   return check_launch("gemm_pair");
+}
+}  // namespace mmnas
+
+extern "C" int mmnas_gemm_pair(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, void* stream) {
+  return gemm_pair_aux(dgrad, wgrad, nullptr, (hipStream_t)stream);
 }

@@ -158,9 +158,11 @@ extern "C" int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream) {
   // 1. through LayerNorm and the output dropout
   const float* dz = op->dy;   // gradient wrt z = x + drop(core)
   const float* dt = op->dy;   // gradient wrt core
+  AuxReduce lnred;   // the LayerNorm parameter-gradient reduction rides on the first gradient-pair launch below
+  lnred.part = nullptr;
   if (norm) {
-    if ((rc = mmnas_layernorm_bwd(L.z, op->ln_a, op->dy, L.dz, op->dln_a, op->dln_b, drop ? L.dt : nullptr, nullptr,
-                                  L.lnws, drop ? op->drop_p : 0.f, op->seed, 1, Mq, d, op->eps, stream)))
+    if ((rc = layernorm_bwd_deferred(L.z, op->ln_a, op->dy, L.dz, op->dln_a, op->dln_b, drop ? L.dt : nullptr, nullptr,
+                                     L.lnws, drop ? op->drop_p : 0.f, op->seed, 1, Mq, d, op->eps, (hipStream_t)stream, &lnred)))
       return rc;
     dz = L.dz; dt = drop ? L.dt : L.dz;
   } else if (drop) {
@@ -176,7 +178,7 @@ extern "C" int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream) {
   gemm_init(w, MMNAS_GEMM_TN, di, Mq, d, di, di);
   w.g[0].M = d; w.g[0].A[0] = dt; w.g[0].B[0] = L.att; w.g[0].C = op->dWm;
   w.accumulate = 1;
-  if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
+  if ((rc = gemm_pair_aux(&g, &w, &lnred, (hipStream_t)stream))) return rc;
 
   // 4. attention core backward
   mmnas_mha_desc m;
@@ -342,13 +344,15 @@ extern "C" int mmnas_mlp_op_bwd(const mmnas_mlp_op* op, void* stream) {
   const float* dz = op->dy;
   const float* dt = op->dy;
   bool last_bias_done = false;
+  AuxReduce lnred;   // pending LayerNorm reduction: rides on the first gradient-pair launch
+  lnred.part = nullptr;
   if (norm) {
     MMNAS_REQUIRE(op->ln_a && op->dln_a && op->dln_b, MMNAS_E_ARG, "mlp_op_bwd: NORM gradients missing");
     // the column sums of the dropped gradient are the last layer's bias gradient: fused when a
     // separate dt buffer exists
     float* dcol = (drop && op->db[nl - 1]) ? op->db[nl - 1] : nullptr;
-    if ((rc = mmnas_layernorm_bwd(L.z, op->ln_a, op->dy, L.dz, op->dln_a, op->dln_b, drop ? L.dt : nullptr, dcol,
-                                  L.lnws, drop ? op->drop_p : 0.f, op->seed, 1, M, d, op->eps, stream)))
+    if ((rc = layernorm_bwd_deferred(L.z, op->ln_a, op->dy, L.dz, op->dln_a, op->dln_b, drop ? L.dt : nullptr, dcol,
+                                     L.lnws, drop ? op->drop_p : 0.f, op->seed, 1, M, d, op->eps, (hipStream_t)stream, &lnred)))
       return rc;
     dz = L.dz; dt = drop ? L.dt : L.dz;
     last_bias_done = dcol != nullptr;
@@ -377,13 +381,13 @@ extern "C" int mmnas_mlp_op_bwd(const mmnas_mlp_op* op, void* stream) {
     if (i == 0) {
       g.g[0].C = op->dx;
       if (fl & MMNAS_F_RESIDUAL) { g.g[0].residual = dz; g.ldres = d; }
-      if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
+      if ((rc = gemm_pair_aux(&g, &w, i == nl - 1 ? &lnred : nullptr, (hipStream_t)stream))) return rc;
     } else {
       float* out = L.dp[(nl - 1 - i) & 1];
       g.g[0].C = out;
       g.g[0].gate = L.h[i]; g.ldgate = nin; g.gate_scale = gate_scale;  // relu' and dropout replay from h_i
       g.g[0].colsum = op->db[i - 1];   // db_{i-1} += column sums of dpre_{i-1} (may be NULL: layer without bias)
-      if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
+      if ((rc = gemm_pair_aux(&g, &w, i == nl - 1 ? &lnred : nullptr, (hipStream_t)stream))) return rc;
       dpre = out;
     }
   }

@@ -331,14 +331,14 @@ static int ln_bwd_blocks(int M) {   // <= 2 workgroups (8 waves) per CU; each wa
 
 extern "C" size_t mmnas_layernorm_bwd_ws_floats(int M, int d) { return (size_t)ln_bwd_blocks(M) * 3 * d; }
 
-extern "C" int mmnas_layernorm_bwd(const float* x, const float* a, const float* dy, float* dx, float* da,
-                                   float* db, float* ddrop, float* dcol, float* ws, float drop_p, uint64_t seed,
-                                   uint32_t site, int M, int d, float eps, void* stream) {
+namespace mmnas {
+int layernorm_bwd_deferred(const float* x, const float* a, const float* dy, float* dx, float* da, float* db, float* ddrop,
+                           float* dcol, float* ws, float drop_p, uint64_t seed, uint32_t site, int M, int d, float eps,
+                           hipStream_t st, AuxReduce* aux) {
   MMNAS_REQUIRE(x && a && dy && dx, MMNAS_E_ARG, "layernorm_bwd: null pointer");
   MMNAS_REQUIRE(M > 0 && d >= 4 && d % 4 == 0 && d <= 2048, MMNAS_E_SHAPE,
                 "layernorm_bwd: M=%d d=%d (need d %% 4 == 0, 4 <= d <= 2048)", M, d);
   MMNAS_REQUIRE(dcol == nullptr || ddrop != nullptr, MMNAS_E_ARG, "layernorm_bwd: dcol needs ddrop");
-  hipStream_t st = (hipStream_t)stream;
   const int nb = ln_bwd_blocks(M);
   dim3 grid(nb), block(256);
   const DropCfg dc = make_drop(drop_p, seed, site);
@@ -347,8 +347,27 @@ extern "C" int mmnas_layernorm_bwd(const float* x, const float* a, const float* 
 #define LNB(NV) MMNAS_LAUNCH(ln_bwd_kernel<NV>, grid, block, 0, st, x, a, dy, dx, da, db, ddrop, dcol, ws, dc, M, d, eps)
   if (nv <= 1) LNB(1); else if (nv <= 2) LNB(2); else if (nv <= 4) LNB(4); else LNB(8);
 #undef LNB
-  if (ws) MMNAS_LAUNCH(ln_bwd_reduce_kernel, dim3(cdiv(d, 16), 3), dim3(1024), 0, st, ws, nb, d, da, db, dcol);
+  aux->part = ws; aux->nrows = nb; aux->d = d;
+  aux->out[0] = da; aux->out[1] = db; aux->out[2] = dcol;
+  if (!ws || (!da && !db && !dcol)) aux->part = nullptr;
   return check_launch("layernorm_bwd");
+}
+
+int launch_aux_reduce(const AuxReduce& a, hipStream_t st) {
+  if (!a.part) return MMNAS_OK;
+  ProfScope ps(MMNAS_K_ROWOPS, 0.0, 4.0 * a.nrows * 3.0 * a.d, st);
+  MMNAS_LAUNCH(ln_bwd_reduce_kernel, dim3(cdiv(a.d, 16), 3), dim3(1024), 0, st, a.part, a.nrows, a.d, a.out[0], a.out[1], a.out[2]);
+  return check_launch("layernorm_bwd_reduce");
+}
+}  // namespace mmnas
+
+extern "C" int mmnas_layernorm_bwd(const float* x, const float* a, const float* dy, float* dx, float* da,
+                                   float* db, float* ddrop, float* dcol, float* ws, float drop_p, uint64_t seed,
+                                   uint32_t site, int M, int d, float eps, void* stream) {
+  AuxReduce aux;
+  const int rc = layernorm_bwd_deferred(x, a, dy, dx, da, db, ddrop, dcol, ws, drop_p, seed, site, M, d, eps, (hipStream_t)stream, &aux);
+  if (rc) return rc;
+  return launch_aux_reduce(aux, (hipStream_t)stream);
 }
 
 extern "C" int mmnas_colsum(const float* x, float* out, int M, int N, int ldx, void* stream) {

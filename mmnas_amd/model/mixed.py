@@ -44,6 +44,11 @@ def sample_indices(probs_cpu, mode):
     return [a], [i for i in range(n) if i != a]
 
 
+def sample_rows(probs_cpu):
+    """probs_cpu: [n, width] CPU tensor, one distribution per row -> list of n sampled column indices (MODE None)."""
+    return torch.multinomial(probs_cpu, 1, generator=_sampler).view(-1).tolist()
+
+
 class MixedOp(nn.Module):
     MODE = None  # None | 'full' | 'two'
 
