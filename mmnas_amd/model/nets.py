@@ -91,6 +91,8 @@ def make_mask(feature):
     [B,100,2048] region tensor) take one pass of mmnas_row_is_zero; token indices keep the torch expression."""
     if feature.dtype == torch.float32 and feature.is_cuda:
         return ops.row_is_zero(feature).unsqueeze(1).unsqueeze(2)
+    if feature.shape[-1] == 1:   # token indices [B, S, 1]: sum(|x|) == 0 is x == 0 (one kernel instead of three)
+        return (feature.squeeze(-1) == 0).unsqueeze(1).unsqueeze(2)
     return (torch.sum(torch.abs(feature), dim=-1) == 0).unsqueeze(1).unsqueeze(2)
 
 
