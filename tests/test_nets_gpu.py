@@ -174,3 +174,62 @@ def test_supernet_sampling_and_readout():
         net.reset_binary_gates()
         cnt[m0.active_index[0]] += 1
     assert np.abs(cnt / 400 - probs).max() < 0.1
+
+
+def test_full_size_net_properties():
+    """BASELINE configs[1] at full size (arch/mmnas_vqa.json, HSIZE 512, B=64, 100 regions, 14 tokens), where the
+    oracle is too slow to be the checker: properties that hold for the reference by construction.
+      (a) samples are independent: permuting the batch permutes the logits;
+      (b) the loss is a sum over samples: gradients of the whole batch = sum of the gradients of its two halves;
+      (c) padding is inert: values at padded positions of the relation inputs (masked keys are REPLACED by -1e9,
+          padded query rows are masked later, modules.py:193-196,79-81) do not change the logits."""
+    from mmnas.model.full_vqa import Net_Full
+    B = 64
+    c = cases.net_case('vqa', 'mmnas_vqa', 11, HSIZE=512, B=B, Sx=14, Sy=100, token_size=2000, ans_size=3129)
+    c['cfg'].DROPOUT_R = 0.0            # (train mode: the MIOpen LSTM has no backward in eval mode)
+    net = Net_Full(c['cfg'], _init(c))
+    net.load_state_dict({k: T(v) for k, v in c['P'].items()}, strict=True)
+    net = net.to(DEV).train()
+    inp = [T(a).to(DEV) for a in c['inputs']]
+    tgt = T(c['target']).to(DEV)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+
+    def grads(sel):
+        net.zero_grad(set_to_none=True)
+        out = net(tuple(t[sel] for t in inp))
+        bce(out, tgt[sel], reduction='sum').backward()
+        return out.detach(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    full = torch.arange(B, device=DEV)
+    out, g_all = grads(full)
+    assert torch.isfinite(out).all()
+    scale = float(out.abs().max())
+    # (a)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to(DEV)
+    out_p, _ = grads(perm)
+    assert float((out_p - out[perm]).abs().max()) <= 2e-5 * scale
+    # (b)
+    _, g_lo = grads(full[:B // 2])
+    _, g_hi = grads(full[B // 2:])
+    gmax = max(float(v.abs().max()) for v in g_all.values())
+    bad = []
+    for k, v in g_all.items():
+        err = float((v - (g_lo[k] + g_hi[k])).abs().max())
+        # (fp32 sums over 6400 rows vs 2 x 3200 through 30 layers: the gradient tolerance of the parity tests)
+        if err > 2e-3 * max(float(v.abs().max()), 1e-3 * gmax):
+            bad.append((k, err, float(v.abs().max())))
+    assert not bad, bad[:6]
+    # (c)
+    rs = np.random.RandomState(5)
+    frcn, _, y_rel, ques, x_rel = c['inputs']
+    y2, x2 = y_rel.copy(), x_rel.copy()
+    for b in range(B):
+        ny = int((np.abs(frcn[b]).sum(-1) != 0).sum())
+        nx = int((ques[b] != 0).sum())
+        y2[b, ny:] = rs.standard_normal(y2[b, ny:].shape) * 3
+        y2[b, :, ny:] = rs.standard_normal(y2[b, :, ny:].shape) * 3
+        x2[b, nx:] = rs.standard_normal(x2[b, nx:].shape) * 3
+        x2[b, :, nx:] = rs.standard_normal(x2[b, :, nx:].shape) * 3
+    with torch.no_grad():
+        out_j = net((inp[0], inp[1], T(y2).to(DEV), inp[3], T(x2).to(DEV)))
+    assert float((out_j - out).abs().max()) <= 1e-5 * scale
