@@ -114,6 +114,23 @@ int mmnas_gemm(const mmnas_gemm_desc* d, void* stream);
  * The outputs must not overlap each other or either product's inputs. */
 int mmnas_gemm_pair(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, void* stream);
 
+/* Single-layer LSTM with zero initial state: nn.LSTM(batch_first=True) of the nets' language stem
+ * (hygr_vqa.py:86-92 construction, :106-107 call; torch/nn/modules/rnn.py for the gate equations), one launch per time
+ * step (recurrent product + gate arithmetic) instead of MIOpen's GEMM + pointwise kernels + weight-buffer copies.
+ * Time-major buffers; gate columns INTERLEAVED: row / column 4j+g of the weight / gate arrays is gate g (i, f, g, o) of
+ * hidden unit j, i.e. nn.LSTM's [i|f|g|o] row blocks permuted by the caller; bias = b_ih + b_hh likewise.
+ *   fwd: x_tm [T,B,E]; Wih [4H,E]; Whh [4H,H]; xp [T,B,4H] scratch; Hall, Call [T+1,B,H] with slice 0 ZEROED by the
+ *        caller (h_t, c_t land in slice t+1); Gall [T,B,4H] activated gates (saved for backward); out [B,T,H] = h_t.
+ *   bwd: dout [B,T,H]; DG [T+1,B,4H] with slice T ZEROED (receives d pre-activations, slice t); dc [B,H] ZEROED
+ *        (running cell gradient); scratch [B,H].  The weight / input gradients are ordinary products of DG[0:T]
+ *        (TN with Hall[0:T] and x_tm, NN with Wih) issued by the caller through mmnas_gemm.
+ * mmnas_lstm_supported: hidden size a multiple of 32. */
+int mmnas_lstm_supported(int E, int H);
+int mmnas_lstm_fwd(const float* x_tm, const float* Wih, const float* Whh, const float* bias, float* xp, float* Hall,
+                   float* Call, float* Gall, float* out, int T, int B, int E, int H, void* stream);
+int mmnas_lstm_bwd(const float* dout, const float* Whh, const float* Call, const float* Gall, float* DG, float* dc,
+                   float* scratch, int T, int B, int H, void* stream);
+
 /* Scheduling knobs of mmnas_gemm (MMNAS_GEMM_TILE, _SK, _WGS, _MIN_UNITS, _GENERIC, _GM, _XCD: tuning and tests only)
  * and the opt-in MMNAS_GEMM_SPLIT=3|6 (products as 3 / 6 bf16-MFMA products of exactly split fp32 operands, fp32
  * accumulation; default 0 = fp32 MFMA) are read from the environment on the first call; this re-reads them. */

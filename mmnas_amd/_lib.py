@@ -83,6 +83,9 @@ SYMBOLS = {
     'mmnas_gemm': (_i, [C.POINTER(GemmDesc), _fp]),
     'mmnas_gemm_pair': (_i, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), _fp]),
     'mmnas_gemm_reload_tuning': (_i, []),
+    'mmnas_lstm_supported': (_i, [_i, _i]),
+    'mmnas_lstm_fwd': (_i, [_fp] * 9 + [_i, _i, _i, _i, _fp]),
+    'mmnas_lstm_bwd': (_i, [_fp] * 7 + [_i, _i, _i, _fp]),
     'mmnas_layernorm_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _fp]),
     'mmnas_layernorm_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _u64, _u32, _i, _i, _f, _fp]),
     'mmnas_layernorm_bwd_ws_floats': (_sz, [_i, _i]),

@@ -70,6 +70,19 @@ struct GemmK {
   float alpha, gate_scale;
   DropCfg drop;
   GemmGroupK g[3];
+  // LSTM time-step epilogues (EPI template parameter; lstm_* entry points below).  M = batch rows.
+  //   EPI 1 (forward, N = 4H with column 4j+gate = gate `gate` of unit j): pre-activations = result + residual;
+  //     gates -> lg_gates[M,4H], c = f c_prev + i g -> lg_cout[M,H], h = o tanh(c) -> C[M,H] and lg_h2 (ld lg_ldh2)
+  //   EPI 2 (backward, N = H): dh = result + residual; with the step's saved gates, c, c_prev and the running dc
+  //     (lg_dc, updated in place) writes the pre-activation gradients lg_gates[M,4H]; C is not written
+  const float* lg_cprev;
+  const float* lg_c;
+  float* lg_cout;
+  float* lg_gates;
+  float* lg_h2;
+  float* lg_dc;
+  const float* lg_act;
+  int lg_ldh2, lg_pad;
 };
 
 enum { MODE_TILE = 0, MODE_SPLIT = 1, MODE_STREAM = 2 };
@@ -182,7 +195,7 @@ struct GemmShape {
 
 // The work of workgroup `bid` of `nwg` on problem p (the kernel's own blockIdx / gridDim, or its position inside one
 // section of a two-section launch); `koff` = byte offset of p inside the kernel-argument segment.
-template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS>
+template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0>
 __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const int nwg, const int koff,
                                           float* __restrict__ As, float* __restrict__ Bs, int& s_old) {
   static_assert(NS == 0 || (FAST && BK == 32), "the bf16-split path exists for the buffer-load path only");
@@ -197,17 +210,17 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
   // Touch every line up front so the misses overlap (measured: -3.5 us per launch).
   {
     const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr() + koff;
-    unsigned t0, t1, t2, t3, t4, t5, t6;
+    unsigned t0, t1, t2, t3, t4, t5, t6, t7;
     asm volatile(
-        "s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %7, 0x40\n\ts_load_dword %2, %7, 0x80\n\t"
-        "s_load_dword %3, %7, 0xc0\n\ts_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\t"
-        "s_load_dword %6, %7, 0x180\n\ts_waitcnt lgkmcnt(0)"
-        : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6)   // early-clobber: the loads
-                                                  // return while later ones are still being issued from %7
+        "s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\t"
+        "s_load_dword %3, %8, 0xc0\n\ts_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\t"
+        "s_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\ts_waitcnt lgkmcnt(0)"
+        : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7)   // early-clobber: the
+                                                  // loads return while later ones are still being issued from %8
         : "s"(ka)
         : "memory");
   }
-  static_assert(sizeof(GemmK) > 0x140 && sizeof(GemmK) <= 0x1c0, "update the kernel-argument warm-up loads");
+  static_assert(sizeof(GemmK) > 0x1c0 && sizeof(GemmK) <= 0x200, "update the kernel-argument warm-up loads");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -590,6 +603,15 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     // independent loads (clamped row index instead of a branch) before any arithmetic.
     const bool has_res = resp != nullptr, has_gate = gatep != nullptr, has_acc = p.accumulate != 0;
     const bool has_drop = p.drop.thresh != 0, has_relu = p.relu != 0;
+    // (LSTM epilogues: the extra operands into registers once, as for the group fields above)
+    const float* __restrict__ const lg_cprev = EPI ? p.lg_cprev : nullptr;
+    const float* __restrict__ const lg_c = EPI ? p.lg_c : nullptr;
+    const float* __restrict__ const lg_act = EPI ? p.lg_act : nullptr;
+    float* __restrict__ const lg_cout = EPI ? p.lg_cout : nullptr;
+    float* __restrict__ const lg_gates = EPI ? p.lg_gates : nullptr;
+    float* __restrict__ const lg_h2 = EPI ? p.lg_h2 : nullptr;
+    float* __restrict__ const lg_dc = EPI ? p.lg_dc : nullptr;
+    const int lg_ldh2 = EPI ? p.lg_ldh2 : 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -598,6 +620,52 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         const bool cok = col < p.N;
         const int colc = cok ? col : p.N - 1;
         const int rbase = m0 + wm * WM + i * 32 + 4 * hh;
+        if (EPI == 1) {   // LSTM forward step: column = 4 * unit + gate; the 4 lanes of a quad hold one unit's gates
+          const int unit = col >> 2, gate = col & 3, Hn = p.N >> 2;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            const bool ok = cok && row < Mg;
+            const int rowc = row < Mg ? row : Mg - 1;
+            const float pre = acc[i][j][r] + resp[(size_t)rowc * p.ldres + colc];
+            // i, f, o: logistic; g: tanh
+            const float a = gate == 2 ? tanhf(pre) : 1.0f / (1.0f + __expf(-pre));
+            const int q = lane & ~3;
+            const float gi = __shfl(a, q, 64), gf = __shfl(a, q + 1, 64), gg = __shfl(a, q + 2, 64), go = __shfl(a, q + 3, 64);
+            if (ok) {
+              lg_gates[(size_t)row * p.N + col] = a;
+              if (gate == 0) {
+                const float c = gf * lg_cprev[(size_t)row * Hn + unit] + gi * gg;
+                const float hv = go * tanhf(c);
+                lg_cout[(size_t)row * Hn + unit] = c;
+                Cp[(size_t)row * p.ldc + unit] = hv;
+                lg_h2[(size_t)row * lg_ldh2 + unit] = hv;
+              }
+            }
+          }
+          continue;
+        }
+        if (EPI == 2) {   // LSTM backward step: column = unit
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            if (!(cok && row < Mg)) continue;
+            const size_t o = (size_t)row * p.N + col;
+            const float dh = acc[i][j][r] + resp[(size_t)row * p.ldres + col];
+            const float4 g4 = *reinterpret_cast<const float4*>(lg_act + 4 * o);   // i, f, g, o (activated)
+            const float c = lg_c[o], cp = lg_cprev[o];
+            const float tc = tanhf(c);
+            const float dc = lg_dc[o] + dh * g4.w * (1.0f - tc * tc);
+            float4 d;
+            d.x = dc * g4.z * g4.x * (1.0f - g4.x);        // d pre_i
+            d.y = dc * cp * g4.y * (1.0f - g4.y);          // d pre_f
+            d.z = dc * g4.x * (1.0f - g4.z * g4.z);        // d pre_g
+            d.w = dh * tc * g4.w * (1.0f - g4.w);          // d pre_o
+            *reinterpret_cast<float4*>(lg_gates + 4 * o) = d;
+            lg_dc[o] = dc * g4.y;
+          }
+          continue;
+        }
         if (atomic_out) {
           // "C +=" piece: plain adds.  (Kept free of anything that waits on memory: a bias load here made the
           // compiler drain vmcnt -- i.e. all earlier atomics -- first.)  Bias / residual ride on the piece that
@@ -664,12 +732,12 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
   }
 }
 
-template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS>
+template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0>
 __global__ void __launch_bounds__(256, NS == 3 ? (BM == 128 ? 1 : 3) : (BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64)) gemm_kernel(const GemmK p) {
   __shared__ __attribute__((aligned(16))) float As[2 * GemmShape<BM, BN, NS>::A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[2 * GemmShape<BM, BN, NS>::B_SZ];
   __shared__ int s_old;
-  gemm_body<BM, BN, AKC, BKC, FAST, NS>(p, blockIdx.x, gridDim.x, 0, As, Bs, s_old);
+  gemm_body<BM, BN, AKC, BKC, FAST, NS, EPI>(p, blockIdx.x, gridDim.x, 0, As, Bs, s_old);
 }
 
 // Two independent problems in ONE launch: the data gradient (NN) and the weight gradient (TN) of a linear layer.
@@ -1058,4 +1126,87 @@ int gemm_pair_aux(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, co
 
 extern "C" int mmnas_gemm_pair(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, void* stream) {
   return gemm_pair_aux(dgrad, wgrad, nullptr, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// LSTM (single layer, zero initial state) on the step-fused GEMM epilogues above.  Replaces the MIOpen path of
+// nn.LSTM (hygr_vqa.py:106-107 `self.lstm(lang_feat)`), which issues a GEMM + a pointwise kernel per time step and
+// direction plus weight-buffer copies: ~110 launches per training step for 14 steps of a 64-row problem.
+// Layouts: time-major buffers; gate columns interleaved (column 4j+g = gate g of unit j, g in i,f,g,o) -- the host
+// side permutes nn.LSTM's [i|f|g|o] row blocks accordingly.
+// ------------------------------------------------------------------------------------------
+namespace mmnas {
+// units_per_wg: 0 = whole tiles, one per workgroup; > 0 = stream-K runs of that many K-tiles
+static int lstm_step_plan(GemmPlan& pl, const mmnas_gemm_desc& d, hipStream_t st, const char* who, int units_per_wg) {
+  int rc = plan_gemm(&d, st, pl);
+  if (rc) return rc;
+  MMNAS_REQUIRE(pl.fast && !pl.big, MMNAS_E_SHAPE, "%s: shape outside the step kernel's range (hidden size %% 32 == 0, aligned buffers)", who);
+  GemmK& k = pl.k;
+  k.n_full = k.full_per = k.sk_per = 0;
+  if (units_per_wg <= 0 || units_per_wg >= k.T) {
+    k.mode = MODE_TILE; k.P = k.T; pl.nwg = k.ntiles;
+  } else {
+    SkWorkspace w;
+    if ((rc = get_workspace(st, &w))) return rc;
+    k.ws = w.ws; k.cnt = w.cnt;
+    k.mode = MODE_STREAM; k.P = units_per_wg; k.U = k.ntiles * k.T;
+    pl.nwg = (k.U + k.P - 1) / k.P;
+  }
+  return MMNAS_OK;
+}
+}  // namespace mmnas
+
+extern "C" int mmnas_lstm_supported(int E, int H) { return E > 0 && H >= 32 && H % 32 == 0 && H <= 4096; }
+
+extern "C" int mmnas_lstm_fwd(const float* x_tm, const float* Wih, const float* Whh, const float* bias, float* xp, float* Hall,
+                              float* Call, float* Gall, float* out, int T, int B, int E, int H, void* stream) {
+  MMNAS_REQUIRE(x_tm && Wih && Whh && bias && xp && Hall && Call && Gall && out, MMNAS_E_ARG, "lstm_fwd: null pointer");
+  MMNAS_REQUIRE(T > 0 && B > 0 && mmnas_lstm_supported(E, H), MMNAS_E_SHAPE, "lstm_fwd: T=%d B=%d E=%d H=%d", T, B, E, H);
+  hipStream_t st = (hipStream_t)stream;
+  mmnas_gemm_desc d;
+  // input projection of all time steps: xp[T*B, 4H] = x W_ih^T + (b_ih + b_hh)
+  memset(&d, 0, sizeof(d));
+  d.layout = MMNAS_GEMM_NT; d.ngroups = 1; d.nseg = 1; d.N = 4 * H; d.K = E; d.lda = E; d.ldb = E; d.ldc = 4 * H;
+  d.alpha = 1.f; d.gate_scale = 1.f; d.split_k = 1;
+  d.g[0].M = T * B; d.g[0].A[0] = x_tm; d.g[0].B[0] = Wih; d.g[0].C = xp; d.g[0].bias = bias;
+  int rc = mmnas_gemm(&d, stream);
+  if (rc) return rc;
+  const size_t bh = (size_t)B * H, bg = (size_t)B * 4 * H;
+  for (int t = 0; t < T; ++t) {
+    memset(&d, 0, sizeof(d));
+    d.layout = MMNAS_GEMM_NT; d.ngroups = 1; d.nseg = 1; d.N = 4 * H; d.K = H; d.lda = H; d.ldb = H; d.ldc = H;
+    d.ldres = 4 * H; d.alpha = 1.f; d.gate_scale = 1.f; d.split_k = 1;
+    d.g[0].M = B; d.g[0].A[0] = Hall + t * bh; d.g[0].B[0] = Whh; d.g[0].C = Hall + (t + 1) * bh; d.g[0].residual = xp + t * bg;
+    GemmPlan pl;
+    if ((rc = lstm_step_plan(pl, d, st, "lstm_fwd", env_int("MMNAS_LSTM_FWD_P", 0)))) return rc;
+    pl.k.lg_cprev = Call + t * bh; pl.k.lg_cout = Call + (t + 1) * bh; pl.k.lg_gates = Gall + t * bg;
+    pl.k.lg_h2 = out + (size_t)t * H; pl.k.lg_ldh2 = T * H;
+    ProfScope ps(MMNAS_K_GEMM, pl.flops, pl.bytes, st, pl.tag);
+    MMNAS_LAUNCH((gemm_kernel<64, 64, true, true, true, 0, 1>), dim3(pl.nwg), dim3(256), 0, st, pl.k);
+  }
+  return check_launch("lstm_fwd");
+}
+
+extern "C" int mmnas_lstm_bwd(const float* dout, const float* Whh, const float* Call, const float* Gall, float* DG, float* dc,
+                              float* scratch, int T, int B, int H, void* stream) {
+  MMNAS_REQUIRE(dout && Whh && Call && Gall && DG && dc && scratch, MMNAS_E_ARG, "lstm_bwd: null pointer");
+  MMNAS_REQUIRE(T > 0 && B > 0 && mmnas_lstm_supported(1, H), MMNAS_E_SHAPE, "lstm_bwd: T=%d B=%d H=%d", T, B, H);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t bh = (size_t)B * H, bg = (size_t)B * 4 * H;
+  for (int t = T - 1; t >= 0; --t) {
+    mmnas_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    // dh_t = dout[:, t] + dG_{t+1} W_hh     [B, 4H] x [4H, H]
+    d.layout = MMNAS_GEMM_NN; d.ngroups = 1; d.nseg = 1; d.N = H; d.K = 4 * H; d.lda = 4 * H; d.ldb = H; d.ldc = H;
+    d.ldres = T * H; d.alpha = 1.f; d.gate_scale = 1.f; d.split_k = 1;
+    d.g[0].M = B; d.g[0].A[0] = DG + (t + 1) * bg; d.g[0].B[0] = Whh; d.g[0].C = scratch; d.g[0].residual = dout + (size_t)t * H;
+    GemmPlan pl;
+    int rc;
+    if ((rc = lstm_step_plan(pl, d, st, "lstm_bwd", env_int("MMNAS_LSTM_BWD_P", 8)))) return rc;
+    pl.k.lg_act = Gall + t * bg; pl.k.lg_c = Call + (t + 1) * bh; pl.k.lg_cprev = Call + t * bh;
+    pl.k.lg_dc = dc; pl.k.lg_gates = DG + t * bg;
+    ProfScope ps(MMNAS_K_GEMM, pl.flops, pl.bytes, st, pl.tag);
+    MMNAS_LAUNCH((gemm_kernel<64, 64, true, false, true, 0, 2>), dim3(pl.nwg), dim3(256), 0, st, pl.k);
+  }
+  return check_launch("lstm_bwd");
 }

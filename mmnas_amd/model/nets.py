@@ -140,7 +140,9 @@ class _Net(nn.Module):
         C = self._cfg
         x_mask = make_mask(ques_ix.unsqueeze(2))
         y_mask = make_mask(frcn_feat)
-        x_in, _ = self.lstm(self.embedding(ques_ix))
+        emb = self.embedding(ques_ix)
+        # (MIOpen's LSTM; the step-fused HIP one is an opt-in experiment, see ops.lstm_enabled)
+        x_in = ops.lstm(emb, self.lstm) if (ops.lstm_enabled() and ops.lstm_supported(emb, self.lstm)) else self.lstm(emb)[0]
         if C.BBOX_FEATURE:
             bb = ops.linear(bbox_feat, self.bboxfeat_linear.weight, self.bboxfeat_linear.bias)
             frcn_feat = torch.cat((frcn_feat, bb), dim=-1)

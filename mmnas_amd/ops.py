@@ -357,6 +357,96 @@ class LinearFn(torch.autograd.Function):
         return dx, rets[0], rets[1], None
 
 
+_lstm_idx = {}
+
+
+def _lstm_index(H, dev):
+    """(perm, inv): interleaved row 4j+g <- nn.LSTM row g*H+j, and back."""
+    key = (H, str(dev))
+    if key not in _lstm_idx:
+        n = torch.arange(4 * H, device=dev)
+        perm = (n % 4) * H + n // 4
+        inv = torch.empty_like(perm)
+        inv[perm] = n
+        _lstm_idx[key] = (perm, inv)
+    return _lstm_idx[key]
+
+
+class LstmFn(torch.autograd.Function):
+    """nn.LSTM(num_layers=1, batch_first=True), zero initial state, full output sequence (hygr_vqa.py:106-107) on
+    mmnas_lstm_fwd/bwd: one launch per time step and direction, the weight / input gradients as three large products."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        lib = L.lib()
+        x = _f32c(x)
+        B, T, E = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        perm, inv = _lstm_index(H, dev)
+        Wih, Whh = w_ih.index_select(0, perm), w_hh.index_select(0, perm)
+        bias = (b_ih + b_hh).index_select(0, perm)
+        x_tm = x.transpose(0, 1).contiguous()
+        hc = torch.empty(2, T + 1, B, H, dtype=torch.float32, device=dev)
+        hc[:, 0].zero_()
+        Gall = torch.empty(T, B, 4 * H, dtype=torch.float32, device=dev)
+        xp = torch.empty(T, B, 4 * H, dtype=torch.float32, device=dev)
+        out = torch.empty(B, T, H, dtype=torch.float32, device=dev)
+        L.check(lib.mmnas_lstm_fwd(L.fptr(x_tm), L.fptr(Wih), L.fptr(Whh), L.fptr(bias), L.fptr(xp), L.fptr(hc[0]),
+                                   L.fptr(hc[1]), L.fptr(Gall), L.fptr(out), T, B, E, H, L.stream()))
+        ctx.save_for_backward(x_tm, Wih, Whh, hc, Gall)
+        ctx.dims = (B, T, E, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.lib()
+        x_tm, Wih, Whh, hc, Gall = ctx.saved_tensors
+        B, T, E, H = ctx.dims
+        dev = dout.device
+        dout = _f32c(dout)
+        perm, inv = _lstm_index(H, dev)
+        DG = torch.empty(T + 1, B, 4 * H, dtype=torch.float32, device=dev)
+        DG[T].zero_()
+        small = torch.zeros(2, B, H, dtype=torch.float32, device=dev)   # running dc, scratch
+        L.check(lib.mmnas_lstm_bwd(L.fptr(dout), L.fptr(Whh), L.fptr(hc[1]), L.fptr(Gall), L.fptr(DG), L.fptr(small[0]),
+                                   L.fptr(small[1]), T, B, H, L.stream()))
+        dg = DG[:T].view(T * B, 4 * H)
+        # parameter gradients in the interleaved row order: [dW_hh | dW_ih | db] in one zeroed buffer
+        flat = torch.zeros(4 * H * (H + E + 1), dtype=torch.float32, device=dev)
+        dWhh = flat[:4 * H * H].view(4 * H, H)
+        dWih = flat[4 * H * H:4 * H * (H + E)].view(4 * H, E)
+        db = flat[4 * H * (H + E):]
+        gemm(L.GEMM_TN, [dict(M=4 * H, A=[dg], B=[hc[0, :T].view(T * B, H)], C=dWhh)], H, T * B, 4 * H, H, H, accumulate=True)
+        gemm(L.GEMM_TN, [dict(M=4 * H, A=[dg], B=[x_tm.view(T * B, E)], C=dWih)], E, T * B, 4 * H, E, E, accumulate=True)
+        L.check(lib.mmnas_colsum(L.fptr(dg), L.fptr(db), T * B, 4 * H, 4 * H, L.stream()))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx_tm = torch.empty(T * B, E, dtype=torch.float32, device=dev)
+            gemm(L.GEMM_NN, [dict(M=T * B, A=[dg], B=[Wih], C=dx_tm)], E, 4 * H, 4 * H, E, E)
+            dx = dx_tm.view(T, B, E).transpose(0, 1)
+        dbo = db.index_select(0, inv)
+        return dx, dWih.index_select(0, inv), dWhh.index_select(0, inv), dbo, dbo
+
+
+def lstm(x, mod):
+    """mod: nn.LSTM(num_layers=1, batch_first=True, unidirectional); returns the output sequence [B, T, H]."""
+    return LstmFn.apply(x, mod.weight_ih_l0, mod.weight_hh_l0, mod.bias_ih_l0, mod.bias_hh_l0)
+
+
+def lstm_enabled():
+    """The step-fused LSTM is opt-in (MMNAS_LSTM=1): measured this round it issues ~50 launches instead of MIOpen's
+    ~110 but its per-step kernels (the general GEMM at M = 64: ~20 us of launch-to-launch latency each) make the
+    training step 1.5 % and the supernet step 4 % SLOWER than MIOpen's GEMM + pointwise pairs."""
+    import os
+    return os.environ.get('MMNAS_LSTM', '0') == '1'
+
+
+def lstm_supported(x, mod):
+    return (x.is_cuda and x.dtype == torch.float32 and mod.num_layers == 1 and not mod.bidirectional and mod.batch_first
+            and mod.bias and mod.proj_size == 0 and bool(L.lib().mmnas_lstm_supported(mod.input_size, mod.hidden_size)))
+
+
 def linear(x, W, b=None, relu=False):
     return LinearFn.apply(x, W, b, relu)
 

@@ -736,3 +736,28 @@ def test_pack_adam_sumsq():
         assert torch.equal(flat[o:o + nseg], before[o:o + nseg] * 3.0)
         assert torch.equal(flat[o + nseg:o + nseg + 64], before[o + nseg:o + nseg + 64])     # gaps untouched
         o += nseg + 64
+
+
+@pytest.mark.parametrize('B,T,E,H', [(64, 14, 300, 512), (3, 5, 20, 64), (70, 3, 300, 256), (64, 15, 300, 96)])
+def test_lstm_vs_torch_fp64(B, T, E, H):
+    """Step-fused LSTM (mmnas_lstm_fwd/bwd; opt-in in the nets, MMNAS_LSTM=1) against torch.nn.LSTM evaluated in float64
+    on the CPU: output sequence and every gradient (input, both weight matrices, both biases)."""
+    from mmnas_amd import ops
+    torch.manual_seed(B + T + H)
+    ref = torch.nn.LSTM(input_size=E, hidden_size=H, num_layers=1, batch_first=True).double()
+    x = torch.randn(B, T, E, dtype=torch.float64, requires_grad=True)
+    go = torch.randn(B, T, H, dtype=torch.float64)
+    y = ref(x)[0]
+    y.backward(go)
+    mod = torch.nn.LSTM(input_size=E, hidden_size=H, num_layers=1, batch_first=True)
+    mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    mod = mod.to(DEV)
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    assert ops.lstm_supported(xd, mod)
+    yd = ops.lstm(xd, mod)
+    yd.backward(go.float().to(DEV))
+    assert rel_err(yd.detach().cpu().numpy(), y.detach().numpy()) < 2e-5
+    assert rel_err(xd.grad.cpu().numpy(), x.grad.numpy()) < 1e-4
+    for k, p in mod.named_parameters():
+        want = dict(ref.named_parameters())[k].grad.numpy()
+        assert rel_err(p.grad.cpu().numpy(), want) < 1e-4, k
