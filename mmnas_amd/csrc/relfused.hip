@@ -93,7 +93,7 @@ constexpr int RF_LDH = RF_R + 4;   // LDS row stride of the hid / dhid image (16
 // weights through ~1300 scalar loads per element: 285 us per launch, latency-bound.
 template <int C, int NG>   // NG = groups of 8 heads (H <= 8 * NG)
 __global__ void __launch_bounds__(256, NG == 1 ? 2 : 1)
-rel_fused_bwd_kernel(const RelFusedK p, long ntiles, int tiles_per_b, const float* __restrict__ Wy,
+rel_fused_bwd_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const float* __restrict__ Wy,
                      const float* __restrict__ by, const float* __restrict__ Wr, const float* __restrict__ br) {
   constexpr int DP = 8 * NG;
   __shared__ __attribute__((aligned(16))) float sHidAll[4][32 * RF_LDH];
@@ -148,38 +148,47 @@ rel_fused_bwd_kernel(const RelFusedK p, long ntiles, int tiles_per_b, const floa
 #pragma unroll
     for (int r = 0; r < 4; ++r) accbr[g][r] = 0.f;
 
-  const long SS = (long)p.Sq * p.Sk;
-  const long nwaves = (long)gridDim.x * 4;
+  // 32-bit index arithmetic throughout (host: B * tiles_per_b < 2^31, Sq * Sk < 2^31): the 64-bit divisions this
+  // used to do per tile and lane are emulated in hundreds of VALU cycles each.  (batch, tile-in-batch) advance
+  // incrementally by the grid stride.
+  const unsigned SS = (unsigned)p.Sq * (unsigned)p.Sk;
+  const int nwaves = (int)gridDim.x * 4;
+  const int adv_b = nwaves / tiles_per_b, adv_t = nwaves - adv_b * tiles_per_b;
   // loads of one tile: the lane's raw row (gathered, 16 B) and its heads' dbias; issued one tile ahead
   float ext[RF_CP], db[NG][4];
-  auto tile_load = [&](long tile, float* ex, float (*dbv)[4]) {
+  auto tile_load = [&](int b, int tb, float* ex, float (*dbv)[4]) {
     // element of this lane: b, flattened f = k * Sq + q (dbiasT is contiguous in f)
-    const int b = (int)(tile / tiles_per_b);
-    const long f = (tile - (long)b * tiles_per_b) * 32 + l31;
-    const bool ok = tile < ntiles && f < SS;
-    const long fc = ok ? f : 0;
+    const unsigned f = (unsigned)tb * 32u + (unsigned)l31;
+    const bool ok = b < p.B && f < SS;
+    const unsigned fc = ok ? f : 0u;
     const int bc = ok ? b : 0;
-    const int k = (int)(fc / p.Sq), q = (int)(fc - (long)k * p.Sq);
+    const unsigned k = fc / (unsigned)p.Sq, q = fc - k * (unsigned)p.Sq;
     const float* src = p.raw + (((size_t)bc * p.Sq + q) * p.Sk + k) * C;
 #pragma unroll
     for (int c = 0; c < RF_CP; ++c) ex[c] = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) ex[c] = ok ? src[c] : 0.f;   // (address clamped above: the load itself is unconditional)
     ex[C] = ok ? 1.f : 0.f;
+    const float* dbp = p.dbiasT + (size_t)bc * H * SS + fc;
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int h = 8 * g + r + 4 * hh;
-        const float v = p.dbiasT[((size_t)bc * H + (h < H ? h : 0)) * SS + fc];
+        const float v = dbp[(size_t)(h < H ? h : 0) * SS];
         dbv[g][r] = (ok && h < H) ? v : 0.f;
       }
   };
-  long tile = (long)blockIdx.x * 4 + w;
-  tile_load(tile, ext, db);
+  int tile = (int)blockIdx.x * 4 + w;
+  int cb = tile / tiles_per_b, ct = tile - cb * tiles_per_b;           // this tile
+  int nb_ = cb + adv_b, nt_ = ct + adv_t;                              // the next one of this wave
+  if (nt_ >= tiles_per_b) { nt_ -= tiles_per_b; ++nb_; }
+  tile_load(cb, ct, ext, db);
   for (; tile < ntiles; tile += nwaves) {
     float ext_n[RF_CP], db_n[NG][4];
-    tile_load(tile + nwaves, ext_n, db_n);   // in flight during this tile's MFMA chain
+    tile_load(nb_, nt_, ext_n, db_n);   // in flight during this tile's MFMA chain
+    nb_ += adv_b; nt_ += adv_t;
+    if (nt_ >= tiles_per_b) { nt_ -= tiles_per_b; ++nb_; }
     // 1. hidden layer (transposed: rows j, columns e)
     f32x16 hid[2];
 #pragma unroll
@@ -436,7 +445,8 @@ extern "C" int mmnas_rel_fused_bwd(const float* raw, const float* Wy, const floa
   k.raw = raw; k.Wy = Wy; k.by = by; k.Wr = Wr; k.br = br; k.biasT = nullptr; k.dbiasT = dbiasT; k.part = ws;
   k.B = B; k.Sq = Sq; k.Sk = Sk; k.C = C; k.H = H; k.nbq = cdiv(Sq, 64); k.nbk = cdiv(Sk, 4);
   const int tpb = (int)rf_tiles_per_b(Sq, Sk);
-  const long ntiles = (long)B * tpb;
+  MMNAS_REQUIRE((long)B * tpb < (1l << 30) && (long)Sq * Sk < (1l << 30), MMNAS_E_SHAPE, "rel_fused_bwd: problem too large for 32-bit tile indices");
+  const int ntiles = B * tpb;
   const int grid = rf_grid(ntiles);
   hipStream_t st = (hipStream_t)stream;
   const double n = (double)B * Sq * Sk;
