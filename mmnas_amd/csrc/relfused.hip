@@ -137,11 +137,21 @@ rel_fused_bwd_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const float
       for (int t = 0; t < 2; ++t) wrT[t][g][r] = h < H ? Wr[h * RF_R + 32 * t + l31] : 0.f;
     }
 
-  f32x16 accWr[2], accWy[2];
+  // Parameter-gradient accumulators.  H <= 8 (NG == 1, every shipped configuration): the two contractions of
+  // step 5 run on v_mfma_f32_16x16x4_f32 -- their operands come from LDS, so the layout is free, and 16-wide tiles
+  // halve the zero padding (8 heads / 5 raw channels) of the 32x32x2 form: 64 instead of 128 MFMA-cycles per element.
+  constexpr bool T16 = NG == 1;
+  f32x16 accWr[T16 ? 1 : 2], accWy[T16 ? 1 : 2];   // (32x32x2 form; one dummy entry when unused)
+  f32x4 accWr16[4], accWy16[4];                     // dWr[h = 4*q4 + r][j = 16 n + l15], dWy_ext[j = 16 m + 4*q4 + r][c = l15]
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < (T16 ? 1 : 2); ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accWr[t][r] = 0.f; accWy[t][r] = 0.f; }
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { accWr16[n][r] = 0.f; accWy16[n][r] = 0.f; }
+  const int l15 = lane & 15, q4 = lane >> 4;
   float accbr[NG][4];
 #pragma unroll
   for (int g = 0; g < NG; ++g)
@@ -249,6 +259,26 @@ rel_fused_bwd_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const float
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // 5a. dWr[h, j] += sum_e dpre[h, e] hid[j, e]
+    if constexpr (T16) {
+      const int hcl = l15 < DP ? l15 : 0;
+#pragma unroll
+      for (int s0 = 0; s0 < 8; s0 += 2) {
+        float av[2], bv[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int e = 4 * (s0 + u) + q4;
+          av[u] = sDpre[e * DP + hcl];
+#pragma unroll
+          for (int n = 0; n < 4; ++n) bv[u][n] = sHid[e * RF_LDH + 16 * n + l15];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const float a = l15 < DP ? av[u] : 0.f;
+#pragma unroll
+          for (int n = 0; n < 4; ++n) accWr16[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[u][n], accWr16[n], 0, 0, 0);
+        }
+      }
+    } else {
     const int hcl = l31 < DP ? l31 : 0;
 #pragma unroll
     for (int s0 = 0; s0 < 16; s0 += 4) {
@@ -264,8 +294,9 @@ rel_fused_bwd_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const float
       for (int u = 0; u < 4; ++u) {
         const float a = l31 < DP ? av[u] : 0.f;
         accWr[0] = mfma32(a, b0[u], accWr[0]);
-        accWr[1] = mfma32(a, b1[u], accWr[1]);
+        accWr[T16 ? 0 : 1] = mfma32(a, b1[u], accWr[T16 ? 0 : 1]);
       }
+    }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -276,6 +307,26 @@ rel_fused_bwd_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const float
             make_float4(dh[t][4 * u], dh[t][4 * u + 1], dh[t][4 * u + 2], dh[t][4 * u + 3]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // 5b. dWy_ext[j, c] += sum_e dhid[j, e] raw_ext[e, c]   (column C of raw_ext is 1: dby)
+    if constexpr (T16) {
+      const int ccl = l15 < RF_CP ? l15 : 0;
+#pragma unroll
+      for (int s0 = 0; s0 < 8; s0 += 2) {
+        float av[2][4], bv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int e = 4 * (s0 + u) + q4;
+          bv[u] = sRaw[e * RF_CP + ccl];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) av[u][m] = sHid[e * RF_LDH + 16 * m + l15];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const float bb = l15 < RF_CP ? bv[u] : 0.f;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) accWy16[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][m], bb, accWy16[m], 0, 0, 0);
+        }
+      }
+    } else {
     const int ccl = l31 < RF_CP ? l31 : 0;
 #pragma unroll
     for (int s0 = 0; s0 < 16; s0 += 4) {
@@ -291,8 +342,9 @@ rel_fused_bwd_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const float
       for (int u = 0; u < 4; ++u) {
         const float bb = l31 < RF_CP ? bv[u] : 0.f;
         accWy[0] = mfma32(a0[u], bb, accWy[0]);
-        accWy[1] = mfma32(a1[u], bb, accWy[1]);
+        accWy[T16 ? 0 : 1] = mfma32(a1[u], bb, accWy[T16 ? 0 : 1]);
       }
+    }
     }
 #pragma unroll
     for (int c = 0; c < RF_CP; ++c) ext[c] = ext_n[c];
@@ -321,20 +373,36 @@ rel_fused_bwd_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const float
   for (int turn = 0; turn < 4; ++turn) {
     if (w == turn) {
       const bool first = turn == 0, last = turn == 3;
+      if constexpr (T16) {   // (rows h >= 16 of the partial row stay unwritten: the reduction only uses h < H <= 8)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o1 = (4 * q4 + r) * RF_R + 16 * n + l15;                  // dWr[h][j]
+            const float v1 = accWr16[n][r] + (first ? 0.f : srow[o1]);
+            if (last) grow[o1] = v1; else srow[o1] = v1;
+            if (l15 < RF_CP) {
+              const int o2 = RF_HP * RF_R + (16 * n + 4 * q4 + r) * RF_CP + l15;  // dWy_ext[j][c]
+              const float v2 = accWy16[n][r] + (first ? 0.f : srow[o2]);
+              if (last) grow[o2] = v2; else srow[o2] = v2;
+            }
+          }
+      } else {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int i = acc_row(r, hh);
           const int o1 = i * RF_R + 32 * t + l31;                               // dWr[h = i][j]
-          const float v1 = accWr[t][r] + (first ? 0.f : srow[o1]);
+          const float v1 = accWr[T16 ? 0 : t][r] + (first ? 0.f : srow[o1]);
           if (last) grow[o1] = v1; else srow[o1] = v1;
           if (l31 < RF_CP) {
             const int o2 = RF_HP * RF_R + (32 * t + i) * RF_CP + l31;           // dWy_ext[j][c]
-            const float v2 = accWy[t][r] + (first ? 0.f : srow[o2]);
+            const float v2 = accWy[T16 ? 0 : t][r] + (first ? 0.f : srow[o2]);
             if (last) grow[o2] = v2; else srow[o2] = v2;
           }
         }
+      }
       // dbr: lane (l31 == 0, half) carries heads 8g + 4*half + r; the other slots of the 32-head block are zero
       if (hh == 0) {
         const int o3 = RF_HP * RF_R + RF_R * RF_CP + l31;
