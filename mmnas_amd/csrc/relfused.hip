@@ -429,6 +429,9 @@ rel_fused_bwd_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const float
 __global__ void __launch_bounds__(256) rel_fused_reduce_kernel(const float* __restrict__ part, int nrows, int C, int H,
                                                                float* dWr, float* dbr, float* dWy, float* dby) {
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  // a block of 64 columns inside the dWr region is one head's row: heads >= H are padding (and, in the 16-wide form
+  // of the backward kernel, not even written) -- 75 % of the partial rows for 8 heads
+  if (blockIdx.x < RF_HP && (int)blockIdx.x >= H) return;
   float s = 0.f;
   if (col < RF_ROW) {
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
