@@ -7,7 +7,7 @@ dropout enabled is therefore checked by *mask replay*: the kernels derive every 
 decision from (seed, site, element index) with the hash below, this file derives the
 same mask on the CPU, and the oracle applies it as an explicit multiplier.
 
-    h    = fmix32(fmix32(idx * 0x9E3779B1 + seed_lo) ^ (site * 0x85EBCA77 + seed_hi))
+    h    = fmix32((idx * 0x9E3779B1 + seed_lo) ^ (site * 0x85EBCA77 + seed_hi))
     keep = (h >> 8) >= floor(p * 2^24)
     drop(x) = keep ? x / (1 - p) : 0          (inverted dropout, modules.py semantics)
 
@@ -40,7 +40,6 @@ def keep_mask(seed, site, n, p):
     hi = np.uint64((seed >> 32) & 0xFFFFFFFF)
     idx = np.arange(n, dtype=np.uint64)
     a = (idx * np.uint64(0x9E3779B1) + lo) & _M32
-    a = _fmix32(a)
     b = (np.uint64(int(site) & 0xFFFFFFFF) * np.uint64(0x85EBCA77) + hi) & _M32
     h = _fmix32(a ^ b)
     return (h >> np.uint64(8)) >= np.uint64(dropout_threshold(p))
