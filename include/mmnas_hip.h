@@ -202,6 +202,11 @@ int mmnas_relation_embedding(const float* bbox, const int* nobj, float* out, int
  * sampling (mixed.py:131-158) without a host->device copy / stream synchronisation. */
 int mmnas_onehot_rows(float* out, int rows, int width, const int* idx_host, void* stream);
 
+/* nn.Embedding backward (hygr_vqa.py:85,105; aten embedding_dense_backward): dW[idx[t], :] += dy[t, :] for the n_tok
+ * int64 token indices -- straight into the (already zeroed or accumulating) gradient buffer instead of a dense
+ * [V, E] temporary.  Indices outside [0, V) are ignored. */
+int mmnas_embedding_bwd(const long* idx, const float* dy, float* dW, long n_tok, int E, long V, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Relation bias of RelMHAtt (modules.py:231-235):
  *   biasT[b,h,k,q] = log(max(relu(rel[b,q,k,:] . Wr[h,:] + br[h]), 1e-6))

@@ -230,3 +230,27 @@ extern "C" int mmnas_onehot_rows(float* out, int rows, int width, const int* idx
   MMNAS_LAUNCH(onehot_rows_kernel, dim3(cdiv((long)rows * width, 256)), dim3(256), 0, (hipStream_t)stream, out, rows, width, a);
   return check_launch("onehot_rows");
 }
+
+// ------------------------------------------------------------------------------------------
+// Embedding backward (nn.Embedding of the language stem, hygr_vqa.py:85,105): dW[idx[t], :] += dy[t, :].
+// ATen builds a dense [V, E] gradient (24 MB at V = 20000: zero-fill + scatter kernel, 61 us) that autograd then adds
+// onto the parameter's gradient (another 48 MB pass); the rows of the ~900 tokens of a batch are all that changes, so
+// they are added straight into the gradient buffer.
+// ------------------------------------------------------------------------------------------
+namespace mmnas {
+__global__ void __launch_bounds__(256) embedding_bwd_kernel(const long* __restrict__ idx, const float* __restrict__ dy,
+                                                            float* __restrict__ dW, long n_tok, int E, long V) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_tok * E) return;
+  const long t = i / E;
+  const int c = (int)(i - t * E);
+  const long row = idx[t];
+  if (row >= 0 && row < V) atomicAdd(dW + row * E + c, dy[i]);
+}
+}  // namespace mmnas
+
+extern "C" int mmnas_embedding_bwd(const long* idx, const float* dy, float* dW, long n_tok, int E, long V, void* stream) {
+  MMNAS_REQUIRE(idx && dy && dW && n_tok > 0 && E > 0 && V > 0, MMNAS_E_ARG, "embedding_bwd: bad arguments");
+  MMNAS_LAUNCH(embedding_bwd_kernel, dim3((unsigned)cdiv(n_tok * E, 256)), dim3(256), 0, (hipStream_t)stream, idx, dy, dW, n_tok, E, V);
+  return check_launch("embedding_bwd");
+}

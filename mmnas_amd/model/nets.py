@@ -140,7 +140,7 @@ class _Net(nn.Module):
         C = self._cfg
         x_mask = make_mask(ques_ix.unsqueeze(2))
         y_mask = make_mask(frcn_feat)
-        emb = self.embedding(ques_ix)
+        emb = ops.embedding(ques_ix, self.embedding)
         # (MIOpen's LSTM; the step-fused HIP one is an opt-in experiment, see ops.lstm_enabled)
         x_in = ops.lstm(emb, self.lstm) if (ops.lstm_enabled() and ops.lstm_supported(emb, self.lstm)) else self.lstm(emb)[0]
         if C.BBOX_FEATURE:

@@ -357,6 +357,36 @@ class LinearFn(torch.autograd.Function):
         return dx, rets[0], rets[1], None
 
 
+class EmbeddingFn(torch.autograd.Function):
+    """nn.Embedding lookup whose backward adds the touched rows straight into the weight's gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, idx, weight):
+        ctx.weight = weight
+        ctx.save_for_backward(idx)
+        return torch.nn.functional.embedding(idx, weight)
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx, = ctx.saved_tensors
+        w = ctx.weight
+        dy = _f32c(dy)
+        idx = idx.contiguous()
+        (dW,), rets, sinks = _grad_bufs([w], dy.device)
+        L.check(L.lib().mmnas_embedding_bwd(L.ptr(idx), L.fptr(dy), L.fptr(dW), idx.numel(), w.shape[1], w.shape[0], L.stream()))
+        for sk in sinks:
+            sk.done()
+        return None, rets[0]
+
+
+def embedding(idx, mod):
+    """mod: nn.Embedding without padding_idx / max_norm / sparse gradients (the nets' language stem)."""
+    if (idx.is_cuda and idx.dtype == torch.int64 and mod.weight.dtype == torch.float32 and mod.padding_idx is None
+            and mod.max_norm is None and not mod.sparse and not mod.scale_grad_by_freq):
+        return EmbeddingFn.apply(idx, mod.weight)
+    return mod(idx)
+
+
 _lstm_idx = {}
 
 

@@ -761,3 +761,30 @@ def test_lstm_vs_torch_fp64(B, T, E, H):
     for k, p in mod.named_parameters():
         want = dict(ref.named_parameters())[k].grad.numpy()
         assert rel_err(p.grad.cpu().numpy(), want) < 1e-4, k
+
+
+def test_embedding_backward_adds_rows_into_the_gradient():
+    """ops.embedding: forward = nn.Embedding; backward adds dy rows into the weight gradient (duplicates accumulate),
+    with and without a gradient sink (flat gradient buffer)."""
+    from mmnas_amd import ops, dp
+    torch.manual_seed(3)
+    V, E, B, S = 50, 300, 7, 14
+    ref = torch.nn.Embedding(V, E).double()
+    idx = torch.randint(0, V, (B, S))
+    idx[:, -3:] = 0                       # many duplicates of token 0 (the padding token of the loaders)
+    go = torch.randn(B, S, E, dtype=torch.float64)
+    ref(idx).backward(go)
+    for use_sink in (False, True):
+        mod = torch.nn.Embedding(V, E)
+        mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+        mod = mod.to(DEV)
+        if use_sink:
+            fg = dp.FlatGrads([mod.weight])
+            fg.attach()
+            fg.enable_sinks(None)
+        y = ops.embedding(idx.to(DEV), mod)
+        assert torch.equal(y.detach().cpu(), mod.weight.detach().cpu()[idx])
+        y.backward(go.float().to(DEV))
+        assert rel_err(mod.weight.grad.cpu().numpy(), ref.weight.grad.numpy()) < 1e-6
+        if use_sink:
+            assert mod.weight.grad.data_ptr() == fg.views[0].data_ptr()
