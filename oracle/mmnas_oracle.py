@@ -272,10 +272,10 @@ def att_flat(P, x, x_mask, glimpses, drops=None):
 
 
 def relation_embedding(bbox):
-    """Loader-side relation features (load_data_vqa.py:224-239 = load_data_vgd.py:7-33 = load_data_itm.py:5-31) for one
-    sample: bbox [n,4] -> [n,n,4].  PARITY UNPINNED for this function: the loader modules cannot be imported in the
-    build container (they import en_vectors_web_lg / spacy at module level), so this restatement follows the source
-    text only and no golden vector backs it."""
+    """Loader-side relation features (load_data_vqa.py:7-33 = load_data_vgd.py:7-33 = load_data_itm.py:5-31) for one
+    sample: bbox [n,4] -> [n,n,4].  Pinned by tests/golden/loader.npz (the reference function, compiled from the
+    loader's source by `ast` in the build container: the module itself imports en_vectors_web_lg and cannot be
+    imported)."""
     x_min, y_min, x_max, y_max = torch.chunk(bbox, 4, dim=1)
     cx, cy = (x_min + x_max) * 0.5, (y_min + y_max) * 0.5
     w, h = (x_max - x_min) + 1., (y_max - y_min) + 1.
@@ -284,6 +284,46 @@ def relation_embedding(bbox):
     dw = torch.log(w / w.view(1, -1))
     dh = torch.log(h / h.view(1, -1))
     return torch.stack((dx, dy, dw, dh), -1)
+
+
+def semantic_embedding(ques_ix, pretrained_emb, size):
+    """Token-relation features of one question (load_data_vqa.py:36-58): `size` = min(#words, max_token) leading
+    tokens of ques_ix -> [size,size,3] = (L2 distance of the GloVe rows, their dot product over
+    sqrt(|a|)*sqrt(|b|) + 1e-6 -- the reference takes the square root of the norms --, |i-j|/size)."""
+    g = torch.as_tensor(pretrained_emb)[torch.as_tensor(ques_ix[:size], dtype=torch.long)].float()
+    l2 = torch.norm(g.view(size, 1, -1) - g.view(1, size, -1), dim=-1)
+    mod = torch.sqrt(torch.norm(g, dim=-1))
+    cos = (g.view(size, 1, -1) * g.view(1, size, -1)).sum(-1) / (mod.view(size, 1) * mod.view(1, size) + 1e-6)
+    pos = torch.arange(size).float()
+    sub = torch.abs(pos.view(-1, 1) - pos.view(1, -1)) / size
+    return torch.stack((l2, cos, sub), -1)
+
+
+def tokenize(question, token_to_ix, max_token):
+    """proc_ques (load_data_vqa.py:278-296): lower-case, strip punctuation, '-' and '/' to spaces, UNK for unknown
+    words, zero padding.  Returns (ques_ix int64 [max_token], number of words)."""
+    words = re.sub(r"([.,'!?\"()*#:;])", '', question.lower()).replace('-', ' ').replace('/', ' ').split()
+    ix = np.zeros(max_token, np.int64)
+    for i, w in enumerate(words[:max_token]):
+        ix[i] = token_to_ix.get(w, token_to_ix['UNK'])
+    return ix, len(words)
+
+
+def pad_rows(feat, pad_size):
+    """proc_img_feat (load_data_vqa.py:252-263)."""
+    feat = np.asarray(feat)[:pad_size]
+    return np.pad(feat, ((0, pad_size - feat.shape[0]), (0, 0)), mode='constant', constant_values=0)
+
+
+def bbox_features(bbox, img_shape):
+    """proc_bbox_feat (load_data_vqa.py:266-275); img_shape = (h, w)."""
+    out = np.zeros((bbox.shape[0], 5), dtype=np.float32)
+    out[:, 0] = bbox[:, 0] / float(img_shape[1])
+    out[:, 1] = bbox[:, 1] / float(img_shape[0])
+    out[:, 2] = bbox[:, 2] / float(img_shape[1])
+    out[:, 3] = bbox[:, 3] / float(img_shape[0])
+    out[:, 4] = (bbox[:, 2] - bbox[:, 0]) * (bbox[:, 3] - bbox[:, 1]) / float(img_shape[0] * img_shape[1])
+    return out
 
 
 def make_mask(feature):
@@ -453,3 +493,66 @@ def default_cfg(**over):
              WORD_EMBED_SIZE=300, ALPHA_INIT_TYPE='normal', SCORES_LOSS='kld', GENOTYPE=None)
     c.update(over)
     return SimpleNamespace(**c)
+
+
+# ----------------------------------------------------------------------------
+# step harness: losses and the optimizer of the bilevel loop
+# ----------------------------------------------------------------------------
+
+def itm_bce_loss(scores_pos, scores_negc, scores_negi):
+    """BCE_Loss (mmnas/utils/itm_loss.py:12-24, REDUCTION='sum'): the positive term is counted twice."""
+    lp = F.binary_cross_entropy(scores_pos, torch.ones_like(scores_pos), reduction='sum')
+    lc = F.binary_cross_entropy(scores_negc, torch.zeros_like(scores_negc), reduction='sum')
+    li = F.binary_cross_entropy(scores_negi, torch.zeros_like(scores_negi), reduction='sum')
+    return lp + lc + lp + li
+
+
+def vgd_loss(pred_scores, pred_reg, scores, scores_mask, bbox, bbox_mask, lam=0.5):
+    """train_vgd.py:316-333 with SCORES_LOSS='kld', REDUCTION='sum', LOSS_AVG=True, LOSS_LAMBDA=0.5: KLDiv of the masked
+    log-scores against the masked soft labels / sum(mask) + lam * SmoothL1 of the masked boxes / sum(mask)."""
+    ls = F.kl_div(pred_scores * scores_mask, scores * scores_mask, reduction='sum') / scores_mask.sum()
+    lr = F.smooth_l1_loss(pred_reg * bbox_mask, bbox * bbox_mask, reduction='sum') / bbox_mask.sum()
+    return ls + lam * lr, ls, lr
+
+
+def warmup_rate(lr_base, step, epoch_steps, warmup=True):
+    """WarmupOptimizer.rate (mmnas/utils/optimizer.py:24-42)."""
+    if warmup:
+        for k in (1, 2, 3):
+            if step <= int(epoch_steps * k):
+                return lr_base * k / 4.
+    return lr_base
+
+
+def clip_grad_norm(grads, max_norm):
+    """nn.utils.clip_grad_norm_ (search_vqa.py:298): scales the list in place, returns the total norm."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return float(total)
+
+
+class Adam:
+    """torch.optim.Adam's arithmetic (no amsgrad, no weight decay) over a dict of tensors with ONE global step count:
+    what the reference loop amounts to, since its `0 * sum(p.sum())` terms (search_vqa.py:285-288) give every parameter
+    -- also those of candidates that were not sampled -- a (zero) gradient at every step."""
+
+    def __init__(self, params, betas, eps):
+        self.params, self.betas, self.eps = params, betas, eps
+        self.m = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.t = 0
+
+    @torch.no_grad()
+    def step(self, grads, lr):
+        self.t += 1
+        b1, b2 = self.betas
+        for k, p in self.params.items():
+            g = grads.get(k)
+            if g is None:
+                g = torch.zeros_like(p)
+            self.m[k].mul_(b1).add_(g, alpha=1 - b1)
+            self.v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (self.v[k].sqrt() / math.sqrt(1 - b2 ** self.t)).add_(self.eps)
+            p.addcdiv_(self.m[k], denom, value=-lr / (1 - b1 ** self.t))

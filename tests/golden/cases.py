@@ -252,3 +252,63 @@ def mixed_case(mode, kind, seed):
     g = rs.standard_normal((B, S, d)).astype(np.float32)
     return dict(cfg=cfg, P=P, act=act, inact=inact, s=s, pre=pre, sm=sm, pm=pm, rel=rel, g=g, kind=kind,
                 mode=mode)
+
+
+# ---- capture (v): optimizer trajectory of the bilevel loop (make_golden.gen_traj) ---------------------------------
+# search_vqa.py:135-161 values except the learning rate (25x: visible parameter motion in two fp32 steps) and
+# epoch_steps = 1, so the three warm-up rates of WarmupOptimizer (1/4, 2/4, 3/4) are all exercised
+TRAJ_HYPER = dict(net_lr=0.002, net_betas=(0.9, 0.98), net_eps=1e-9, clip=1.0, epoch_steps=1,
+                  alpha_lr=0.1, alpha_betas=(0.0, 0.999))
+TRAJ_FULL_KEYS = ('proj.bias', 'proj_norm.a_2', 'linear_y_rel.weight', 'imgfeat_linear.bias',
+                  'backnone.cells_enc.0.dag.0.0.candidate_ops.0.ln.a_2',
+                  'backnone.cells_enc.0.dag.0.0.candidate_ops.1.ln.a_2',
+                  'backnone.cells_dec.0.dag.3.0.candidate_ops.2.mhatt.linear_merge.weight')
+
+
+def traj_setup(seed=9100):
+    """Weights + batch of the weight steps, batch of the arch step, and the four injected samples."""
+    c = net_case('vqa', None, seed, search=True)
+    rs = np.random.RandomState(seed + 50000)
+    plans = [search_plan(rs, None), search_plan(rs, None), search_plan(rs, 'full'), search_plan(rs, None)]
+    c2 = net_case('vqa', None, seed + 1, search=True)   # only its inputs/target are used (the eval_loader batch)
+    return c, c2, plans
+
+
+# ---- loader functions (make_golden.gen_loader) ---------------------------------------------------------------------
+LOADER_VOCAB = ['PAD', 'UNK', 'what', 'is', 'the', 'man', 'holding', 'color', 'of', 'cat', 'how', 'many', 'dogs',
+                'are', 'there', 'in', 'this', 'picture', 'on', 'table', 'a', 'red', 'ball', 'left', 'right', 'side']
+LOADER_QUESTIONS = ('What is the man holding?', "What color is the cat's ball?", 'How many dogs are there?',
+                    'Is there a red ball on the left-side of the table in this picture, or on the right/left side of it?',
+                    'Why?')
+
+
+def loader_boxes(n, seed, w=640.0, h=480.0):
+    """n boxes (x1, y1, x2, y2) inside a w x h image, float32; includes a duplicated box and equal centres."""
+    rs = np.random.RandomState(seed)
+    x1 = rs.uniform(0, w * 0.8, n); y1 = rs.uniform(0, h * 0.8, n)
+    x2 = x1 + rs.uniform(1, w * 0.2, n); y2 = y1 + rs.uniform(1, h * 0.2, n)
+    b = np.stack([x1, y1, x2, y2], 1).astype(np.float32)
+    if n > 2:
+        b[2] = b[0]                 # identical boxes: delta clamps at 1e-3
+        b[1, 0::2] = b[0, 0::2]     # same centre x, different height
+    return b
+
+
+def loader_glove(V, seed):
+    e = np.random.RandomState(seed).standard_normal((V, 300)).astype(np.float32)
+    e[0] = 0                        # PAD row, as in the spaCy table
+    return e
+
+
+def vgd_targets(c, seed):
+    """The VGD step's supervision tensors (train_vgd.py:309-313): soft scores, score mask, box targets, box mask."""
+    rs = np.random.RandomState(seed)
+    B, Sy = c['inputs'][0].shape[:2]
+    scores = rs.uniform(size=(B, Sy)).astype(np.float32)
+    scores /= scores.sum(-1, keepdims=True)
+    smask = (rs.uniform(size=(B, Sy)) < 0.7).astype(np.float32)
+    smask[:, 0] = 1
+    bbox = rs.standard_normal((B, Sy, 4)).astype(np.float32)
+    bmask = (rs.uniform(size=(B, Sy, 1)) < 0.4).astype(np.float32) * np.ones((1, 1, 4), np.float32)
+    bmask[:, 0] = 1
+    return dict(scores=scores, scores_mask=smask, bbox=bbox, bbox_mask=bmask)

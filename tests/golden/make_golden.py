@@ -11,6 +11,9 @@ Files written (npz, float32 unless noted):
     prims.npz        LayerNorm, AttFlat, make_mask, LSTM stand-alone
     mixed.npz        MixedOp algebra: forward modes, alpha-gradient, rescale, genotype
     nets.npz         Net_Full(arch/*.json) for vqa/vgd/itm and Net_Search weight/arch steps
+    traj.npz         capture (v): two Adam weight steps + one 'full' arch step of the reference loop (loss trajectory)
+    loader.npz       loader functions (relation_embedding, semantic_embedding, proc_img_feat, proc_bbox_feat, proc_ques)
+    losses.npz       ITM triplet step with BCE_Loss; VGD KLDiv + SmoothL1 loss
 """
 import os
 import sys
@@ -32,14 +35,20 @@ torch.set_num_threads(4)
 
 
 def _import_reference():
-    # the repo ships an alias package also called `mmnas`; make sure the reference wins here
+    """Bind the name `mmnas` to the REFERENCE tree.  The repo ships a regular alias package also called `mmnas`
+    (a regular package beats the reference's namespace package whatever the sys.path order), so the reference is
+    bound explicitly: a synthetic package whose __path__ is the reference's mmnas/ directory."""
+    import types
     for k in [k for k in sys.modules if k == 'mmnas' or k.startswith('mmnas.')]:
         del sys.modules[k]
-    sys.path.insert(0, REF)
+    pkg = types.ModuleType('mmnas')
+    pkg.__path__ = [os.path.join(REF, 'mmnas')]
+    sys.modules['mmnas'] = pkg
     import mmnas.model.modules as rm
     import mmnas.model.mixed as rmix
     import mmnas.utils.ops_adapter as roa
-    assert rm.__file__.startswith(REF), rm.__file__
+    for m in (rm, rmix, roa):
+        assert m.__file__.startswith(REF), m.__file__
     return rm, rmix, roa
 
 
@@ -366,7 +375,200 @@ def gen_nets():
     print('nets.npz', len(out), 'arrays')
 
 
+
+def _inject(mops, flat_plan, MixedOp, mode):
+    """What reset_binary_gates()/binarize() leave behind (mixed.py:131-163), with the draw replaced by `flat_plan`."""
+    MixedOp.MODE = mode
+    for m, (act, inact) in zip(mops, flat_plan):
+        m.alpha_gate.data.zero_()
+        m.alpha_gate.data[act[0]] = 1.0
+        m.active_index, m.inactive_index = list(act), list(inact)
+        for op in m.candidate_ops:
+            for prm in op.parameters():
+                prm.grad = None
+
+
+def gen_traj():
+    """Capture (v): the reference's own statement sequence (search_vqa.py:279-337) on the reference Net_Search with the
+    reference WarmupOptimizer (mmnas/utils/optimizer.py) over torch Adam: weight step, weight step (another sample),
+    'full' arch step, then the forward loss of a third weight step.  Samples injected, dropout 0, single process."""
+    from mmnas.utils.optimizer import WarmupOptimizer
+    import torch.optim as Optim
+    out = {}
+    MixedOp = RMIX.MixedOp
+    c, c2, plans = cases.traj_setup()
+    init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+            'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
+    net = hygr_vqa.Net_Search(c['cfg'], init)
+    net.train()
+    load_state(net, c['P'])
+    H = cases.TRAJ_HYPER
+    net_optim = WarmupOptimizer(H['net_lr'], Optim.Adam(net.net_parameters(), lr=0, betas=H['net_betas'], eps=H['net_eps'],
+                                                        weight_decay=0), H['epoch_steps'], warmup=True)
+    alpha_optim = Optim.Adam(net.alpha_prob_parameters(), H['alpha_lr'], betas=H['alpha_betas'], weight_decay=0)
+    loss_fn = torch.nn.BCEWithLogitsLoss(reduction='sum')
+    mops = net.redundant_modules
+    inp = tuple(T(a) for a in c['inputs']); tgt = T(c['target'])
+    inp2 = tuple(T(a) for a in c2['inputs']); tgt2 = T(c2['target'])
+    losses, gnorms = [], []
+    P0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+
+    def weight_step(plan, step_optim=True):
+        _inject(mops, plan['enc'] + plan['dec'], MixedOp, None)
+        net.unused_modules_off()
+        pred = net(inp)
+        loss = loss_fn(pred, tgt)
+        loss += 0 * sum(p.sum() for p in net.alpha_prob_parameters())
+        loss += 0 * sum(p.sum() for p in net.alpha_gate_parameters())
+        loss += 0 * sum(p.sum() for p in net.net_parameters())
+        net.zero_grad()
+        loss.backward()
+        losses.append(loss.item())
+        if step_optim:
+            gnorms.append(float(torch.nn.utils.clip_grad_norm_(net.net_parameters(), H['clip'])))
+            net_optim.step()
+        net.unused_modules_back()
+
+    def snapshot(tag):
+        sd = net.state_dict()
+        keys = sorted(k for k in sd if 'alpha' not in k)
+        out['traj|%s|keys' % tag] = np.array(keys)
+        out['traj|%s|delta_norm' % tag] = np.array([float((sd[k].double() - P0[k].double()).norm()) for k in keys])
+        for k in cases.TRAJ_FULL_KEYS:
+            out['traj|%s|P:%s' % (tag, k)] = sd[k].detach().numpy().copy()
+
+    weight_step(plans[0]); snapshot('w1')
+    weight_step(plans[1]); snapshot('w2')
+    # arch step (search_vqa.py:317-337)
+    _inject(mops, plans[2]['enc'] + plans[2]['dec'], MixedOp, 'full')
+    net.unused_modules_off()
+    pred = net(inp2)
+    loss = loss_fn(pred, tgt2)
+    loss += 0 * sum(p.sum() for p in net.alpha_prob_parameters())
+    loss += 0 * sum(p.sum() for p in net.net_parameters())
+    net.zero_grad()
+    loss.backward()
+    losses.append(loss.item())
+    out['traj|arch|gate_grads'] = np.stack([np.pad(m.alpha_gate.grad.numpy(), (0, 4 - m.n_choices)) for m in mops])
+    net.set_arch_param_grad()
+    out['traj|arch|prob_grads'] = np.stack([np.pad(m.alpha_prob.grad.numpy(), (0, 4 - m.n_choices)) for m in mops])
+    alpha_optim.step()
+    net.unused_modules_back()
+    MixedOp.MODE = None
+    out['traj|arch|alpha_after'] = np.stack([np.pad(m.alpha_prob.detach().numpy(), (0, 4 - m.n_choices)) for m in mops])
+    snapshot('a')   # the arch step must leave the network weights alone
+    weight_step(plans[3], step_optim=False)
+    out['traj|losses'] = np.array(losses, np.float64)
+    out['traj|grad_norms'] = np.array(gnorms, np.float64)
+    out['traj|lr'] = np.array([net_optim.rate(s) for s in (1, 2, 3)], np.float64)
+    for i, pl in enumerate(plans):
+        out['traj|plan%d' % i] = np.array([a[0] for a, _ in pl['enc'] + pl['dec']], np.int64)
+    np.savez_compressed(os.path.join(HERE, 'traj.npz'), **out)
+    print('traj.npz', len(out), 'arrays; losses', losses, 'grad norms', gnorms)
+
+
+def _extract_functions(path, names):
+    """Compile the named top-level functions / methods of a reference source file that cannot be imported as a module
+    (the loaders import en_vectors_web_lg / spacy at module level).  Nothing but the selected defs is executed."""
+    import ast
+    import re
+    tree = ast.parse(open(path).read(), filename=path)
+    picked = []
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            picked.append(node)
+    mod = ast.Module(body=picked, type_ignores=[])
+    ns = {'np': np, 'torch': torch, 're': re}
+    exec(compile(mod, path, 'exec'), ns)
+    return ns
+
+
+def gen_loader():
+    """Loader-side functions of mmnas/loader/load_data_vqa.py:7-58,252-296 on deterministic inputs."""
+    ns = _extract_functions(os.path.join(REF, 'mmnas', 'loader', 'load_data_vqa.py'),
+                            {'relation_embedding', 'semantic_embedding', 'proc_img_feat', 'proc_bbox_feat', 'proc_ques'})
+    out = {}
+    for i, (n, seed) in enumerate(((7, 1), (36, 2), (100, 3), (1, 4))):
+        bbox = cases.loader_boxes(n, seed)
+        out['rel|%d|bbox' % i] = bbox
+        out['rel|%d|out' % i] = ns['relation_embedding'](T(bbox)).numpy()
+    for i, (n, pad, d) in enumerate(((5, 8, 6), (12, 8, 6), (8, 8, 3))):
+        f = np.random.RandomState(10 + i).standard_normal((n, d)).astype(np.float32)
+        out['pad|%d|in' % i] = f
+        out['pad|%d|out' % i] = ns['proc_img_feat'](None, f, pad)
+    for i, (n, shape) in enumerate(((9, (480, 640)), (3, (333, 500)))):
+        bbox = cases.loader_boxes(n, 20 + i, w=shape[1], h=shape[0])
+        out['bboxfeat|%d|bbox' % i] = bbox
+        out['bboxfeat|%d|shape' % i] = np.array(shape, np.int64)
+        out['bboxfeat|%d|out' % i] = ns['proc_bbox_feat'](None, bbox, shape)
+    emb = cases.loader_glove(50, 31)
+    out['sem|emb'] = emb
+    tok = {w: i for i, w in enumerate(cases.LOADER_VOCAB)}
+    for i, q in enumerate(cases.LOADER_QUESTIONS):
+        ix = ns['proc_ques'](None, {'question': q}, tok, 14)
+        out['sem|%d|ques_ix' % i] = ix
+        out['sem|%d|out' % i] = ns['semantic_embedding']({'question': q}, ix, emb, max_token=14).numpy()
+    np.savez_compressed(os.path.join(HERE, 'loader.npz'), **out)
+    print('loader.npz', len(out), 'arrays')
+
+
+def gen_losses():
+    """Task harness steps: the ITM triplet step with BCE_Loss (train_itm.py:380-391, mmnas/utils/itm_loss.py:4-24) and
+    the VGD loss (train_vgd.py:252-256,316-333: KLDiv on masked log-scores + 0.5 * SmoothL1 on masked boxes, LOSS_AVG)."""
+    from mmnas.utils.itm_loss import BCE_Loss
+    from types import SimpleNamespace
+    out = {}
+    # --- ITM: three forwards, one backward
+    c = cases.net_case('itm', 'mmnas_itm', 9201)
+    neg = cases.net_case('itm', 'mmnas_itm', 9202)
+    init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+            'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
+    net = full_itm.Net_Full(c['cfg'], init)
+    net.train()
+    load_state(net, c['P'])
+    pos = tuple(T(a) for a in c['inputs']); ng = tuple(T(a) for a in neg['inputs'])
+    inp_negc = (pos[0], pos[1], pos[2], ng[3], ng[4])
+    inp_negi = (ng[0], ng[1], ng[2], pos[3], pos[4])
+    loss_fn = BCE_Loss(SimpleNamespace(REDUCTION='sum'))
+    sp, sc, si = net(pos), net(inp_negc), net(inp_negi)
+    loss = loss_fn(sp, sc, si)
+    loss.backward()
+    out['itm|scores'] = np.stack([sp.detach().numpy(), sc.detach().numpy(), si.detach().numpy()])
+    out['itm|loss'] = np.float64(loss.item())
+    keys = sorted(k for k, _ in net.named_parameters())
+    g = dict(net.named_parameters())
+    out['itm|gradnorm_keys'] = np.array(keys)
+    out['itm|gradnorms'] = np.array([0.0 if g[k].grad is None else float(g[k].grad.double().norm()) for k in keys])
+    out['itm|g:proj.weight'] = g['proj.weight'].grad.numpy()
+    # --- VGD loss
+    c = cases.net_case('vgd', 'mmnas_vgd', 9203)
+    init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+            'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
+    net = full_vgd.Net_Full(c['cfg'], init)
+    net.train()
+    load_state(net, c['P'])
+    t = cases.vgd_targets(c, 9204)
+    pred_scores, pred_reg = net(tuple(T(a) for a in c['inputs']))
+    scores_loss = torch.nn.KLDivLoss(reduction='sum')
+    reg_loss = torch.nn.SmoothL1Loss(reduction='sum')
+    sm, bm = T(t['scores_mask']), T(t['bbox_mask'])
+    loss_scores = scores_loss(pred_scores * sm, T(t['scores']) * sm)
+    loss_reg = reg_loss(pred_reg * bm, T(t['bbox']) * bm)
+    loss_scores = loss_scores / torch.sum(sm)
+    loss_reg = loss_reg / torch.sum(bm)
+    loss = loss_scores + 0.5 * loss_reg
+    loss.backward()
+    out['vgd|pred_scores'] = pred_scores.detach().numpy(); out['vgd|pred_reg'] = pred_reg.detach().numpy()
+    out['vgd|loss_parts'] = np.array([loss_scores.item(), loss_reg.item(), loss.item()], np.float64)
+    keys = sorted(k for k, _ in net.named_parameters())
+    g = dict(net.named_parameters())
+    out['vgd|gradnorm_keys'] = np.array(keys)
+    out['vgd|gradnorms'] = np.array([0.0 if g[k].grad is None else float(g[k].grad.double().norm()) for k in keys])
+    np.savez_compressed(os.path.join(HERE, 'losses.npz'), **out)
+    print('losses.npz', len(out), 'arrays')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['ops', 'ops_shapes', 'prims', 'mixed', 'nets']
+    which = sys.argv[1:] or ['ops', 'ops_shapes', 'prims', 'mixed', 'nets', 'traj', 'loader', 'losses']
     for w in which:
         globals()['gen_' + w]()
