@@ -202,6 +202,32 @@ int mmnas_relation_embedding(const float* bbox, const int* nobj, float* out, int
  * sampling (mixed.py:131-158) without a host->device copy / stream synchronisation. */
 int mmnas_onehot_rows(float* out, int rows, int width, const int* idx_host, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * MixedOp plumbing of the architecture step (mmnas/model/mixed.py).
+ *   mmnas_mixed_sum_fwd: out = sum_j gate[j] * o_j over a node's n <= MMNAS_MIXED_MAX candidate outputs
+ *     (MixedOp.forward in modes 'full' / 'two', mixed.py:59-68; replaces select + mul + add per candidate).
+ *     outs_host is a HOST array of n device pointers (read at call time, carried in the kernel arguments); a NULL
+ *     entry is a candidate that takes no part (mode 'two' evaluates two of them): skipped, its gate gradient += 0;
+ *     gate is the node's alpha_gate row (device); count = elements per output, a multiple of 4.
+ *   mmnas_mixed_sum_bwd: dgate[j] += <dout, o_j> for every candidate (the detached ones included: the gate, not the
+ *     output, carries their gradient), d_active = gate[active] * dout (the one candidate that is differentiated;
+ *     NULL to skip).  ws: mmnas_mixed_sum_ws_floats() floats of scratch (per-workgroup partials, summed in a fixed
+ *     order by a second tiny launch: bitwise reproducible).
+ *   mmnas_alpha_full_step: for every node r (row of the [rows, width] alpha_prob block; unused columns hold -inf):
+ *     p = softmax(alpha_r); dalpha_i = sum_j g_j p_j (delta_ij - p_i) (set_arch_param_grad, mixed.py:194-198, 'full'
+ *     mode) and the torch.optim.Adam update of alpha_optim (search_vqa.py:194) with its moments m, v [rows, width] at
+ *     step `step` (1-based).  prob_grad (nullable) receives dalpha.  One launch instead of ~6 ATen kernels per node
+ *     plus the optimizer's.
+ * ------------------------------------------------------------------------------------------ */
+#define MMNAS_MIXED_MAX 8
+size_t mmnas_mixed_sum_ws_floats(void);   /* host only */
+int mmnas_mixed_sum_fwd(const float* const* outs_host, int n, const float* gate, float* out, size_t count,
+                        void* stream);
+int mmnas_mixed_sum_bwd(const float* const* outs_host, int n, const float* gate, const float* dout,
+                        float* d_active, int active, float* dgate, float* ws, size_t count, void* stream);
+int mmnas_alpha_full_step(float* prob, const float* gate_grad, float* m, float* v, float* prob_grad, int rows,
+                          int width, float lr, float beta1, float beta2, float eps, int step, void* stream);
+
 /* nn.Embedding backward (hygr_vqa.py:85,105; aten embedding_dense_backward): dW[idx[t], :] += dy[t, :] for the n_tok
  * int64 token indices -- straight into the (already zeroed or accumulating) gradient buffer instead of a dense
  * [V, E] temporary.  Indices outside [0, V) are ignored. */

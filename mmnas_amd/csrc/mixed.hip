@@ -1,0 +1,158 @@
+// Supernet node plumbing of the architecture step (MixedOp, mmnas/model/mixed.py):
+//   * the gated sum of a node's candidate outputs (mixed.py:59-68) and its backward -- the gradient of every gate is
+//     the inner product <dL/dout, o_j>, which the reference obtains from ~10 ATen kernels per candidate
+//     (select, mul, add, and their autograd: expand, mul, sum);
+//   * the architecture-parameter update of all nodes in one launch: dL/dalpha from dL/dgate (mixed.py:171-198,
+//     'full' mode) followed by the Adam step of alpha_optim (search_vqa.py:194,331-332).
+// HBM-bound streaming kernels (one pass over the candidate outputs).
+#include "common.h"
+
+namespace mmnas {
+
+constexpr int MAXC = MMNAS_MIXED_MAX;
+
+struct MixArgs {
+  const float* o[MAXC];
+  int n;
+};
+
+__global__ void __launch_bounds__(256) mixed_sum_fwd_kernel(MixArgs a, const float* __restrict__ gate, float* __restrict__ out,
+                                                            size_t n4) {
+  float g[MAXC];
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) g[j] = j < a.n ? gate[j] : 0.f;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j)
+      if (j < a.n && a.o[j]) {
+        const float4 v = reinterpret_cast<const float4*>(a.o[j])[i];
+        acc.x += g[j] * v.x; acc.y += g[j] * v.y; acc.z += g[j] * v.z; acc.w += g[j] * v.w;
+      }
+    reinterpret_cast<float4*>(out)[i] = acc;
+  }
+}
+
+// partial inner products <dout, o_j> of this workgroup's slice -> part[blockIdx.x][MAXC]; d_active = gate[active] * dout
+__global__ void __launch_bounds__(256) mixed_sum_bwd_kernel(MixArgs a, const float* __restrict__ gate, const float* __restrict__ dout,
+                                                            float* __restrict__ d_active, int active, float* __restrict__ part,
+                                                            size_t n4) {
+  __shared__ float red[4][MAXC];
+  float s[MAXC];
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) s[j] = 0.f;
+  const float ga = d_active ? gate[active] : 0.f;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 d = reinterpret_cast<const float4*>(dout)[i];
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j)
+      if (j < a.n && a.o[j]) {
+        const float4 v = reinterpret_cast<const float4*>(a.o[j])[i];
+        s[j] += (d.x * v.x + d.y * v.y) + (d.z * v.z + d.w * v.w);
+      }
+    if (d_active) reinterpret_cast<float4*>(d_active)[i] = make_float4(ga * d.x, ga * d.y, ga * d.z, ga * d.w);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) {
+    const float t = wave_sum(s[j]);
+    if (lane == 0) red[wave][j] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < MAXC)
+    part[(size_t)blockIdx.x * MAXC + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// dgate[j] += sum over workgroups (fixed order: bitwise reproducible)
+__global__ void __launch_bounds__(64) mixed_sum_reduce_kernel(const float* __restrict__ part, int nwg, int n, float* __restrict__ dgate) {
+  const int j = threadIdx.x;
+  if (j >= n) return;
+  float t = 0.f;
+  for (int b = 0; b < nwg; ++b) t += part[(size_t)b * MAXC + j];
+  dgate[j] += t;
+}
+
+// one thread per node (row): 'full'-mode architecture gradient + Adam
+__global__ void alpha_full_step_kernel(float* __restrict__ prob, const float* __restrict__ gate_grad, float* __restrict__ m,
+                                       float* __restrict__ v, float* __restrict__ prob_grad, int rows, int width, float lr,
+                                       float b1, float b2, float eps, float c1, float c2s) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float* a = prob + (size_t)r * width;
+  const float* g = gate_grad + (size_t)r * width;
+  float mx = -INFINITY;
+  for (int i = 0; i < width; ++i) mx = fmaxf(mx, a[i]);
+  float den = 0.f;
+  for (int i = 0; i < width; ++i) den += expf(a[i] - mx);   // padding columns hold -inf: exp = 0
+  float dot = 0.f;
+  for (int i = 0; i < width; ++i) dot += g[i] * (expf(a[i] - mx) / den);
+  for (int i = 0; i < width; ++i) {
+    const float p = expf(a[i] - mx) / den;
+    const float grad = p * (g[i] - dot);                    // sum_j g_j p_j (delta_ij - p_i), mixed.py:194-198
+    if (prob_grad) prob_grad[(size_t)r * width + i] = grad;
+    if (p == 0.f && !(a[i] > -INFINITY)) continue;          // padding column: stays -inf
+    const size_t o = (size_t)r * width + i;
+    const float mi = b1 * m[o] + (1.f - b1) * grad;
+    const float vi = b2 * v[o] + (1.f - b2) * grad * grad;
+    m[o] = mi; v[o] = vi;
+    a[i] -= (lr / c1) * mi / (sqrtf(vi) / c2s + eps);
+  }
+}
+
+}  // namespace mmnas
+
+using namespace mmnas;
+
+static int mix_grid(size_t n4) {
+  const size_t b = (n4 + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+}
+
+extern "C" size_t mmnas_mixed_sum_ws_floats(void) { return (size_t)512 * MAXC; }
+
+extern "C" int mmnas_mixed_sum_fwd(const float* const* outs_host, int n, const float* gate, float* out, size_t count,
+                                   void* stream) {
+  MMNAS_REQUIRE(outs_host && gate && out, MMNAS_E_ARG, "mmnas_mixed_sum_fwd: null pointer");
+  MMNAS_REQUIRE(n >= 1 && n <= MAXC, MMNAS_E_SHAPE, "mmnas_mixed_sum_fwd: 1..%d candidates, got %d", MAXC, n);
+  MMNAS_REQUIRE(count % 4 == 0, MMNAS_E_SHAPE, "mmnas_mixed_sum_fwd: element count must be a multiple of 4");
+  MixArgs a;
+  a.n = n;
+  for (int j = 0; j < MAXC; ++j) {
+    a.o[j] = j < n ? outs_host[j] : nullptr;
+    MMNAS_REQUIRE(((uintptr_t)a.o[j] & 15) == 0, MMNAS_E_ARG, "mmnas_mixed_sum_fwd: candidate %d unaligned", j);
+  }
+  if (count == 0) return MMNAS_OK;
+  ProfScope ps(MMNAS_K_ROWOPS, 2.0 * n * count, 4.0 * (n + 1) * count, (hipStream_t)stream, "mixed_sum_fwd");
+  MMNAS_LAUNCH(mixed_sum_fwd_kernel, dim3(mix_grid(count / 4)), dim3(256), 0, (hipStream_t)stream, a, gate, out, count / 4);
+  return check_launch("mixed_sum_fwd");
+}
+
+extern "C" int mmnas_mixed_sum_bwd(const float* const* outs_host, int n, const float* gate, const float* dout,
+                                   float* d_active, int active, float* dgate, float* ws, size_t count, void* stream) {
+  MMNAS_REQUIRE(outs_host && gate && dout && dgate && ws, MMNAS_E_ARG, "mmnas_mixed_sum_bwd: null pointer");
+  MMNAS_REQUIRE(n >= 1 && n <= MAXC, MMNAS_E_SHAPE, "mmnas_mixed_sum_bwd: 1..%d candidates, got %d", MAXC, n);
+  MMNAS_REQUIRE(count % 4 == 0, MMNAS_E_SHAPE, "mmnas_mixed_sum_bwd: element count must be a multiple of 4");
+  MMNAS_REQUIRE(!d_active || (active >= 0 && active < n), MMNAS_E_ARG, "mmnas_mixed_sum_bwd: active index out of range");
+  MixArgs a;
+  a.n = n;
+  for (int j = 0; j < MAXC; ++j) a.o[j] = j < n ? outs_host[j] : nullptr;
+  if (count == 0) return MMNAS_OK;
+  const int g = mix_grid(count / 4);
+  ProfScope ps(MMNAS_K_ROWOPS, 2.0 * n * count, 4.0 * (n + 2) * count, (hipStream_t)stream, "mixed_sum_bwd");
+  MMNAS_LAUNCH(mixed_sum_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, a, gate, dout, d_active, active, ws, count / 4);
+  MMNAS_LAUNCH(mixed_sum_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)ws, g, n, dgate);
+  return check_launch("mixed_sum_bwd");
+}
+
+extern "C" int mmnas_alpha_full_step(float* prob, const float* gate_grad, float* m, float* v, float* prob_grad, int rows,
+                                     int width, float lr, float beta1, float beta2, float eps, int step, void* stream) {
+  MMNAS_REQUIRE(prob && gate_grad && m && v && step >= 1 && rows >= 0 && width >= 1, MMNAS_E_ARG, "mmnas_alpha_full_step: bad arguments");
+  if (rows == 0) return MMNAS_OK;
+  const float c1 = 1.f - powf(beta1, (float)step);
+  const float c2s = sqrtf(1.f - powf(beta2, (float)step));
+  MMNAS_LAUNCH(alpha_full_step_kernel, dim3(cdiv(rows, 64)), dim3(64), 0, (hipStream_t)stream, prob, gate_grad, m, v, prob_grad,
+               rows, width, lr, beta1, beta2, eps, c1, c2s);
+  return check_launch("alpha_full_step");
+}

@@ -65,19 +65,49 @@ class FlatGrads:
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
         self.index = {id(p): i for i, p in enumerate(self.params)}
+        # dirty[i]: the view of params[i] may hold non-zero data (it has been attached as p.grad, or a gradient was
+        # copied into it) since the last zero().  FlatAdam's dense mode relies on "not dirty => all zeros".
+        self.dirty = [False] * len(self.params)
 
     def attach(self, which=None):
         """Point p.grad at its view (all parameters, or the given subset; others get grad=None)."""
         if which is None:
             for p, v in zip(self.params, self.views):
                 p.grad = v
+            self.dirty = [True] * len(self.params)
             return
         keep = {id(p) for p in which}
-        for p, v in zip(self.params, self.views):
-            p.grad = v if id(p) in keep else None
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
+            if id(p) in keep:
+                p.grad = v
+                self.dirty[i] = True
+            else:
+                p.grad = None
 
     def zero(self):
         self.flat.zero_()
+        self.dirty = [False] * len(self.params)
+
+    def adopt(self, i):
+        """Bring a gradient that was produced OUTSIDE the flat buffer into it: the driver called `net.zero_grad()` /
+        set `p.grad = None` after the views were attached (the reference loop does, search_vqa.py:290), so backward
+        allocated a fresh tensor.  The view takes its value (the buffer was zeroed when the step began, and nothing
+        else wrote into this view since: sinks only write while `p.grad is view`) and becomes p.grad again."""
+        p, v = self.params[i], self.views[i]
+        g = p.grad
+        if g is None or g is v:
+            return False
+        if g.data_ptr() != v.data_ptr():
+            v.copy_(g)
+        p.grad = v
+        self.dirty[i] = True
+        return True
+
+    def adopt_strays(self, which=None):
+        n = 0
+        for i in (range(len(self.params)) if which is None else which):
+            n += bool(self.adopt(i))
+        return n
 
     def enable_sinks(self, callback=None):
         """Let the operators' backward kernels write parameter gradients directly into the views
@@ -95,10 +125,12 @@ class FlatGrads:
 class GradReducer:
     """Bucketed, backward-overlapped all-reduce of a fixed parameter set (Net_Full training)."""
 
-    def __init__(self, params, bucket_mb=64.0, group=None):
+    def __init__(self, params, bucket_mb=64.0, group=None, force_collectives=False):
+        """force_collectives: issue the collectives also in a one-rank group (tests of the RCCL path on a one-GPU box)."""
         self.fg = FlatGrads(params)
         self.group = group
         self.world = _world()
+        self.comm = self.world > 1 or (force_collectives and dist.is_initialized())
         self.is_cuda = self.fg.flat.is_cuda
         self.fg.attach()
         # buckets over the flat buffer, filled in REVERSE parameter order (~ backward order)
@@ -123,8 +155,8 @@ class GradReducer:
         self._seen = [True] * len(self.fg.params)   # armed by begin_step()
         self._works = []
         self._launched = [False] * len(self.buckets)
-        self.comm_stream = torch.cuda.Stream() if (self.is_cuda and self.world > 1) else None
-        if self.world > 1:
+        self.comm_stream = torch.cuda.Stream() if (self.is_cuda and self.comm) else None
+        if self.comm:
             for i, p in enumerate(self.fg.params):
                 # The hook is the ONLY arrival signal.  Autograd runs a parameter's AccumulateGrad node -- and
                 # this hook -- once per backward, after every use of the parameter has run its backward, also
@@ -139,6 +171,7 @@ class GradReducer:
         if self._seen[i]:
             return
         self._seen[i] = True
+        self.fg.adopt(i)   # (a gradient autograd accumulated outside the flat buffer: see FlatGrads.adopt)
         b = self.bucket_of[i]
         self._pending[b] -= 1
         if self._pending[b] == 0:
@@ -170,7 +203,7 @@ class GradReducer:
         """Call before forward: zero the gradient buffer and arm the buckets."""
         self.fg.zero()
         self.fg.attach()
-        if self.world == 1:
+        if not self.comm:
             return
         self._pending = [len(idxs) for (_, _, idxs) in self.buckets]
         self._seen = [False] * len(self.fg.params)
@@ -179,9 +212,12 @@ class GradReducer:
 
     def finish(self):
         """Call after backward: flush buckets whose gradients never arrived, wait for all collectives."""
-        if self.world == 1:
+        if not self.comm:
+            self.fg.adopt_strays()
             return
         for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self.fg.adopt_strays(self.buckets[b][2])
             self._launch(b)
         if self.is_cuda:
             with torch.cuda.stream(self.comm_stream):   # (the scaling of a summed bucket stays on the comm stream)
@@ -199,13 +235,21 @@ class GradReducer:
 
 
 class SupernetReducer:
-    """Gradient exchange for Net_Search: stem/head + sampled candidates on weight steps, the
-    alpha_gate block on arch steps."""
+    """Gradient exchange for Net_Search: stem/head + sampled candidates on weight steps, the alpha_gate block on arch
+    steps.
 
-    def __init__(self, net, group=None):
+    Layout: the flat buffer holds [stem | head | rel-stem | node 0 cand 0 | node 0 cand 1 | ... ], every candidate one
+    contiguous run, so a step's exchange set is a STATIC segment per shared run plus one segment per sampled
+    candidate -- nothing is sorted or merged per step.  The segments are dealt to `n_buckets` buckets in backward order
+    (head and the last decoder nodes first, the encoder and the stem last); a bucket is gathered into its own staging
+    slice by one kernel and all-reduced on a side stream as soon as autograd has accumulated its last gradient, while
+    backward continues with the earlier nodes (search_vqa.py:292 behind DDP's bucketing, but over ~1/3 of the bytes)."""
+
+    def __init__(self, net, group=None, n_buckets=3, force_collectives=False):
         self.net = net
         self.group = group
         self.world = _world()
+        self.comm = self.world > 1 or (force_collectives and dist.is_initialized())
         mops = net.redundant_modules
         cand = set()
         for m in mops:
@@ -219,50 +263,167 @@ class SupernetReducer:
                 ordered += ps
         self.fg = FlatGrads(ordered)
         self.is_cuda = self.fg.flat.is_cuda
-        self.staging = None
         self._active = None
+        fg = self.fg
+
+        def span(params):   # contiguous by construction
+            if not params:
+                return None
+            i0, i1 = fg.index[id(params[0])], fg.index[id(params[-1])]
+            return (fg.offsets[i0], fg.offsets[i1] + _align(params[-1].numel()) - fg.offsets[i0])
+
+        # shared parameters: head = used after the backbone (its gradients arrive FIRST in backward)
+        head_ids = set()
+        for name in ('attflat_x', 'attflat_y', 'attfc_y', 'proj_norm', 'proj', 'proj_scores', 'proj_reg'):
+            mod = getattr(net, name, None)
+            if mod is not None:
+                head_ids.update(id(p) for p in mod.parameters())
+        runs = []   # maximal runs of consecutive shared parameters of the same kind: (is_head, [param indices])
+        for p in self.shared:
+            i = fg.index[id(p)]
+            h = id(p) in head_ids
+            if runs and runs[-1][0] == h and runs[-1][1][-1] == i - 1:
+                runs[-1][1].append(i)
+            else:
+                runs.append((h, [i]))
+        # units in backward order: head runs, nodes from the last to the first, stem runs
+        n = len(mops)
+        node_size = [max((sum(_align(p.numel()) for p in ps) for ps in node), default=0) for node in self.per_op]
+        units = [('run', r) for r in runs if r[0]] + [('node', k) for k in reversed(range(n))] + [('run', r) for r in runs if not r[0]]
+        sizes = [sum(_align(fg.params[i].numel()) for i in u[1][1]) if u[0] == 'run' else node_size[u[1]] for u in units]
+        total = sum(sizes) or 1
+        n_buckets = max(1, min(int(n_buckets), len(units)))
+        self.n_buckets = n_buckets
+        self.bucket_static = [[] for _ in range(n_buckets)]      # static (offset, n) segments
+        self.bucket_static_params = [[] for _ in range(n_buckets)]
+        self.bucket_nodes = [[] for _ in range(n_buckets)]
+        self.bucket_of_param = {}
+        acc = 0
+        for u, sz in zip(units, sizes):
+            b = min(n_buckets - 1, acc * n_buckets // total)
+            if u[0] == 'run' and not u[1][0]:
+                b = n_buckets - 1                                   # the stem always closes the exchange
+            acc += sz
+            if u[0] == 'run':
+                idxs = u[1][1]
+                self.bucket_static[b].append(span([fg.params[i] for i in idxs]))
+                self.bucket_static_params[b] += idxs
+                for i in idxs:
+                    self.bucket_of_param[i] = b
+            else:
+                k = u[1]
+                self.bucket_nodes[b].append(k)
+                for ps in self.per_op[k]:
+                    for p in ps:
+                        self.bucket_of_param[fg.index[id(p)]] = b
+        self.cand_span = [[span(ps) for ps in node] for node in self.per_op]
+        self.cand_idx = [[[fg.index[id(p)] for p in ps] for ps in node] for node in self.per_op]
+        self.cap = [sum(n_ for _, n_ in self.bucket_static[b]) + sum(node_size[k] for k in self.bucket_nodes[b])
+                    for b in range(n_buckets)]
+        self.staging = None
+        self._segs = [None] * n_buckets
+        self._pending = [0] * n_buckets
+        self._launched = [True] * n_buckets
+        self._armed = set()
+        self._works = []
+        self.comm_stream = torch.cuda.Stream() if (self.is_cuda and self.comm) else None
+        if self.comm:
+            for i, p in enumerate(fg.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))   # (see GradReducer: the only arrival signal)
         if self.is_cuda:
             self.fg.enable_sinks(None)   # HIP backward kernels add straight into the flat buffer
 
-    def _segments(self, params):
-        """Merge the flat ranges of `params` into maximal contiguous (offset, n) runs."""
-        rng = sorted((self.fg.offsets[self.fg.index[id(p)]], _align(p.numel())) for p in params)
-        out = []
-        for o, n in rng:
-            if out and out[-1][0] + out[-1][1] == o:
-                out[-1][1] += n
-            else:
-                out.append([o, n])
-        return out
-
+    # -- weight step --------------------------------------------------------------------------------------------
     def begin_weight_step(self):
         """After reset_binary_gates(): zero the buffer, give gradient views to the stem/head and the
-        sampled candidates only (unsampled candidates keep grad=None, mixed.py:160-163)."""
+        sampled candidates only (unsampled candidates keep grad=None, mixed.py:160-163), arm the buckets."""
+        mops = self.net.redundant_modules
         active = list(self.shared)
-        for m, node in zip(self.net.redundant_modules, self.per_op):
+        for m, node in zip(mops, self.per_op):
             for i in m.active_index:
                 active += node[i]
         self.fg.zero()
         self.fg.attach(active)
         self._active = active
+        if not self.comm:
+            return
+        armed = set()
+        for b in range(self.n_buckets):
+            segs = list(self.bucket_static[b])
+            idxs = list(self.bucket_static_params[b])
+            for k in self.bucket_nodes[b]:
+                a = mops[k].active_index[0]
+                if self.cand_span[k][a] is not None:
+                    segs.append(self.cand_span[k][a])
+                    idxs += self.cand_idx[k][a]
+            self._segs[b] = segs
+            self._pending[b] = len(idxs)
+            armed.update(idxs)
+        self._armed = armed
+        self._launched = [False] * self.n_buckets
+        self._works = []
+        if self.staging is None:
+            self.staging = [torch.empty(max(c, 64), dtype=torch.float32, device=self.fg.flat.device) for c in self.cap]
+
+    def _make_hook(self, i):
+        def hook(_p):
+            if i not in self._armed:
+                return
+            self._armed.discard(i)
+            self.fg.adopt(i)
+            b = self.bucket_of_param[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        if self._launched[b]:
+            return
+        self._launched[b] = True
+        segs = self._segs[b]
+        total = sum(n for _, n in segs)
+        if total == 0:
+            return
+        stg = self.staging[b][:total]
+        avg = _has_avg(self.group)
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        if self.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self._pack(segs, stg, 0)
+                w = dist.all_reduce(stg, op=op, group=self.group, async_op=True)
+        else:
+            self._pack(segs, stg, 0)
+            w = dist.all_reduce(stg, op=op, group=self.group, async_op=True)
+        self._works.append((w, b, stg, not avg))
 
     def finish_weight_step(self):
-        if self.world == 1:
+        """After backward: flush the buckets that are still open (always the stem's), wait, scatter the averaged
+        gradients back into the flat buffer."""
+        if not self.comm:
+            self.fg.adopt_strays([self.fg.index[id(p)] for p in self._active])
             return
-        segs = self._segments(self._active)
-        total = sum(n for _, n in segs)
-        if self.staging is None or self.staging.numel() < total:
-            self.staging = torch.empty(total, dtype=torch.float32, device=self.fg.flat.device)
-        stg = self.staging[:total]
-        self._pack(segs, stg, 0)
-        if _has_avg(self.group):
-            dist.all_reduce(stg, op=dist.ReduceOp.AVG, group=self.group)
+        for i in list(self._armed):          # gradients that never arrived through a hook (e.g. produced under no hook)
+            self.fg.adopt(i)
+        self._armed = set()
+        for b in range(self.n_buckets):
+            self._launch(b)
+        if self.is_cuda:
+            with torch.cuda.stream(self.comm_stream):
+                for w, b, stg, need_div in self._works:
+                    w.wait()
+                    self._pack(self._segs[b], stg, 1, 1.0 / self.world if need_div else 1.0)
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
         else:
-            dist.all_reduce(stg, op=dist.ReduceOp.SUM, group=self.group)
-            stg.mul_(1.0 / self.world)
-        self._pack(segs, stg, 1)
+            for w, b, stg, need_div in self._works:
+                w.wait()
+                self._pack(self._segs[b], stg, 1, 1.0 / self.world if need_div else 1.0)
+        self._works = []
 
-    def _pack(self, segs, stg, direction):
+    def _pack(self, segs, stg, direction, scale=1.0):
         if self.is_cuda:
             from . import _lib as L
             arr = (L.Segment * len(segs))()
@@ -272,35 +433,44 @@ class SupernetReducer:
                 arr[k].ptr, arr[k].offset, arr[k].n = base + 4 * o, off, n
                 off += n
             # the table rides in the kernel arguments: no host->device copy, no stream synchronisation per step
-            L.check(L.lib().mmnas_pack_segments_host(arr, len(segs), L.fptr(stg), 1.0, direction, L.stream()))
+            L.check(L.lib().mmnas_pack_segments_host(arr, len(segs), L.fptr(stg), float(scale), direction, L.stream()))
         else:  # CPU tensors (gloo tests): host plumbing only
             off = 0
             for o, n in segs:
                 if direction == 0:
                     stg[off:off + n].copy_(self.fg.flat[o:o + n])
                 else:
-                    self.fg.flat[o:o + n].copy_(stg[off:off + n])
+                    self.fg.flat[o:o + n].copy_(stg[off:off + n] * scale if scale != 1.0 else stg[off:off + n])
                 off += n
 
+    # -- arch step ----------------------------------------------------------------------------------------------
     def reduce_alpha_gate_grads(self):
-        """Arch step: average dL/dgate over ranks (the only gradient the arch step uses, mixed.py:172)."""
-        if self.world == 1:
+        """Arch step: average dL/dgate over ranks (the only gradient the arch step uses, mixed.py:172).  When the
+        gate gradients live in the net's flat [n_nodes, width] block (Net_Search.begin_arch_step) that block is
+        all-reduced in place: one collective, no copies."""
+        if not self.comm:
             return
         mops = self.net.redundant_modules
-        width = max(m.n_choices for m in mops)
-        dev = mops[0].alpha_gate.device
-        g = torch.zeros(len(mops), width, device=dev)
-        for i, m in enumerate(mops):
-            if m.alpha_gate.grad is not None:
-                g[i, :m.n_choices] = m.alpha_gate.grad
+        block = None
+        fl = getattr(self.net, '_flat_grads', None)
+        if fl is not None and all(m.alpha_gate.grad is getattr(m.alpha_gate, '_mmnas_gate_grad', None) and
+                                  m.alpha_gate.grad is not None for m in mops):
+            block = fl[0]
+        if block is None:   # gradients autograd allocated one by one (reference-style loop): stage them
+            width = max(m.n_choices for m in mops)
+            block = torch.zeros(len(mops), width, device=mops[0].alpha_gate.device)
+            for i, m in enumerate(mops):
+                if m.alpha_gate.grad is not None:
+                    block[i, :m.n_choices] = m.alpha_gate.grad
         if _has_avg(self.group):
-            dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
+            dist.all_reduce(block, op=dist.ReduceOp.AVG, group=self.group)
         else:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-            g.mul_(1.0 / self.world)
-        for i, m in enumerate(mops):
-            if m.alpha_gate.grad is not None:
-                m.alpha_gate.grad.copy_(g[i, :m.n_choices])
+            dist.all_reduce(block, op=dist.ReduceOp.SUM, group=self.group)
+            block.mul_(1.0 / self.world)
+        if fl is None or block is not fl[0]:
+            for i, m in enumerate(mops):
+                if m.alpha_gate.grad is not None:
+                    m.alpha_gate.grad.copy_(block[i, :m.n_choices])
 
 
 def check_same_architecture(net, group=None):

@@ -68,13 +68,20 @@ class MixedOp(nn.Module):
 
     def forward(self, s, pre=None, s_mask=None, pre_mask=None, rel_embed=None):
         if MixedOp.MODE in ('full', 'two'):
+            outs = [None] * self.n_choices
+            a = self.active_index[0]
+            outs[a] = self.candidate_ops[a](s, pre, s_mask, pre_mask, rel_embed)
+            with torch.no_grad():   # these only feed the gate gradient (`.detach()` in mixed.py:67)
+                for i in self.inactive_index:
+                    outs[i] = self.candidate_ops[i](s, pre, s_mask, pre_mask, rel_embed)
+            if outs[a].is_cuda and len(self.active_index) == 1 and outs[a].numel() % 4 == 0:
+                from .. import ops   # one kernel: sum_j gate[j] * o_j; its backward gives every gate <dout, o_j>
+                return ops.mixed_sum(self.alpha_gate, outs, a)
             out = 0
             for i in self.active_index:
-                out = out + self.alpha_gate[i] * self.candidate_ops[i](s, pre, s_mask, pre_mask, rel_embed)
-            with torch.no_grad():
-                detached = [(i, self.candidate_ops[i](s, pre, s_mask, pre_mask, rel_embed)) for i in self.inactive_index]
-            for i, o in detached:
-                out = out + self.alpha_gate[i] * o
+                out = out + self.alpha_gate[i] * outs[i]
+            for i in self.inactive_index:
+                out = out + self.alpha_gate[i] * outs[i]
             return out
         return self.active_op(s, pre, s_mask, pre_mask, rel_embed)
 

@@ -76,15 +76,20 @@ class LayerNorm(nn.Module):
 
     def __init__(self, size, eps=1e-6, dim=-1):
         super().__init__()
-        if dim != -1:
-            raise ValueError('LayerNorm over a dim other than the last is not used by any operator')
         self.eps = eps
         self.dim = dim
         self.a_2 = nn.Parameter(torch.ones(size))
         self.b_2 = nn.Parameter(torch.zeros(size))
 
     def forward(self, x):
-        return ops.layer_norm(x, self.a_2, self.b_2, self.eps)
+        if self.dim in (-1, x.dim() - 1):
+            return ops.layer_norm(x, self.a_2, self.b_2, self.eps)
+        # statistics over another axis (no operator does this; kept because the class accepts `dim`): normalise with
+        # that axis moved last (unit scale, zero shift), then the reference's broadcast of a_2 / b_2 over the LAST axis
+        xt = x.transpose(self.dim, -1).contiguous()
+        one = torch.ones(xt.shape[-1], dtype=x.dtype, device=x.device)
+        n = ops.layer_norm(xt, one, torch.zeros_like(one), self.eps).transpose(self.dim, -1)
+        return self.a_2 * n + self.b_2
 
 
 class AttFlat(nn.Module):
@@ -192,19 +197,20 @@ class MHAtt(nn.Module):
 
     def __init__(self, __C, base=64, hsize_k=None, bias=False):
         super().__init__()
-        if bias:
-            raise ValueError('the reference never enables projection biases (modules.py:159)')
+        self.has_bias = bool(bias)   # (no reference call site enables it, modules.py:159; served by the composed path)
         self.HBASE = base
         self.HSIZE_INSIDE = int(__C.HSIZE * hsize_k) if hsize_k else __C.HSIZE
         assert self.HSIZE_INSIDE % self.HBASE == 0
         self.HHEAD = int(self.HSIZE_INSIDE / self.HBASE)
         self.drop_p = __C.DROPOUT_R
-        self.linear_v = nn.Linear(__C.HSIZE, self.HSIZE_INSIDE, bias=False)
-        self.linear_k = nn.Linear(__C.HSIZE, self.HSIZE_INSIDE, bias=False)
-        self.linear_q = nn.Linear(__C.HSIZE, self.HSIZE_INSIDE, bias=False)
-        self.linear_merge = nn.Linear(self.HSIZE_INSIDE, __C.HSIZE, bias=False)
+        self.linear_v = nn.Linear(__C.HSIZE, self.HSIZE_INSIDE, bias=bias)
+        self.linear_k = nn.Linear(__C.HSIZE, self.HSIZE_INSIDE, bias=bias)
+        self.linear_q = nn.Linear(__C.HSIZE, self.HSIZE_INSIDE, bias=bias)
+        self.linear_merge = nn.Linear(self.HSIZE_INSIDE, __C.HSIZE, bias=bias)
 
     def run(self, xq, xkv, mask, rel, ln, norm, residual, training):
+        if self.has_bias:
+            raise ValueError('the fused attention operators have bias-free projections, as every registry entry does')
         lr = getattr(self, 'linear_r', None)
         wy = by = None
         if lr is not None and isinstance(rel, RelHandle):
@@ -221,11 +227,9 @@ class MHAtt(nn.Module):
             eps=ln.eps if norm else 1e-6, rel_Wy=wy, rel_by=by)
 
     def forward(self, v, k, q, mask=None):
-        if v is not k:
-            raise NotImplementedError('every reference call site passes the same tensor as key and value source')
         # stand-alone call: only the attention-map dropout applies (modules.py:197); the operator
         # wrappers below add the output dropout / residual / LayerNorm
-        return _bare_attention(self, q, None if q is k else k, mask, None)
+        return _bare_attention(self, v, k, q, mask, None)
 
 
 class RelMHAtt(MHAtt):
@@ -237,18 +241,28 @@ class RelMHAtt(MHAtt):
 
     def forward(self, v, k, q, mask=None, rel_embed=None):
         assert rel_embed is not None
-        if v is not k:
-            raise NotImplementedError('every reference call site passes the same tensor as key and value source')
-        return _bare_attention(self, q, None if q is k else k, mask, rel_embed)
+        return _bare_attention(self, v, k, q, mask, rel_embed)
 
 
-def _bare_attention(m, xq, xkv, mask, rel):
-    """MHAtt/RelMHAtt called directly (no output dropout / residual / LayerNorm).  The fused
-    operator always pairs the attention-map dropout with the output dropout, so a stand-alone call
-    is supported in eval mode or with DROPOUT_R = 0; no reference call site needs more."""
-    if m.training and m.drop_p > 0:
-        raise NotImplementedError('stand-alone MHAtt in training mode with dropout: use the operator wrappers')
-    return m.run(xq, xkv, mask, rel, None, False, False, False)
+def _bare_attention(m, v, k, q, mask, rel):
+    """MHAtt / RelMHAtt called directly (modules.py:178-199, 224-245): no output dropout / residual / LayerNorm.
+    With key and value from the same tensor and no active dropout this is the fused operator; the general form --
+    distinct key / value sources, or training mode, where ONLY the attention map is dropped (modules.py:197) -- is
+    composed from the same kernels: three projections, (relation bias,) the attention core, the merge projection."""
+    train_drop = m.training and m.drop_p > 0
+    if v is k and not train_drop and not m.has_bias:
+        return m.run(q, None if q is k else k, mask, rel, None, False, False, False)
+    Q = ops.linear(q, m.linear_q.weight, m.linear_q.bias)
+    K = ops.linear(k, m.linear_k.weight, m.linear_k.bias)
+    V = ops.linear(v, m.linear_v.weight, m.linear_v.bias)
+    biasT = None
+    if rel is not None:
+        if isinstance(rel, RelHandle):
+            rel = rel.materialize()
+        biasT = ops.rel_bias(rel, m.linear_r.weight, m.linear_r.bias)
+    p = m.drop_p if train_drop else 0.0
+    att = ops.mha_core(Q, K, V, mask, biasT, m.HBASE, p, ops.next_seed() if p > 0 else 0)
+    return ops.linear(att, m.linear_merge.weight, m.linear_merge.bias)
 
 
 class _AttWrapper(nn.Module):

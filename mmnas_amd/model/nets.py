@@ -196,6 +196,7 @@ class NetSearchBase(_Net):
         self._net_weights = [(n, p) for n, p in self.named_parameters()
                              if 'alpha_prob' not in n and 'alpha_gate' not in n]
         self._flat = None
+        self._flat_grads = None
         self._probs_cache = None
 
     # -- architecture parameters ------------------------------------------------------------
@@ -240,8 +241,23 @@ class NetSearchBase(_Net):
             m.alpha_prob.data = prob[i, :m.n_choices]
             m.alpha_gate.data = gate[i, :m.n_choices]
         self._flat = (prob, gate)
+        self._flat_grads = (torch.zeros_like(gate), torch.zeros_like(gate))   # dL/dgate, dL/dalpha blocks
         self._probs_cache = None
         return self._flat
+
+    def begin_arch_step(self):
+        """Arch step, before forward: zero the [n_nodes, width] gate-gradient block and make every node's
+        alpha_gate.grad a row of it -- the fused gated-sum backward (ops.MixedSumFn) then adds the gate gradients
+        straight into the block, which is what the data-parallel exchange all-reduces and the fused architecture
+        update (harness.ArchAdam) reads.  Returns (gate_grad, prob_grad)."""
+        self._flat_alphas()
+        gg, pg = self._flat_grads
+        gg.zero_()
+        for i, m in enumerate(self.redundant_modules):
+            row = gg[i, :m.n_choices]
+            m.alpha_gate.grad = row
+            m.alpha_gate._mmnas_gate_grad = row
+        return gg, pg
 
     def _probs_cpu(self, prob):
         """softmax(alpha_prob) of every node on the host.  The alphas change only at architecture steps (one in six

@@ -35,6 +35,21 @@ def next_seed():
 
 
 _plan_cache = {}
+_sinks_on = [True]
+
+
+class no_sinks:
+    """Context manager: inside it the backward kernels hand every parameter gradient to autograd as a tensor instead
+    of adding it straight into the flat gradient buffer.  Needed around `torch.autograd.grad(loss, params)`: a sink
+    gives autograd None for the parameter, which autograd.grad would report as an unused / zero gradient."""
+
+    def __enter__(self):
+        self._old = _sinks_on[0]
+        _sinks_on[0] = False
+
+    def __exit__(self, *a):
+        _sinks_on[0] = self._old
+
 
 
 def _grad_bufs(params, dev):
@@ -50,7 +65,7 @@ def _grad_bufs(params, dev):
             bufs.append(None); rets.append(None)
             continue
         s = getattr(t, '_mmnas_sink', None)
-        if s is not None and t.grad is s.view:
+        if s is not None and t.grad is s.view and _sinks_on[0]:
             bufs.append(s.view); rets.append(None); sinks.append(s)
         else:
             bufs.append(t); rets.append(t); fresh.append(len(bufs) - 1)
@@ -160,6 +175,9 @@ class AttentionOp(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.keep is None:
+            raise RuntimeError('AttentionOp: backward ran a second time -- the saved block is released after the first '
+                               'backward (retain_graph / double backward are not supported by the HIP operators)')
         lib = L.lib()
         op = ctx.op
         xq, xkv, m8, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, save, Wy, by = ctx.keep
@@ -195,6 +213,81 @@ def attention_op(xq, xkv, mask, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, ln_b, *, dh, 
         seed = next_seed() if (training and drop_p > 0) else 0
     return AttentionOp.apply(xq, xkv, mask, rel, Wq, Wk, Wv, Wm, Wr, br, ln_a, ln_b, rel_Wy, rel_by, dh, norm,
                              residual, float(drop_p), bool(training), seed, eps)
+
+
+class MhaCoreFn(torch.autograd.Function):
+    """MHAtt.att (modules.py:191-199) on already projected Q [B,Sq,di], K, V [B,Sk,di] (head h = columns
+    [h*dh, (h+1)*dh)): mmnas_mha_core_fwd/bwd.  biasT: [B,H,Sk,Sq] additive score bias (RelMHAtt) or None."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, mask, biasT, dh, drop_p, seed):
+        lib = L.lib()
+        Q, K, V = _f32c(Q), _f32c(K), _f32c(V)
+        B, Sq, di = Q.shape
+        Sk = K.shape[1]
+        H = di // dh
+        m8 = _mask_u8(mask, B, Sk)
+        biasT = _f32c(biasT) if biasT is not None else None
+        O = torch.empty_like(Q)
+        lse = torch.empty(B, H, Sq, 2, dtype=torch.float32, device=Q.device)
+        d = L.MhaDesc()
+        d.B, d.H, d.Sq, d.Sk, d.dh = B, H, Sq, Sk, dh
+        d.ldq = d.ldk = d.ldv = d.ldo = di
+        d.Q, d.K, d.V, d.mask, d.biasT = L.fptr(Q), L.fptr(K), L.fptr(V), L.ptr(m8), L.fptr(biasT)
+        d.O, d.lse = L.fptr(O), L.fptr(lse)
+        d.drop_p, d.drop_site, d.drop_seed = float(drop_p), 0, int(seed)
+        L.check(lib.mmnas_mha_core_fwd(C.byref(d), L.stream()))
+        ctx.desc = d
+        ctx.save_for_backward(Q, K, V, O, lse, m8, biasT)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        lib = L.lib()
+        Q, K, V, O, lse, m8, biasT = ctx.saved_tensors
+        d = ctx.desc
+        dO = _f32c(dO)
+        dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+        dbias = torch.empty_like(biasT) if (biasT is not None and ctx.needs_input_grad[4]) else None
+        delta = torch.empty(d.B, d.H, d.Sq, dtype=torch.float32, device=Q.device)
+        d.dO, d.dQ, d.dK, d.dV, d.dbiasT, d.delta = L.fptr(dO), L.fptr(dQ), L.fptr(dK), L.fptr(dV), L.fptr(dbias), L.fptr(delta)
+        L.check(lib.mmnas_mha_core_bwd(C.byref(d), L.stream()))
+        return dQ, dK, dV, None, dbias, None, None, None
+
+
+def mha_core(Q, K, V, mask, biasT, dh, drop_p=0.0, seed=0):
+    return MhaCoreFn.apply(Q, K, V, mask, biasT, int(dh), float(drop_p), int(seed))
+
+
+class RelBiasFn(torch.autograd.Function):
+    """biasT[b,h,k,q] = log(max(relu(rel[b,q,k,:] . Wr[h] + br[h]), 1e-6)) (modules.py:231-235) from a materialised
+    relation embedding rel [B,Sq,Sk,R]: mmnas_rel_bias_fwd/bwd."""
+
+    @staticmethod
+    def forward(ctx, rel, Wr, br):
+        rel, Wr, br = _f32c(rel), _f32c(Wr), _f32c(br)
+        B, Sq, Sk, R = rel.shape
+        H = Wr.shape[0]
+        out = torch.empty(B, H, Sk, Sq, dtype=torch.float32, device=rel.device)
+        L.check(L.lib().mmnas_rel_bias_fwd(L.fptr(rel), L.fptr(Wr), L.fptr(br), L.fptr(out), B, Sq, Sk, R, H, L.stream()))
+        ctx.save_for_backward(rel, Wr, br)
+        return out
+
+    @staticmethod
+    def backward(ctx, dbias):
+        rel, Wr, br = ctx.saved_tensors
+        B, Sq, Sk, R = rel.shape
+        H = Wr.shape[0]
+        dbias = _f32c(dbias)
+        drel = torch.empty_like(rel) if ctx.needs_input_grad[0] else None
+        dWr, dbr = torch.zeros_like(Wr), torch.zeros_like(br)
+        L.check(L.lib().mmnas_rel_bias_bwd(L.fptr(rel), L.fptr(Wr), L.fptr(br), L.fptr(dbias), L.fptr(drel), L.fptr(dWr),
+                                           L.fptr(dbr), 0, B, Sq, Sk, R, H, L.stream()))
+        return drel, dWr, dbr
+
+
+def rel_bias(rel, Wr, br):
+    return RelBiasFn.apply(rel, Wr, br)
 
 
 # ------------------------------------------------------------------------------------------
@@ -246,6 +339,9 @@ class MlpOp(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.keep is None:
+            raise RuntimeError('MlpOp: backward ran a second time -- the saved block is released after the first '
+                               'backward (retain_graph / double backward are not supported by the HIP operators)')
         lib = L.lib()
         op = ctx.op
         x, Ws, bs, ln_a, save = ctx.keep
@@ -690,6 +786,63 @@ class AttFlatPoolFn(torch.autograd.Function):
 
 def attflat_pool(logits, x, mask):
     return AttFlatPoolFn.apply(logits, x, mask)
+
+
+class MixedSumFn(torch.autograd.Function):
+    """out = sum_j gate[j] * o_j over the evaluated candidates of one supernet node (MixedOp.forward in modes 'full' /
+    'two', mixed.py:59-68).  Only the active candidate's output is differentiated; every gate gets its gradient
+    <dout, o_j>.  When the gate parameter's .grad is a row of the net's flat gate-gradient block (begin_arch_step) the
+    kernel adds straight into it and autograd receives None."""
+
+    @staticmethod
+    def forward(ctx, gate, o_active, active, n, idx, *detached):
+        lib = L.lib()
+        o_active = _f32c(o_active)
+        outs = [None] * n
+        outs[active] = o_active
+        for i, t in zip(idx, detached):
+            outs[i] = _f32c(t)
+        arr = (C.c_void_p * n)(*[L.fptr(t) for t in outs])
+        g = _f32c(gate.detach())
+        out = torch.empty_like(o_active)
+        L.check(lib.mmnas_mixed_sum_fwd(arr, n, L.fptr(g), L.fptr(out), out.numel(), L.stream()))
+        ctx.keep = (outs, g, arr)
+        ctx.gate_param, ctx.active, ctx.n, ctx.n_detached = gate, active, n, len(detached)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.keep is None:
+            raise RuntimeError('MixedSumFn: backward ran a second time (its buffers are released after the first)')
+        lib = L.lib()
+        outs, g, arr = ctx.keep
+        dout = _f32c(dout)
+        gate = ctx.gate_param
+        sink = getattr(gate, '_mmnas_gate_grad', None)
+        if sink is not None and gate.grad is sink:
+            dgate, ret = sink, None
+        else:
+            dgate = torch.zeros(ctx.n, dtype=torch.float32, device=dout.device)
+            ret = dgate
+        d_active = torch.empty_like(dout)
+        ws = torch.empty(lib.mmnas_mixed_sum_ws_floats(), dtype=torch.float32, device=dout.device)
+        L.check(lib.mmnas_mixed_sum_bwd(arr, ctx.n, L.fptr(g), L.fptr(dout), L.fptr(d_active), ctx.active, L.fptr(dgate),
+                                        L.fptr(ws), dout.numel(), L.stream()))
+        ctx.keep = None
+        return (ret, d_active, None, None, None) + (None,) * ctx.n_detached
+
+
+def mixed_sum(gate, outs, active):
+    """outs: list over the node's candidates (None = not evaluated); outs[active] carries the autograd graph."""
+    idx = tuple(i for i, t in enumerate(outs) if t is not None and i != active)
+    return MixedSumFn.apply(gate, outs[active], active, len(outs), idx, *[outs[i] for i in idx])
+
+
+def alpha_full_step(prob, gate_grad, m, v, prob_grad, lr, betas, eps, step):
+    """All nodes' architecture update in one launch (mmnas_alpha_full_step): prob/gate_grad/m/v [nodes, width]."""
+    L.check(L.lib().mmnas_alpha_full_step(L.fptr(prob), L.fptr(gate_grad), L.fptr(m), L.fptr(v), L.fptr(prob_grad),
+                                          prob.shape[0], prob.shape[1], float(lr), float(betas[0]), float(betas[1]),
+                                          float(eps), int(step), L.stream()))
 
 
 def row_is_zero(feature):

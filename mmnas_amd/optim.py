@@ -4,9 +4,15 @@ fp32 buffers, replacing `clip_grad_norm_` + `torch.optim.Adam` over ~230 small t
 (mmnas/utils/optimizer.py).
 
 Semantics kept from the reference stack:
-  * torch.optim.Adam arithmetic (bias correction with a PER-PARAMETER step count: a candidate operator
-    that was not sampled has grad None, is skipped and its moments do not decay -- the reason
-    `MixedOp.binarize` clears the candidates' grads, mixed.py:160-163);
+  * torch.optim.Adam arithmetic.  What happens to a parameter WITHOUT a gradient is selectable:
+      absent_grads='zero' (default) -- the reference loop's behaviour.  `MixedOp.binarize` clears the candidates'
+        grads (mixed.py:160-163), but the loop then adds `0 * sum(p.sum() for p in net_parameters())` to the loss
+        (search_vqa.py:285-288), so EVERY parameter -- unsampled candidates included -- reaches torch Adam with a
+        (zero) gradient at every step: its moments decay, it keeps moving on stale momentum, and there is one
+        global step count.  Here: one Adam launch over the whole flat buffer, absent gradients read as the zeros
+        the buffer holds.  Pinned by tests/golden/traj.npz (the reference loop itself).
+      absent_grads='skip' -- torch Adam's own rule for `grad is None` (the parameter is frozen, per-parameter step
+        counts): what the loop would do WITHOUT the `0 * sum` lines.  Kept as an option, not the default.
   * clip_grad_norm_ over the parameters that have a gradient: total norm in one device scalar, the
     scale min(1, max_norm / (norm + 1e-6)) applied inside the Adam kernel (no host round trip);
   * WarmupOptimizer's schedule: lr = base * {1/4, 2/4, 3/4, 1} over the first three epochs, `decay()`.
@@ -18,7 +24,10 @@ from .dp import FlatGrads
 
 
 class FlatAdam:
-    def __init__(self, params, lr=0.0, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.0, grads=None):
+    def __init__(self, params, lr=0.0, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.0, grads=None, absent_grads='zero'):
+        if absent_grads not in ('zero', 'skip'):
+            raise ValueError("absent_grads must be 'zero' or 'skip'")
+        self.absent_grads = absent_grads
         self.fg = grads if grads is not None else FlatGrads(list(params))
         self.params = self.fg.params
         dev = self.fg.flat.device
@@ -33,13 +42,21 @@ class FlatAdam:
             p.data = view
         self.m = torch.zeros_like(self.flat_p)
         self.v = torch.zeros_like(self.flat_p)
-        self.steps = [0] * len(self.params)
+        self.steps = [0] * len(self.params)   # per-parameter step counts ('skip' mode)
+        self.global_step = 0                  # 'zero' mode
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.param_groups = [{'lr': lr, 'params': self.params}]   # WarmupOptimizer writes param_groups[i]['lr']
 
     def zero_grad(self, set_to_none=True):
-        for p in self.params:
-            p.grad = None
+        """Zero the flat gradient buffer.  'zero' mode keeps every p.grad attached to its view (so the backward
+        kernels keep accumulating straight into the buffer and a data-parallel reducer armed before this call still
+        sees the gradients); 'skip' mode detaches them: there `grad is None` is the signal that freezes a parameter."""
+        self.fg.zero()
+        if self.absent_grads == 'zero':
+            self.fg.attach()
+        else:
+            for p in self.params:
+                p.grad = None
 
     def _live_runs(self):
         """Maximal runs of consecutive parameters that have a gradient and share a step count."""
@@ -61,8 +78,37 @@ class FlatAdam:
                 runs.append([o, end, self.steps[i], [i]])
         return runs
 
+    def _step_dense(self, max_norm):
+        """'zero' mode: Adam over the whole buffer in one launch, one global step."""
+        lib = L.lib()
+        st = L.stream()
+        lr = self.param_groups[0]['lr']
+        fg = self.fg
+        stale = []
+        for i, p in enumerate(self.params):
+            if p.grad is None:
+                if fg.dirty[i]:          # a view that held a gradient earlier and was then dropped: must read as zero
+                    stale.append(i)
+            else:
+                fg.adopt(i)
+        for i in stale:
+            fg.views[i].zero_()
+            fg.dirty[i] = False
+        n = fg.total
+        sumsq_ptr = None
+        if max_norm is not None and max_norm > 0:
+            self._sumsq.zero_()
+            L.check(lib.mmnas_sumsq(L.fptr(fg.flat), n, L.fptr(self._sumsq), st))
+            sumsq_ptr = L.fptr(self._sumsq)
+        self.global_step += 1
+        L.check(lib.mmnas_adam_step(L.fptr(self.flat_p), L.fptr(fg.flat), L.fptr(self.m), L.fptr(self.v), n, lr,
+                                    self.betas[0], self.betas[1], self.eps, self.weight_decay, sumsq_ptr,
+                                    float(max_norm or 0.0), self.global_step, st))
+
     @torch.no_grad()
     def step(self, max_norm=None):
+        if self.absent_grads == 'zero':
+            return self._step_dense(max_norm)
         lib = L.lib()
         st = L.stream()
         lr = self.param_groups[0]['lr']

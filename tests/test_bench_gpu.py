@@ -19,8 +19,8 @@ def _json_line(out):
     return json.loads(lines[0])
 
 
-def _check(d, world):
-    assert d['n_gpus'] == world and d['steps'] == 2 and d['warmup'] == 1
+def _check(d, world, steps=2, warmup=1):
+    assert d['n_gpus'] == world and d['steps'] == steps and d['warmup'] == warmup
     assert d['unit'] == 'steps/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
     assert d['value'] > 0 and abs(d['value'] - world * 1000.0 / d['ms_per_step']) < 1e-6 * d['value']
     assert d['final_loss'] == d['final_loss'] and abs(d['final_loss']) < 1e9
@@ -29,15 +29,55 @@ def _check(d, world):
     assert r['bound'] == 'mfma' and 0 < r['frac'] < 1 and r['unit'] == 'TFLOP/s' and r['achieved'] > 0
 
 
-@pytest.mark.parametrize('workload', ['train_vqa', 'search_vqa'])
+@pytest.mark.parametrize('workload', ['train_vqa', 'search_vqa', 'arch_vqa'])
 def test_bench_single_gpu(workload):
     p = subprocess.run([sys.executable, 'bench.py', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--workload', workload],
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
-    _check(_json_line(p.stdout), 1)
+    d = _json_line(p.stdout)
+    _check(d, 1)
+    assert ('supernet' in d['metric']) == (workload != 'train_vqa')   # the label follows the workload
 
 
-@pytest.mark.parametrize('workload', ['train_vqa', 'search_vqa'])
+def test_bench_default_line_is_the_supernet_weight_step_with_sub_records():
+    """The driver's command (no --workload): headline = the BASELINE metric's workload, the other three under `sub`,
+    every record with its own roofline and CPU baseline."""
+    p = subprocess.run([sys.executable, 'bench.py', '--steps', '6', '--warmup', '1', '--cpu-budget', '3'],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _json_line(p.stdout)
+    _check(d, 1, steps=6)
+    assert d['metric'].startswith('supernet fwd+bwd steps/sec') and 'WEIGHT step' in d['config']['workload']
+    assert set(d['sub']) == {'arch_step', 'bilevel', 'train_vqa'}
+    for r in [d] + list(d['sub'].values()):
+        assert r['value'] > 0 and 0 < r['roofline']['frac'] < 1
+        cb = r['cpu_baseline']
+        assert cb['kind'] == 'port' and cb['value'] > 0 and cb['cores'] >= 1 and cb['unit'] == 'steps/s'
+    assert d['sub']['bilevel']['steps'] == 6
+
+
+def test_bench_gpus_flag_must_match_the_launch():
+    """--gpus N under a launcher that started a different number of ranks is refused, never mislabelled."""
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    p = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-cpu-baseline',
+                        '--workload', 'search_vqa'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and 'WORLD_SIZE' in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith('{')]
+
+
+def test_bench_gpus_flag_self_spawns_ranks():
+    """--gpus 2 without a launcher starts the two ranks itself (here both on the one GPU, gloo transport)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(MMNAS_BENCH_BACKEND='gloo', MMNAS_BENCH_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+                        '--workload', 'search_vqa'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    d = _json_line(p.stdout)
+    _check(d, 2)
+    assert d['config']['rccl_ranks'] == 2
+
+
+@pytest.mark.parametrize('workload', ['train_vqa', 'search_vqa', 'bilevel_vqa'])
 def test_bench_two_ranks_one_gpu(workload):
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -50,5 +90,8 @@ def test_bench_two_ranks_one_gpu(workload):
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     d = _json_line(p.stdout)
-    _check(d, 2)
+    if workload == 'bilevel_vqa':
+        _check(d, 2, steps=6, warmup=6)
+    else:
+        _check(d, 2)
     assert d['config']['parallelism'] == 'dp2' and d['config']['grad_allreduce'] == 'gloo'

@@ -112,12 +112,140 @@ def _w_supernet_reducer(rank):
     assert not dp.check_same_architecture(net)
 
 
+def _w_zero_grad_between_begin_and_backward(rank):
+    """The reference's order (search_vqa.py:290: net.zero_grad() right before loss.backward()): the views attached by
+    begin_step() are dropped, autograd allocates fresh gradient tensors -- they must be adopted into the flat buffer
+    before the all-reduce, not silently left out of it."""
+    from mmnas_amd import dp
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 300), torch.nn.ReLU(), torch.nn.Linear(300, 40), torch.nn.Linear(40, 7))
+    dp.broadcast_parameters(net)
+    red = dp.GradReducer(list(net.parameters()), bucket_mb=0.02)
+    x = torch.randn(5, 16, generator=torch.Generator().manual_seed(10 + rank))
+    red.begin_step()
+    net.zero_grad()                                     # set_to_none=True: every p.grad is None now
+    net(x).pow(2).sum().backward()
+    assert any(red._launched)                           # buckets still go out from the backward thread
+    red.finish()
+    ref = torch.nn.Sequential(torch.nn.Linear(16, 300), torch.nn.ReLU(), torch.nn.Linear(300, 40), torch.nn.Linear(40, 7))
+    ref.load_state_dict(net.state_dict())
+    grads = []
+    for r in range(WORLD):
+        xr = torch.randn(5, 16, generator=torch.Generator().manual_seed(10 + r))
+        ref.zero_grad()
+        ref(xr).pow(2).sum().backward()
+        grads.append([p.grad.clone() for p in ref.parameters()])
+    for i, p in enumerate(net.parameters()):
+        want = sum(g[i] for g in grads) / WORLD
+        assert torch.allclose(p.grad, want, rtol=1e-5, atol=1e-6), i
+        assert p.grad.data_ptr() == red.fg.views[i].data_ptr()
+
+
+class _FakeNode(torch.nn.Module):
+    def __init__(self, d, n):
+        super().__init__()
+        self.candidate_ops = torch.nn.ModuleList([torch.nn.Linear(d, d) for _ in range(n)])
+        self.alpha_prob = torch.nn.Parameter(torch.zeros(n))
+        self.alpha_gate = torch.nn.Parameter(torch.zeros(n))
+        self.n_choices = n
+        self.active_index, self.inactive_index = [0], list(range(1, n))
+
+    def forward(self, x):
+        return x + torch.tanh(self.candidate_ops[self.active_index[0]](x))
+
+
+class _FakeSupernet(torch.nn.Module):
+    """A torch-only stand-in with the surface SupernetReducer reads (redundant_modules, net_parameters, the head's
+    attribute names): the real Net_Search only runs on the GPU."""
+
+    def __init__(self, d=24, nodes=6):
+        super().__init__()
+        self.imgfeat_linear = torch.nn.Linear(10, d)                  # stem
+        self.backnone = torch.nn.ModuleList([_FakeNode(d, 2 + (i % 3)) for i in range(nodes)])
+        self.proj_norm = torch.nn.LayerNorm(d)                        # head
+        self.proj = torch.nn.Linear(d, 5)
+        self.linear_y_rel = torch.nn.Linear(4, 8)                     # stem parameter that gets no gradient here
+
+    @property
+    def redundant_modules(self):
+        return list(self.backnone)
+
+    def net_parameters(self):
+        return [p for n, p in self.named_parameters() if 'alpha' not in n]
+
+    def forward(self, x):
+        h = self.imgfeat_linear(x)
+        for node in self.backnone:
+            h = node(h)
+        return self.proj(self.proj_norm(h))
+
+
+def _w_supernet_reducer_overlapped_buckets(rank):
+    from mmnas_amd import dp
+    torch.manual_seed(5)
+    net = _FakeSupernet()
+    dp.broadcast_parameters(net)
+    red = dp.SupernetReducer(net, n_buckets=3)
+    assert red.comm and red.n_buckets == 3
+    assert sorted(k for b in red.bucket_nodes for k in b) == list(range(6))
+    assert 5 in red.bucket_nodes[0] and 0 in red.bucket_nodes[2]      # backward order: last node first
+    ref = _FakeSupernet()
+    ref.load_state_dict(net.state_dict())
+    for step in range(3):
+        for k, (m, mr) in enumerate(zip(net.redundant_modules, ref.redundant_modules)):
+            a = (step + k) % m.n_choices                              # same sample on both ranks
+            m.active_index = mr.active_index = [a]
+            m.inactive_index = mr.inactive_index = [i for i in range(m.n_choices) if i != a]
+        red.begin_weight_step()
+        if step == 2:
+            net.zero_grad()                                           # the reference's order: adopt the strays
+        x = torch.randn(7, 10, generator=torch.Generator().manual_seed(100 * step + rank))
+        net(x).pow(2).sum().backward()
+        launched_early = list(red._launched)
+        red.finish_weight_step()
+        assert launched_early[0] and not launched_early[2]            # head bucket left during backward, the stem's at the end
+        grads = []
+        for r in range(WORLD):
+            xr = torch.randn(7, 10, generator=torch.Generator().manual_seed(100 * step + r))
+            ref.zero_grad()
+            ref(xr).pow(2).sum().backward()
+            grads.append({n: (p.grad.clone() if p.grad is not None else None) for n, p in ref.named_parameters()})
+        for n, p in net.named_parameters():
+            if 'alpha' in n:
+                continue
+            if grads[0][n] is None:
+                assert p.grad is None or not torch.any(p.grad != 0), n
+                continue
+            want = sum(g[n] for g in grads) / WORLD
+            assert p.grad is not None and torch.allclose(p.grad, want, rtol=1e-5, atol=1e-6), (step, n)
+    # arch step: gate gradients in the flat block travel in place
+    block = torch.zeros(6, 4)
+    net._flat_grads = (block, torch.zeros(6, 4))
+    for i, m in enumerate(net.redundant_modules):
+        row = block[i, :m.n_choices]
+        row.fill_(float(rank + i))
+        m.alpha_gate.grad = row
+        m.alpha_gate._mmnas_gate_grad = row
+    red.reduce_alpha_gate_grads()
+    for i, m in enumerate(net.redundant_modules):
+        assert torch.allclose(m.alpha_gate.grad, torch.full((m.n_choices,), 0.5 + i))
+        assert m.alpha_gate.grad.data_ptr() == block[i].data_ptr()
+
+
 def test_grad_reducer_buckets_overlap_and_average():
     _run('_w_grad_reducer', _free_port())
 
 
 def test_supernet_reducer_sampled_segments_and_alpha():
     _run('_w_supernet_reducer', _free_port())
+
+
+def test_zero_grad_between_begin_step_and_backward():
+    _run('_w_zero_grad_between_begin_and_backward', _free_port())
+
+
+def test_supernet_reducer_overlapped_buckets_real_backward():
+    _run('_w_supernet_reducer_overlapped_buckets', _free_port())
 
 
 def test_single_process_is_a_noop():

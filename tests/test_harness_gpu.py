@@ -1,0 +1,248 @@
+"""The step harness on the GPU against goldens made by the reference's own loop / losses:
+  * capture (v) (tests/golden/traj.npz): two clip+Adam weight steps and one 'full' arch step with injected samples,
+    replayed through SearchLoop = SupernetReducer + FlatAdam(absent_grads='zero') + WarmupOptimizer + ArchAdam;
+  * the ITM triplet step with BCE_Loss and the VGD loss (tests/golden/losses.npz);
+  * the kernels under them (gated sum of a MixedOp, fused alpha update, dense Adam) against torch."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import cases
+from tests.util import TOL, load, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+T = torch.from_numpy
+
+
+def _build(cls, c):
+    init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+            'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
+    net = cls(c['cfg'], init)
+    net.load_state_dict({k: T(v) for k, v in c['P'].items()})
+    return net.to(DEV).train()
+
+
+def _plan_list(plan):
+    return plan['enc'] + plan['dec']
+
+
+def test_bilevel_trajectory_vs_reference_loop():
+    from mmnas.model.hygr_vqa import Net_Search
+    from mmnas_amd.harness import SearchLoop
+    from tests.test_oracle_golden2 import check_trajectory
+    c, c2, plans = cases.traj_setup()
+    H = cases.TRAJ_HYPER
+    net = _build(Net_Search, c)
+    loop = SearchLoop(net, net_lr=H['net_lr'], net_betas=H['net_betas'], net_eps=H['net_eps'], clip=H['clip'],
+                      epoch_steps=H['epoch_steps'], warmup=True, alpha_lr=H['alpha_lr'], alpha_betas=H['alpha_betas'])
+    try:
+        inp = tuple(T(a).to(DEV) for a in c['inputs']); tgt = T(c['target']).to(DEV)
+        inp2 = tuple(T(a).to(DEV) for a in c2['inputs']); tgt2 = T(c2['target']).to(DEV)
+        net_keys = [k for k, _ in net.named_parameters() if 'alpha' not in k]
+        named = dict(net.named_parameters())
+        res = {'losses': [], 'gnorms': [], 'snap': {}, 'P0': {k: T(c['P'][k]) for k in net_keys}}
+
+        def snap(tag):
+            res['snap'][tag] = {k: named[k].detach().cpu().clone() for k in net_keys}
+
+        for i in (0, 1):
+            loss = loop.weight_step(inp, tgt, plan=_plan_list(plans[i]))
+            res['losses'].append(float(loss.detach()))
+            res['gnorms'].append(loop.net_optim.optimizer.grad_norm())
+            snap('w%d' % (i + 1))
+        loss = loop.arch_step(inp2, tgt2, plan=_plan_list(plans[2]))
+        res['losses'].append(float(loss.detach()))
+        gg, pg = net._flat_grads
+        res['gate_grads'] = gg.cpu().numpy()
+        res['prob_grads'] = pg.cpu().numpy()
+        res['alpha_after'] = np.stack([np.pad(m.alpha_prob.detach().cpu().numpy(), (0, 4 - m.n_choices))
+                                       for m in net.redundant_modules])
+        snap('a')
+        loss = loop.weight_step(inp, tgt, optimize=False, plan=_plan_list(plans[3]))
+        res['losses'].append(float(loss.detach()))
+        assert loop.net_optim._step == 2 and abs(loop.net_optim._rate - load('traj.npz')['traj|lr'][1]) < 1e-12
+        check_trajectory(res)
+    finally:
+        loop.reducer.fg.disable_sinks()
+
+
+def test_arch_step_fused_path_matches_per_module_path():
+    """SearchLoop.arch_step (gated-sum kernel + gate-gradient block + fused alpha Adam) against the reference-shaped
+    per-module sequence on the same net: MixedOp.set_arch_param_grad + torch.optim.Adam."""
+    from mmnas.model.hygr_vqa import Net_Search
+    from mmnas.model.mixed import MixedOp
+    from mmnas_amd.harness import SearchLoop
+    c = cases.net_case('vqa', None, 4141, search=True)
+    plan = _plan_list(cases.search_plan(np.random.RandomState(5), 'full'))
+    inp = tuple(T(a).to(DEV) for a in c['inputs']); tgt = T(c['target']).to(DEV)
+    loss_fn = torch.nn.BCEWithLogitsLoss(reduction='sum')
+    # (a) per-module path, plain autograd gate gradients
+    net = _build(Net_Search, c)
+    opt = torch.optim.Adam(list(net.alpha_prob_parameters()), 0.1, betas=(0.0, 0.999))
+    MixedOp.MODE = 'full'
+    try:
+        net.set_sampled(plan)
+        loss_a = loss_fn(net(inp), tgt)
+        net.zero_grad()
+        loss_a.backward()
+        gate_a = np.stack([np.pad(m.alpha_gate.grad.cpu().numpy(), (0, 4 - m.n_choices)) for m in net.redundant_modules])
+        net.set_arch_param_grad()
+        opt.step()
+        alpha_a = np.stack([np.pad(m.alpha_prob.detach().cpu().numpy(), (0, 4 - m.n_choices)) for m in net.redundant_modules])
+    finally:
+        MixedOp.MODE = None
+    # (b) fused path
+    net2 = _build(Net_Search, c)
+    loop = SearchLoop(net2)
+    try:
+        loss_b = loop.arch_step(inp, tgt, plan=plan)
+        gg, _ = net2._flat_grads
+        alpha_b = np.stack([np.pad(m.alpha_prob.detach().cpu().numpy(), (0, 4 - m.n_choices)) for m in net2.redundant_modules])
+        assert abs(float(loss_a) - float(loss_b)) < 1e-5 * abs(float(loss_a))
+        assert rel_err(gg.cpu().numpy(), gate_a) < 1e-4
+        assert rel_err(alpha_b, alpha_a) < 1e-4
+        # the sampling cache sees the update
+        p1 = net2._probs_cpu(net2._flat_alphas()[0]).numpy()
+        assert rel_err(p1[12:], torch.softmax(T(alpha_b[12:]), 1).numpy()) < 1e-5
+    finally:
+        loop.reducer.fg.disable_sinks()
+
+
+def test_mixed_sum_kernels_vs_torch():
+    from mmnas_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for n, shape, active in ((4, (64, 100, 256), 2), (2, (3, 14, 64), 0), (4, (5, 7, 36), 3)):
+        outs = [torch.randn(shape, generator=g).to(DEV) for _ in range(n)]
+        gate = torch.randn(n, generator=g).to(DEV).requires_grad_(True)
+        a = outs[active].clone().requires_grad_(True)
+        lst = list(outs); lst[active] = a
+        if n == 4:
+            lst[(active + 1) % n] = None                  # a candidate that takes no part (mode 'two')
+        y = ops.mixed_sum(gate, lst, active)
+        dout = torch.randn(shape, generator=g).to(DEV)
+        y.backward(dout)
+        gate64 = gate.detach().double()
+        want = sum(gate64[j] * (lst[j].detach().double()) for j in range(n) if lst[j] is not None)
+        assert rel_err(y.detach().cpu().numpy(), want.cpu().numpy()) < 1e-6
+        wg = torch.stack([(dout.double() * lst[j].detach().double()).sum() if lst[j] is not None else torch.zeros((), dtype=torch.float64, device=DEV)
+                          for j in range(n)])
+        assert rel_err(gate.grad.cpu().numpy(), wg.cpu().numpy()) < 1e-5
+        assert rel_err(a.grad.cpu().numpy(), (gate64[active] * dout.double()).cpu().numpy()) < 1e-6
+
+
+def test_alpha_full_step_kernel_vs_torch_adam():
+    from mmnas_amd import ops
+    g = torch.Generator().manual_seed(9)
+    rows, width = 30, 4
+    a = torch.randn(rows, width, generator=g)
+    a[:12, 2:] = float('-inf')                          # encoder nodes have two candidates
+    prob = a.clone().to(DEV)
+    m = torch.zeros_like(prob); v = torch.zeros_like(prob); pg = torch.zeros_like(prob)
+    ps = [torch.nn.Parameter(a[i, :(2 if i < 12 else 4)].clone().double()) for i in range(rows)]
+    opt = torch.optim.Adam(ps, 0.1, betas=(0.0, 0.999))
+    for step in (1, 2, 3):
+        gg = torch.randn(rows, width, generator=g)
+        gg[:12, 2:] = 0
+        for i, p in enumerate(ps):
+            gi = gg[i, :p.numel()].double()
+            pr = torch.softmax(p.detach(), 0)
+            p.grad = pr * (gi - (gi * pr).sum())
+        opt.step()
+        ops.alpha_full_step(prob, gg.to(DEV), m, v, pg, 0.1, (0.0, 0.999), 1e-8, step)
+        for i, p in enumerate(ps):
+            n = p.numel()
+            assert rel_err(pg[i, :n].cpu().numpy(), p.grad.numpy()) < 1e-5
+            assert rel_err(prob[i, :n].cpu().numpy(), p.detach().numpy()) < 1e-5
+            assert bool(torch.all(torch.isinf(prob[i, n:]))), 'padding columns must stay -inf'
+
+
+def test_flat_adam_dense_mode_is_torch_adam_with_zero_gradients():
+    """absent_grads='zero': what the reference loop amounts to (search_vqa.py:285-300) -- parameters without a gradient
+    are stepped with a zero gradient, one global step count; 'skip' mode freezes them."""
+    from mmnas_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(1)
+    shapes = [(33, 17), (5,), (64, 64), (7, 3)]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    for mode in ('zero', 'skip'):
+        ps = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+        ref = [torch.nn.Parameter(t.clone().double()) for t in init]
+        opt = FlatAdam(ps, lr=1e-2, betas=(0.9, 0.98), eps=1e-9, absent_grads=mode)
+        ropt = torch.optim.Adam(ref, lr=1e-2, betas=(0.9, 0.98), eps=1e-9)
+        for step in range(4):
+            live = [0, 1, 2, 3] if step == 0 else ([0, 2] if step % 2 else [1, 2, 3])
+            opt.zero_grad()
+            grads = {i: torch.randn(shapes[i], generator=g) for i in live}
+            for i in range(4):
+                if i in grads:
+                    if ps[i].grad is None:
+                        ps[i].grad = grads[i].to(DEV)                 # a stray gradient outside the flat buffer
+                    else:
+                        ps[i].grad.copy_(grads[i].to(DEV))
+                    ref[i].grad = grads[i].double()
+                else:
+                    ps[i].grad = None
+                    ref[i].grad = torch.zeros_like(ref[i]) if mode == 'zero' else None
+            tot = torch.sqrt(sum((gr.double() ** 2).sum() for gr in grads.values()))
+            coef = min(1.0, 0.5 / (float(tot) + 1e-6))
+            for i in live:
+                ref[i].grad.mul_(coef)
+            opt.step(max_norm=0.5)
+            ropt.step()
+            assert abs(opt.grad_norm() - float(tot)) < 1e-4 * float(tot)
+            for i in range(4):
+                assert rel_err(ps[i].detach().cpu().numpy(), ref[i].detach().numpy()) < 2e-5, (mode, step, i)
+
+
+def test_itm_triplet_step_vs_reference():
+    from mmnas.model.full_itm import Net_Full
+    from mmnas.utils.itm_loss import BCE_Loss
+    from mmnas_amd.harness import itm_triplet_step
+    npz = load('losses.npz')
+    c = cases.net_case('itm', 'mmnas_itm', 9201)
+    neg = cases.net_case('itm', 'mmnas_itm', 9202)
+    net = _build(Net_Full, c)
+    pos = tuple(T(a).to(DEV) for a in c['inputs']); ng = tuple(T(a).to(DEV) for a in neg['inputs'])
+    loss = itm_triplet_step(net, BCE_Loss(), pos, ng)
+    assert abs(float(loss) - float(npz['itm|loss'])) < TOL * float(npz['itm|loss'])
+    sp = net(pos)
+    assert rel_err(sp.detach().cpu().numpy(), npz['itm|scores'][0]) < TOL
+    keys = [str(k) for k in npz['itm|gradnorm_keys']]
+    named = dict(net.named_parameters())
+    top = float(np.max(npz['itm|gradnorms']))
+    for k, n in zip(keys, npz['itm|gradnorms']):
+        mine = 0.0 if named[k].grad is None else float(named[k].grad.double().norm())
+        assert abs(mine - n) <= 2e-3 * n + 1e-5 * top, (k, mine, n)
+    assert rel_err(named['proj.weight'].grad.cpu().numpy(), npz['itm|g:proj.weight']) < TOL
+
+
+def test_vgd_loss_vs_reference():
+    from mmnas.model.full_vgd import Net_Full
+    from mmnas_amd.harness import vgd_loss
+    npz = load('losses.npz')
+    c = cases.net_case('vgd', 'mmnas_vgd', 9203)
+    t = {k: T(v).to(DEV) for k, v in cases.vgd_targets(c, 9204).items()}
+    net = _build(Net_Full, c)
+    ps, pr = net(tuple(T(a).to(DEV) for a in c['inputs']))
+    loss = vgd_loss(ps, pr, t['scores'], t['scores_mask'], t['bbox'], t['bbox_mask'])
+    loss.backward()
+    assert rel_err(ps.detach().cpu().numpy(), npz['vgd|pred_scores']) < TOL
+    assert rel_err(pr.detach().cpu().numpy(), npz['vgd|pred_reg']) < TOL
+    assert abs(float(loss) - float(npz['vgd|loss_parts'][2])) < TOL * abs(float(npz['vgd|loss_parts'][2]))
+    keys = [str(k) for k in npz['vgd|gradnorm_keys']]
+    named = dict(net.named_parameters())
+    top = float(np.max(npz['vgd|gradnorms']))
+    for k, n in zip(keys, npz['vgd|gradnorms']):
+        mine = 0.0 if named[k].grad is None else float(named[k].grad.double().norm())
+        assert abs(mine - n) <= 2e-3 * n + 1e-5 * top, (k, mine, n)
+
+
+def test_operator_backward_twice_raises_a_clear_error():
+    from mmnas.utils.ops_adapter import OpsAdapter
+    cfg = cases.small_cfg(HSIZE=128)
+    op = OpsAdapter().OPS['feed_forward'](cfg, norm=True, residual=True).to(DEV)
+    x = torch.randn(2, 5, 128, device=DEV, requires_grad=True)
+    y = op(x, None, None, None, None).sum()
+    y.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match='second time'):
+        y.backward()

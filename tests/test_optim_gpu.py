@@ -13,14 +13,14 @@ T = torch.from_numpy
 
 def test_flat_adam_matches_torch_adam_with_clipping_and_skipped_params():
     """FlatAdam == clip_grad_norm_ + torch.optim.Adam (search_vqa.py:296-300), including a parameter whose
-    gradient is None on some steps (unsampled candidate: skipped, its moments and step count frozen)."""
+    gradient is None on some steps (absent_grads='skip': the parameter is frozen, its moments and step count too)."""
     from mmnas_amd.optim import FlatAdam, WarmupOptimizer
     rs = np.random.RandomState(0)
     shapes = [(64, 33), (7,), (128, 128), (5, 3, 2)]
     init = [rs.standard_normal(s).astype(np.float32) for s in shapes]
     mine = [torch.nn.Parameter(T(a.copy()).to(DEV)) for a in init]
     ref = [torch.nn.Parameter(T(a.copy())) for a in init]
-    opt = WarmupOptimizer(4e-4, FlatAdam(mine, lr=0, betas=(0.9, 0.98), eps=1e-9), epoch_steps=2, warmup=True, max_norm=1.0)
+    opt = WarmupOptimizer(4e-4, FlatAdam(mine, lr=0, betas=(0.9, 0.98), eps=1e-9, absent_grads='skip'), epoch_steps=2, warmup=True, max_norm=1.0)
     ropt = torch.optim.Adam(ref, lr=0, betas=(0.9, 0.98), eps=1e-9)
     fg = opt.optimizer.fg
     for step in range(6):
@@ -101,7 +101,7 @@ def test_supernet_step_with_reducer_and_fused_optimizer():
             'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
     net = Net_Search(c['cfg'], init).to(DEV).train()
     red = dp.SupernetReducer(net)
-    net_optim = WarmupOptimizer(4e-4, FlatAdam(red.fg.params, betas=(0.9, 0.98), eps=1e-9, grads=red.fg), 10, True, max_norm=1.0)
+    net_optim = WarmupOptimizer(4e-4, FlatAdam(red.fg.params, betas=(0.9, 0.98), eps=1e-9, grads=red.fg, absent_grads='skip'), 10, True, max_norm=1.0)
     alpha_optim = torch.optim.Adam(list(net.alpha_prob_parameters()), 0.1, betas=(0.0, 0.999))
     inp = tuple(T(a).to(DEV) for a in c['inputs'])
     tgt = T(c['target']).to(DEV)
