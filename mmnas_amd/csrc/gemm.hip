@@ -195,9 +195,13 @@ struct GemmShape {
 
 // The work of workgroup `bid` of `nwg` on problem p (the kernel's own blockIdx / gridDim, or its position inside one
 // section of a two-section launch); `koff` = byte offset of p inside the kernel-argument segment.
-template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0>
+// PF: K-tiles of operand loads kept in flight ahead of the MFMA block (1: the tile after the current one; 2: two tiles,
+// a second register stage -- the products of the d = 256 supernet have 8 K-tiles and 1-2 resident workgroups per CU, so
+// with one tile in flight every iteration waits out a full L2 / Infinity-Cache round trip, ~2x its 0.43 us of MFMA).
+template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1>
 __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const int nwg, const int koff,
                                           float* __restrict__ As, float* __restrict__ Bs, int& s_old) {
+  static_assert(PF == 1 || (PF == 2 && FAST && NS == 0), "the two-stage prefetch exists for the fp32 buffer-load path");
   static_assert(NS == 0 || (FAST && BK == 32), "the bf16-split path exists for the buffer-load path only");
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   // split rows: NS parts of 32 bf16 (64 B) + 16 B pad -> 144 / 208 B, an odd number of 16-B words (conflict-free b128)
@@ -305,6 +309,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[NA], rb[NB];
+    float4 ra2[NA], rb2[NB];   // second register stage (PF == 2; dead otherwise)
 
     // FAST path: per-thread byte offsets of its loads inside the operand (k = 0), ~0u when the row is
     // outside the matrix (the buffer range check then returns zeros)
@@ -346,7 +351,9 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
       bytesb = (unsigned)(BKC ? p.N : p.K) * (unsigned)p.ldb * 4u;
     }
 
-    auto gload = [&](int q) {  // unit q of the tile: segment q / ntk, K-tile q % ntk
+    // unit q of the tile: segment q / ntk, K-tile q % ntk; `live` false (FAST path only): every offset is put out of
+    // range, the buffer bounds check answers with zeros and no memory request is made -- a branch-free "no load"
+    auto gload_to = [&](int q, bool live, float4 (&ra)[NA], float4 (&rb)[NB]) {
       const int seg = q / p.ntk;
       const int kt = q - seg * p.ntk;
       const float* __restrict__ Ap = seg == 0 ? Aseg[0] : (seg == 1 ? Aseg[1] : Aseg[2]);
@@ -356,9 +363,9 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, bytesb, 0x00020000);
         const unsigned ka = (unsigned)kt * stepa, kb = (unsigned)kt * stepb;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = buf_load4(ra_src, offa[i] == ~0u ? ~0u : offa[i] + ka);
+        for (int i = 0; i < NA; ++i) ra[i] = buf_load4(ra_src, (offa[i] == ~0u || !live) ? ~0u : offa[i] + ka);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = buf_load4(rb_src, offb[i] == ~0u ? ~0u : offb[i] + kb);
+        for (int i = 0; i < NB; ++i) rb[i] = buf_load4(rb_src, (offb[i] == ~0u || !live) ? ~0u : offb[i] + kb);
         return;
       }
       const int k0 = kt * BK, kend = p.K;
@@ -429,8 +436,9 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         rb[i] = v4;
       }
     };
+    auto gload = [&](int q) { gload_to(q, true, ra, rb); };
 
-    auto lstore = [&](int buf) {
+    auto lstore_from = [&](int buf, const float4 (&ra)[NA], const float4 (&rb)[NB]) {
       float* a = As + buf * A_SZ;
       float* b = Bs + buf * B_SZ;
       if (NS) {
@@ -475,14 +483,9 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         }
       }
     };
+    auto lstore = [&](int buf) { lstore_from(buf, ra, rb); };
 
-    gload(q0);
-    lstore(0);
-    __syncthreads();
-
-    for (int t = 0; t < nq; ++t) {
-      const int buf = t & 1;
-      if (t + 1 < nq) gload(q0 + t + 1);  // in flight during the MFMA block
+    auto mfma_block = [&](int buf) {
       const float* a = As + buf * A_SZ;
       const float* b = Bs + buf * B_SZ;
       if (NS) {
@@ -543,8 +546,38 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[i][w], bf[j][w], acc[i][j]);
       }
-      if (t + 1 < nq) lstore(buf ^ 1);
+    };
+
+    if (PF == 2) {
+      // two register stages: while tile t is multiplied out of LDS, tile t+1 sits in (or is arriving into) one stage
+      // and the loads of tile t+2 are issued into the other; the loop is unrolled by two so the stages are static
+      gload_to(q0, true, ra, rb);
+      gload_to(q0 + 1, nq > 1, ra2, rb2);
+      lstore_from(0, ra, rb);
       __syncthreads();
+      for (int t = 0; t < nq; t += 2) {
+        gload_to(q0 + t + 2, t + 2 < nq, ra, rb);
+        mfma_block(0);
+        if (t + 1 >= nq) break;
+        lstore_from(1, ra2, rb2);
+        __syncthreads();
+        gload_to(q0 + t + 3, t + 3 < nq, ra2, rb2);
+        mfma_block(1);
+        if (t + 2 < nq) lstore_from(0, ra, rb);
+        __syncthreads();
+      }
+      __syncthreads();
+    } else {
+      gload(q0);
+      lstore(0);
+      __syncthreads();
+      for (int t = 0; t < nq; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nq) gload(q0 + t + 1);  // in flight during the MFMA block
+        mfma_block(buf);
+        if (t + 1 < nq) lstore(buf ^ 1);
+        __syncthreads();
+      }
     }
 
     // ---- partial tile: hand the accumulators over; the last contributor to arrive finishes the tile ----
@@ -732,12 +765,12 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
   }
 }
 
-template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0>
+template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1>
 __global__ void __launch_bounds__(256, NS == 3 ? (BM == 128 ? 1 : 3) : (BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64)) gemm_kernel(const GemmK p) {
   __shared__ __attribute__((aligned(16))) float As[2 * GemmShape<BM, BN, NS>::A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[2 * GemmShape<BM, BN, NS>::B_SZ];
   __shared__ int s_old;
-  gemm_body<BM, BN, AKC, BKC, FAST, NS, EPI>(p, blockIdx.x, gridDim.x, 0, As, Bs, s_old);
+  gemm_body<BM, BN, AKC, BKC, FAST, NS, EPI, PF>(p, blockIdx.x, gridDim.x, 0, As, Bs, s_old);
 }
 
 // Two independent problems in ONE launch: the data gradient (NN) and the weight gradient (TN) of a linear layer.
@@ -784,7 +817,7 @@ __device__ __forceinline__ void aux_reduce_body(const AuxReduceK& a, int job, fl
   }
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, int PF = 1>
 __global__ void __launch_bounds__(256, NS == 3 ? 3 : MMNAS_OCC64) gemm_pair_kernel(const GemmK q0, const GemmK q1, const int nwg0,
                                                                                     const int nwg0p, const AuxReduceK aux,
                                                                                     const int naux8) {
@@ -798,9 +831,9 @@ __global__ void __launch_bounds__(256, NS == 3 ? 3 : MMNAS_OCC64) gemm_pair_kern
   }
   bid -= naux8;
   if (bid < nwg0p) {
-    if (bid < nwg0) gemm_body<BM, BN, true, false, true, NS>(q0, bid, nwg0, 0, As, Bs, s_old);
+    if (bid < nwg0) gemm_body<BM, BN, true, false, true, NS, 0, PF>(q0, bid, nwg0, 0, As, Bs, s_old);
   } else {
-    gemm_body<BM, BN, false, false, true, NS>(q1, bid - nwg0p, (int)gridDim.x - naux8 - nwg0p, (int)sizeof(GemmK), As, Bs, s_old);
+    gemm_body<BM, BN, false, false, true, NS, 0, PF>(q1, bid - nwg0p, (int)gridDim.x - naux8 - nwg0p, (int)sizeof(GemmK), As, Bs, s_old);
   }
 }
 
@@ -819,8 +852,9 @@ static int env_int(const char* name, int dflt) {
 //   MMNAS_GEMM_GM=n        row-panels per tile-order block (default 8)     MMNAS_GEMM_XCD=0 identity workgroup mapping
 //   MMNAS_GEMM_SPLIT=0|3|6 products on the fp32 MFMA (default) / as 3 / 6 bf16 MFMA products of split operands
 //   MMNAS_GEMM_PAIR=0      mmnas_gemm_pair launches its two products separately
-struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split, pair, split_slots, split_p; bool loaded; };
-static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 0, 1, 0, 24, false};
+//   MMNAS_GEMM_PF=1|2      K-tiles of operand loads in flight ahead of the MFMA block (64^2 fp32 buffer-load path)
+struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split, pair, split_slots, split_p, pf; bool loaded; };
+static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 0, 1, 0, 24, 2, false};
 static void load_tuning() {
   g_tune.tile = env_int("MMNAS_GEMM_TILE", 0);
   g_tune.generic = getenv("MMNAS_GEMM_GENERIC") != nullptr;
@@ -836,6 +870,7 @@ static void load_tuning() {
   g_tune.split_slots = env_int("MMNAS_GEMM_SPLIT_SLOTS", 0);
   g_tune.split_p = env_int("MMNAS_GEMM_SPLIT_P", 24);           // K-tiles per split-K piece
   if (g_tune.split_p < 1) g_tune.split_p = 1;
+  g_tune.pf = env_int("MMNAS_GEMM_PF", 2) == 1 ? 1 : 2;            // register stages of operand prefetch (64^2 fp32 path)
   g_tune.loaded = true;
 }
 
@@ -867,13 +902,13 @@ static int get_workspace(hipStream_t st, SkWorkspace* out) {
   return MMNAS_OK;
 }
 
-template <int BM, int BN, bool FAST, int NS>
+template <int BM, int BN, bool FAST, int NS, int PF = 1>
 static int launch(GemmK& k, int layout, int nwg, hipStream_t st) {
   dim3 grid(nwg), block(256);
   switch (layout) {
-    case MMNAS_GEMM_NT: MMNAS_LAUNCH((gemm_kernel<BM, BN, true, true, FAST, NS>), grid, block, 0, st, k); break;
-    case MMNAS_GEMM_NN: MMNAS_LAUNCH((gemm_kernel<BM, BN, true, false, FAST, NS>), grid, block, 0, st, k); break;
-    default: MMNAS_LAUNCH((gemm_kernel<BM, BN, false, false, FAST, NS>), grid, block, 0, st, k); break;
+    case MMNAS_GEMM_NT: MMNAS_LAUNCH((gemm_kernel<BM, BN, true, true, FAST, NS, 0, PF>), grid, block, 0, st, k); break;
+    case MMNAS_GEMM_NN: MMNAS_LAUNCH((gemm_kernel<BM, BN, true, false, FAST, NS, 0, PF>), grid, block, 0, st, k); break;
+    default: MMNAS_LAUNCH((gemm_kernel<BM, BN, false, false, FAST, NS, 0, PF>), grid, block, 0, st, k); break;
   }
   return check_launch("gemm");
 }
@@ -1075,6 +1110,7 @@ static int launch_plan(GemmPlan& pl, hipStream_t st) {
   }
   if (ns == 2) return launch<64, 64, true, 2>(k, pl.layout, pl.nwg, st);
   if (ns == 3) return launch<64, 64, true, 3>(k, pl.layout, pl.nwg, st);
+  if (pl.fast && g_tune.pf == 2) return launch<64, 64, true, 0, 2>(k, pl.layout, pl.nwg, st);
   return pl.fast ? launch<64, 64, true, 0>(k, pl.layout, pl.nwg, st) : launch<64, 64, false, 0>(k, pl.layout, pl.nwg, st);
 }
 
@@ -1118,7 +1154,10 @@ int gemm_pair_aux(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, co
   switch (g_tune.split) {
     case 2: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8); break;
     case 3: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8); break;
-    default: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 0>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8); break;
+    default:
+      if (g_tune.pf == 2) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 0, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
+      else MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 0>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
+      break;
   }
   return check_launch("gemm_pair");
 }

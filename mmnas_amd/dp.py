@@ -365,6 +365,10 @@ class SupernetReducer:
         if self.staging is None:
             self.staging = [torch.empty(max(c, 64), dtype=torch.float32, device=self.fg.flat.device) for c in self.cap]
 
+    def exchanged_segments(self):
+        """(offset, n) runs of the flat buffer that travel in this step's exchange (all buckets)."""
+        return [seg for segs in self._segs if segs for seg in segs]
+
     def _make_hook(self, i):
         def hook(_p):
             if i not in self._armed:

@@ -79,8 +79,12 @@ def test_standalone_mhatt_forms(variant):
         assert rel_err(k.grad.cpu().numpy(), k64.grad.cpu().numpy()) < TOL
     if v is not k:
         assert rel_err(v.grad.cpu().numpy(), v64.grad.cpu().numpy()) < TOL
+    # (the key bias shifts every score of a row by the same amount: its gradient is mathematically zero, round-off on
+    #  both sides -- the denominator is floored at 1e-4 of the largest parameter gradient)
+    gscale = max(float(P[n].grad.abs().max()) for n in P)
     for n, p in m.named_parameters():
-        assert rel_err(p.grad.cpu().numpy(), P[n].grad.cpu().numpy()) < TOL, n
+        diff = float((p.grad.double() - P[n].grad).abs().max())
+        assert diff <= TOL * max(float(P[n].grad.abs().max()), 1e-4 * gscale), n
 
 
 def test_layernorm_over_another_axis():

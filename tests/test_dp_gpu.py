@@ -112,7 +112,8 @@ def _w_supernet(rank):
     both = [torch.zeros_like(local) for _ in range(WORLD)]
     dist.all_gather(both, local)
     mean = (both[0] + both[1]) / WORLD
-    segs = red._segments(red._active)
+    segs = red.exchanged_segments()
+    assert sum(n for _, n in segs) >= sum(p.numel() for p in red._active)
     covered = 0
     for o, n in segs:
         assert torch.allclose(red.fg.flat[o:o + n], mean[o:o + n], rtol=1e-5, atol=1e-7)

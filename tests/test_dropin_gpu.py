@@ -88,6 +88,7 @@ def _w_reference_loop(rank):
                                 epoch_steps=10, warmup=True)
     alpha_optim = torch.optim.Adam(ddp.module.alpha_prob_parameters(), 0.1, betas=(0.0, 0.999))
     inp, tgt = batch(rank)
+    named = dict(ddp.module.named_parameters())          # (before unused_modules_off() hides the idle candidates)
 
     # ---- network step, search_vqa.py:279-300 (sampling replaced by an injected sample, as in the goldens) ----
     MixedOp.MODE = None
@@ -100,7 +101,6 @@ def _w_reference_loop(rank):
     loss += 0 * sum(p.sum() for p in ddp.module.net_parameters())
     ddp.zero_grad()
     loss.backward()
-    named = dict(ddp.module.named_parameters())
     top = max(float(g.abs().max()) for g in want_w.values() if g is not None)
     for k, g in want_w.items():
         if 'alpha' in k:
