@@ -295,7 +295,8 @@ def main():
     mixed.seed_arch_sampler(888)
     emb = torch.randn(VOCAB, 300, generator=torch.Generator().manual_seed(1)).numpy()
     init = {'token_size': VOCAB, 'ans_size': ANS, 'pretrained_emb': emb}
-    loss_fn = torch.nn.BCEWithLogitsLoss(reduction='sum')
+    from mmnas_amd.harness import fused_loss
+    loss_fn = fused_loss(torch.nn.BCEWithLogitsLoss(reduction='sum'))
     wanted = list(WORKLOADS) if args.workload == 'all' else [args.workload]
 
     state = {}

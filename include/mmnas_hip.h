@@ -131,6 +131,27 @@ int mmnas_lstm_fwd(const float* x_tm, const float* Wih, const float* Whh, const 
 int mmnas_lstm_bwd(const float* dout, const float* Whh, const float* Call, const float* Gall, float* DG, float* dc,
                    float* scratch, int T, int B, int H, void* stream);
 
+/* The same LSTM (nn.LSTM(batch_first=True), one layer, zero initial state; hygr_vqa.py:86-92,106-107) as ONE persistent
+ * launch per pass: the recurrent matrix is split over workgroups by hidden unit and stays in registers for the whole
+ * sequence, the state vector is handed between workgroups once per step (agent-scope counter + acquire, no host
+ * involvement).  Batch-first buffers, nn.LSTM's NATIVE gate order (rows / columns g*H + u, g in i,f,g,o): no weight
+ * permutation, and the weight gradients below come out in the parameters' own layout.
+ *   fwd: xp [B,T,4H] = x W_ih^T + b_ih (caller: one mmnas_gemm over the B*T rows); bhh [4H] (nullable);
+ *        outputs Hprev [B,T,H] (Hprev[b][t] = h_{t-1}, slice 0 zero), Cs [B,T,H] (c_t), Gall [B,T,4H] (activated gates),
+ *        out [B,T,H] (h_t).  Nothing needs zeroing by the caller.
+ *   bwd: dout [B,T,H] -> DG [B,T,4H] (gradients of the pre-activations).  The caller finishes with ordinary products:
+ *        dW_ih += DG^T x, dW_hh += DG^T Hprev (mmnas_gemm TN over the B*T rows), db += column sums of DG,
+ *        dx = DG W_ih (mmnas_gemm NN).
+ * Supported: H in {64, 128, 256, 512}, any T >= 1, B <= 3840 (blocks of 64 samples run independently).
+ * mmnas_lstm_seq_timed_out(stream): synchronises and returns 1 if a step hand-off of the last launch gave up waiting
+ * (a workgroup was not resident: results are garbage), 0 otherwise -- tests / debugging. */
+int mmnas_lstm_seq_supported(int H, int B);
+int mmnas_lstm_seq_fwd(const float* xp, const float* bhh, const float* Whh, float* Hprev, float* Cs, float* Gall,
+                       float* out, int T, int B, int H, void* stream);
+int mmnas_lstm_seq_bwd(const float* dout, const float* Whh, const float* Cs, const float* Gall, float* DG, int T,
+                       int B, int H, void* stream);
+int mmnas_lstm_seq_timed_out(void* stream);
+
 /* Scheduling knobs of mmnas_gemm (MMNAS_GEMM_TILE, _SK, _WGS, _MIN_UNITS, _GENERIC, _GM, _XCD: tuning and tests only)
  * and the opt-in MMNAS_GEMM_SPLIT=3|6 (products as 3 / 6 bf16-MFMA products of exactly split fp32 operands, fp32
  * accumulation; default 0 = fp32 MFMA) are read from the environment on the first call; this re-reads them. */
@@ -371,6 +392,84 @@ typedef struct mmnas_mlp_op {
 int mmnas_mlp_op_plan(const mmnas_mlp_op* op, mmnas_plan* plan);
 int mmnas_mlp_op_fwd(const mmnas_mlp_op* op, void* stream);
 int mmnas_mlp_op_bwd(const mmnas_mlp_op* op, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backbone chain: every cell operator of a backbone in ONE call per direction (Backbone_*.forward, hygr_vqa.py:45-52,
+ * full_vqa.py:46-53; Cell_*.forward, hygr_vqa.py:23-27, for single-operator nodes of the attention / MLP families).
+ *   ops[]: host array in evaluation order, encoder nodes (on_y = 0: language stream x, [B*Sx, d]) first, then decoder
+ *   nodes (on_y = 1: image stream y, [B*Sy, d]; a guided operator reads the FINAL language state).  Each record holds
+ *   an operator descriptor as for mmnas_att_op_* / mmnas_mlp_op_* with the parameters, flags (NORM, RESIDUAL, TRAIN, SELF,
+ *   REL, RELRAW), dropout rate / seed, R, C, Wy / by and -- for backward -- the parameter-gradient pointers filled in;
+ *   shapes, masks, relation tensors and every activation / scratch pointer are set by the chain.
+ *   arena: mmnas_chain_plan() bytes, written by fwd, read by bwd; it must stay alive until the backward's side-stream
+ *   work has been joined (mmnas_chain_join).
+ *   fwd: x_out [B*Sx,d], y_out [B*Sy,d].  bwd: dx_out (nullable = 0), dy_out -> dx_in, dy_in; parameter gradients are
+ *   ACCUMULATED as by the per-operator calls.
+ *   use_side_stream != 0 (bwd): the call's stream carries only the data-gradient chain; weight-gradient products,
+ *   LayerNorm parameter reductions and the relation-bias backward run on a library-owned side stream behind one
+ *   event per operator.  mmnas_chain_join(main, waiting) makes `waiting` wait for everything issued to main's side
+ *   stream so far -- call it (with waiting = main) before anything reads the parameter gradients.
+ * ------------------------------------------------------------------------------------------ */
+#define MMNAS_CHAIN_MAX_OPS 64
+enum { MMNAS_CHAIN_ATT = 0, MMNAS_CHAIN_MLP = 1 };
+typedef struct mmnas_chain_op {
+  int kind, on_y;
+  mmnas_att_op att;
+  mmnas_mlp_op mlp;
+} mmnas_chain_op;
+typedef struct mmnas_chain {
+  int n_ops;
+  const mmnas_chain_op* ops;
+  int B, Sx, Sy, d;
+  const float* x_in; const float* y_in;
+  const uint8_t* x_mask; const uint8_t* y_mask;   /* [B,Sx], [B,Sy] or NULL */
+  const float* x_rel; const float* y_rel;         /* relation tensors of the REL operators (raw with RELRAW) or NULL */
+  void* arena;
+  float* x_out; float* y_out;
+  const float* dx_out; const float* dy_out;
+  float* dx_in; float* dy_in;
+  int use_side_stream, reserved;
+} mmnas_chain;
+int mmnas_chain_plan(const mmnas_chain* c, size_t* arena_bytes);   /* host only */
+int mmnas_chain_fwd(const mmnas_chain* c, void* stream);
+int mmnas_chain_bwd(const mmnas_chain* c, void* stream);
+int mmnas_chain_join(void* main_stream, void* waiting_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Answer head: AttFlat over the language state + AttFlat over the image state, their sum, LayerNorm and the answer
+ * projection (Net_*.forward, hygr_vqa.py:113-119 / full_vqa.py:105-114; AttFlat modules.py:59-85; MLP / FC
+ * modules.py:13-41) in one call per direction.
+ *   side: x [B*S, d], key mask [B,S] (nullable), MLP fc (W1 [MID,d], b1), glimpse linear (W2 [G,MID], b2), merge
+ *   (Wm [OUT, G*d], bm); seed = the dropout seed of the side's FC (site 0).
+ *   fwd: logits [B, ANS] = proj(LN(attflat_x + attflat_y)).   bwd: dlogits -> sx.dx, sy.dx (overwritten); every
+ *   parameter gradient is ACCUMULATED (+=).  arena: mmnas_head_plan() bytes, written by fwd, read by bwd.
+ * Also the loss of the VQA scripts (BCEWithLogitsLoss(reduction='sum'), search_vqa.py:211 / train_vqa.py:237) as two
+ * kernels: mmnas_bce_logits_sum_fwd ADDS sum(max(x,0) - x t + log1p(exp(-|x|))) to loss[0] (zero it first);
+ * mmnas_bce_logits_bwd writes dlogits = go[0] * (sigmoid(x) - t) (go: device scalar, the loss's upstream gradient).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mmnas_attflat_side {
+  int S, reserved;
+  const float* x; const uint8_t* mask;
+  const float* W1; const float* b1; const float* W2; const float* b2; const float* Wm; const float* bm;
+  float* dW1; float* db1; float* dW2; float* db2; float* dWm; float* dbm;
+  uint64_t seed;
+  float* dx;
+} mmnas_attflat_side;
+typedef struct mmnas_head {
+  int B, d, MID, G, OUT, ANS, flags, reserved;
+  float drop_p, eps;
+  mmnas_attflat_side sx, sy;
+  const float* ln_a; const float* ln_b; float* dln_a; float* dln_b;
+  const float* Wp; const float* bp; float* dWp; float* dbp;
+  float* logits;
+  const float* dlogits;
+  void* arena;
+} mmnas_head;
+int mmnas_head_plan(const mmnas_head* hd, size_t* arena_bytes);   /* host only */
+int mmnas_head_fwd(const mmnas_head* hd, void* stream);
+int mmnas_head_bwd(const mmnas_head* hd, void* stream);
+int mmnas_bce_logits_sum_fwd(const float* logits, const float* target, float* loss, size_t n, void* stream);
+int mmnas_bce_logits_bwd(const float* logits, const float* target, const float* go, float* dlogits, size_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 1-D convolutions over the sequence axis of x[B,S,d] (channels last, zero "same" padding, odd

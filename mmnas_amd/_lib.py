@@ -63,6 +63,33 @@ class MlpOp(C.Structure):
                 ('dln_a', _fp), ('dln_b', _fp)]
 
 
+class ChainOp(C.Structure):
+    _fields_ = [('kind', C.c_int), ('on_y', C.c_int), ('att', AttOp), ('mlp', MlpOp)]
+
+
+class Chain(C.Structure):
+    _fields_ = [('n_ops', C.c_int), ('ops', C.POINTER(ChainOp)), ('B', C.c_int), ('Sx', C.c_int), ('Sy', C.c_int),
+                ('d', C.c_int), ('x_in', _fp), ('y_in', _fp), ('x_mask', _fp), ('y_mask', _fp), ('x_rel', _fp),
+                ('y_rel', _fp), ('arena', _fp), ('x_out', _fp), ('y_out', _fp), ('dx_out', _fp), ('dy_out', _fp),
+                ('dx_in', _fp), ('dy_in', _fp), ('use_side_stream', C.c_int), ('reserved', C.c_int)]
+
+
+CHAIN_MAX_OPS = 64
+
+
+class AttFlatSide(C.Structure):
+    _fields_ = [('S', C.c_int), ('reserved', C.c_int), ('x', _fp), ('mask', _fp), ('W1', _fp), ('b1', _fp), ('W2', _fp),
+                ('b2', _fp), ('Wm', _fp), ('bm', _fp), ('dW1', _fp), ('db1', _fp), ('dW2', _fp), ('db2', _fp), ('dWm', _fp),
+                ('dbm', _fp), ('seed', C.c_uint64), ('dx', _fp)]
+
+
+class Head(C.Structure):
+    _fields_ = [('B', C.c_int), ('d', C.c_int), ('MID', C.c_int), ('G', C.c_int), ('OUT', C.c_int), ('ANS', C.c_int),
+                ('flags', C.c_int), ('reserved', C.c_int), ('drop_p', C.c_float), ('eps', C.c_float),
+                ('sx', AttFlatSide), ('sy', AttFlatSide), ('ln_a', _fp), ('ln_b', _fp), ('dln_a', _fp), ('dln_b', _fp),
+                ('Wp', _fp), ('bp', _fp), ('dWp', _fp), ('dbp', _fp), ('logits', _fp), ('dlogits', _fp), ('arena', _fp)]
+
+
 class ProfStat(C.Structure):
     _fields_ = [('ms', C.c_double), ('flops', C.c_double), ('bytes', C.c_double), ('launches', C.c_long)]
 
@@ -86,6 +113,10 @@ SYMBOLS = {
     'mmnas_lstm_supported': (_i, [_i, _i]),
     'mmnas_lstm_fwd': (_i, [_fp] * 9 + [_i, _i, _i, _i, _fp]),
     'mmnas_lstm_bwd': (_i, [_fp] * 7 + [_i, _i, _i, _fp]),
+    'mmnas_lstm_seq_supported': (_i, [_i, _i]),
+    'mmnas_lstm_seq_fwd': (_i, [_fp] * 7 + [_i, _i, _i, _fp]),
+    'mmnas_lstm_seq_bwd': (_i, [_fp] * 5 + [_i, _i, _i, _fp]),
+    'mmnas_lstm_seq_timed_out': (_i, [_fp]),
     'mmnas_layernorm_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _fp]),
     'mmnas_layernorm_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _u64, _u32, _i, _i, _f, _fp]),
     'mmnas_layernorm_bwd_ws_floats': (_sz, [_i, _i]),
@@ -119,6 +150,15 @@ SYMBOLS = {
     'mmnas_mlp_op_plan': (_i, [C.POINTER(MlpOp), C.POINTER(Plan)]),
     'mmnas_mlp_op_fwd': (_i, [C.POINTER(MlpOp), _fp]),
     'mmnas_mlp_op_bwd': (_i, [C.POINTER(MlpOp), _fp]),
+    'mmnas_chain_plan': (_i, [C.POINTER(Chain), C.POINTER(C.c_size_t)]),
+    'mmnas_chain_fwd': (_i, [C.POINTER(Chain), _fp]),
+    'mmnas_chain_bwd': (_i, [C.POINTER(Chain), _fp]),
+    'mmnas_chain_join': (_i, [_fp, _fp]),
+    'mmnas_head_plan': (_i, [C.POINTER(Head), C.POINTER(C.c_size_t)]),
+    'mmnas_head_fwd': (_i, [C.POINTER(Head), _fp]),
+    'mmnas_head_bwd': (_i, [C.POINTER(Head), _fp]),
+    'mmnas_bce_logits_sum_fwd': (_i, [_fp, _fp, _fp, _sz, _fp]),
+    'mmnas_bce_logits_bwd': (_i, [_fp, _fp, _fp, _fp, _sz, _fp]),
     'mmnas_im2col_seq': (_i, [_fp, _fp, _i, _i, _i, _i, _fp]),
     'mmnas_col2im_seq': (_i, [_fp, _fp, _i, _i, _i, _i, _fp]),
     'mmnas_dwconv_seq_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),

@@ -254,3 +254,42 @@ extern "C" int mmnas_embedding_bwd(const long* idx, const float* dy, float* dW, 
   MMNAS_LAUNCH(embedding_bwd_kernel, dim3((unsigned)cdiv(n_tok * E, 256)), dim3(256), 0, (hipStream_t)stream, idx, dy, dW, n_tok, E, V);
   return check_launch("embedding_bwd");
 }
+
+
+// ---- BCEWithLogitsLoss(reduction='sum') (search_vqa.py:211): loss and gradient, one kernel each ----
+namespace mmnas {
+__global__ void __launch_bounds__(256) bce_logits_sum_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                             float* __restrict__ loss, size_t n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    s += fmaxf(v, 0.f) - v * t[i] + log1pf(expf(-fabsf(v)));
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ void __launch_bounds__(256) bce_logits_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                             const float* __restrict__ go, float* __restrict__ dx, size_t n) {
+  const float g = go ? go[0] : 1.0f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dx[i] = g * (1.0f / (1.0f + expf(-x[i])) - t[i]);
+}
+}  // namespace mmnas
+
+extern "C" int mmnas_bce_logits_sum_fwd(const float* logits, const float* target, float* loss, size_t n, void* stream) {
+  MMNAS_REQUIRE(logits && target && loss, MMNAS_E_ARG, "bce_logits_sum_fwd: null pointer");
+  if (n == 0) return MMNAS_OK;
+  const int blocks = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+  MMNAS_LAUNCH(mmnas::bce_logits_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, target, loss, n);
+  return mmnas::check_launch("bce_logits_sum_fwd");
+}
+extern "C" int mmnas_bce_logits_bwd(const float* logits, const float* target, const float* go, float* dlogits, size_t n, void* stream) {
+  MMNAS_REQUIRE(logits && target && dlogits, MMNAS_E_ARG, "bce_logits_bwd: null pointer");
+  if (n == 0) return MMNAS_OK;
+  const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  MMNAS_LAUNCH(mmnas::bce_logits_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, target, go, dlogits, n);
+  return mmnas::check_launch("bce_logits_bwd");
+}

@@ -1,0 +1,345 @@
+// Single-layer LSTM over a short sequence as ONE persistent launch per direction (forward pass / backward pass).
+//
+// Replaces the MIOpen path behind nn.LSTM in the nets' language stem (hygr_vqa.py:86-92 construction, :106-107 call):
+// for 14 time steps of a 64-row problem MIOpen issues a GEMM + a pointwise kernel per step and direction plus
+// weight-buffer copies -- ~110 dependent launches of 3-8 us each, ~0.6 ms of a 7 ms supernet step.
+//
+// Decomposition (MI355X): the recurrent matrix is split over workgroups by HIDDEN UNIT, so that every workgroup keeps
+// its slice of W_hh in REGISTERS (MFMA A-operand fragments) for the whole sequence and only the 64 x H state vector
+// travels between workgroups once per step:
+//   forward : workgroup = 8 units = 32 gate rows (native nn.LSTM order: row g*H + u, g in i,f,g,o); 4 waves split the
+//             reduction over H; per step 2 x (H/8) v_mfma_f32_32x32x2_f32 per wave, a 32 KB LDS reduction across the
+//             waves, then the gate arithmetic with the cell state held in registers.
+//   backward: workgroup = 16 units; dh_t = dout_t + dG_{t+1} W_hh needs W_hh[:, units] (reduction over the 4H gate
+//             rows): 8 waves split it, v_mfma_f32_16x16x4_f32 (16-unit tiles: no padding), running dc in registers.
+// Step hand-off between workgroups (h_t forward, dG_t backward): the payload is stored write-through (sc1), every
+// storing wave drains its stores, one lane adds to a per-sample-block arrival counter (agent scope); one lane polls
+// the counter (relaxed, bounded), ONE agent-scope acquire, workgroup barrier, plain loads -- the R1 recipe of the
+// CDNA programming guide, placement-independent.  Samples are independent: blocks of 64 samples have their own
+// counter and never wait for each other.  Counters are zeroed by a memset node in front of every launch.
+#include <string.h>
+#include <map>
+#include <mutex>
+#include <utility>
+#include "common.h"
+
+namespace mmnas {
+
+constexpr int LSTM_MAX_SB = 60;
+
+struct LstmSeqK {
+  const float* xp;      // [B,T,4H] input projection x W_ih^T + b_ih (native gate order)
+  const float* bhh;     // [4H] b_hh (added in the gate arithmetic)
+  const float* Whh;     // [4H,H]
+  float* Hprev;         // [B,T,H]  Hprev[b][t] = h_{t-1} (slice t = 0 zero): exchange buffer + saved for dW_hh
+  float* Cs;            // [B,T,H]  c_t
+  float* Gall;          // [B,T,4H] activated gates
+  float* out;           // [B,T,H]  h_t
+  const float* dout;    // [B,T,H]
+  float* DG;            // [B,T,4H] pre-activation gradients: exchange buffer + operand of the weight gradients
+  unsigned* cnt;        // [LSTM_MAX_SB] arrival counters (one per block of 64 samples), then one timeout word
+  int T, B, H, nsb;
+};
+
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Arrive at / wait for step barrier `target` arrivals on counter c.  Called by every thread of the workgroup.
+__device__ __forceinline__ void step_barrier(unsigned* c, unsigned target, unsigned* tmo) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its write-through stores have landed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 22)) {   // a workgroup of this launch is not resident: give up loudly instead of hanging
+        __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------- forward
+template <int H>
+__global__ void __launch_bounds__(256, 1) lstm_seq_fwd_kernel(const LstmSeqK p) {
+  constexpr int U = 8, R = 4 * U;          // units / gate rows per workgroup
+  constexpr int KW = H / 4;                // reduction range of one wave
+  constexpr int NS = KW / 8;               // 8-wide k groups per wave (one float4 per lane and group)
+  static_assert(H % 32 == 0, "hidden size must be a multiple of 32");
+  __shared__ float part[4][R][64];         // per-wave partial pre-activations [gate row][sample]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int u0 = blockIdx.x * U, n0 = blockIdx.y * 64;
+  const int T = p.T, B = p.B;
+  const unsigned nub = gridDim.x;
+  unsigned* const cnt = p.cnt + blockIdx.y;
+  unsigned* const tmo = p.cnt + LSTM_MAX_SB;
+
+  // W_hh slice as MFMA A fragments: local row l31 = gate (l31 >> 3), unit (l31 & 7); k = wave*KW + 8s + 4hh + 0..3
+  float4 wa[NS];
+  {
+    const float* w = p.Whh + (size_t)((l31 >> 3) * H + u0 + (l31 & 7)) * H + wave * KW + 4 * hh;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) wa[s] = *reinterpret_cast<const float4*>(w + 8 * s);
+  }
+  // gate arithmetic: thread owns (unit, sample) pairs i = 0, 1: pair index tid + 256 i -> unit = idx >> 6, sample = idx & 63
+  float cst[2] = {0.f, 0.f};
+  float bh[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int u = (tid + 256 * i) >> 6;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bh[i][g] = p.bhh ? p.bhh[g * H + u0 + u] : 0.f;
+  }
+
+  for (int t = 0; t < T; ++t) {
+    // input-projection terms of this step (independent of the recurrence: issued first)
+    float xv[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, u = idx >> 6, n = n0 + (idx & 63);
+      const bool ok = n < B;
+      const float* x = p.xp + ((size_t)(ok ? n : 0) * T + t) * (4 * H) + u0 + u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xv[i][g] = ok ? x[g * H] : 0.f;
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    if (t > 0) {   // h_{-1} = 0
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + 32 * j + l31;
+        const bool ok = n < B;
+        const float* hsrc = p.Hprev + ((size_t)(ok ? n : 0) * T + t) * H + wave * KW + 4 * hh;
+        float4 hb[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) hb[s] = ok ? *reinterpret_cast<const float4*>(hsrc + 8 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          acc[j] = mfma32(wa[s].x, hb[s].x, acc[j]);
+          acc[j] = mfma32(wa[s].y, hb[s].y, acc[j]);
+          acc[j] = mfma32(wa[s].z, hb[s].z, acc[j]);
+          acc[j] = mfma32(wa[s].w, hb[s].w, acc[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[wave][acc_row(r, hh)][32 * j + l31] = acc[j][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, u = idx >> 6, nl = idx & 63, n = n0 + nl;
+      float pre[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        pre[g] = ((part[0][g * U + u][nl] + part[1][g * U + u][nl]) + (part[2][g * U + u][nl] + part[3][g * U + u][nl])) + (xv[i][g] + bh[i][g]);
+      const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = tanhf(pre[2]), go = sigmoidf_(pre[3]);
+      const float c = gf * cst[i] + gi * gg;
+      const float hv = go * tanhf(c);
+      cst[i] = c;
+      if (n < B) {
+        const size_t row = (size_t)n * T + t;
+        float* ga = p.Gall + row * (4 * H) + u0 + u;
+        ga[0] = gi; ga[H] = gf; ga[2 * H] = gg; ga[3 * H] = go;
+        p.Cs[row * H + u0 + u] = c;
+        p.out[row * H + u0 + u] = hv;
+        if (t + 1 < T) st_sc1(p.Hprev + (row + 1) * H + u0 + u, hv);   // the next step's input, read by every workgroup
+        if (t == 0) p.Hprev[row * H + u0 + u] = 0.f;
+      }
+    }
+    if (t + 1 < T) step_barrier(cnt, (unsigned)(t + 1) * nub, tmo);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+template <int H>
+__global__ void __launch_bounds__(512, 1) lstm_seq_bwd_kernel(const LstmSeqK p) {
+  constexpr int U = 16;
+  constexpr int K = 4 * H, KW = K / 8, NS = KW / 16;   // 8 waves split the reduction over the 4H gate rows
+  static_assert(H % 32 == 0, "hidden size must be a multiple of 32");
+  __shared__ float part[8][U][64];                     // per-wave partial dh [unit][sample]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+  const int u0 = blockIdx.x * U, n0 = blockIdx.y * 64;
+  const int T = p.T, B = p.B;
+  const unsigned nub = gridDim.x;
+  unsigned* const cnt = p.cnt + blockIdx.y;
+  unsigned* const tmo = p.cnt + LSTM_MAX_SB;
+
+  // W_hh[:, units] as A fragments of the 16x16x4 MFMA: row = unit l15, k = wave*KW + 16 s + 4 kq + 0..3
+  float wa[NS][4];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wa[s][w] = p.Whh[(size_t)(wave * KW + 16 * s + 4 * kq + w) * H + u0 + l15];
+  float dcr[2] = {0.f, 0.f};   // running cell-state gradient of the thread's two (unit, sample) pairs
+
+  for (int t = T - 1; t >= 0; --t) {
+    // saved activations of this step (independent of the recurrence: issued first)
+    float gate[2][4], cc[2], cp[2], dov[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 512 * i, u = idx >> 6, n = n0 + (idx & 63);
+      const bool ok = n < B;
+      const size_t row = (size_t)(ok ? n : 0) * T + t;
+      const float* ga = p.Gall + row * (4 * H) + u0 + u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gate[i][g] = ok ? ga[g * H] : 0.f;
+      cc[i] = ok ? p.Cs[row * H + u0 + u] : 0.f;
+      cp[i] = (ok && t > 0) ? p.Cs[(row - 1) * H + u0 + u] : 0.f;
+      dov[i] = ok ? p.dout[row * H + u0 + u] : 0.f;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t + 1 < T) {   // dG_T = 0
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + 16 * j + l15;
+        const bool ok = n < B;
+        const float* src = p.DG + ((size_t)(ok ? n : 0) * T + t + 1) * K + wave * KW + 4 * kq;
+        float4 b[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) b[s] = ok ? *reinterpret_cast<const float4*>(src + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][0], b[s].x, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][1], b[s].y, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][2], b[s].z, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][3], b[s].w, acc[j], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[wave][4 * kq + r][16 * j + l15] = acc[j][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 512 * i, u = idx >> 6, nl = idx & 63, n = n0 + nl;
+      float dh = dov[i];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) dh += part[w][u][nl];
+      const float gi = gate[i][0], gf = gate[i][1], gg = gate[i][2], go = gate[i][3];
+      const float tc = tanhf(cc[i]);
+      const float dc = dcr[i] + dh * go * (1.0f - tc * tc);
+      dcr[i] = dc * gf;
+      if (n < B) {
+        float* dg = p.DG + ((size_t)n * T + t) * K + u0 + u;
+        st_sc1(dg, dc * gg * gi * (1.0f - gi));             // d pre_i
+        st_sc1(dg + H, dc * cp[i] * gf * (1.0f - gf));      // d pre_f
+        st_sc1(dg + 2 * H, dc * gi * (1.0f - gg * gg));     // d pre_g
+        st_sc1(dg + 3 * H, dh * tc * go * (1.0f - go));     // d pre_o
+      }
+    }
+    if (t > 0) step_barrier(cnt, (unsigned)(T - t) * nub, tmo);
+  }
+}
+
+// ---- per-(device, stream) sync words: LSTM_MAX_SB counters + a timeout word (64 words) ----
+struct LstmSync { unsigned* words; };
+static std::mutex g_ls_mu;
+static std::map<std::pair<int, hipStream_t>, LstmSync> g_ls;
+
+static int lstm_sync_words(hipStream_t st, unsigned** out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("lstm: hipGetDevice failed"); return MMNAS_E_LAUNCH; }
+  std::lock_guard<std::mutex> lk(g_ls_mu);
+  auto key = std::make_pair(dev, st);
+  auto it = g_ls.find(key);
+  if (it == g_ls.end()) {
+    LstmSync s{nullptr};
+    if (hipMalloc((void**)&s.words, 256) != hipSuccess) { set_error("lstm: cannot allocate the step counters"); return MMNAS_E_LAUNCH; }
+    it = g_ls.emplace(key, s).first;
+  }
+  *out = it->second.words;
+  return MMNAS_OK;
+}
+
+template <int H>
+static void launch_fwd(const LstmSeqK& k, dim3 grid, hipStream_t st) {
+  MMNAS_LAUNCH((lstm_seq_fwd_kernel<H>), grid, dim3(256), 0, st, k);
+}
+template <int H>
+static void launch_bwd(const LstmSeqK& k, dim3 grid, hipStream_t st) {
+  MMNAS_LAUNCH((lstm_seq_bwd_kernel<H>), grid, dim3(512), 0, st, k);
+}
+
+}  // namespace mmnas
+
+using namespace mmnas;
+
+extern "C" int mmnas_lstm_seq_supported(int H, int B) {
+  return (H == 64 || H == 128 || H == 256 || H == 512) && B >= 1 && (B + 63) / 64 <= LSTM_MAX_SB;
+}
+
+extern "C" int mmnas_lstm_seq_fwd(const float* xp, const float* bhh, const float* Whh, float* Hprev, float* Cs, float* Gall,
+                                  float* out, int T, int B, int H, void* stream) {
+  MMNAS_REQUIRE(xp && Whh && Hprev && Cs && Gall && out, MMNAS_E_ARG, "lstm_seq_fwd: null pointer");
+  MMNAS_REQUIRE(T >= 1 && mmnas_lstm_seq_supported(H, B), MMNAS_E_SHAPE, "lstm_seq_fwd: T=%d B=%d H=%d unsupported", T, B, H);
+  MMNAS_REQUIRE((((uintptr_t)Whh | (uintptr_t)Hprev) & 15) == 0, MMNAS_E_ARG, "lstm_seq_fwd: W_hh / state buffers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  LstmSeqK k;
+  memset(&k, 0, sizeof(k));
+  k.xp = xp; k.bhh = bhh; k.Whh = Whh; k.Hprev = Hprev; k.Cs = Cs; k.Gall = Gall; k.out = out;
+  k.T = T; k.B = B; k.H = H; k.nsb = (B + 63) / 64;
+  int rc = lstm_sync_words(st, &k.cnt);
+  if (rc) return rc;
+  if (hipMemsetAsync(k.cnt, 0, 256, st) != hipSuccess) { set_error("lstm_seq_fwd: memset failed"); return MMNAS_E_LAUNCH; }
+  const dim3 grid(H / 8, k.nsb);
+  ProfScope ps(MMNAS_K_GEMM, 2.0 * T * B * 4.0 * H * H, 4.0 * (4.0 * H * H + 7.0 * T * B * H), st, "lstm_seq_fwd");
+  switch (H) {
+    case 64: launch_fwd<64>(k, grid, st); break;
+    case 128: launch_fwd<128>(k, grid, st); break;
+    case 256: launch_fwd<256>(k, grid, st); break;
+    default: launch_fwd<512>(k, grid, st); break;
+  }
+  return check_launch("lstm_seq_fwd");
+}
+
+extern "C" int mmnas_lstm_seq_bwd(const float* dout, const float* Whh, const float* Cs, const float* Gall, float* DG, int T,
+                                  int B, int H, void* stream) {
+  MMNAS_REQUIRE(dout && Whh && Cs && Gall && DG, MMNAS_E_ARG, "lstm_seq_bwd: null pointer");
+  MMNAS_REQUIRE(T >= 1 && mmnas_lstm_seq_supported(H, B), MMNAS_E_SHAPE, "lstm_seq_bwd: T=%d B=%d H=%d unsupported", T, B, H);
+  MMNAS_REQUIRE(((uintptr_t)DG & 15) == 0, MMNAS_E_ARG, "lstm_seq_bwd: DG must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  LstmSeqK k;
+  memset(&k, 0, sizeof(k));
+  k.Whh = Whh; k.Cs = const_cast<float*>(Cs); k.Gall = const_cast<float*>(Gall); k.dout = dout; k.DG = DG;
+  k.T = T; k.B = B; k.H = H; k.nsb = (B + 63) / 64;
+  int rc = lstm_sync_words(st, &k.cnt);
+  if (rc) return rc;
+  if (hipMemsetAsync(k.cnt, 0, 256, st) != hipSuccess) { set_error("lstm_seq_bwd: memset failed"); return MMNAS_E_LAUNCH; }
+  const dim3 grid(H / 16, k.nsb);
+  ProfScope ps(MMNAS_K_GEMM, 2.0 * T * B * 4.0 * H * H, 4.0 * (4.0 * H * H + 12.0 * T * B * H), st, "lstm_seq_bwd");
+  switch (H) {
+    case 64: launch_bwd<64>(k, grid, st); break;
+    case 128: launch_bwd<128>(k, grid, st); break;
+    case 256: launch_bwd<256>(k, grid, st); break;
+    default: launch_bwd<512>(k, grid, st); break;
+  }
+  return check_launch("lstm_seq_bwd");
+}
+
+// 1 when a step barrier of the last mmnas_lstm_seq_* launch on `stream` gave up waiting (a workgroup was not resident);
+// synchronises the stream.  Tests and debugging: results of such a launch are garbage.
+extern "C" int mmnas_lstm_seq_timed_out(void* stream) {
+  unsigned* w = nullptr;
+  if (lstm_sync_words((hipStream_t)stream, &w)) return -1;
+  unsigned host[64];
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+  if (hipMemcpy(host, w, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return host[LSTM_MAX_SB] != 0 ? 1 : 0;   // (the timeout word sits behind nsb <= LSTM_MAX_SB counters)
+}

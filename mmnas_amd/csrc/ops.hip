@@ -10,6 +10,8 @@
 //           dW{q,k,v} grouped GEMM -> dx GEMM(s) with fused residual add -> (rel bias bwd)
 //   MLP family (FeedForward modules.py:351-362, FeedForward_deep :389-400).
 #include <string.h>
+#include <functional>
+#include <vector>
 #include "common.h"
 
 namespace mmnas {
@@ -140,7 +142,34 @@ extern "C" int mmnas_att_op_fwd(const mmnas_att_op* op, void* stream) {
   return MMNAS_OK;
 }
 
-extern "C" int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream) {
+namespace mmnas {
+// Parameter-gradient work set aside by the backward functions below when a queue is given: launches that nothing on
+// the data-gradient chain waits for (weight-gradient products, LayerNorm parameter reductions, the relation-bias
+// backward).  The caller decides when and on which stream they run (SideQueue::flush).
+struct SideQueue {
+  std::vector<std::function<int(hipStream_t)>> work;
+  // everything `main` has been given so far finishes first; then the queued launches run on `side`
+  int flush(hipStream_t main, hipStream_t side, hipEvent_t ev) {
+    if (work.empty()) return MMNAS_OK;
+    hipStream_t s = side;
+    if (hipEventRecord(ev, main) != hipSuccess || hipStreamWaitEvent(side, ev, 0) != hipSuccess)
+      s = main;   // (cannot order the streams: stay on the main one, which is always correct)
+    for (auto& f : work) {
+      const int rc = f(s);
+      if (rc) return rc;
+    }
+    work.clear();
+    return MMNAS_OK;
+  }
+};
+
+// sq == nullptr: the single-stream order (data- and weight-gradient products paired in one launch).
+// With a queue: `stream` carries only the chain the NEXT operator's backward waits for -- LayerNorm backward, the
+// data-gradient products, the attention core; the weight-gradient products, the LayerNorm parameter reduction and the
+// whole relation-bias backward (~40 % of an operator's backward time, read by nothing before the optimizer / the
+// gradient exchange) are queued.
+static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* sq) {
+  const bool side = sq != nullptr;
   int rc = att_check(op, "att_op_bwd");
   if (rc) return rc;
   MMNAS_REQUIRE(op->xq && op->xkv && op->Wq && op->Wk && op->Wv && op->Wm && op->save && op->ws && op->dy &&
@@ -170,15 +199,16 @@ extern "C" int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream) {
     dt = L.dt;
   }
 
-  mmnas_gemm_desc g, w;
+  mmnas_gemm_desc g, w, wm, w2;
   // 2. d(att) = dt Wm            [Mq,d] x [d,di]
   gemm_init(g, MMNAS_GEMM_NN, di, d, d, di, di);
   g.g[0].M = Mq; g.g[0].A[0] = dt; g.g[0].B[0] = op->Wm; g.g[0].C = L.datt;
   // 3. dWm += dt^T att           [d,di], reduction over the Mq rows (same launch: mmnas_gemm_pair)
-  gemm_init(w, MMNAS_GEMM_TN, di, Mq, d, di, di);
-  w.g[0].M = d; w.g[0].A[0] = dt; w.g[0].B[0] = L.att; w.g[0].C = op->dWm;
-  w.accumulate = 1;
-  if ((rc = gemm_pair_aux(&g, &w, &lnred, (hipStream_t)stream))) return rc;
+  gemm_init(wm, MMNAS_GEMM_TN, di, Mq, d, di, di);
+  wm.g[0].M = d; wm.g[0].A[0] = dt; wm.g[0].B[0] = L.att; wm.g[0].C = op->dWm;
+  wm.accumulate = 1;
+  if (side) { if ((rc = mmnas_gemm(&g, stream))) return rc; }
+  else if ((rc = gemm_pair_aux(&g, &wm, &lnred, (hipStream_t)stream))) return rc;
 
   // 4. attention core backward
   mmnas_mha_desc m;
@@ -206,7 +236,9 @@ extern "C" int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream) {
     g.g[0].A[1] = L.dK; g.g[0].B[1] = op->Wk;
     g.g[0].A[2] = L.dV; g.g[0].B[2] = op->Wv;
     if (fl & MMNAS_F_RESIDUAL) { g.g[0].residual = dz; g.ldres = d; }
-    if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
+    if (side) {
+      if ((rc = mmnas_gemm(&g, stream))) return rc;
+    } else if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
   } else {
     gemm_init(w, MMNAS_GEMM_TN, d, Mq, di, d, d);
     w.g[0].M = di; w.g[0].A[0] = L.dQ; w.g[0].B[0] = op->xq; w.g[0].C = op->dWq;
@@ -214,30 +246,54 @@ extern "C" int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream) {
     gemm_init(g, MMNAS_GEMM_NN, d, di, di, d, d);
     g.g[0].M = Mq; g.g[0].C = op->dxq; g.g[0].A[0] = L.dQ; g.g[0].B[0] = op->Wq;
     if (fl & MMNAS_F_RESIDUAL) { g.g[0].residual = dz; g.ldres = d; }
-    if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
-    gemm_init(w, MMNAS_GEMM_TN, d, Mk, di, d, d);
-    w.ngroups = 2;
-    w.g[0].M = di; w.g[0].A[0] = L.dK; w.g[0].B[0] = op->xkv; w.g[0].C = op->dWk;
-    w.g[1].M = di; w.g[1].A[0] = L.dV; w.g[1].B[0] = op->xkv; w.g[1].C = op->dWv;
-    w.accumulate = 1;
+    if (side) {
+      if ((rc = mmnas_gemm(&g, stream))) return rc;
+    } else if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
+    gemm_init(w2, MMNAS_GEMM_TN, d, Mk, di, d, d);
+    w2.ngroups = 2;
+    w2.g[0].M = di; w2.g[0].A[0] = L.dK; w2.g[0].B[0] = op->xkv; w2.g[0].C = op->dWk;
+    w2.g[1].M = di; w2.g[1].A[0] = L.dV; w2.g[1].B[0] = op->xkv; w2.g[1].C = op->dWv;
+    w2.accumulate = 1;
     gemm_init(g, MMNAS_GEMM_NN, d, di, di, d, d);
     g.nseg = 2;
     g.g[0].M = Mk; g.g[0].C = op->dxkv;
     g.g[0].A[0] = L.dK; g.g[0].B[0] = op->Wk;
     g.g[0].A[1] = L.dV; g.g[0].B[1] = op->Wv;
-    if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
+    if (side) {
+      if ((rc = mmnas_gemm(&g, stream))) return rc;
+    } else if ((rc = mmnas_gemm_pair(&g, &w2, stream))) return rc;
   }
 
+  // Parameter-gradient work.  Single stream: the weight gradients went out paired above, the relation-bias backward
+  // follows.  Side stream: all of it goes there, behind ONE event recorded at this point of `stream`.
+  if (side) {
+    sq->work.push_back([lnred](hipStream_t s) { return launch_aux_reduce(lnred, s); });
+    sq->work.push_back([wm](hipStream_t s) { return mmnas_gemm(&wm, s); });
+    sq->work.push_back([w](hipStream_t s) { return mmnas_gemm(&w, s); });
+    if (!self) sq->work.push_back([w2](hipStream_t s) { return mmnas_gemm(&w2, s); });
+  }
   // 7. relation bias
   if (rel && (fl & MMNAS_F_RELRAW)) {
     MMNAS_REQUIRE(op->Wy && op->by && op->dWy && op->dby, MMNAS_E_ARG, "att_op_bwd: RELRAW gradients missing");
-    return mmnas_rel_fused_bwd(op->rel, op->Wy, op->by, op->Wr, op->br, L.dbiasT, op->dWy, op->dby, op->dWr, op->dbr,
-                               L.relws, op->B, op->Sq, op->Sk, op->C, op->R, op->H, stream);
+    const mmnas_att_op o = *op;
+    float* const dbiasT = L.dbiasT;
+    float* const relws = L.relws;
+    auto relb = [o, dbiasT, relws](hipStream_t s) {
+      return mmnas_rel_fused_bwd(o.rel, o.Wy, o.by, o.Wr, o.br, dbiasT, o.dWy, o.dby, o.dWr, o.dbr, relws, o.B, o.Sq, o.Sk,
+                                 o.C, o.R, o.H, s);
+    };
+    if (side) { sq->work.push_back(relb); return MMNAS_OK; }
+    return relb(stream);
   }
-  if (rel)
+  if (rel)   // (a materialised relation tensor's own gradient may feed the caller: main stream)
     return mmnas_rel_bias_bwd(op->rel, op->Wr, op->br, L.dbiasT, op->drel, op->dWr, op->dbr, 0, op->B, op->Sq,
                               op->Sk, op->R, op->H, stream);
   return MMNAS_OK;
+}
+}  // namespace mmnas
+
+extern "C" int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream) {
+  return att_bwd_impl(op, (hipStream_t)stream, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------ MLP
@@ -246,7 +302,7 @@ namespace mmnas {
 struct MlpLayout {
   float* h[3];      // h[i] = input of layer i (h[0] = x, not stored); saved for i >= 1
   float* z;
-  float *dz, *dt, *dp[2], *lnws;
+  float *dz, *dt, *dp[3], *lnws;
   size_t save_bytes, ws_bwd_bytes;
 };
 
@@ -267,6 +323,7 @@ static MlpLayout mlp_layout(const mmnas_mlp_op* op) {
   L.dt = drop ? w.take(M * op->dims[0]) : nullptr;
   L.dp[0] = w.take(M * maxh);
   L.dp[1] = op->nl > 2 ? w.take(M * maxh) : nullptr;
+  L.dp[2] = nullptr;
   L.lnws = norm ? w.take(mmnas_layernorm_bwd_ws_floats(op->M, op->dims[0])) : nullptr;
   L.ws_bwd_bytes = w.off;
   return L;
@@ -329,7 +386,9 @@ extern "C" int mmnas_mlp_op_fwd(const mmnas_mlp_op* op, void* stream) {
   return MMNAS_OK;
 }
 
-extern "C" int mmnas_mlp_op_bwd(const mmnas_mlp_op* op, void* stream) {
+namespace mmnas {
+static int mlp_bwd_impl(const mmnas_mlp_op* op, hipStream_t stream, SideQueue* sq) {
+  const bool side = sq != nullptr;
   int rc = mlp_check(op, "mlp_op_bwd");
   if (rc) return rc;
   MMNAS_REQUIRE(op->x && op->save && op->ws && op->dy && op->dx, MMNAS_E_ARG, "mlp_op_bwd: null pointer");
@@ -364,15 +423,18 @@ extern "C" int mmnas_mlp_op_bwd(const mmnas_mlp_op* op, void* stream) {
   const float gate_scale = drop ? 1.0f / (1.0f - op->drop_p) : 1.0f;
   const float* dpre = dt;  // gradient wrt the pre-activation output of layer i
   mmnas_gemm_desc g;
+  mmnas_gemm_desc wd[3];   // the weight-gradient products (side-stream mode: issued after the data-gradient chain)
+  const bool last_colsum = op->db[nl - 1] && !last_bias_done;
+  if (last_colsum && !side)
+    if ((rc = mmnas_colsum(dpre, op->db[nl - 1], M, op->dims[nl], op->dims[nl], stream))) return rc;
   for (int i = nl - 1; i >= 0; --i) {
     const float* hin = i == 0 ? op->x : L.h[i];
     const int nout = op->dims[i + 1], nin = op->dims[i];
-    // bias gradient: column sums of dpre.  The last layer's ride on the LayerNorm backward when possible; a hidden
-    // layer's are accumulated by the epilogue of the data-gradient product that writes its dpre (below)
-    if (op->db[i] && i == nl - 1 && !last_bias_done)
-      if ((rc = mmnas_colsum(dpre, op->db[i], M, nout, nout, stream))) return rc;
-    // weight gradient dW_i[nout,nin] += dpre^T hin and data gradient, one launch
-    mmnas_gemm_desc w;
+    // bias gradient: column sums of dpre.  The last layer's ride on the LayerNorm backward when possible (else the
+    // colsum launch above / on the side stream); a hidden layer's are accumulated by the epilogue of the data-gradient
+    // product that writes its dpre (below)
+    // weight gradient dW_i[nout,nin] += dpre^T hin and data gradient, one launch (or: the side stream)
+    mmnas_gemm_desc& w = wd[i];
     gemm_init(w, MMNAS_GEMM_TN, nin, M, nout, nin, nin);
     w.g[0].M = nout; w.g[0].A[0] = dpre; w.g[0].B[0] = hin; w.g[0].C = op->dW[i];
     w.accumulate = 1;
@@ -381,15 +443,421 @@ extern "C" int mmnas_mlp_op_bwd(const mmnas_mlp_op* op, void* stream) {
     if (i == 0) {
       g.g[0].C = op->dx;
       if (fl & MMNAS_F_RESIDUAL) { g.g[0].residual = dz; g.ldres = d; }
-      if ((rc = gemm_pair_aux(&g, &w, i == nl - 1 ? &lnred : nullptr, (hipStream_t)stream))) return rc;
     } else {
-      float* out = L.dp[(nl - 1 - i) & 1];
+      float* out = L.dp[(nl - 1 - i) % 3];   // (side-stream mode reads every dpre later: no buffer is reused)
       g.g[0].C = out;
       g.g[0].gate = L.h[i]; g.ldgate = nin; g.gate_scale = gate_scale;  // relu' and dropout replay from h_i
       g.g[0].colsum = op->db[i - 1];   // db_{i-1} += column sums of dpre_{i-1} (may be NULL: layer without bias)
-      if ((rc = gemm_pair_aux(&g, &w, i == nl - 1 ? &lnred : nullptr, (hipStream_t)stream))) return rc;
-      dpre = out;
     }
+    if (side) {
+      if ((rc = mmnas_gemm(&g, stream))) return rc;
+    } else if ((rc = gemm_pair_aux(&g, &w, i == nl - 1 ? &lnred : nullptr, (hipStream_t)stream))) return rc;
+    if (i > 0) dpre = g.g[0].C;
+  }
+  if (side) {
+    sq->work.push_back([lnred](hipStream_t s) { return launch_aux_reduce(lnred, s); });
+    if (last_colsum) {
+      float* const db = op->db[nl - 1];
+      const int n = op->dims[nl];
+      sq->work.push_back([dt, db, M, n](hipStream_t s) { return mmnas_colsum(dt, db, M, n, n, s); });
+    }
+    for (int i = nl - 1; i >= 0; --i) {
+      const mmnas_gemm_desc w = wd[i];
+      sq->work.push_back([w](hipStream_t s) { return mmnas_gemm(&w, s); });
+    }
+  }
+  return MMNAS_OK;
+}
+}  // namespace mmnas
+
+extern "C" int mmnas_mlp_op_bwd(const mmnas_mlp_op* op, void* stream) {
+  return mlp_bwd_impl(op, (hipStream_t)stream, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------ backbone chain
+// One call = every cell operator of a backbone (Backbone_*.forward, hygr_vqa.py:45-52 / full_vqa.py:46-53) in
+// evaluation order: the host issues O(1) calls per step instead of one autograd node, six allocations and a descriptor
+// per operator and direction.  Intermediate activations, saved blocks and backward scratch live in ONE caller-owned
+// arena laid out by mmnas_chain_plan.
+#include <map>
+#include <mutex>
+#include <utility>
+namespace mmnas {
+
+struct ChainLayout {
+  size_t y[MMNAS_CHAIN_MAX_OPS], save[MMNAS_CHAIN_MAX_OPS], ws[MMNAS_CHAIN_MAX_OPS], dx[MMNAS_CHAIN_MAX_OPS],
+      tmp[MMNAS_CHAIN_MAX_OPS];
+  size_t dpre, encdy, total;
+  int last_x, last_y, first_x, first_y, n_guided;
+};
+
+static int chain_check(const mmnas_chain* c, const char* who) {
+  MMNAS_REQUIRE(c && c->ops, MMNAS_E_ARG, "%s: null chain", who);
+  MMNAS_REQUIRE(c->n_ops >= 1 && c->n_ops <= MMNAS_CHAIN_MAX_OPS, MMNAS_E_SHAPE, "%s: %d operators (1..%d)", who, c->n_ops, MMNAS_CHAIN_MAX_OPS);
+  MMNAS_REQUIRE(c->B > 0 && c->Sx > 0 && c->Sy > 0 && c->d > 0, MMNAS_E_SHAPE, "%s: B=%d Sx=%d Sy=%d d=%d", who, c->B, c->Sx, c->Sy, c->d);
+  bool seen_y = false;
+  for (int i = 0; i < c->n_ops; ++i) {
+    const mmnas_chain_op& o = c->ops[i];
+    MMNAS_REQUIRE(o.kind == MMNAS_CHAIN_ATT || o.kind == MMNAS_CHAIN_MLP, MMNAS_E_ARG, "%s: operator %d: kind %d", who, i, o.kind);
+    if (o.on_y) seen_y = true;
+    else MMNAS_REQUIRE(!seen_y, MMNAS_E_ARG, "%s: encoder operators must precede the decoder's (operator %d)", who, i);
+    if (o.kind == MMNAS_CHAIN_ATT && !(o.att.flags & MMNAS_F_SELF))
+      MMNAS_REQUIRE(o.on_y, MMNAS_E_ARG, "%s: operator %d: guided attention needs the decoder stream", who, i);
+  }
+  return MMNAS_OK;
+}
+
+// operator i with its stream-dependent fields filled in (shapes, masks, relation tensors); buffers come later
+static void chain_op_setup(const mmnas_chain* c, int i, mmnas_att_op& a, mmnas_mlp_op& m) {
+  const mmnas_chain_op& o = c->ops[i];
+  const int S = o.on_y ? c->Sy : c->Sx;
+  if (o.kind == MMNAS_CHAIN_ATT) {
+    a = o.att;
+    a.B = c->B; a.d = c->d; a.Sq = S;
+    const bool self = a.flags & MMNAS_F_SELF;
+    a.Sk = self ? S : c->Sx;
+    const uint8_t* mask = (self && o.on_y) ? c->y_mask : c->x_mask;
+    a.mask = mask;
+    if (mask) a.flags |= MMNAS_F_MASK; else a.flags &= ~MMNAS_F_MASK;
+    if (a.flags & MMNAS_F_REL) a.rel = o.on_y ? c->y_rel : c->x_rel;
+  } else {
+    m = o.mlp;
+    m.M = c->B * S;
+  }
+}
+
+static int chain_layout(const mmnas_chain* c, ChainLayout& L) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t r = off; off += al(bytes); return r; };
+  L.last_x = L.last_y = L.first_x = L.first_y = -1;
+  L.n_guided = 0;
+  for (int i = 0; i < c->n_ops; ++i) {
+    if (c->ops[i].on_y) { if (L.first_y < 0) L.first_y = i; L.last_y = i; }
+    else { if (L.first_x < 0) L.first_x = i; L.last_x = i; }
+  }
+  const size_t nx = (size_t)c->B * c->Sx * c->d * sizeof(float), ny = (size_t)c->B * c->Sy * c->d * sizeof(float);
+  for (int i = 0; i < c->n_ops; ++i) {
+    const mmnas_chain_op& o = c->ops[i];
+    mmnas_att_op a; mmnas_mlp_op m;
+    chain_op_setup(c, i, a, m);
+    mmnas_plan pl;
+    int rc = o.kind == MMNAS_CHAIN_ATT ? mmnas_att_op_plan(&a, &pl) : mmnas_mlp_op_plan(&m, &pl);
+    if (rc) return rc;
+    const size_t n = o.on_y ? ny : nx;
+    L.y[i] = take(n);
+    L.save[i] = take(pl.save_bytes);
+    L.ws[i] = take(pl.ws_bwd_bytes);
+    L.dx[i] = take(n);
+    const bool guided = o.kind == MMNAS_CHAIN_ATT && !(a.flags & MMNAS_F_SELF);
+    L.tmp[i] = guided ? take(nx) : 0;
+    L.n_guided += guided;
+  }
+  L.dpre = take(nx);
+  L.encdy = take(nx);
+  L.total = off;
+  return MMNAS_OK;
+}
+
+// ---- side stream + events, one set per (device, main stream) ----
+struct SideCtx { hipStream_t side; hipEvent_t ev[MMNAS_CHAIN_MAX_OPS + 2]; bool used; };
+static std::mutex g_side_mu;
+static std::map<std::pair<int, hipStream_t>, SideCtx> g_side;
+
+static SideCtx* side_ctx(hipStream_t main, bool create) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  auto key = std::make_pair(dev, main);
+  auto it = g_side.find(key);
+  if (it == g_side.end()) {
+    if (!create) return nullptr;
+    SideCtx s;
+    memset(&s, 0, sizeof(s));
+    // lowest priority: when both streams have workgroups to dispatch, the data-gradient chain goes first
+    int least = 0, greatest = 0;
+    const bool prio = !(getenv("MMNAS_SIDE_PRIO") && getenv("MMNAS_SIDE_PRIO")[0] == '0') &&
+                      hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
+    if ((prio ? hipStreamCreateWithPriority(&s.side, hipStreamNonBlocking, least)
+              : hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking)) != hipSuccess) return nullptr;
+    for (auto& e : s.ev)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    it = g_side.emplace(key, s).first;
+  }
+  return &it->second;
+}
+
+}  // namespace mmnas
+
+extern "C" int mmnas_chain_plan(const mmnas_chain* c, size_t* arena_bytes) {
+  int rc = chain_check(c, "chain_plan");
+  if (rc) return rc;
+  MMNAS_REQUIRE(arena_bytes, MMNAS_E_ARG, "chain_plan: null output");
+  ChainLayout L;
+  if ((rc = chain_layout(c, L))) return rc;
+  *arena_bytes = L.total;
+  return MMNAS_OK;
+}
+
+extern "C" int mmnas_chain_fwd(const mmnas_chain* c, void* stream) {
+  int rc = chain_check(c, "chain_fwd");
+  if (rc) return rc;
+  MMNAS_REQUIRE(c->x_in && c->y_in && c->x_out && c->y_out && c->arena, MMNAS_E_ARG, "chain_fwd: null pointer");
+  ChainLayout L;
+  if ((rc = chain_layout(c, L))) return rc;
+  char* base = (char*)c->arena;
+  const float* cur_x = c->x_in;
+  const float* cur_y = c->y_in;
+  const size_t nx = (size_t)c->B * c->Sx * c->d * sizeof(float), ny = (size_t)c->B * c->Sy * c->d * sizeof(float);
+  for (int i = 0; i < c->n_ops; ++i) {
+    const mmnas_chain_op& o = c->ops[i];
+    mmnas_att_op a; mmnas_mlp_op m;
+    chain_op_setup(c, i, a, m);
+    const float* cur = o.on_y ? cur_y : cur_x;
+    float* out = i == L.last_x ? c->x_out : (i == L.last_y ? c->y_out : (float*)(base + L.y[i]));
+    if (o.kind == MMNAS_CHAIN_ATT) {
+      a.xq = cur;
+      a.xkv = (a.flags & MMNAS_F_SELF) ? cur : cur_x;   // guided: keys / values from the FINAL language state
+      a.y = out; a.save = base + L.save[i]; a.ws = base + L.ws[i];
+      if ((rc = mmnas_att_op_fwd(&a, stream))) return rc;
+    } else {
+      m.x = cur; m.y = out; m.save = base + L.save[i]; m.ws = base + L.ws[i];
+      if ((rc = mmnas_mlp_op_fwd(&m, stream))) return rc;
+    }
+    if (o.on_y) cur_y = out; else cur_x = out;
+  }
+  if (L.last_x < 0 && hipMemcpyAsync(c->x_out, c->x_in, nx, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return MMNAS_E_LAUNCH;
+  if (L.last_y < 0 && hipMemcpyAsync(c->y_out, c->y_in, ny, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return MMNAS_E_LAUNCH;
+  return MMNAS_OK;
+}
+
+extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
+  int rc = chain_check(c, "chain_bwd");
+  if (rc) return rc;
+  MMNAS_REQUIRE(c->x_in && c->y_in && c->x_out && c->y_out && c->arena && c->dy_out && c->dx_in && c->dy_in, MMNAS_E_ARG,
+                "chain_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  ChainLayout L;
+  if ((rc = chain_layout(c, L))) return rc;
+  SideCtx* sc = c->use_side_stream ? side_ctx(st, true) : nullptr;
+  MMNAS_REQUIRE(!c->use_side_stream || sc, MMNAS_E_LAUNCH, "chain_bwd: cannot create the side stream");
+  hipStream_t side = sc ? sc->side : nullptr;
+  if (sc) sc->used = true;
+  SideQueue q;
+  SideQueue* sq = sc ? &q : nullptr;
+  // When the queued parameter-gradient work is released: MMNAS_SIDE_FLUSH=op -> behind every operator (it then competes
+  // with the data-gradient chain for the CUs); default -> once behind the decoder and once behind the encoder, so it
+  // fills the latency-bound tail of the backward pass (encoder on 896 rows, LSTM, stem) instead.
+  static const bool per_op = getenv("MMNAS_SIDE_FLUSH") && !strcmp(getenv("MMNAS_SIDE_FLUSH"), "op");
+  char* base = (char*)c->arena;
+  const size_t ex = (size_t)c->B * c->Sx * c->d, ey = (size_t)c->B * c->Sy * c->d;
+  float* dpre = (float*)(base + L.dpre);
+  if (L.n_guided && hipMemsetAsync(dpre, 0, ex * sizeof(float), st) != hipSuccess) return MMNAS_E_LAUNCH;
+  // inputs of operator i = outputs of the previous operator on its stream
+  auto input_of = [&](int i) -> const float* {
+    const bool oy = c->ops[i].on_y;
+    for (int j = i - 1; j >= 0; --j)
+      if ((bool)c->ops[j].on_y == oy) return j == L.last_x ? c->x_out : (j == L.last_y ? c->y_out : (const float*)(base + L.y[j]));
+    return oy ? c->y_in : c->x_in;
+  };
+  const float* x_final = L.last_x >= 0 ? c->x_out : c->x_in;
+  const float* cur_dy = c->dy_out;
+  for (int i = c->n_ops - 1; i >= 0; --i) {
+    const mmnas_chain_op& o = c->ops[i];
+    if (sq && i == L.last_x && (rc = q.flush(st, side, sc->ev[0]))) return rc;   // the decoder's parameter-gradient work
+    if (!o.on_y && i == L.last_x) {   // entering the encoder: its output gradient = head's + the guided operators'
+      if (c->dx_out && L.n_guided) {
+        float* g0 = (float*)(base + L.encdy);
+        if ((rc = mmnas_drop_add(c->dx_out, dpre, g0, ex, 0.f, 0, 0, stream))) return rc;
+        cur_dy = g0;
+      } else cur_dy = c->dx_out ? c->dx_out : dpre;
+      MMNAS_REQUIRE(c->dx_out || L.n_guided, MMNAS_E_ARG, "chain_bwd: no gradient reaches the encoder (dx_out NULL, no guided operator)");
+    }
+    mmnas_att_op a; mmnas_mlp_op m;
+    chain_op_setup(c, i, a, m);
+    float* dx = i == L.first_x ? c->dx_in : (i == L.first_y ? c->dy_in : (float*)(base + L.dx[i]));
+    if (o.kind == MMNAS_CHAIN_ATT) {
+      const bool self = a.flags & MMNAS_F_SELF;
+      a.xq = input_of(i);
+      a.xkv = self ? a.xq : x_final;
+      a.save = base + L.save[i]; a.ws = base + L.ws[i];
+      a.dy = cur_dy; a.dxq = dx;
+      a.dxkv = self ? nullptr : (float*)(base + L.tmp[i]);
+      a.drel = nullptr;
+      if ((rc = att_bwd_impl(&a, st, sq))) return rc;
+      if (!self && (rc = mmnas_drop_add(a.dxkv, dpre, dpre, ex, 0.f, 0, 0, stream))) return rc;
+    } else {
+      m.x = input_of(i); m.save = base + L.save[i]; m.ws = base + L.ws[i];
+      m.dy = cur_dy; m.dx = dx;
+      if ((rc = mlp_bwd_impl(&m, st, sq))) return rc;
+    }
+    if (sq && per_op && (rc = q.flush(st, side, sc->ev[i + 1]))) return rc;
+    cur_dy = dx;
+  }
+  if (sq && (rc = q.flush(st, side, sc->ev[1]))) return rc;
+  if (L.first_y < 0 && hipMemcpyAsync(c->dy_in, c->dy_out, ey * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return MMNAS_E_LAUNCH;
+  if (L.first_x < 0) {
+    const float* g0 = c->dx_out;
+    if (c->dx_out && L.n_guided) {
+      if ((rc = mmnas_drop_add(c->dx_out, dpre, c->dx_in, ex, 0.f, 0, 0, stream))) return rc;
+      g0 = nullptr;
+    } else if (!c->dx_out) g0 = dpre;
+    if (g0 && hipMemcpyAsync(c->dx_in, g0, ex * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return MMNAS_E_LAUNCH;
+  }
+  return MMNAS_OK;
+}
+
+extern "C" int mmnas_chain_join(void* main_stream, void* waiting_stream) {
+  SideCtx* sc = side_ctx((hipStream_t)main_stream, false);
+  if (!sc || !sc->used) return MMNAS_OK;
+  hipEvent_t e = sc->ev[MMNAS_CHAIN_MAX_OPS];
+  if (hipEventRecord(e, sc->side) != hipSuccess || hipStreamWaitEvent((hipStream_t)waiting_stream, e, 0) != hipSuccess) {
+    set_error("chain_join: event record / wait failed");
+    return MMNAS_E_LAUNCH;
+  }
+  return MMNAS_OK;
+}
+
+// ------------------------------------------------------------------------------------------ answer head
+// AttFlat(x) + AttFlat(y) -> LayerNorm -> answer projection (hygr_vqa.py:113-119 / full_vqa.py:105-114 with
+// modules.py:59-85) as one call per direction: ~28 launches issued back to back instead of ~75 behind 40 autograd
+// nodes (the head's kernels take 5-15 us each, so the per-node host cost -- not the GPU -- set its duration).
+namespace mmnas {
+
+struct HeadSideLayout { float *h, *logit, *probs, *pooled, *dpooled, *dlog, *dh, *dxpool; };
+struct HeadLayout {
+  HeadSideLayout s[2];
+  float *xo, *sum, *xy, *dxy, *dsum, *lnws;
+  size_t total;
+};
+
+static HeadLayout head_layout(const mmnas_head* hd) {
+  HeadLayout L;
+  Carver c(hd->arena);
+  const size_t B = hd->B;
+  for (int k = 0; k < 2; ++k) {
+    const mmnas_attflat_side& sd = k ? hd->sy : hd->sx;
+    const size_t M = B * sd.S;
+    HeadSideLayout& s = L.s[k];
+    s.h = c.take(M * hd->MID); s.logit = c.take(M * hd->G); s.probs = c.take(M * hd->G); s.pooled = c.take(B * hd->G * hd->d);
+    s.dpooled = c.take(B * hd->G * hd->d); s.dlog = c.take(M * hd->G); s.dh = c.take(M * hd->MID); s.dxpool = c.take(M * hd->d);
+  }
+  L.xo = c.take(B * hd->OUT); L.sum = c.take(B * hd->OUT); L.xy = c.take(B * hd->OUT);
+  L.dxy = c.take(B * hd->OUT); L.dsum = c.take(B * hd->OUT);
+  L.lnws = c.take(mmnas_layernorm_bwd_ws_floats(hd->B, hd->OUT));
+  L.total = c.off;
+  return L;
+}
+
+static int head_check(const mmnas_head* hd, const char* who) {
+  MMNAS_REQUIRE(hd, MMNAS_E_ARG, "%s: null descriptor", who);
+  MMNAS_REQUIRE(hd->B > 0 && hd->d > 0 && hd->MID > 0 && hd->G > 0 && hd->OUT > 0 && hd->ANS > 0 && hd->sx.S > 0 && hd->sy.S > 0,
+                MMNAS_E_SHAPE, "%s: B=%d d=%d MID=%d G=%d OUT=%d ANS=%d Sx=%d Sy=%d", who, hd->B, hd->d, hd->MID, hd->G, hd->OUT,
+                hd->ANS, hd->sx.S, hd->sy.S);
+  MMNAS_REQUIRE(hd->d % 4 == 0 && hd->MID % 4 == 0 && hd->OUT % 4 == 0, MMNAS_E_SHAPE, "%s: d, MID, OUT must be multiples of 4", who);
+  return MMNAS_OK;
+}
+
+}  // namespace mmnas
+
+extern "C" int mmnas_head_plan(const mmnas_head* hd, size_t* arena_bytes) {
+  int rc = head_check(hd, "head_plan");
+  if (rc) return rc;
+  MMNAS_REQUIRE(arena_bytes, MMNAS_E_ARG, "head_plan: null output");
+  mmnas_head tmp = *hd;
+  tmp.arena = nullptr;
+  *arena_bytes = head_layout(&tmp).total;
+  return MMNAS_OK;
+}
+
+extern "C" int mmnas_head_fwd(const mmnas_head* hd, void* stream) {
+  int rc = head_check(hd, "head_fwd");
+  if (rc) return rc;
+  MMNAS_REQUIRE(hd->arena && hd->logits && hd->ln_a && hd->ln_b && hd->Wp, MMNAS_E_ARG, "head_fwd: null pointer");
+  HeadLayout L = head_layout(hd);
+  const bool drop = (hd->flags & MMNAS_F_TRAIN) && hd->drop_p > 0.f;
+  const int B = hd->B, d = hd->d, MID = hd->MID, G = hd->G, OUT = hd->OUT;
+  mmnas_gemm_desc g;
+  for (int k = 0; k < 2; ++k) {
+    const mmnas_attflat_side& sd = k ? hd->sy : hd->sx;
+    const HeadSideLayout& s = L.s[k];
+    MMNAS_REQUIRE(sd.x && sd.W1 && sd.W2 && sd.Wm, MMNAS_E_ARG, "head_fwd: side %d null pointer", k);
+    const int M = B * sd.S;
+    // h = drop(relu(x W1^T + b1))                                   (FC, modules.py:13-31)
+    gemm_init(g, MMNAS_GEMM_NT, MID, d, d, d, MID);
+    g.g[0].M = M; g.g[0].A[0] = sd.x; g.g[0].B[0] = sd.W1; g.g[0].bias = sd.b1; g.g[0].C = s.h; g.relu = 1;
+    if (drop) { g.drop_p = hd->drop_p; g.drop_seed = sd.seed; g.drop_site = 0; }
+    if ((rc = mmnas_gemm(&g, stream))) return rc;
+    // glimpse logits = h W2^T + b2                                   (MLP.linear, modules.py:34-41)
+    gemm_init(g, MMNAS_GEMM_NT, G, MID, MID, MID, G);
+    g.g[0].M = M; g.g[0].A[0] = s.h; g.g[0].B[0] = sd.W2; g.g[0].bias = sd.b2; g.g[0].C = s.logit;
+    if ((rc = mmnas_gemm(&g, stream))) return rc;
+    // masked softmax over the sequence + weighted sum                (modules.py:78-84)
+    if ((rc = mmnas_attflat_pool_fwd(s.logit, sd.x, sd.mask, s.probs, s.pooled, B, sd.S, d, G, stream))) return rc;
+    // merge; the image side adds the language side's result (x_out + y_out, hygr_vqa.py:116)
+    gemm_init(g, MMNAS_GEMM_NT, OUT, G * d, G * d, G * d, OUT);
+    g.g[0].M = B; g.g[0].A[0] = s.pooled; g.g[0].B[0] = sd.Wm; g.g[0].bias = sd.bm; g.g[0].C = k ? L.sum : L.xo;
+    if (k) { g.g[0].residual = L.xo; g.ldres = OUT; }
+    if ((rc = mmnas_gemm(&g, stream))) return rc;
+  }
+  if ((rc = mmnas_layernorm_fwd(L.sum, hd->ln_a, hd->ln_b, L.xy, B, OUT, hd->eps, stream))) return rc;
+  gemm_init(g, MMNAS_GEMM_NT, hd->ANS, OUT, OUT, OUT, hd->ANS);
+  g.g[0].M = B; g.g[0].A[0] = L.xy; g.g[0].B[0] = hd->Wp; g.g[0].bias = hd->bp; g.g[0].C = hd->logits;
+  return mmnas_gemm(&g, stream);
+}
+
+extern "C" int mmnas_head_bwd(const mmnas_head* hd, void* stream) {
+  int rc = head_check(hd, "head_bwd");
+  if (rc) return rc;
+  MMNAS_REQUIRE(hd->arena && hd->dlogits && hd->ln_a && hd->dln_a && hd->dln_b && hd->Wp && hd->dWp, MMNAS_E_ARG, "head_bwd: null pointer");
+  HeadLayout L = head_layout(hd);
+  const bool drop = (hd->flags & MMNAS_F_TRAIN) && hd->drop_p > 0.f;
+  const float gate_scale = drop ? 1.0f / (1.0f - hd->drop_p) : 1.0f;
+  const int B = hd->B, d = hd->d, MID = hd->MID, G = hd->G, OUT = hd->OUT, ANS = hd->ANS;
+  hipStream_t st = (hipStream_t)stream;
+  mmnas_gemm_desc g, w;
+  // answer projection
+  gemm_init(w, MMNAS_GEMM_TN, OUT, B, ANS, OUT, OUT);
+  w.g[0].M = ANS; w.g[0].A[0] = hd->dlogits; w.g[0].B[0] = L.xy; w.g[0].C = hd->dWp; w.accumulate = 1;
+  gemm_init(g, MMNAS_GEMM_NN, OUT, ANS, ANS, OUT, OUT);
+  g.g[0].M = B; g.g[0].A[0] = hd->dlogits; g.g[0].B[0] = hd->Wp; g.g[0].C = L.dxy;
+  if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
+  if (hd->dbp && (rc = mmnas_colsum(hd->dlogits, hd->dbp, B, ANS, ANS, stream))) return rc;
+  // proj_norm
+  AuxReduce lnred;
+  lnred.part = nullptr;
+  if ((rc = layernorm_bwd_deferred(L.sum, hd->ln_a, L.dxy, L.dsum, hd->dln_a, hd->dln_b, nullptr, nullptr, L.lnws, 0.f, 0, 0, B, OUT,
+                                   hd->eps, st, &lnred)))
+    return rc;
+  for (int k = 1; k >= 0; --k) {
+    const mmnas_attflat_side& sd = k ? hd->sy : hd->sx;
+    const HeadSideLayout& s = L.s[k];
+    MMNAS_REQUIRE(sd.x && sd.dx && sd.dW1 && sd.dW2 && sd.dWm, MMNAS_E_ARG, "head_bwd: side %d null pointer", k);
+    const int M = B * sd.S;
+    // merge: the sum's gradient reaches both sides unchanged
+    gemm_init(w, MMNAS_GEMM_TN, G * d, B, OUT, G * d, G * d);
+    w.g[0].M = OUT; w.g[0].A[0] = L.dsum; w.g[0].B[0] = s.pooled; w.g[0].C = sd.dWm; w.accumulate = 1;
+    gemm_init(g, MMNAS_GEMM_NN, G * d, OUT, OUT, G * d, G * d);
+    g.g[0].M = B; g.g[0].A[0] = L.dsum; g.g[0].B[0] = sd.Wm; g.g[0].C = s.dpooled;
+    if ((rc = gemm_pair_aux(&g, &w, k ? &lnred : nullptr, st))) return rc;
+    if (sd.dbm && (rc = mmnas_colsum(L.dsum, sd.dbm, B, OUT, OUT, stream))) return rc;
+    // pooling
+    if ((rc = mmnas_attflat_pool_bwd(s.probs, sd.x, sd.mask, s.dpooled, s.dlog, s.dxpool, B, sd.S, d, G, stream))) return rc;
+    // glimpse-logit linear: dh = dlog W2 with relu' and the dropout replay from h; db1 rides as column sums of dh
+    gemm_init(w, MMNAS_GEMM_TN, MID, M, G, MID, MID);
+    w.g[0].M = G; w.g[0].A[0] = s.dlog; w.g[0].B[0] = s.h; w.g[0].C = sd.dW2; w.accumulate = 1;
+    gemm_init(g, MMNAS_GEMM_NN, MID, G, G, MID, MID);
+    g.g[0].M = M; g.g[0].A[0] = s.dlog; g.g[0].B[0] = sd.W2; g.g[0].C = s.dh;
+    g.g[0].gate = s.h; g.ldgate = MID; g.gate_scale = gate_scale;
+    g.g[0].colsum = sd.db1;
+    if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
+    if (sd.db2 && (rc = mmnas_colsum(s.dlog, sd.db2, M, G, G, stream))) return rc;
+    // FC: dx = dh W1 + the pooling path's share
+    gemm_init(w, MMNAS_GEMM_TN, d, M, MID, d, d);
+    w.g[0].M = MID; w.g[0].A[0] = s.dh; w.g[0].B[0] = sd.x; w.g[0].C = sd.dW1; w.accumulate = 1;
+    gemm_init(g, MMNAS_GEMM_NN, d, MID, MID, d, d);
+    g.g[0].M = M; g.g[0].A[0] = s.dh; g.g[0].B[0] = sd.W1; g.g[0].C = sd.dx;
+    g.g[0].residual = s.dxpool; g.ldres = d;
+    if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
   }
   return MMNAS_OK;
 }

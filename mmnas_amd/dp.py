@@ -40,14 +40,21 @@ def _align(n, a=64):
 class _Sink:
     """Handle a parameter carries (`p._mmnas_sink`) while its gradient lives in a flat buffer: the HIP
     backward kernels accumulate straight into `view` (mmnas_amd.ops._grad_bufs) and call `done()`."""
-    __slots__ = ('view', 'index', 'callback')
+    __slots__ = ('view', 'index', 'callback', 'ready_cb')
 
-    def __init__(self, view, index, callback):
-        self.view, self.index, self.callback = view, index, callback
+    def __init__(self, view, index, callback, ready_cb=None):
+        self.view, self.index, self.callback, self.ready_cb = view, index, callback, ready_cb
 
     def done(self):
+        """One operator has enqueued its contribution (a parameter shared by several operators gets several)."""
         if self.callback is not None:
             self.callback(self.index)
+
+    def ready(self):
+        """The parameter's WHOLE gradient of this backward pass has been enqueued (sent by ops.BackboneFn, whose
+        parameters are not autograd inputs and therefore never reach a post-accumulate hook)."""
+        if self.ready_cb is not None:
+            self.ready_cb(self.index)
 
 
 class FlatGrads:
@@ -109,12 +116,12 @@ class FlatGrads:
             n += bool(self.adopt(i))
         return n
 
-    def enable_sinks(self, callback=None):
+    def enable_sinks(self, callback=None, ready_cb=None):
         """Let the operators' backward kernels write parameter gradients directly into the views
-        (no per-operator zero-fill, no autograd accumulate kernel).  `callback(i)` fires when the
-        gradient of params[i] has been enqueued."""
+        (no per-operator zero-fill, no autograd accumulate kernel).  `callback(i)` fires when one operator has
+        enqueued its share of params[i]'s gradient, `ready_cb(i)` when the whole gradient has been (see _Sink)."""
         for i, (p, v) in enumerate(zip(self.params, self.views)):
-            p._mmnas_sink = _Sink(v, i, callback)
+            p._mmnas_sink = _Sink(v, i, callback, ready_cb)
 
     def disable_sinks(self):
         for p in self.params:
@@ -165,7 +172,8 @@ class GradReducer:
                 # before its last gradients were enqueued.)
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
         if self.is_cuda:
-            self.fg.enable_sinks(None)   # HIP backward kernels add straight into the flat buffer
+            # HIP backward kernels add straight into the flat buffer; the backbone chain reports its parameters itself
+            self.fg.enable_sinks(None, self._arrived if self.comm else None)
 
     def _arrived(self, i):
         if self._seen[i]:
@@ -191,8 +199,10 @@ class GradReducer:
         avg = _has_avg(self.group)
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
         if self.is_cuda:
+            from . import ops
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
+            ops.side_stream_barrier(self.comm_stream)   # weight gradients the backbone chain put on its side stream
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
                 self._works.append((dist.all_reduce(chunk, op=op, group=self.group, async_op=True), chunk, not avg))
@@ -245,8 +255,12 @@ class SupernetReducer:
     slice by one kernel and all-reduced on a side stream as soon as autograd has accumulated its last gradient, while
     backward continues with the earlier nodes (search_vqa.py:292 behind DDP's bucketing, but over ~1/3 of the bytes)."""
 
-    def __init__(self, net, group=None, n_buckets=3, force_collectives=False):
+    def __init__(self, net, group=None, n_buckets=3, force_collectives=False, attach_all=False):
+        """attach_all: every parameter keeps its gradient view attached for good (unsampled candidates then show a ZERO
+        gradient instead of None -- what the reference loop's `0 * sum(p.sum())` terms produce, search_vqa.py:285-288);
+        saves re-pointing ~900 `.grad` attributes per step.  Only the exchange set still follows the sample."""
         self.net = net
+        self.attach_all = attach_all
         self.group = group
         self.world = _world()
         self.comm = self.world > 1 or (force_collectives and dist.is_initialized())
@@ -331,20 +345,28 @@ class SupernetReducer:
             for i, p in enumerate(fg.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))   # (see GradReducer: the only arrival signal)
         if self.is_cuda:
-            self.fg.enable_sinks(None)   # HIP backward kernels add straight into the flat buffer
+            self.fg.enable_sinks(None, self._arrived if self.comm else None)   # (see GradReducer)
 
     # -- weight step --------------------------------------------------------------------------------------------
     def begin_weight_step(self):
         """After reset_binary_gates(): zero the buffer, give gradient views to the stem/head and the
         sampled candidates only (unsampled candidates keep grad=None, mixed.py:160-163), arm the buckets."""
         mops = self.net.redundant_modules
-        active = list(self.shared)
-        for m, node in zip(mops, self.per_op):
-            for i in m.active_index:
-                active += node[i]
         self.fg.zero()
-        self.fg.attach(active)
-        self._active = active
+        if self.attach_all:
+            p0 = self.fg.params[-1]
+            if p0.grad is not self.fg.views[-1] or self.fg.params[0].grad is not self.fg.views[0]:
+                self.fg.attach()
+            else:
+                self.fg.dirty = [True] * len(self.fg.params)
+            self._active = None
+        else:
+            active = list(self.shared)
+            for m, node in zip(mops, self.per_op):
+                for i in m.active_index:
+                    active += node[i]
+            self.fg.attach(active)
+            self._active = active
         if not self.comm:
             return
         armed = set()
@@ -369,16 +391,19 @@ class SupernetReducer:
         """(offset, n) runs of the flat buffer that travel in this step's exchange (all buckets)."""
         return [seg for segs in self._segs if segs for seg in segs]
 
+    def _arrived(self, i):
+        if i not in self._armed:
+            return
+        self._armed.discard(i)
+        self.fg.adopt(i)
+        b = self.bucket_of_param[i]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
     def _make_hook(self, i):
         def hook(_p):
-            if i not in self._armed:
-                return
-            self._armed.discard(i)
-            self.fg.adopt(i)
-            b = self.bucket_of_param[i]
-            self._pending[b] -= 1
-            if self._pending[b] == 0:
-                self._launch(b)
+            self._arrived(i)
         return hook
 
     def _launch(self, b):
@@ -393,8 +418,10 @@ class SupernetReducer:
         avg = _has_avg(self.group)
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
         if self.is_cuda:
+            from . import ops
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
+            ops.side_stream_barrier(self.comm_stream)   # weight gradients the backbone chain put on its side stream
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
                 self._pack(segs, stg, 0)
@@ -408,7 +435,7 @@ class SupernetReducer:
         """After backward: flush the buckets that are still open (always the stem's), wait, scatter the averaged
         gradients back into the flat buffer."""
         if not self.comm:
-            self.fg.adopt_strays([self.fg.index[id(p)] for p in self._active])
+            self.fg.adopt_strays(None if self._active is None else [self.fg.index[id(p)] for p in self._active])
             return
         for i in list(self._armed):          # gradients that never arrived through a hook (e.g. produced under no hook)
             self.fg.adopt(i)

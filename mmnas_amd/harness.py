@@ -25,6 +25,22 @@ from .model.mixed import MixedOp
 from .optim import FlatAdam, WarmupOptimizer
 
 
+class BCEWithLogitsSum(nn.Module):
+    """torch.nn.BCEWithLogitsLoss(reduction='sum') (search_vqa.py:211) as one HIP kernel per direction on the GPU."""
+
+    def forward(self, pred, target):
+        if pred.is_cuda and pred.dtype == torch.float32:
+            return ops.bce_with_logits_sum(pred, target)
+        return F.binary_cross_entropy_with_logits(pred, target, reduction='sum')
+
+
+def fused_loss(loss_fn):
+    """The HIP form of a loss module the scripts use, when there is one."""
+    if isinstance(loss_fn, nn.BCEWithLogitsLoss) and loss_fn.reduction == 'sum' and loss_fn.weight is None and loss_fn.pos_weight is None:
+        return BCEWithLogitsSum()
+    return loss_fn
+
+
 class BCE_Loss(nn.Module):
     """mmnas/utils/itm_loss.py:4-24: BCE on the sigmoid scores, label 1 for the matching pair and 0 for the two
     negatives; the positive term enters twice (`loss_pos + loss_negc + loss_pos + loss_negi`)."""
@@ -109,8 +125,11 @@ class SearchLoop:
             raise NotImplementedError("SearchLoop fuses the architecture update for ALPHA_BINARY_MODE 'full' (the shipped "
                                       "setting, search_vqa.py:151); drive mode 'two' through MixedOp's own methods")
         self.net = net
-        self.loss_fn = loss_fn if loss_fn is not None else nn.BCEWithLogitsLoss(reduction='sum')
-        self.reducer = dp.SupernetReducer(net, group=group, n_buckets=n_buckets, force_collectives=force_collectives)
+        self.loss_fn = fused_loss(loss_fn if loss_fn is not None else nn.BCEWithLogitsLoss(reduction='sum'))
+        dense = absent_grads == 'zero'
+        self.reducer = dp.SupernetReducer(net, group=group, n_buckets=n_buckets, force_collectives=force_collectives,
+                                          attach_all=dense)
+        net.keep_candidate_grads = dense
         self.net_optim = WarmupOptimizer(net_lr, FlatAdam(self.reducer.fg.params, betas=net_betas, eps=net_eps,
                                                           grads=self.reducer.fg, absent_grads=absent_grads),
                                          epoch_steps=epoch_steps, warmup=warmup, max_norm=clip if clip and clip > 0 else None)
@@ -124,8 +143,9 @@ class SearchLoop:
             self.net.reset_binary_gates()
         else:            # injected (active, inactive) lists per node: tests / replay of a logged search
             self.net.set_sampled(plan)
-            for m in self.net.redundant_modules:
-                m.clear_candidate_grads()
+            if not getattr(self.net, 'keep_candidate_grads', False):
+                for m in self.net.redundant_modules:
+                    m.clear_candidate_grads()
 
     def weight_step(self, inputs, target, optimize=True, plan=None):
         net, red = self.net, self.reducer

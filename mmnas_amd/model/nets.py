@@ -60,6 +60,14 @@ class Cell_Full(_Cell):
              for node in __C.GENOTYPE[type]])
 
 
+def _op_params(op):
+    """An operator's parameter list (cached on the module: walking the module tree 30 times per step is host time)."""
+    ps = op.__dict__.get('_mmnas_params')
+    if ps is None:
+        ps = op.__dict__['_mmnas_params'] = list(op.parameters())
+    return ps
+
+
 class _Backbone(nn.Module):
     CELL = None
 
@@ -68,7 +76,64 @@ class _Backbone(nn.Module):
         self.cells_enc = nn.ModuleList([self.CELL(__C, type='enc') for _ in range(__C.LAYERS)])
         self.cells_dec = nn.ModuleList([self.CELL(__C, type='dec') for _ in range(__C.LAYERS)])
 
+    def _chain(self, x, y, x_mask, y_mask, x_rel_embed, y_rel_embed):
+        """The whole backbone as ONE native call per direction (ops.BackboneFn) -- possible when every node holds a
+        single attention- or MLP-family operator, relation operators can take the lazy handle, and every parameter's
+        gradient lives in a flat buffer the kernels may add into (a reducer / FlatAdam is attached).  Returns None
+        when any of that does not hold: the per-operator path below serves every other case."""
+        from .modules import FeedForward, FeedForward_deep, GuidedAtt, RelSelfAtt, SelfAtt
+        if not (ops.chain_enabled() and x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32):
+            return None
+        if MixedOp.MODE is not None:
+            return None
+        records, params = [], []
+        for on_y, cells in ((0, self.cells_enc), (1, self.cells_dec)):
+            rel = y_rel_embed if on_y else x_rel_embed
+            for cell in cells:
+                for node in cell.dag:
+                    if len(node) != 1:
+                        return None
+                    op = node[0]
+                    if isinstance(op, MixedOp):
+                        op = op.active_op
+                    t = type(op)
+                    if t is SelfAtt or t is GuidedAtt or t is RelSelfAtt:
+                        if t is GuidedAtt and not on_y:
+                            return None
+                        rh = None
+                        if t is RelSelfAtt:
+                            if not (isinstance(rel, RelHandle) and rel.fusable(op.mhatt.linear_r.weight.shape[0])):
+                                return None
+                            rh = rel
+                        ps = _op_params(op)
+                        if not ops._sinked((ps[0], ps[-1])) or (rh is not None and not ops._sinked((rh.weight, rh.bias))):
+                            return None
+                        rec, used = ops.chain_att_record_cached(op, on_y, t is not GuidedAtt, rh)
+                    elif t is FeedForward or t is FeedForward_deep:
+                        ps = _op_params(op)
+                        if not ops._sinked((ps[0], ps[-1])):
+                            return None
+                        m = op.mlp
+                        if t is FeedForward:
+                            ws, bs = [m.fc.linear.weight, m.linear.weight], [m.fc.linear.bias, m.linear.bias]
+                        else:
+                            ws = [op.fc.linear.weight, m.fc.linear.weight, m.linear.weight]
+                            bs = [op.fc.linear.bias, m.fc.linear.bias, m.linear.bias]
+                        rec, used = ops.chain_mlp_record_cached(op, on_y, ws, bs)
+                    else:
+                        return None
+                    records.append(rec)
+                    params += used
+        if not records or len(records) > 64:
+            return None
+        xr = x_rel_embed.raw if isinstance(x_rel_embed, RelHandle) else None
+        yr = y_rel_embed.raw if isinstance(y_rel_embed, RelHandle) else None
+        return ops.backbone_chain(x, y, x_mask, y_mask, xr, yr, records, params)
+
     def forward(self, x, y, x_mask, y_mask, x_rel_embed, y_rel_embed):
+        out = self._chain(x, y, x_mask, y_mask, x_rel_embed, y_rel_embed)
+        if out is not None:
+            return out
         # encoder cells over the language stream, then decoder cells over the image stream with
         # pre = final language state (hygr_vqa.py:45-52)
         for cell in self.cells_enc:
@@ -141,7 +206,7 @@ class _Net(nn.Module):
         x_mask = make_mask(ques_ix.unsqueeze(2))
         y_mask = make_mask(frcn_feat)
         emb = ops.embedding(ques_ix, self.embedding)
-        # (MIOpen's LSTM; the step-fused HIP one is an opt-in experiment, see ops.lstm_enabled)
+        # (one persistent launch per pass: ops.LstmFn; nn.LSTM = MIOpen only for shapes outside its range)
         x_in = ops.lstm(emb, self.lstm) if (ops.lstm_enabled() and ops.lstm_supported(emb, self.lstm)) else self.lstm(emb)[0]
         if C.BBOX_FEATURE:
             bb = ops.linear(bbox_feat, self.bboxfeat_linear.weight, self.bboxfeat_linear.bias)
@@ -158,6 +223,12 @@ class _Net(nn.Module):
                 x_rel_embed = ops.linear(x_rel_embed, self.linear_x_rel.weight, self.linear_x_rel.bias, relu=True)
             y_rel_embed = ops.linear(y_rel_embed, self.linear_y_rel.weight, self.linear_y_rel.bias, relu=True)
         x_out, y_out = self.backnone(x_in, y_in, x_mask, y_mask, x_rel_embed, y_rel_embed)
+        if self.TASK != 'vgd' and ops.chain_enabled() and x_out.is_cuda:
+            # AttFlat x 2 + proj_norm + proj as one native call per direction (needs the flat-gradient sinks)
+            hd, hp = ops.head_record(self.attflat_x, self.attflat_y, self.proj_norm, self.proj, self.training)
+            if hd is not None:
+                out = ops.HeadFn.apply(x_out, y_out, x_mask, y_mask, hd, hp)
+                return torch.sigmoid(out.squeeze(-1)) if self.TASK == 'itm' else out
         x_out = self.attflat_x(x_out, x_mask)
         if self.TASK == 'vgd':  # per-object scores + box regression (full_vgd.py:105-114)
             y_out = ops.linear(y_out, self.attfc_y.weight, self.attfc_y.bias)
@@ -281,6 +352,8 @@ class NetSearchBase(_Net):
         probs = self._probs_cpu(prob)
         mops = self.redundant_modules
         idx = (ctypes.c_int * len(mops))()
+        # a reducer that keeps every gradient view attached (dp.SupernetReducer(attach_all=True)) zeroes the buffer itself
+        keep = getattr(self, 'keep_candidate_grads', False)
         if MixedOp.MODE is None:
             # one draw for all nodes (rows of the cached probability matrix; padding columns have probability 0):
             # 30 separate multinomial calls were 0.3 ms of host time per step
@@ -289,13 +362,15 @@ class NetSearchBase(_Net):
                 a = drawn[i]
                 m.set_active([a], [j for j in range(m.n_choices) if j != a], write_gate=False)
                 idx[i] = a
-                m.clear_candidate_grads()
+                if not keep:
+                    m.clear_candidate_grads()
         else:
             for i, m in enumerate(mops):
                 act, inact = sample_indices(probs[i, :m.n_choices], MixedOp.MODE)
                 m.set_active(act, inact, write_gate=False)
                 idx[i] = act[0]
-                m.clear_candidate_grads()
+                if not keep:
+                    m.clear_candidate_grads()
         if gate.is_cuda and len(mops) <= 128:
             from .. import _lib as L
             L.check(L.lib().mmnas_onehot_rows(L.fptr(gate), gate.shape[0], gate.shape[1], idx, L.stream()))

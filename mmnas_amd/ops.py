@@ -483,76 +483,53 @@ def embedding(idx, mod):
     return mod(idx)
 
 
-_lstm_idx = {}
-
-
-def _lstm_index(H, dev):
-    """(perm, inv): interleaved row 4j+g <- nn.LSTM row g*H+j, and back."""
-    key = (H, str(dev))
-    if key not in _lstm_idx:
-        n = torch.arange(4 * H, device=dev)
-        perm = (n % 4) * H + n // 4
-        inv = torch.empty_like(perm)
-        inv[perm] = n
-        _lstm_idx[key] = (perm, inv)
-    return _lstm_idx[key]
-
-
 class LstmFn(torch.autograd.Function):
     """nn.LSTM(num_layers=1, batch_first=True), zero initial state, full output sequence (hygr_vqa.py:106-107) on
-    mmnas_lstm_fwd/bwd: one launch per time step and direction, the weight / input gradients as three large products."""
+    mmnas_lstm_seq_fwd/bwd: the input projection is one product over all B*T rows, the recurrence ONE persistent
+    launch per pass, the parameter / input gradients three products (native gate order: nothing is permuted)."""
 
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
         lib = L.lib()
-        x = _f32c(x)
+        ctx.params = (w_ih, w_hh, b_ih, b_hh)   # the parameter objects: their gradient sinks are looked up in backward
+        x, Wih, Whh = _f32c(x), _f32c(w_ih), _f32c(w_hh)
         B, T, E = x.shape
-        H = w_hh.shape[1]
+        H = Whh.shape[1]
         dev = x.device
-        perm, inv = _lstm_index(H, dev)
-        Wih, Whh = w_ih.index_select(0, perm), w_hh.index_select(0, perm)
-        bias = (b_ih + b_hh).index_select(0, perm)
-        x_tm = x.transpose(0, 1).contiguous()
-        hc = torch.empty(2, T + 1, B, H, dtype=torch.float32, device=dev)
-        hc[:, 0].zero_()
-        Gall = torch.empty(T, B, 4 * H, dtype=torch.float32, device=dev)
-        xp = torch.empty(T, B, 4 * H, dtype=torch.float32, device=dev)
-        out = torch.empty(B, T, H, dtype=torch.float32, device=dev)
-        L.check(lib.mmnas_lstm_fwd(L.fptr(x_tm), L.fptr(Wih), L.fptr(Whh), L.fptr(bias), L.fptr(xp), L.fptr(hc[0]),
-                                   L.fptr(hc[1]), L.fptr(Gall), L.fptr(out), T, B, E, H, L.stream()))
-        ctx.save_for_backward(x_tm, Wih, Whh, hc, Gall)
+        xp = torch.empty(B, T, 4 * H, dtype=torch.float32, device=dev)
+        gemm(L.GEMM_NT, [dict(M=B * T, A=[x], B=[Wih], C=xp, bias=_f32c(b_ih))], 4 * H, E, E, E, 4 * H)
+        st = torch.empty(3, B, T, H, dtype=torch.float32, device=dev)      # Hprev, Cs, out
+        Gall = torch.empty(B, T, 4 * H, dtype=torch.float32, device=dev)
+        L.check(lib.mmnas_lstm_seq_fwd(L.fptr(xp), L.fptr(_f32c(b_hh)), L.fptr(Whh), L.fptr(st[0]), L.fptr(st[1]), L.fptr(Gall),
+                                       L.fptr(st[2]), T, B, H, L.stream()))
+        ctx.save_for_backward(x, Wih, Whh, st, Gall)
         ctx.dims = (B, T, E, H)
-        return out
+        return st[2]
 
     @staticmethod
     def backward(ctx, dout):
         lib = L.lib()
-        x_tm, Wih, Whh, hc, Gall = ctx.saved_tensors
+        x, Wih, Whh, st, Gall = ctx.saved_tensors
         B, T, E, H = ctx.dims
         dev = dout.device
         dout = _f32c(dout)
-        perm, inv = _lstm_index(H, dev)
-        DG = torch.empty(T + 1, B, 4 * H, dtype=torch.float32, device=dev)
-        DG[T].zero_()
-        small = torch.zeros(2, B, H, dtype=torch.float32, device=dev)   # running dc, scratch
-        L.check(lib.mmnas_lstm_bwd(L.fptr(dout), L.fptr(Whh), L.fptr(hc[1]), L.fptr(Gall), L.fptr(DG), L.fptr(small[0]),
-                                   L.fptr(small[1]), T, B, H, L.stream()))
-        dg = DG[:T].view(T * B, 4 * H)
-        # parameter gradients in the interleaved row order: [dW_hh | dW_ih | db] in one zeroed buffer
-        flat = torch.zeros(4 * H * (H + E + 1), dtype=torch.float32, device=dev)
-        dWhh = flat[:4 * H * H].view(4 * H, H)
-        dWih = flat[4 * H * H:4 * H * (H + E)].view(4 * H, E)
-        db = flat[4 * H * (H + E):]
-        gemm(L.GEMM_TN, [dict(M=4 * H, A=[dg], B=[hc[0, :T].view(T * B, H)], C=dWhh)], H, T * B, 4 * H, H, H, accumulate=True)
-        gemm(L.GEMM_TN, [dict(M=4 * H, A=[dg], B=[x_tm.view(T * B, E)], C=dWih)], E, T * B, 4 * H, E, E, accumulate=True)
-        L.check(lib.mmnas_colsum(L.fptr(dg), L.fptr(db), T * B, 4 * H, 4 * H, L.stream()))
+        DG = torch.empty(B, T, 4 * H, dtype=torch.float32, device=dev)
+        L.check(lib.mmnas_lstm_seq_bwd(L.fptr(dout), L.fptr(Whh), L.fptr(st[1]), L.fptr(Gall), L.fptr(DG), T, B, H, L.stream()))
+        (dWih, dWhh, dbih, dbhh), rets, sinks = _grad_bufs(ctx.params, dev)
+        M = B * T
+        wg_ih = gemm_desc(L.GEMM_TN, [dict(M=4 * H, A=[DG], B=[x], C=dWih)], E, M, 4 * H, E, E, accumulate=True)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx_tm = torch.empty(T * B, E, dtype=torch.float32, device=dev)
-            gemm(L.GEMM_NN, [dict(M=T * B, A=[dg], B=[Wih], C=dx_tm)], E, 4 * H, 4 * H, E, E)
-            dx = dx_tm.view(T, B, E).transpose(0, 1)
-        dbo = db.index_select(0, inv)
-        return dx, dWih.index_select(0, inv), dWhh.index_select(0, inv), dbo, dbo
+            dx = torch.empty_like(x)
+            gemm_pair(gemm_desc(L.GEMM_NN, [dict(M=M, A=[DG], B=[Wih], C=dx)], E, 4 * H, 4 * H, E, E), wg_ih)
+        else:
+            L.check(lib.mmnas_gemm(C.byref(wg_ih), L.stream()))
+        gemm(L.GEMM_TN, [dict(M=4 * H, A=[DG], B=[st[0]], C=dWhh)], H, M, 4 * H, H, H, accumulate=True)
+        L.check(lib.mmnas_colsum(L.fptr(DG), L.fptr(dbih), M, 4 * H, 4 * H, L.stream()))
+        L.check(lib.mmnas_colsum(L.fptr(DG), L.fptr(dbhh), M, 4 * H, 4 * H, L.stream()))
+        for sk in sinks:
+            sk.done()
+        return dx, rets[0], rets[1], rets[2], rets[3]
 
 
 def lstm(x, mod):
@@ -561,16 +538,15 @@ def lstm(x, mod):
 
 
 def lstm_enabled():
-    """The step-fused LSTM is opt-in (MMNAS_LSTM=1): measured this round it issues ~50 launches instead of MIOpen's
-    ~110 but its per-step kernels (the general GEMM at M = 64: ~20 us of launch-to-launch latency each) make the
-    training step 1.5 % and the supernet step 4 % SLOWER than MIOpen's GEMM + pointwise pairs."""
+    """The persistent-kernel LSTM is the default; MMNAS_LSTM=0 falls back to nn.LSTM (MIOpen: ~110 launches per step)."""
     import os
-    return os.environ.get('MMNAS_LSTM', '0') == '1'
+    return os.environ.get('MMNAS_LSTM', '1') != '0'
 
 
 def lstm_supported(x, mod):
-    return (x.is_cuda and x.dtype == torch.float32 and mod.num_layers == 1 and not mod.bidirectional and mod.batch_first
-            and mod.bias and mod.proj_size == 0 and bool(L.lib().mmnas_lstm_supported(mod.input_size, mod.hidden_size)))
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and mod.num_layers == 1 and not mod.bidirectional
+            and mod.batch_first and mod.bias and mod.proj_size == 0 and mod.input_size % 4 == 0
+            and bool(L.lib().mmnas_lstm_seq_supported(mod.hidden_size, x.shape[0])))
 
 
 def linear(x, W, b=None, relu=False):
@@ -786,6 +762,311 @@ class AttFlatPoolFn(torch.autograd.Function):
 
 def attflat_pool(logits, x, mask):
     return AttFlatPoolFn.apply(logits, x, mask)
+
+
+# ------------------------------------------------------------------------------------------
+# backbone chain: all cell operators of a backbone in one C call per direction
+# ------------------------------------------------------------------------------------------
+def chain_enabled():
+    import os
+    return os.environ.get('MMNAS_CHAIN', '1') != '0'
+
+
+def side_stream_enabled():
+    """Weight-gradient work of the backbone chain on a second stream (MMNAS_SIDE_STREAM=1).  OFF by default: measured on
+    the supernet and training steps it does not pay -- unpaired data- / weight-gradient launches cost more than the
+    paired ones save, and workgroups of the deferred products delay the short, latency-bound encoder / LSTM kernels they
+    were meant to fill the gaps of (6.99 -> 7.05 ms released per operator, 7.35 ms released per phase)."""
+    import os
+    return os.environ.get('MMNAS_SIDE_STREAM', '0') == '1'
+
+
+_side_pending = []          # arenas / inputs the side stream may still be reading (released by join_side_stream)
+_side_join_queued = [False]
+
+
+def join_side_stream():
+    """Make the current stream wait for the parameter-gradient work the last backbone backward put on the library's
+    side stream, then release the buffers that work reads.  Runs automatically at the end of every backward pass that
+    used the side stream; call it by hand only when reading parameter gradients from inside a backward hook."""
+    _side_join_queued[0] = False
+    st = L.stream()
+    L.check(L.lib().mmnas_chain_join(st, st))
+    del _side_pending[:]
+
+
+def side_stream_barrier(waiting_stream):
+    """Make another stream (a communication stream about to all-reduce gradients) wait for the side-stream work issued so
+    far for the current stream's backbone backward."""
+    L.check(L.lib().mmnas_chain_join(L.stream(), waiting_stream.cuda_stream))
+
+
+def _sinked(params):
+    """True when every parameter's gradient is a view of a flat gradient buffer the kernels may add into."""
+    if not _sinks_on[0]:
+        return False
+    for p in params:
+        s = getattr(p, '_mmnas_sink', None)
+        if s is None or p.grad is not s.view:
+            return False
+    return True
+
+
+def _cached_record(owner, key, first, build):
+    """Per-module cache of a prefilled descriptor: rebuilt when the key (stream, mode, relation stem) or the storage of
+    the module's first parameter / of its gradient view changes (.to(device), a new flat buffer); the seed is per call."""
+    c = owner.__dict__.get('_mmnas_rec')
+    g = first.grad
+    if c is not None and c[0] == key and c[1] == first.data_ptr() and g is not None and c[2] == g.data_ptr():
+        return c[3], c[4]
+    rec, params = build()
+    if rec is not None:
+        owner.__dict__['_mmnas_rec'] = (key, first.data_ptr(), first.grad.data_ptr(), rec, params)
+    return rec, params
+
+
+def chain_att_record_cached(op, on_y, self_att, rel_handle):
+    mh = op.mhatt
+    key = (on_y, op.training, id(rel_handle.weight) if rel_handle is not None else 0)
+    rec, params = _cached_record(op, key, mh.linear_q.weight, lambda: chain_att_record(
+        on_y, mh, op.ln if op.norm else None, op.norm, op.residual, self_att, rel_handle, op.training))
+    if rec.att.drop_p > 0:
+        rec.att.seed = next_seed()
+    return rec, params
+
+
+def chain_mlp_record_cached(op, on_y, weights, biases):
+    key = (on_y, op.training, 0)
+    rec, params = _cached_record(op, key, weights[0], lambda: chain_mlp_record(
+        on_y, weights, biases, op.ln if op.norm else None, op.norm, op.residual, op.drop_p, op.training))
+    if rec.mlp.drop_p > 0:
+        rec.mlp.seed = next_seed()
+    return rec, params
+
+
+def chain_att_record(on_y, mh, ln, norm, residual, self_att, rel_handle, training):
+    """(ChainOp, params) for an attention-family operator: mh = its MHAtt / RelMHAtt, rel_handle = a fusable RelHandle
+    or None."""
+    rec = L.ChainOp()
+    rec.kind, rec.on_y = 0, int(on_y)
+    a = rec.att
+    Wq, Wk, Wv, Wm = mh.linear_q.weight, mh.linear_k.weight, mh.linear_v.weight, mh.linear_merge.weight
+    params = [Wq, Wk, Wv, Wm]
+    a.di, a.dh = Wq.shape[0], mh.HBASE
+    a.H = a.di // a.dh
+    drop = mh.drop_p if training else 0.0
+    flags = (L.F_NORM if norm else 0) | (L.F_RESIDUAL if residual else 0) | (L.F_SELF if self_att else 0)
+    if drop > 0:
+        flags |= L.F_TRAIN
+    a.drop_p, a.eps = float(drop), float(ln.eps if norm else 1e-6)
+    a.seed = 0   # (drawn per call by the cached wrapper)
+    a.Wq, a.Wk, a.Wv, a.Wm = Wq.data_ptr(), Wk.data_ptr(), Wv.data_ptr(), Wm.data_ptr()
+    a.dWq, a.dWk, a.dWv, a.dWm = Wq.grad.data_ptr(), Wk.grad.data_ptr(), Wv.grad.data_ptr(), Wm.grad.data_ptr()
+    if norm:
+        a.ln_a, a.ln_b = ln.a_2.data_ptr(), ln.b_2.data_ptr()
+        a.dln_a, a.dln_b = ln.a_2.grad.data_ptr(), ln.b_2.grad.data_ptr()
+        params += [ln.a_2, ln.b_2]
+    if rel_handle is not None:
+        lr = mh.linear_r
+        flags |= L.F_REL | L.F_RELRAW
+        a.R, a.C = lr.weight.shape[1], rel_handle.weight.shape[1]
+        a.Wr, a.br, a.dWr, a.dbr = lr.weight.data_ptr(), lr.bias.data_ptr(), lr.weight.grad.data_ptr(), lr.bias.grad.data_ptr()
+        a.Wy, a.by = rel_handle.weight.data_ptr(), rel_handle.bias.data_ptr()
+        a.dWy, a.dby = rel_handle.weight.grad.data_ptr(), rel_handle.bias.grad.data_ptr()
+        params += [lr.weight, lr.bias, rel_handle.weight, rel_handle.bias]
+    a.flags = flags
+    return rec, params
+
+
+def chain_mlp_record(on_y, weights, biases, ln, norm, residual, drop_p, training):
+    rec = L.ChainOp()
+    rec.kind, rec.on_y = 1, int(on_y)
+    m = rec.mlp
+    nl = len(weights)
+    m.nl = nl
+    m.dims[0] = weights[0].shape[1]
+    params = []
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        m.dims[i + 1] = w.shape[0]
+        m.W[i], m.dW[i] = w.data_ptr(), w.grad.data_ptr()
+        params.append(w)
+        if b is not None:
+            m.b[i], m.db[i] = b.data_ptr(), b.grad.data_ptr()
+            params.append(b)
+    drop = drop_p if training else 0.0
+    flags = (L.F_NORM if norm else 0) | (L.F_RESIDUAL if residual else 0)
+    if drop > 0:
+        flags |= L.F_TRAIN
+    m.flags, m.drop_p, m.eps = flags, float(drop), float(ln.eps if norm else 1e-6)
+    m.seed = 0   # (drawn per call by the cached wrapper)
+    if norm:
+        m.ln_a, m.ln_b, m.dln_a, m.dln_b = ln.a_2.data_ptr(), ln.b_2.data_ptr(), ln.a_2.grad.data_ptr(), ln.b_2.grad.data_ptr()
+        params += [ln.a_2, ln.b_2]
+    return rec, params
+
+
+class BackboneFn(torch.autograd.Function):
+    """Backbone_*.forward (hygr_vqa.py:45-52) through mmnas_chain_fwd/bwd.  Parameter gradients go straight into the
+    flat gradient buffer (every parameter of the chain has an attached sink: checked by the caller), so the parameters
+    are not autograd inputs of this node."""
+
+    @staticmethod
+    def forward(ctx, x, y, x_mask, y_mask, x_rel, y_rel, records, params):
+        lib = L.lib()
+        x, y = _f32c(x), _f32c(y)
+        B, Sx, d = x.shape
+        Sy = y.shape[1]
+        n = len(records)
+        arr = (L.ChainOp * n)(*records)
+        ch = L.Chain()
+        ch.n_ops, ch.ops = n, arr
+        ch.B, ch.Sx, ch.Sy, ch.d = B, Sx, Sy, d
+        xm, ym = _mask_u8(x_mask, B, Sx), _mask_u8(y_mask, B, Sy)
+        xr = _f32c(x_rel) if x_rel is not None else None
+        yr = _f32c(y_rel) if y_rel is not None else None
+        ch.x_in, ch.y_in, ch.x_mask, ch.y_mask = L.fptr(x), L.fptr(y), L.ptr(xm), L.ptr(ym)
+        ch.x_rel, ch.y_rel = L.fptr(xr), L.fptr(yr)
+        sz = C.c_size_t()
+        L.check(lib.mmnas_chain_plan(C.byref(ch), C.byref(sz)))   # (host arithmetic only: a few microseconds)
+        arena = _bytes(sz.value, x.device)
+        x_out, y_out = torch.empty_like(x), torch.empty_like(y)
+        ch.arena, ch.x_out, ch.y_out = L.ptr(arena), L.fptr(x_out), L.fptr(y_out)
+        L.check(lib.mmnas_chain_fwd(C.byref(ch), L.stream()))
+        ctx.keep = (ch, arr, arena, x, y, xm, ym, xr, yr, x_out, y_out, params)
+        return x_out, y_out
+
+    @staticmethod
+    def backward(ctx, dx_out, dy_out):
+        if ctx.keep is None:
+            raise RuntimeError('BackboneFn: backward ran a second time (its arena is released after the first)')
+        lib = L.lib()
+        ch, arr, arena, x, y, xm, ym, xr, yr, x_out, y_out, params = ctx.keep
+        dx_out = _f32c(dx_out) if dx_out is not None else None
+        dy_out = _f32c(dy_out) if dy_out is not None else torch.zeros_like(y_out)
+        dx_in, dy_in = torch.empty_like(x), torch.empty_like(y)
+        ch.dx_out, ch.dy_out, ch.dx_in, ch.dy_in = L.fptr(dx_out), L.fptr(dy_out), L.fptr(dx_in), L.fptr(dy_in)
+        side = side_stream_enabled()
+        ch.use_side_stream = int(side)
+        L.check(lib.mmnas_chain_bwd(C.byref(ch), L.stream()))
+        ctx.keep = None
+        if side:
+            # the side stream still reads the arena and the saved inputs: keep them until the join at the end of
+            # this backward pass (queued once per pass)
+            _side_pending.append((arena, x, y, xm, ym, xr, yr, x_out, y_out, dx_out, dy_out, arr))
+            if not _side_join_queued[0]:
+                _side_join_queued[0] = True
+                torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
+        for p in params:      # data-parallel reducers learn that these gradients have been enqueued
+            p._mmnas_sink.ready()
+        return dx_in, dy_in, None, None, None, None, None, None
+
+
+def backbone_chain(x, y, x_mask, y_mask, x_rel, y_rel, records, params):
+    return BackboneFn.apply(x, y, x_mask, y_mask, x_rel, y_rel, records, params)
+
+
+class HeadFn(torch.autograd.Function):
+    """AttFlat(x) + AttFlat(y) -> proj_norm -> proj (hygr_vqa.py:113-119) through mmnas_head_fwd/bwd: one native call
+    per direction.  As for BackboneFn the parameters' gradients go straight into the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, x, y, x_mask, y_mask, hd, params):
+        lib = L.lib()
+        x, y = _f32c(x), _f32c(y)
+        B, Sx, d = x.shape
+        Sy = y.shape[1]
+        xm, ym = _mask_u8(x_mask, B, Sx), _mask_u8(y_mask, B, Sy)
+        hd.B, hd.d = B, d
+        hd.sx.S, hd.sy.S = Sx, Sy
+        hd.sx.x, hd.sy.x, hd.sx.mask, hd.sy.mask = L.fptr(x), L.fptr(y), L.ptr(xm), L.ptr(ym)
+        key = ('head', B, Sx, Sy, d, hd.MID, hd.G, hd.OUT, hd.ANS)
+        nbytes = _plan_cache.get(key)
+        if nbytes is None:
+            sz = C.c_size_t()
+            L.check(lib.mmnas_head_plan(C.byref(hd), C.byref(sz)))
+            nbytes = _plan_cache[key] = sz.value
+        arena = _bytes(nbytes, x.device)
+        logits = torch.empty(B, hd.ANS, dtype=torch.float32, device=x.device)
+        hd.arena, hd.logits = L.ptr(arena), L.fptr(logits)
+        L.check(lib.mmnas_head_fwd(C.byref(hd), L.stream()))
+        ctx.keep = (hd, arena, x, y, xm, ym, params)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        if ctx.keep is None:
+            raise RuntimeError('HeadFn: backward ran a second time (its arena is released after the first)')
+        hd, arena, x, y, xm, ym, params = ctx.keep
+        dlogits = _f32c(dlogits)
+        dx, dy = torch.empty_like(x), torch.empty_like(y)
+        hd.dlogits, hd.sx.dx, hd.sy.dx = L.fptr(dlogits), L.fptr(dx), L.fptr(dy)
+        L.check(L.lib().mmnas_head_bwd(C.byref(hd), L.stream()))
+        ctx.keep = None
+        for p in params:
+            p._mmnas_sink.ready()
+        return dx, dy, None, None, None, None
+
+
+def head_record(att_x, att_y, ln, proj, training):
+    """(Head descriptor, params) for AttFlat modules att_x / att_y, the proj_norm LayerNorm and the proj Linear; None when
+    a parameter's gradient does not live in a flat buffer.  Cached on the projection module (see _cached_record)."""
+    first, last = att_x.mlp.fc.linear.weight, proj.bias
+    if not _sinked((first, last)):
+        return None, None
+    hd, params = _cached_record(proj, (training,), first, lambda: _head_record(att_x, att_y, ln, proj, training))
+    if hd is not None and hd.drop_p > 0:
+        hd.sx.seed = next_seed()
+        hd.sy.seed = next_seed()
+    return hd, params
+
+
+def _head_record(att_x, att_y, ln, proj, training):
+    params = []
+    hd = L.Head()
+    for side, af in ((hd.sx, att_x), (hd.sy, att_y)):
+        fc, lin, mg = af.mlp.fc.linear, af.mlp.linear, af.linear_merge
+        ps = [fc.weight, fc.bias, lin.weight, lin.bias, mg.weight, mg.bias]
+        if not _sinked(ps):
+            return None, None
+        side.W1, side.b1, side.W2, side.b2, side.Wm, side.bm = [p.data_ptr() for p in ps]
+        side.dW1, side.db1, side.dW2, side.db2, side.dWm, side.dbm = [p.grad.data_ptr() for p in ps]
+        side.seed = 0   # (drawn per call by head_record)
+        params += ps
+    ps = [ln.a_2, ln.b_2, proj.weight, proj.bias]
+    if not _sinked(ps):
+        return None, None
+    params += ps
+    fc = att_x.mlp.fc
+    drop = fc.dropout_r if training else 0.0
+    hd.MID, hd.G, hd.OUT, hd.ANS = fc.linear.weight.shape[0], att_x.mlp.linear.weight.shape[0], proj.weight.shape[1], proj.weight.shape[0]
+    hd.flags, hd.drop_p, hd.eps = (L.F_TRAIN if drop > 0 else 0), float(drop), float(ln.eps)
+    hd.ln_a, hd.ln_b, hd.dln_a, hd.dln_b = ln.a_2.data_ptr(), ln.b_2.data_ptr(), ln.a_2.grad.data_ptr(), ln.b_2.grad.data_ptr()
+    hd.Wp, hd.bp, hd.dWp, hd.dbp = proj.weight.data_ptr(), proj.bias.data_ptr(), proj.weight.grad.data_ptr(), proj.bias.grad.data_ptr()
+    return hd, params
+
+
+class BceLogitsSumFn(torch.autograd.Function):
+    """BCEWithLogitsLoss(reduction='sum') (search_vqa.py:211, train_vqa.py:237): one kernel forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits, target = _f32c(logits), _f32c(target)
+        loss = torch.zeros((), dtype=torch.float32, device=logits.device)
+        L.check(L.lib().mmnas_bce_logits_sum_fwd(L.fptr(logits), L.fptr(target), L.fptr(loss), logits.numel(), L.stream()))
+        ctx.save_for_backward(logits, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, go):
+        logits, target = ctx.saved_tensors
+        go = _f32c(go)
+        dl = torch.empty_like(logits)
+        L.check(L.lib().mmnas_bce_logits_bwd(L.fptr(logits), L.fptr(target), L.fptr(go), L.fptr(dl), logits.numel(), L.stream()))
+        return dl, None
+
+
+def bce_with_logits_sum(logits, target):
+    return BceLogitsSumFn.apply(logits, target)
 
 
 class MixedSumFn(torch.autograd.Function):

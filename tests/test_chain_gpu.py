@@ -1,0 +1,159 @@
+"""The backbone chain (mmnas_chain_fwd/bwd behind ops.BackboneFn: every cell operator in one native call per direction,
+weight gradients on a side stream) against the per-operator path on the same network, weights, batch and dropout
+seeds: identical operators and kernels in a different issue order, so outputs and data gradients agree to round-off
+and parameter gradients to the float-atomic summation order of the split-K weight-gradient products."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import cases
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+T = torch.from_numpy
+
+
+def _run(task, arch, search, chain, side, monkeypatch, dropout=0.1, plan=None, B=3):
+    import importlib
+    from mmnas_amd import dp, ops
+    from mmnas.model.mixed import MixedOp
+    monkeypatch.setenv('MMNAS_CHAIN', '1' if chain else '0')
+    monkeypatch.setenv('MMNAS_SIDE_STREAM', '1' if side else '0')
+    c = cases.net_case(task, arch, 31337, search=search, B=B, Sx=6, Sy=9)
+    c['cfg'].DROPOUT_R = dropout
+    mod = importlib.import_module('mmnas.model.%s_%s' % ('hygr' if search else 'full', task))
+    cls = mod.Net_Search if search else mod.Net_Full
+    init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+            'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
+    net = cls(c['cfg'], init)
+    net.load_state_dict({k: T(v) for k, v in c['P'].items()})
+    net = net.to(DEV).train()
+    calls = []
+    orig = ops.BackboneFn.apply
+    monkeypatch.setattr(ops, 'backbone_chain', lambda *a: (calls.append(1), orig(*a))[1])
+    inp = tuple(T(a).to(DEV) for a in c['inputs'])
+    tgt = T(c['target']).to(DEV)
+    ops.manual_seed(99)
+    if search:
+        MixedOp.MODE = None
+        net.set_sampled(plan)
+        red = dp.SupernetReducer(net)
+        red.begin_weight_step()
+    else:
+        red = dp.GradReducer(list(net.parameters()))
+        red.begin_step()
+    try:
+        pred = net(inp)
+        if task == 'vgd':
+            loss = (pred[0] * tgt).sum() + 0.5 * (pred[1] ** 2).sum()
+            out = torch.cat([pred[0].reshape(-1), pred[1].reshape(-1)])
+        elif task == 'itm':
+            loss = torch.nn.functional.binary_cross_entropy(pred, tgt, reduction='sum')
+            out = pred
+        else:
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(pred, tgt, reduction='sum')
+            out = pred
+        loss.backward()
+        if search:
+            red.finish_weight_step()
+        else:
+            red.finish()
+        torch.cuda.synchronize()
+        grads = {k: (p.grad.detach().cpu().numpy().copy() if p.grad is not None else None) for k, p in net.named_parameters()}
+        return out.detach().cpu().numpy(), grads, len(calls)
+    finally:
+        red.fg.disable_sinks()
+
+
+def _compare(a, b):
+    out_a, g_a, _ = a
+    out_b, g_b, _ = b
+    assert rel_err(out_a, out_b) < 1e-6
+    top = max(float(np.abs(g).max()) for g in g_b.values() if g is not None)
+    for k in g_b:
+        if g_b[k] is None:
+            assert g_a[k] is None or not np.any(g_a[k]), k
+            continue
+        assert g_a[k] is not None, k
+        diff = float(np.abs(g_a[k] - g_b[k]).max())
+        assert diff <= 2e-5 * max(float(np.abs(g_b[k]).max()), 1e-3 * top), (k, diff)
+
+
+@pytest.mark.parametrize('task,arch', [('vqa', 'mmnas_vqa'), ('vqa', 'mcan'), ('vgd', 'mmnas_vgd'), ('itm', 'mmnas_itm')])
+def test_chain_equals_per_operator_path_net_full(task, arch, monkeypatch):
+    ref = _run(task, arch, False, False, False, monkeypatch)
+    assert ref[2] == 0
+    for side in (False, True):
+        got = _run(task, arch, False, True, side, monkeypatch)
+        assert got[2] == 1, 'the backbone chain was not taken'
+        _compare(got, ref)
+
+
+@pytest.mark.parametrize('task', ['vqa', 'vgd', 'itm'])
+def test_chain_equals_per_operator_path_supernet_weight_step(task, monkeypatch):
+    for seed in (1, 2):
+        plan = cases.search_plan(np.random.RandomState(seed), None)
+        flat = plan['enc'] + plan['dec']
+        ref = _run(task, None, True, False, False, monkeypatch, plan=flat)
+        got = _run(task, None, True, True, True, monkeypatch, plan=flat)
+        assert ref[2] == 0 and got[2] == 1
+        _compare(got, ref)
+
+
+def test_chain_is_skipped_without_gradient_sinks_and_in_arch_mode(monkeypatch):
+    """No flat gradient buffer attached (plain autograd use) or MODE 'full': the per-operator path serves the call."""
+    from mmnas_amd import ops
+    from mmnas.model.full_vqa import Net_Full
+    calls = []
+    orig = ops.BackboneFn.apply
+    monkeypatch.setattr(ops, 'backbone_chain', lambda *a: (calls.append(1), orig(*a))[1])
+    c = cases.net_case('vqa', 'mmnas_vqa', 5)
+    init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+            'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
+    net = Net_Full(c['cfg'], init).to(DEV).train()
+    net(tuple(T(a).to(DEV) for a in c['inputs'])).sum().backward()
+    assert not calls and net.proj.weight.grad is not None
+
+
+def test_chain_full_size_side_stream_repeatable(monkeypatch):
+    """B = 64, 100 regions, d = 512 (BASELINE configs[1]): the side-stream run equals the single-stream run, three
+    times in a row (a missing dependency between the two streams shows up as a changing result)."""
+    import json, os
+    from types import SimpleNamespace
+    from mmnas_amd import dp, ops
+    from mmnas.model.full_vqa import Net_Full
+    from tests.util import REPO
+    g = json.load(open(os.path.join(REPO, 'arch', 'mmnas_vqa.json')))
+    cfg = SimpleNamespace(DROPOUT_R=0.1, REL_SIZE=64, OPS_NORM=True, OPS_RESIDUAL=True, LAYERS=1, NODES={'enc': 12, 'dec': 18},
+                          ATTFLAT_GLIMPSES=1, ATTFLAT_MLP_SIZE=512, FRCNFEAT_SIZE=2048, BBOX_FEATURE=False, BBOXFEAT_EMB_SIZE=1024,
+                          WORD_EMBED_SIZE=300, ALPHA_INIT_TYPE='normal', SCORES_LOSS='kld', HSIZE=512, ATTFLAT_OUT_SIZE=1024,
+                          GENOTYPE=g[sorted(g)[-1]])
+    V, ANS, B = 2000, 3129, 64
+    torch.manual_seed(0)
+    init = {'token_size': V, 'ans_size': ANS, 'pretrained_emb': torch.randn(V, 300).numpy()}
+    net = Net_Full(cfg, init).to(DEV).train()
+    gen = torch.Generator().manual_seed(4)
+    frcn = torch.relu(torch.randn(B, 100, 2048, generator=gen)); frcn[:, 80:] = 0
+    inp = (frcn.to(DEV), torch.zeros(B, 100, 5, device=DEV), torch.randn(B, 100, 100, 4, generator=gen).to(DEV),
+           torch.randint(1, V, (B, 14), generator=gen).to(DEV), torch.randn(B, 14, 14, 3, generator=gen).to(DEV))
+    tgt = (torch.rand(B, ANS, generator=gen) * (torch.rand(B, ANS, generator=gen) < 0.003)).to(DEV)
+    red = dp.GradReducer(list(net.parameters()))
+    results = []
+    try:
+        for side in (False, True, True, True):
+            monkeypatch.setenv('MMNAS_SIDE_STREAM', '1' if side else '0')
+            ops.manual_seed(7)
+            red.begin_step()
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(net(inp), tgt, reduction='sum')
+            loss.backward()
+            red.finish()
+            torch.cuda.synchronize()
+            results.append((float(loss.detach()), red.fg.flat.clone()))
+    finally:
+        red.fg.disable_sinks()
+    ref_loss, ref = results[0]
+    scale = float(ref.abs().max())
+    for loss, flat in results[1:]:
+        assert loss == ref_loss
+        assert float((flat - ref).abs().max()) <= 2e-5 * scale

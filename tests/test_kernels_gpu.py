@@ -738,11 +738,14 @@ def test_pack_adam_sumsq():
         o += nseg + 64
 
 
-@pytest.mark.parametrize('B,T,E,H', [(64, 14, 300, 512), (3, 5, 20, 64), (70, 3, 300, 256), (64, 15, 300, 96)])
+@pytest.mark.parametrize('B,T,E,H', [(64, 14, 300, 512), (3, 5, 20, 64), (70, 3, 300, 256), (64, 14, 300, 256),
+                                     (160, 50, 300, 512), (2, 1, 24, 128), (130, 7, 28, 64)])
 def test_lstm_vs_torch_fp64(B, T, E, H):
-    """Step-fused LSTM (mmnas_lstm_fwd/bwd; opt-in in the nets, MMNAS_LSTM=1) against torch.nn.LSTM evaluated in float64
-    on the CPU: output sequence and every gradient (input, both weight matrices, both biases)."""
-    from mmnas_amd import ops
+    """Persistent-kernel LSTM (mmnas_lstm_seq_fwd/bwd: one launch per pass, the state handed between workgroups once
+    per step) against torch.nn.LSTM evaluated in float64 on the CPU: output sequence and every gradient (input, both
+    weight matrices, both biases).  Several sample blocks (B > 64, ragged last block), one step, 50 steps; repeated
+    to catch a hand-off that only fails now and then."""
+    from mmnas_amd import ops, _lib as L
     torch.manual_seed(B + T + H)
     ref = torch.nn.LSTM(input_size=E, hidden_size=H, num_layers=1, batch_first=True).double()
     x = torch.randn(B, T, E, dtype=torch.float64, requires_grad=True)
@@ -754,13 +757,19 @@ def test_lstm_vs_torch_fp64(B, T, E, H):
     mod = mod.to(DEV)
     xd = x.detach().float().to(DEV).requires_grad_(True)
     assert ops.lstm_supported(xd, mod)
-    yd = ops.lstm(xd, mod)
-    yd.backward(go.float().to(DEV))
-    assert rel_err(yd.detach().cpu().numpy(), y.detach().numpy()) < 2e-5
-    assert rel_err(xd.grad.cpu().numpy(), x.grad.numpy()) < 1e-4
-    for k, p in mod.named_parameters():
-        want = dict(ref.named_parameters())[k].grad.numpy()
-        assert rel_err(p.grad.cpu().numpy(), want) < 1e-4, k
+    for rep in range(4):
+        xd.grad = None
+        mod.zero_grad()
+        junk = torch.randn(1 << 22, device=DEV).mul_(2.0)        # other work in flight, caches disturbed
+        yd = ops.lstm(xd, mod)
+        yd.backward(go.float().to(DEV))
+        assert L.lib().mmnas_lstm_seq_timed_out(L.stream()) == 0
+        assert rel_err(yd.detach().cpu().numpy(), y.detach().numpy()) < 2e-5, rep
+        assert rel_err(xd.grad.cpu().numpy(), x.grad.numpy()) < 1e-4, rep
+        for k, p in mod.named_parameters():
+            want = dict(ref.named_parameters())[k].grad.numpy()
+            assert rel_err(p.grad.cpu().numpy(), want) < 1e-4, (k, rep)
+        del junk
 
 
 def test_embedding_backward_adds_rows_into_the_gradient():

@@ -95,15 +95,19 @@ def test_net_full(task, arch):
     assert rel_err(net.imgfeat_linear.bias.grad.cpu().numpy(), npz[tag + 'g:imgfeat_linear.bias']) <= 3e-3
 
 
-def test_net_full_with_step_fused_lstm(monkeypatch):
-    """The opt-in HIP LSTM (MMNAS_LSTM=1) inside the net: same golden vectors as the MIOpen path."""
-    monkeypatch.setenv('MMNAS_LSTM', '1')
+def test_net_full_uses_the_persistent_lstm_and_has_a_miopen_fallback(monkeypatch):
+    """The nets run the language stem on ops.LstmFn (one persistent launch per pass) by default; MMNAS_LSTM=0 routes it
+    through nn.LSTM (MIOpen).  Both meet the same golden vectors."""
     from mmnas_amd import ops
     calls = []
     orig = ops.LstmFn.apply
     monkeypatch.setattr(ops, 'lstm', lambda x, mod: (calls.append(1), orig(x, mod.weight_ih_l0, mod.weight_hh_l0, mod.bias_ih_l0, mod.bias_hh_l0))[1])
     test_net_full('vqa', 'mmnas_vqa')
-    assert calls, 'the step-fused LSTM was not used'
+    assert calls, 'the persistent-kernel LSTM was not used'
+    n = len(calls)
+    monkeypatch.setenv('MMNAS_LSTM', '0')
+    test_net_full('vqa', 'mmnas_vqa')
+    assert len(calls) == n, 'MMNAS_LSTM=0 must fall back to nn.LSTM'
 
 
 @pytest.mark.parametrize('task,mode', [('vqa', None), ('vqa', 'full'), ('vqa', 'two'), ('vgd', None),
