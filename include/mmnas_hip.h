@@ -519,7 +519,7 @@ int mmnas_sumsq(const float* g, size_t n, float* out, void* stream);
  * flops / bytes; mmnas_prof_collect() synchronises the events, sums per class and resets.
  * ------------------------------------------------------------------------------------------ */
 enum { MMNAS_K_GEMM = 0, MMNAS_K_MHA_FWD = 1, MMNAS_K_MHA_BWD = 2, MMNAS_K_REL_FWD = 3, MMNAS_K_REL_BWD = 4,
-       MMNAS_K_ROWOPS = 5, MMNAS_K_COUNT = 6 };
+       MMNAS_K_ROWOPS = 5, MMNAS_K_LSTM = 6, MMNAS_K_COUNT = 7 };
 typedef struct mmnas_prof_stat { double ms, flops, bytes; long launches; } mmnas_prof_stat;
 int mmnas_prof_enable(int on);
 int mmnas_prof_collect(mmnas_prof_stat* stats /* [MMNAS_K_COUNT] */);

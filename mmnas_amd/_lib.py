@@ -94,7 +94,7 @@ class ProfStat(C.Structure):
     _fields_ = [('ms', C.c_double), ('flops', C.c_double), ('bytes', C.c_double), ('launches', C.c_long)]
 
 
-K_NAMES = ['gemm', 'mha_fwd', 'mha_bwd', 'rel_fwd', 'rel_bwd', 'rowops']
+K_NAMES = ['gemm', 'mha_fwd', 'mha_bwd', 'rel_fwd', 'rel_bwd', 'rowops', 'lstm']
 
 
 class Segment(C.Structure):

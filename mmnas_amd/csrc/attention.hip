@@ -581,6 +581,205 @@ __global__ void __launch_bounds__(64 * NW * QS, (NW == 4 && QS == 1) ? 2 : 1) mh
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// backward, FUSED: dQ, dK, dV (and dZ -> dbiasT) of one (batch, head) pair in ONE workgroup, five products instead
+// of the seven of the query-owner + key-owner pair above.  For dh = 64, Sq <= 128, Sk <= 128 -- every attention of the
+// VQA / VGD / ITM workloads (100 regions, 14 / 50 tokens).  grid (H, B), 4 waves = the 4 query blocks of 32.
+//   * K and V of the head sit in LDS once; a wave keeps the Q / dO rows of its query block in registers, both as the
+//     B fragments of S^T = K Q^T / dA^T = V dO^T and as the B operands of the dK / dV products.
+//   * per (key block, query block) tile the wave computes S^T and dA^T, the softmax backward in registers
+//     (key = register row, query = lane), dQ += dZ K with the tile as MFMA A operand -- as the query-owner kernel does.
+//   * dK += dZ^T Q and dV += A^T dO need the tile with key on the lane: instead of recomputing S in that orientation
+//     (two extra products) the two 32x32 tiles are TRANSPOSED through a wave-private 4 KB LDS image (write rows, read
+//     columns; stride 33: conflict-free) and fed as A operands again.
+//   * the dK / dV contributions of the four query blocks meet in an LDS accumulator [key][64]: at step s wave w works
+//     on key block (w + s) mod NKB, so the waves of one step touch different key blocks; a barrier separates the steps.
+//     With fewer key blocks than waves (guided attention: 14 keys) the waves sharing a block have their own copies,
+//     summed at write-out.
+// LDS: NKB = 4: K, V 68 KB + accumulators 64 KB + transposition 16.5 KB = 148.5 KB (one workgroup per CU).
+// ------------------------------------------------------------------------------------------
+template <int NKB>
+__global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
+  constexpr int DHC = 64, LD = DHC + 4, NS = DHC / 8, JC = 2, NW = 4, KB = 32 * NKB;
+  constexpr int CP = NW / NKB;   // accumulator copies (waves that meet in one key block at a step)
+  __shared__ __attribute__((aligned(16))) float Ks[KB * LD];
+  __shared__ __attribute__((aligned(16))) float Vs[KB * LD];
+  __shared__ __attribute__((aligned(16))) float dKs[CP * KB * DHC];
+  __shared__ __attribute__((aligned(16))) float dVs[CP * KB * DHC];
+  __shared__ float TrAll[NW][32 * 33];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y, h = blockIdx.x;
+  const int Sq = p.Sq, Sk = p.Sk;
+  const int q0 = 32 * w;
+  const bool active = q0 < Sq;   // wave-uniform
+  const int qi = q0 + l31;
+  const bool qok = qi < Sq;
+  const size_t bh = (size_t)b * p.H + h;
+  float* Tr = TrAll[w];
+
+  load_tiles2<KB, KB, DHC, 256>(Ks, p.K + (size_t)(b * Sk) * p.ldk + h * p.dh, Sk, p.ldk,
+                                Vs, p.V + (size_t)(b * Sk) * p.ldv + h * p.dh, Sk, p.ldv, tid);
+  for (int i = tid; i < CP * KB * DHC / 4; i += 256) {
+    reinterpret_cast<float4*>(dKs)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(dVs)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float m = 0.f, inv = 0.f, del = 0.f;
+  float4 qfr[NS], gfr[NS];       // B fragments of S^T = K Q^T and dA^T = V dO^T: this lane's query row
+  float qB[JC][16], gB[JC][16];  // B operands of dK += dZ^T Q, dV += A^T dO: B[k = query acc_row(r, hh)][j = 32 jc + l31]
+  if (active) {
+    if (qok) {
+      m = p.stats[(bh * Sq + qi) * 2];
+      inv = p.stats[(bh * Sq + qi) * 2 + 1];
+    }
+    const size_t row = (size_t)b * Sq + (qok ? qi : Sq - 1);   // clamped: no branch around the loads
+    const float* qrow = p.Q + row * p.ldq + h * p.dh + 4 * hh;
+    const float* grow = p.dO + row * p.ldo + h * p.dh + 4 * hh;
+    const float* orow = p.O + row * p.ldo + h * p.dh + 4 * hh;
+    float part = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      qfr[s] = *reinterpret_cast<const float4*>(qrow + 8 * s);
+      gfr[s] = *reinterpret_cast<const float4*>(grow + 8 * s);
+      const float4 o4 = *reinterpret_cast<const float4*>(orow + 8 * s);
+      part += (gfr[s].x * o4.x + gfr[s].y * o4.y) + (gfr[s].z * o4.z + gfr[s].w * o4.w);
+    }
+    part += __shfl_xor(part, 32, 64);   // delta[q] = sum_j dO[q,j] O[q,j]: the other half-wave holds the other half row
+    del = qok ? part : 0.f;
+    if (!qok) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { qfr[s] = make_float4(0.f, 0.f, 0.f, 0.f); gfr[s] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q = q0 + acc_row(r, hh);
+      const bool ok = q < Sq;
+      const size_t rr = (size_t)b * Sq + (ok ? q : Sq - 1);
+#pragma unroll
+      for (int jc = 0; jc < JC; ++jc) {
+        const float qv = p.Q[rr * p.ldq + h * p.dh + 32 * jc + l31];
+        const float gv = p.dO[rr * p.ldo + h * p.dh + 32 * jc + l31];
+        qB[jc][r] = ok ? qv : 0.f;
+        gB[jc][r] = ok ? gv : 0.f;
+      }
+    }
+  }
+  f32x16 dq[JC];
+#pragma unroll
+  for (int jc = 0; jc < JC; ++jc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[jc][r] = 0.f;
+  __syncthreads();
+
+  const bool has_bias = p.biasT != nullptr, has_mask = p.mask != nullptr, has_drop = p.drop.thresh != 0;
+  const bool put_dbias = p.dbiasT != nullptr;
+  const int qic = qok ? qi : Sq - 1;
+#pragma unroll 1
+  for (int s = 0; s < NKB; ++s) {
+    const int kbi = (w + s) % NKB, k0 = 32 * kbi, cp = w / NKB;
+    if (active) {
+      // the tile's bias / mask operands first: their global-memory latency passes behind the 64 MFMAs below
+      float bias[16], mk[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {   // batched, branch-free operand fetch (clamped indices)
+        const int key = min(k0 + acc_row(r, hh), Sk - 1);
+        bias[r] = has_bias ? p.biasT[(bh * Sk + key) * Sq + qic] : 0.f;
+        mk[r] = has_mask ? (float)p.mask[(size_t)b * Sk + key] : 0.f;
+      }
+      f32x16 acc, dacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; dacc[r] = 0.f; }
+#pragma unroll
+      for (int s8 = 0; s8 < NS; ++s8) {
+        const int fo = 8 * s8 + 4 * hh;
+        const float4 kf = *reinterpret_cast<const float4*>(Ks + (k0 + l31) * LD + fo);
+        const float4 vf = *reinterpret_cast<const float4*>(Vs + (k0 + l31) * LD + fo);
+        MFMA4(acc, kf, qfr[s8])
+        MFMA4(dacc, vf, gfr[s8])
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + acc_row(r, hh);
+        const bool ok = key < Sk && qok;
+        const bool masked = mk[r] != 0.f;
+        float v = acc[r] * p.scale + bias[r];
+        if (masked) v = -1e9f;
+        const float pr = __expf(v - m) * inv;
+        const float dm = has_drop ? drop_mult(p.drop, (uint32_t)((bh * Sq + qi) * Sk + key)) : 1.f;
+        const float dz = (ok && !masked) ? pr * (dacc[r] * dm - del) : 0.f;
+        if (put_dbias && ok) p.dbiasT[(bh * Sk + key) * Sq + qi] = dz;
+        acc[r] = dz * p.scale;          // dZ^T / sqrt(dh)   [key][query]
+        dacc[r] = ok ? pr * dm : 0.f;   // A^T = (P o D)^T   [key][query]
+      }
+      // dQ += dZ K
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kl = k0 + acc_row(r, hh);
+#pragma unroll
+        for (int jc = 0; jc < JC; ++jc) dq[jc] = mfma32(acc[r], Ks[kl * LD + 32 * jc + l31], dq[jc]);
+      }
+      // transpose the two tiles: [key][query] -> registers = query, lane = key (same-wave LDS accesses stay in order)
+      f32x16 tz, tp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Tr[acc_row(r, hh) * 33 + l31] = acc[r];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tz[r] = Tr[l31 * 33 + acc_row(r, hh)];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Tr[acc_row(r, hh) * 33 + l31] = dacc[r];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tp[r] = Tr[l31 * 33 + acc_row(r, hh)];
+      // dK[key][j] += dZ[q][key] Q[q][j] / sqrt(dh),  dV[key][j] += A[q][key] dO[q][j]
+      f32x16 dkp[JC], dvp[JC];
+#pragma unroll
+      for (int jc = 0; jc < JC; ++jc)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dkp[jc][r] = 0.f; dvp[jc][r] = 0.f; }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int jc = 0; jc < JC; ++jc) {
+          dkp[jc] = mfma32(tz[r], qB[jc][r], dkp[jc]);
+          dvp[jc] = mfma32(tp[r], gB[jc][r], dvp[jc]);
+        }
+      float* dka = dKs + (size_t)(cp * KB + k0) * DHC;
+      float* dva = dVs + (size_t)(cp * KB + k0) * DHC;
+#pragma unroll
+      for (int jc = 0; jc < JC; ++jc)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = acc_row(r, hh) * DHC + 32 * jc + l31;
+          dka[o] += dkp[jc][r];
+          dva[o] += dvp[jc][r];
+        }
+    }
+    __syncthreads();
+  }
+  if (active) {
+#pragma unroll
+    for (int jc = 0; jc < JC; ++jc) {
+      const int col = 32 * jc + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = q0 + acc_row(r, hh);
+        if (q < Sq) p.dQ[(size_t)(b * Sq + q) * p.ldq + h * p.dh + col] = dq[jc][r];
+      }
+    }
+  }
+  for (int i = tid; i < Sk * (DHC / 4); i += 256) {
+    const int key = i / (DHC / 4), c4 = i - key * (DHC / 4);
+    float4 a = reinterpret_cast<const float4*>(dKs)[key * (DHC / 4) + c4];
+    float4 v = reinterpret_cast<const float4*>(dVs)[key * (DHC / 4) + c4];
+#pragma unroll
+    for (int c = 1; c < CP; ++c) {
+      const float4 a2 = reinterpret_cast<const float4*>(dKs)[(c * KB + key) * (DHC / 4) + c4];
+      const float4 v2 = reinterpret_cast<const float4*>(dVs)[(c * KB + key) * (DHC / 4) + c4];
+      a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+      v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
+    }
+    *reinterpret_cast<float4*>(p.dK + (size_t)(b * Sk + key) * p.ldk + h * p.dh + 4 * c4) = a;
+    *reinterpret_cast<float4*>(p.dV + (size_t)(b * Sk + key) * p.ldv + h * p.dh + 4 * c4) = v;
+  }
+}
+
 static int fill(const mmnas_mha_desc* d, MhaK& k, bool bwd) {
   MMNAS_REQUIRE(d, MMNAS_E_ARG, "mha: null descriptor");
   MMNAS_REQUIRE(d->B > 0 && d->H > 0 && d->Sq > 0 && d->Sk > 0, MMNAS_E_SHAPE, "mha: B=%d H=%d Sq=%d Sk=%d", d->B,
@@ -679,6 +878,16 @@ extern "C" int mmnas_mha_core_bwd(const mmnas_mha_desc* d, void* stream) {
   const double bhqk = (double)k.B * k.H * k.Sq * k.Sk;
   ProfScope ps(MMNAS_K_MHA_BWD, 10.0 * bhqk * k.dh,
                4.0 * ((double)k.B * k.H * k.dh * (4.0 * k.Sq + 4.0 * k.Sk) + (k.biasT ? 2.0 * bhqk : 0.0)), st);
+  static const bool fused_on = !(getenv("MMNAS_MHA_BWD_FUSED") && getenv("MMNAS_MHA_BWD_FUSED")[0] == '0');
+  if (fused_on && k.dh == 64 && k.Sq <= 128 && k.Sk <= 128 && (((uintptr_t)k.dK | (uintptr_t)k.dV) & 15) == 0) {
+    k.nch = 1;
+    const dim3 grid(k.H, k.B);
+    const int nkb = cdiv(k.Sk, 32);
+    if (nkb <= 1) MMNAS_LAUNCH((mha_bwd_fused_kernel<1>), grid, dim3(256), 0, st, k);
+    else if (nkb <= 2) MMNAS_LAUNCH((mha_bwd_fused_kernel<2>), grid, dim3(256), 0, st, k);
+    else MMNAS_LAUNCH((mha_bwd_fused_kernel<4>), grid, dim3(256), 0, st, k);
+    return check_launch("mha_core_bwd");
+  }
   if (k.dh > 64) {   // several head-dim chunks: delta needs the whole row first (dh <= 64: fused into the dQ kernel)
     const long n = (long)k.B * k.Sq * k.H;
     int blocks = (int)((n + 255) / 256);

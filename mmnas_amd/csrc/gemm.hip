@@ -853,8 +853,8 @@ static int env_int(const char* name, int dflt) {
 //   MMNAS_GEMM_SPLIT=0|3|6 products on the fp32 MFMA (default) / as 3 / 6 bf16 MFMA products of split operands
 //   MMNAS_GEMM_PAIR=0      mmnas_gemm_pair launches its two products separately
 //   MMNAS_GEMM_PF=1|2      K-tiles of operand loads in flight ahead of the MFMA block (64^2 fp32 buffer-load path)
-struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split, pair, split_slots, split_p, pf; bool loaded; };
-static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 0, 1, 0, 24, 2, false};
+struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split, pair, split_slots, split_p, pf, wide_min; bool loaded; };
+static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 0, 1, 0, 24, 2, 200, false};
 static void load_tuning() {
   g_tune.tile = env_int("MMNAS_GEMM_TILE", 0);
   g_tune.generic = getenv("MMNAS_GEMM_GENERIC") != nullptr;
@@ -871,6 +871,7 @@ static void load_tuning() {
   g_tune.split_p = env_int("MMNAS_GEMM_SPLIT_P", 24);           // K-tiles per split-K piece
   if (g_tune.split_p < 1) g_tune.split_p = 1;
   g_tune.pf = env_int("MMNAS_GEMM_PF", 2) == 1 ? 1 : 2;            // register stages of operand prefetch (64^2 fp32 path)
+  g_tune.wide_min = env_int("MMNAS_GEMM_WIDE_MIN", 200);         // fewest 128x64 tiles for that shape to be chosen
   g_tune.loaded = true;
 }
 
@@ -927,7 +928,7 @@ namespace mmnas {
 struct GemmPlan {
   GemmK k;
   int nwg, layout;
-  bool big, fast;
+  bool big, fast, wide;   // big: 128^2 tiles; wide: 128 x 64 tiles (BM x BN); neither: 64^2
   double flops, bytes;
   char tag[96];
 };
@@ -1008,17 +1009,26 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
   const int min_units = g_tune.min_units;
   bool big = ntiles_for(128) >= 2048;
   if (g_tune.tile == 128) big = true;
-  if (g_tune.tile == 64) big = false;
-  const int bt = big ? 128 : 64;
-  k.tiles_n = cdiv(d->N, bt);
+  if (g_tune.tile == 64 || g_tune.tile == 12864) big = false;
+  // 128 x 64 tiles (each wave two 32x32 MFMA tiles down the rows): 1.33x the products per operand byte and per barrier
+  // of 64^2 -- for plain products on the buffer-load path whose rows fill the chip anyway (experiment: MMNAS_GEMM_TILE=12864)
+  bool wide = !big && g_tune.tile == 12864 && !accumulate && fast && g_tune.split == 0;
+  if (wide) {
+    long n = 0;
+    for (int g = 0; g < d->ngroups; ++g) n += (long)cdiv(d->g[g].M, 128) * cdiv(d->N, 64);
+    if (n < g_tune.wide_min) wide = false;
+  }
+  const int bt = big ? 128 : 64;            // tile height (rows) unless wide
+  const int btm = wide ? 128 : bt, btn = bt;
+  k.tiles_n = cdiv(d->N, btn);
   long t0 = 0;
-  for (int g = 0; g < d->ngroups; ++g) { k.g[g].tile0 = (int)t0; t0 += (long)cdiv(d->g[g].M, bt) * k.tiles_n; }
+  for (int g = 0; g < d->ngroups; ++g) { k.g[g].tile0 = (int)t0; t0 += (long)cdiv(d->g[g].M, btm) * k.tiles_n; }
   MMNAS_REQUIRE(t0 < (1l << 30), MMNAS_E_SHAPE, "mmnas_gemm: too many output tiles");
   k.ntiles = (int)t0;
   k.gm = g_tune.gm > 0 ? g_tune.gm : 8;
   k.xcd_remap = g_tune.xcd;
   // co-resident workgroups: 256 CUs x 2 (128^2 tiles: 72 KB LDS each) or x 4
-  const int slots = g_tune.wgs > 0 ? (g_tune.wgs < MAX_WGS ? g_tune.wgs : MAX_WGS) : (big ? 512 : 1024);
+  const int slots = g_tune.wgs > 0 ? (g_tune.wgs < MAX_WGS ? g_tune.wgs : MAX_WGS) : ((big || wide) ? 512 : 1024);
   // how evenly whole tiles load the 256 CUs: mean / max tiles per CU (the dispatcher balances dynamically)
   const double per_cu = (double)k.ntiles / 256.0;
   const double dp_eff = per_cu / (double)(long)(per_cu + 0.999999);
@@ -1046,7 +1056,7 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
       k.mode = MODE_SPLIT;
       nwg = S * k.ntiles;
     }
-  } else if (!accumulate && sk != 0 && !big && U < (1ll << 30) && k.ntiles <= MAX_CNT_TILES && g_tune.wgs == 0 &&
+  } else if (!accumulate && sk != 0 && !big && !wide && U < (1ll << 30) && k.ntiles <= MAX_CNT_TILES && g_tune.wgs == 0 &&
              sk == 1 && k.ntiles > 256 && k.ntiles < 8192 && k.ntiles % 256 != 0 && k.T >= 16) {
     // Single round (every tile resident at once, 3-4 workgroups per CU) with a ragged last "layer": the first
     // floor(ntiles / 256) * 256 tiles are computed whole; the R tail tiles are streamed by ~one extra SHORT workgroup
@@ -1065,7 +1075,7 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
     k.U = (int)Ut;
     nwg = n_full + n_sk;
   } else if (!accumulate && sk != 0 && U < (1ll << 30) && k.ntiles <= MAX_CNT_TILES && k.T >= 2 * min_units &&
-             (sk == 2 || (!big && ((dp_eff < 0.6 && k.T >= 16) || (dp_eff < 0.9 && k.T >= 48))))) {
+             (sk == 2 || (!big && !wide && ((dp_eff < 0.6 && k.T >= 16) || (dp_eff < 0.9 && k.T >= 48))))) {
     // (runs of >= 8 K-tiles when the choice is automatic: fewer contributors per tile in the hand-over, measured
     //  5-20 % faster than 4 on the M = 896 products)
     const int smu = sk == 2 ? min_units : 2 * min_units;
@@ -1090,12 +1100,12 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
   out.tag[0] = 0;
   if (prof_enabled())
     snprintf(out.tag, sizeof(out.tag), "%s M=%d/%d/%d N=%d K=%d seg=%d t%d wg=%d P=%d/%d %s%s", tn ? "TN" : (bkc ? "NT" : "NN"),
-             d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0, d->ngroups > 2 ? d->g[2].M : 0, d->N, d->K, d->nseg, bt, nwg, k.P, k.T,
+             d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0, d->ngroups > 2 ? d->g[2].M : 0, d->N, d->K, d->nseg, wide ? 12864 : bt, nwg, k.P, k.T,
              k.mode == MODE_TILE ? "tile" : (k.mode == MODE_SPLIT ? "split" : (k.n_full ? "hybrid" : "stream")),
              fast ? (g_tune.split == 2 ? " bf16x3" : (g_tune.split == 3 ? " bf16x6" : "")) : " generic");
   out.flops = 2.0 * sumM * d->N * d->K * d->nseg;
   out.bytes = 4.0 * (sumM * d->K * d->nseg + (double)d->N * d->K * d->nseg * d->ngroups + sumM * d->N);
-  out.nwg = nwg; out.layout = d->layout; out.big = big; out.fast = fast;
+  out.nwg = nwg; out.layout = d->layout; out.big = big; out.fast = fast; out.wide = wide;
   return MMNAS_OK;
 }
 
@@ -1108,6 +1118,7 @@ static int launch_plan(GemmPlan& pl, hipStream_t st) {
     if (ns == 3) return launch<128, 128, true, 3>(k, pl.layout, pl.nwg, st);
     return pl.fast ? launch<128, 128, true, 0>(k, pl.layout, pl.nwg, st) : launch<128, 128, false, 0>(k, pl.layout, pl.nwg, st);
   }
+  if (pl.wide) return launch<128, 64, true, 0, 2>(k, pl.layout, pl.nwg, st);
   if (ns == 2) return launch<64, 64, true, 2>(k, pl.layout, pl.nwg, st);
   if (ns == 3) return launch<64, 64, true, 3>(k, pl.layout, pl.nwg, st);
   if (pl.fast && g_tune.pf == 2) return launch<64, 64, true, 0, 2>(k, pl.layout, pl.nwg, st);
@@ -1130,7 +1141,7 @@ int gemm_pair_aux(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, co
   if ((rc = plan_gemm(dgrad, st, p0))) return rc;
   if ((rc = plan_gemm(wgrad, st, p1))) return rc;
   // one launch when both run on the 64^2 buffer-load kernel and the second one needs no workspace of its own
-  const bool pair = g_tune.pair && p0.fast && p1.fast && !p0.big && !p1.big && p0.layout == MMNAS_GEMM_NN &&
+  const bool pair = g_tune.pair && p0.fast && p1.fast && !p0.big && !p1.big && !p0.wide && !p1.wide && p0.layout == MMNAS_GEMM_NN &&
                     p1.layout == MMNAS_GEMM_TN && p1.k.mode != MODE_STREAM;
   if (!pair) {
     if (aux && (rc = launch_aux_reduce(*aux, st))) return rc;
@@ -1179,7 +1190,7 @@ namespace mmnas {
 static int lstm_step_plan(GemmPlan& pl, const mmnas_gemm_desc& d, hipStream_t st, const char* who, int units_per_wg) {
   int rc = plan_gemm(&d, st, pl);
   if (rc) return rc;
-  MMNAS_REQUIRE(pl.fast && !pl.big, MMNAS_E_SHAPE, "%s: shape outside the step kernel's range (hidden size %% 32 == 0, aligned buffers)", who);
+  MMNAS_REQUIRE(pl.fast && !pl.big && !pl.wide, MMNAS_E_SHAPE, "%s: shape outside the step kernel's range (hidden size %% 32 == 0, aligned buffers)", who);
   GemmK& k = pl.k;
   k.n_full = k.full_per = k.sk_per = 0;
   if (units_per_wg <= 0 || units_per_wg >= k.T) {

@@ -299,7 +299,7 @@ extern "C" int mmnas_lstm_seq_fwd(const float* xp, const float* bhh, const float
   if (rc) return rc;
   if (hipMemsetAsync(k.cnt, 0, 256, st) != hipSuccess) { set_error("lstm_seq_fwd: memset failed"); return MMNAS_E_LAUNCH; }
   const dim3 grid(H / 8, k.nsb);
-  ProfScope ps(MMNAS_K_GEMM, 2.0 * T * B * 4.0 * H * H, 4.0 * (4.0 * H * H + 7.0 * T * B * H), st, "lstm_seq_fwd");
+  ProfScope ps(MMNAS_K_LSTM, 2.0 * T * B * 4.0 * H * H, 4.0 * (4.0 * H * H + 7.0 * T * B * H), st, "lstm_seq_fwd");
   switch (H) {
     case 64: launch_fwd<64>(k, grid, st); break;
     case 128: launch_fwd<128>(k, grid, st); break;
@@ -323,7 +323,7 @@ extern "C" int mmnas_lstm_seq_bwd(const float* dout, const float* Whh, const flo
   if (rc) return rc;
   if (hipMemsetAsync(k.cnt, 0, 256, st) != hipSuccess) { set_error("lstm_seq_bwd: memset failed"); return MMNAS_E_LAUNCH; }
   const dim3 grid(H / 16, k.nsb);
-  ProfScope ps(MMNAS_K_GEMM, 2.0 * T * B * 4.0 * H * H, 4.0 * (4.0 * H * H + 12.0 * T * B * H), st, "lstm_seq_bwd");
+  ProfScope ps(MMNAS_K_LSTM, 2.0 * T * B * 4.0 * H * H, 4.0 * (4.0 * H * H + 12.0 * T * B * H), st, "lstm_seq_bwd");
   switch (H) {
     case 64: launch_bwd<64>(k, grid, st); break;
     case 128: launch_bwd<128>(k, grid, st); break;

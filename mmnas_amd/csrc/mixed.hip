@@ -22,14 +22,16 @@ __global__ void __launch_bounds__(256) mixed_sum_fwd_kernel(MixArgs a, const flo
 #pragma unroll
   for (int j = 0; j < MAXC; ++j) g[j] = j < a.n ? gate[j] : 0.f;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
+  // every candidate's loads of an element are issued before the first is used (the compiler hoists them out of
+  // the unrolled loop): n independent 16-byte loads in flight per thread, one pass over each tensor
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v[MAXC];
 #pragma unroll
     for (int j = 0; j < MAXC; ++j)
-      if (j < a.n && a.o[j]) {
-        const float4 v = reinterpret_cast<const float4*>(a.o[j])[i];
-        acc.x += g[j] * v.x; acc.y += g[j] * v.y; acc.z += g[j] * v.z; acc.w += g[j] * v.w;
-      }
+      v[j] = (j < a.n && a.o[j]) ? reinterpret_cast<const float4*>(a.o[j])[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) { acc.x += g[j] * v[j].x; acc.y += g[j] * v[j].y; acc.z += g[j] * v[j].z; acc.w += g[j] * v[j].w; }
     reinterpret_cast<float4*>(out)[i] = acc;
   }
 }
@@ -46,12 +48,12 @@ __global__ void __launch_bounds__(256) mixed_sum_bwd_kernel(MixArgs a, const flo
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const float4 d = reinterpret_cast<const float4*>(dout)[i];
+    float4 v[MAXC];
 #pragma unroll
     for (int j = 0; j < MAXC; ++j)
-      if (j < a.n && a.o[j]) {
-        const float4 v = reinterpret_cast<const float4*>(a.o[j])[i];
-        s[j] += (d.x * v.x + d.y * v.y) + (d.z * v.z + d.w * v.w);
-      }
+      v[j] = (j < a.n && a.o[j]) ? reinterpret_cast<const float4*>(a.o[j])[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) s[j] += (d.x * v[j].x + d.y * v[j].y) + (d.z * v[j].z + d.w * v[j].w);
     if (d_active) reinterpret_cast<float4*>(d_active)[i] = make_float4(ga * d.x, ga * d.y, ga * d.z, ga * d.w);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -107,10 +109,10 @@ using namespace mmnas;
 
 static int mix_grid(size_t n4) {
   const size_t b = (n4 + 255) / 256;
-  return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
-extern "C" size_t mmnas_mixed_sum_ws_floats(void) { return (size_t)512 * MAXC; }
+extern "C" size_t mmnas_mixed_sum_ws_floats(void) { return (size_t)2048 * MAXC; }
 
 extern "C" int mmnas_mixed_sum_fwd(const float* const* outs_host, int n, const float* gate, float* out, size_t count,
                                    void* stream) {
