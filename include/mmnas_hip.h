@@ -142,7 +142,7 @@ int mmnas_lstm_bwd(const float* dout, const float* Whh, const float* Call, const
  *   bwd: dout [B,T,H] -> DG [B,T,4H] (gradients of the pre-activations).  The caller finishes with ordinary products:
  *        dW_ih += DG^T x, dW_hh += DG^T Hprev (mmnas_gemm TN over the B*T rows), db += column sums of DG,
  *        dx = DG W_ih (mmnas_gemm NN).
- * Supported: H in {64, 128, 256, 512}, any T >= 1, B <= 3840 (blocks of 64 samples run independently).
+ * Supported: H in {64, 128, 256, 512}, any T >= 1, B <= 960 (blocks of 32 / 16 samples run independently).
  * mmnas_lstm_seq_timed_out(stream): synchronises and returns 1 if a step hand-off of the last launch gave up waiting
  * (a workgroup was not resident: results are garbage), 0 otherwise -- tests / debugging. */
 int mmnas_lstm_seq_supported(int H, int B);

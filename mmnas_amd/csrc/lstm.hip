@@ -14,8 +14,9 @@
 //             rows): 8 waves split it, v_mfma_f32_16x16x4_f32 (16-unit tiles: no padding), running dc in registers.
 // Step hand-off between workgroups (h_t forward, dG_t backward): the payload is stored write-through (sc1), every
 // storing wave drains its stores, one lane adds to a per-sample-block arrival counter (agent scope); one lane polls
-// the counter (relaxed, bounded), ONE agent-scope acquire, workgroup barrier, plain loads -- the R1 recipe of the
-// CDNA programming guide, placement-independent.  Samples are independent: blocks of 64 samples have their own
+// the counter (relaxed, bounded), workgroup barrier, then EVERY load of the handed-off state is an sc1 (L1-bypassing)
+// 16-byte buffer load -- the R1 recipe of the CDNA programming guide with its all-sc1-loads form in place of the
+// acquire fence, placement-independent.  Samples are independent: blocks of 64 samples have their own
 // counter and never wait for each other.  Counters are zeroed by a memset node in front of every launch.
 #include <string.h>
 #include <map>
@@ -45,6 +46,17 @@ __device__ __forceinline__ void st_sc1(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// 16-byte load that bypasses this CU's L1 (sc1): with EVERY load of the handed-off state done this way (and every
+// store of it write-through, drained before the arrival), the consumer needs no acquire fence after the poll -- the
+// guide's hand-off table, first row -- which takes ~1.7 us off every time step.
+typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_sc1_f4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16 /* sc1 */);
+  float4 f;
+  f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
+  return f;
+}
+
 // Arrive at / wait for step barrier `target` arrivals on counter c.  Called by every thread of the workgroup.
 __device__ __forceinline__ void step_barrier(unsigned* c, unsigned target, unsigned* tmo) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its write-through stores have landed
@@ -59,8 +71,7 @@ __device__ __forceinline__ void step_barrier(unsigned* c, unsigned target, unsig
         break;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the compiler from hoisting loads above the poll)
   }
   __syncthreads();
 }
@@ -68,15 +79,17 @@ __device__ __forceinline__ void step_barrier(unsigned* c, unsigned target, unsig
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // ---------------------------------------------------------------------------------------------- forward
-template <int H>
+template <int H, int SB>   // SB: samples per workgroup (32 or 64)
 __global__ void __launch_bounds__(256, 1) lstm_seq_fwd_kernel(const LstmSeqK p) {
   constexpr int U = 8, R = 4 * U;          // units / gate rows per workgroup
+  constexpr int NJ = SB / 32;              // 32-sample MFMA tiles
+  constexpr int NP = U * SB / 256;         // (unit, sample) pairs per thread in the gate arithmetic
   constexpr int KW = H / 4;                // reduction range of one wave
   constexpr int NS = KW / 8;               // 8-wide k groups per wave (one float4 per lane and group)
   static_assert(H % 32 == 0, "hidden size must be a multiple of 32");
-  __shared__ float part[4][R][64];         // per-wave partial pre-activations [gate row][sample]
+  __shared__ float part[4][R][SB];         // per-wave partial pre-activations [gate row][sample]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-  const int u0 = blockIdx.x * U, n0 = blockIdx.y * 64;
+  const int u0 = blockIdx.x * U, n0 = blockIdx.y * SB;
   const int T = p.T, B = p.B;
   const unsigned nub = gridDim.x;
   unsigned* const cnt = p.cnt + blockIdx.y;
@@ -89,58 +102,62 @@ __global__ void __launch_bounds__(256, 1) lstm_seq_fwd_kernel(const LstmSeqK p) 
 #pragma unroll
     for (int s = 0; s < NS; ++s) wa[s] = *reinterpret_cast<const float4*>(w + 8 * s);
   }
-  // gate arithmetic: thread owns (unit, sample) pairs i = 0, 1: pair index tid + 256 i -> unit = idx >> 6, sample = idx & 63
-  float cst[2] = {0.f, 0.f};
-  float bh[2][4];
+  const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.Hprev, 0, (unsigned)((size_t)B * T * H * 4), 0x00020000);
+  // gate arithmetic: thread owns NP (unit, sample) pairs: pair index tid + 256 i -> unit = idx / SB, sample = idx % SB
+  float cst[NP];
+  float bh[NP][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int u = (tid + 256 * i) >> 6;
+  for (int i = 0; i < NP; ++i) {
+    cst[i] = 0.f;
+    const int u = (tid + 256 * i) / SB;
 #pragma unroll
     for (int g = 0; g < 4; ++g) bh[i][g] = p.bhh ? p.bhh[g * H + u0 + u] : 0.f;
   }
 
   for (int t = 0; t < T; ++t) {
     // input-projection terms of this step (independent of the recurrence: issued first)
-    float xv[2][4];
+    float xv[NP][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i, u = idx >> 6, n = n0 + (idx & 63);
+    for (int i = 0; i < NP; ++i) {
+      const int idx = tid + 256 * i, u = idx / SB, n = n0 + (idx % SB);
       const bool ok = n < B;
       const float* x = p.xp + ((size_t)(ok ? n : 0) * T + t) * (4 * H) + u0 + u;
 #pragma unroll
       for (int g = 0; g < 4; ++g) xv[i][g] = ok ? x[g * H] : 0.f;
     }
-    f32x16 acc[2];
+    f32x16 acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     if (t > 0) {   // h_{-1} = 0
+      float4 hb[NJ][NS];   // every load of the step in flight before the first MFMA
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int n = n0 + 32 * j + l31;
-        const bool ok = n < B;
-        const float* hsrc = p.Hprev + ((size_t)(ok ? n : 0) * T + t) * H + wave * KW + 4 * hh;
-        float4 hb[NS];
+        const unsigned off = n < B ? (unsigned)((((size_t)n * T + t) * H + wave * KW + 4 * hh) * 4) : ~0u;   // out of range: zeros
 #pragma unroll
-        for (int s = 0; s < NS; ++s) hb[s] = ok ? *reinterpret_cast<const float4*>(hsrc + 8 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < NS; ++s) hb[j][s] = ld_sc1_f4(hrsrc, off == ~0u ? ~0u : off + 32u * s);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (the scheduler would otherwise sink the loads between the MFMAs to save registers)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          acc[j] = mfma32(wa[s].x, hb[s].x, acc[j]);
-          acc[j] = mfma32(wa[s].y, hb[s].y, acc[j]);
-          acc[j] = mfma32(wa[s].z, hb[s].z, acc[j]);
-          acc[j] = mfma32(wa[s].w, hb[s].w, acc[j]);
+          acc[j] = mfma32(wa[s].x, hb[j][s].x, acc[j]);
+          acc[j] = mfma32(wa[s].y, hb[j][s].y, acc[j]);
+          acc[j] = mfma32(wa[s].z, hb[j][s].z, acc[j]);
+          acc[j] = mfma32(wa[s].w, hb[j][s].w, acc[j]);
         }
-      }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) part[wave][acc_row(r, hh)][32 * j + l31] = acc[j][r];
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i, u = idx >> 6, nl = idx & 63, n = n0 + nl;
+    for (int i = 0; i < NP; ++i) {
+      const int idx = tid + 256 * i, u = idx / SB, nl = idx % SB, n = n0 + nl;
       float pre[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -164,14 +181,16 @@ __global__ void __launch_bounds__(256, 1) lstm_seq_fwd_kernel(const LstmSeqK p) 
 }
 
 // ---------------------------------------------------------------------------------------------- backward
-template <int H>
+template <int H, int SB>   // SB: samples per workgroup (16, 32 or 64)
 __global__ void __launch_bounds__(512, 1) lstm_seq_bwd_kernel(const LstmSeqK p) {
   constexpr int U = 16;
+  constexpr int NJ = SB / 16;                          // 16-sample MFMA tiles
+  constexpr int NP = (U * SB + 511) / 512;             // (unit, sample) pairs per thread (SB = 16: threads >= 256 have none)
   constexpr int K = 4 * H, KW = K / 8, NS = KW / 16;   // 8 waves split the reduction over the 4H gate rows
   static_assert(H % 32 == 0, "hidden size must be a multiple of 32");
-  __shared__ float part[8][U][64];                     // per-wave partial dh [unit][sample]
+  __shared__ float part[8][U][SB];                     // per-wave partial dh [unit][sample]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
-  const int u0 = blockIdx.x * U, n0 = blockIdx.y * 64;
+  const int u0 = blockIdx.x * U, n0 = blockIdx.y * SB;
   const int T = p.T, B = p.B;
   const unsigned nub = gridDim.x;
   unsigned* const cnt = p.cnt + blockIdx.y;
@@ -183,15 +202,18 @@ __global__ void __launch_bounds__(512, 1) lstm_seq_bwd_kernel(const LstmSeqK p) 
   for (int s = 0; s < NS; ++s)
 #pragma unroll
     for (int w = 0; w < 4; ++w) wa[s][w] = p.Whh[(size_t)(wave * KW + 16 * s + 4 * kq + w) * H + u0 + l15];
-  float dcr[2] = {0.f, 0.f};   // running cell-state gradient of the thread's two (unit, sample) pairs
+  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.DG, 0, (unsigned)((size_t)B * T * K * 4), 0x00020000);
+  float dcr[NP];   // running cell-state gradient of the thread's (unit, sample) pairs
+#pragma unroll
+  for (int i = 0; i < NP; ++i) dcr[i] = 0.f;
 
   for (int t = T - 1; t >= 0; --t) {
     // saved activations of this step (independent of the recurrence: issued first)
-    float gate[2][4], cc[2], cp[2], dov[2];
+    float gate[NP][4], cc[NP], cp[NP], dov[NP];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 512 * i, u = idx >> 6, n = n0 + (idx & 63);
-      const bool ok = n < B;
+    for (int i = 0; i < NP; ++i) {
+      const int idx = tid + 512 * i, u = (idx / SB) % U, n = n0 + (idx % SB);
+      const bool ok = n < B && idx < U * SB;
       const size_t row = (size_t)(ok ? n : 0) * T + t;
       const float* ga = p.Gall + row * (4 * H) + u0 + u;
 #pragma unroll
@@ -200,35 +222,37 @@ __global__ void __launch_bounds__(512, 1) lstm_seq_bwd_kernel(const LstmSeqK p) 
       cp[i] = (ok && t > 0) ? p.Cs[(row - 1) * H + u0 + u] : 0.f;
       dov[i] = ok ? p.dout[row * H + u0 + u] : 0.f;
     }
-    f32x4 acc[4];
+    f32x4 acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t + 1 < T) {   // dG_T = 0
+      float4 bf[NJ][NS];   // every load of the step in flight before the first MFMA
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int n = n0 + 16 * j + l15;
-        const bool ok = n < B;
-        const float* src = p.DG + ((size_t)(ok ? n : 0) * T + t + 1) * K + wave * KW + 4 * kq;
-        float4 b[NS];
+        const unsigned off = n < B ? (unsigned)((((size_t)n * T + t + 1) * K + wave * KW + 4 * kq) * 4) : ~0u;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) b[s] = ok ? *reinterpret_cast<const float4*>(src + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < NS; ++s) bf[j][s] = ld_sc1_f4(grsrc, off == ~0u ? ~0u : off + 64u * s);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (see the forward kernel)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][0], b[s].x, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][1], b[s].y, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][2], b[s].z, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][3], b[s].w, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][0], bf[j][s].x, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][1], bf[j][s].y, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][2], bf[j][s].z, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][3], bf[j][s].w, acc[j], 0, 0, 0);
         }
-      }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) part[wave][4 * kq + r][16 * j + l15] = acc[j][r];
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 512 * i, u = idx >> 6, nl = idx & 63, n = n0 + nl;
+    for (int i = 0; i < NP; ++i) {
+      const int idx = tid + 512 * i, u = (idx / SB) % U, nl = idx % SB, n = n0 + nl;
       float dh = dov[i];
 #pragma unroll
       for (int w = 0; w < 8; ++w) dh += part[w][u][nl];
@@ -236,7 +260,7 @@ __global__ void __launch_bounds__(512, 1) lstm_seq_bwd_kernel(const LstmSeqK p) 
       const float tc = tanhf(cc[i]);
       const float dc = dcr[i] + dh * go * (1.0f - tc * tc);
       dcr[i] = dc * gf;
-      if (n < B) {
+      if (n < B && idx < U * SB) {
         float* dg = p.DG + ((size_t)n * T + t) * K + u0 + u;
         st_sc1(dg, dc * gg * gi * (1.0f - gi));             // d pre_i
         st_sc1(dg + H, dc * cp[i] * gf * (1.0f - gf));      // d pre_f
@@ -268,13 +292,17 @@ static int lstm_sync_words(hipStream_t st, unsigned** out) {
   return MMNAS_OK;
 }
 
+// Samples per workgroup: the state every workgroup reads per step is (its samples) x (all units / all gate columns), so
+// narrower sample blocks divide the per-CU hand-off volume (256 KB per step and workgroup in the backward pass at 64
+// samples) and multiply the CUs that share the work; the blocks are independent, each has its own arrival counter.
+constexpr int SB_FWD = 32, SB_BWD = 16;
 template <int H>
 static void launch_fwd(const LstmSeqK& k, dim3 grid, hipStream_t st) {
-  MMNAS_LAUNCH((lstm_seq_fwd_kernel<H>), grid, dim3(256), 0, st, k);
+  MMNAS_LAUNCH((lstm_seq_fwd_kernel<H, SB_FWD>), grid, dim3(256), 0, st, k);
 }
 template <int H>
 static void launch_bwd(const LstmSeqK& k, dim3 grid, hipStream_t st) {
-  MMNAS_LAUNCH((lstm_seq_bwd_kernel<H>), grid, dim3(512), 0, st, k);
+  MMNAS_LAUNCH((lstm_seq_bwd_kernel<H, SB_BWD>), grid, dim3(512), 0, st, k);
 }
 
 }  // namespace mmnas
@@ -282,7 +310,7 @@ static void launch_bwd(const LstmSeqK& k, dim3 grid, hipStream_t st) {
 using namespace mmnas;
 
 extern "C" int mmnas_lstm_seq_supported(int H, int B) {
-  return (H == 64 || H == 128 || H == 256 || H == 512) && B >= 1 && (B + 63) / 64 <= LSTM_MAX_SB;
+  return (H == 64 || H == 128 || H == 256 || H == 512) && B >= 1 && (B + SB_BWD - 1) / SB_BWD <= LSTM_MAX_SB;
 }
 
 extern "C" int mmnas_lstm_seq_fwd(const float* xp, const float* bhh, const float* Whh, float* Hprev, float* Cs, float* Gall,
@@ -294,7 +322,7 @@ extern "C" int mmnas_lstm_seq_fwd(const float* xp, const float* bhh, const float
   LstmSeqK k;
   memset(&k, 0, sizeof(k));
   k.xp = xp; k.bhh = bhh; k.Whh = Whh; k.Hprev = Hprev; k.Cs = Cs; k.Gall = Gall; k.out = out;
-  k.T = T; k.B = B; k.H = H; k.nsb = (B + 63) / 64;
+  k.T = T; k.B = B; k.H = H; k.nsb = (B + SB_FWD - 1) / SB_FWD;
   int rc = lstm_sync_words(st, &k.cnt);
   if (rc) return rc;
   if (hipMemsetAsync(k.cnt, 0, 256, st) != hipSuccess) { set_error("lstm_seq_fwd: memset failed"); return MMNAS_E_LAUNCH; }
@@ -318,7 +346,7 @@ extern "C" int mmnas_lstm_seq_bwd(const float* dout, const float* Whh, const flo
   LstmSeqK k;
   memset(&k, 0, sizeof(k));
   k.Whh = Whh; k.Cs = const_cast<float*>(Cs); k.Gall = const_cast<float*>(Gall); k.dout = dout; k.DG = DG;
-  k.T = T; k.B = B; k.H = H; k.nsb = (B + 63) / 64;
+  k.T = T; k.B = B; k.H = H; k.nsb = (B + SB_BWD - 1) / SB_BWD;
   int rc = lstm_sync_words(st, &k.cnt);
   if (rc) return rc;
   if (hipMemsetAsync(k.cnt, 0, 256, st) != hipSuccess) { set_error("lstm_seq_bwd: memset failed"); return MMNAS_E_LAUNCH; }
