@@ -46,12 +46,19 @@ WORKLOADS = {
                    '(search_vqa.py:149-150,279-337); one "step" = one of the 6',
     'train_vqa': 'arch/mmnas_vqa.json Net_Full fwd + BCE(sum) + bwd, HSIZE 512, B=64/GPU, 100x2048 regions + 14 tokens, dropout 0.1 '
                  '(train_vqa.py:295-299; BASELINE configs[1])',
+    'train_vgd': 'arch/mmnas_vgd.json Net_Full fwd + KLDiv/SmoothL1 loss + bwd, HSIZE 512, B=64/GPU, 100x2048 regions + 15 tokens, '
+                 'dropout 0.1 (train_vgd.py:309-334; BASELINE configs[3])',
+    'train_itm': 'arch/mmnas_itm.json Net_Full hard-negative triplet step: 3 fwd + BCE_Loss + bwd, HSIZE 512, B=160/GPU, 36x2048 regions '
+                 '+ 50 tokens, dropout 0.1, fp32 (train_itm.py:380-391; BASELINE configs[4] at the reference precision)',
 }
+EXTRA = ('train_vgd', 'train_itm')   # not part of --workload all (the driver line): run them by name
 METRICS = {
     'search_vqa': 'supernet fwd+bwd steps/sec (VQA arch, bs=64)',
     'arch_vqa': 'supernet arch-step (all candidates fwd, sampled bwd) steps/sec (VQA, bs=64)',
     'bilevel_vqa': 'bilevel NAS steps/sec (5 weight + 1 arch per round, optimizers included; VQA, bs=64)',
     'train_vqa': 'fixed-architecture fwd+bwd steps/sec (arch/mmnas_vqa.json, bs=64)',
+    'train_vgd': 'fixed-architecture fwd+bwd steps/sec (arch/mmnas_vgd.json, bs=64)',
+    'train_itm': 'triplet (3 fwd + 1 bwd) steps/sec (arch/mmnas_itm.json, bs=160)',
 }
 
 
@@ -89,9 +96,10 @@ def make_cfg(kind):
              NODES={'enc': 12, 'dec': 18}, ATTFLAT_GLIMPSES=1, ATTFLAT_MLP_SIZE=512, FRCNFEAT_SIZE=2048,
              BBOX_FEATURE=False, BBOXFEAT_EMB_SIZE=1024, WORD_EMBED_SIZE=300, ALPHA_INIT_TYPE='normal',
              SCORES_LOSS='kld', GENOTYPE=None)
-    if kind == 'train':      # train_vqa.py:136-154
+    if kind.startswith('train'):      # train_vqa.py:136-154 (train_vgd.py / train_itm.py: the same values)
         c.update(HSIZE=512, ATTFLAT_OUT_SIZE=1024)
-        with open(os.path.join(REPO, 'arch', 'mmnas_vqa.json')) as f:
+        arch = {'train': 'mmnas_vqa', 'train_vgd': 'mmnas_vgd', 'train_itm': 'mmnas_itm'}[kind]
+        with open(os.path.join(REPO, 'arch', arch + '.json')) as f:
             g = json.load(f)
         c['GENOTYPE'] = g[sorted(g)[-1]]
     else:                    # search_vqa.py:87-114
@@ -238,7 +246,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='all', choices=['all'] + list(WORKLOADS))
+    ap.add_argument('--workload', default='all', choices=['all'] + list(WORKLOADS),
+                    help='all = search_vqa (headline) + arch_vqa + bilevel_vqa + train_vqa; train_vgd / train_itm run by name only')
     ap.add_argument('--batch', type=int, default=B_DEFAULT)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0, help='seconds of CPU work per cpu_baseline record')
@@ -297,7 +306,7 @@ def main():
     init = {'token_size': VOCAB, 'ans_size': ANS, 'pretrained_emb': emb}
     from mmnas_amd.harness import fused_loss
     loss_fn = fused_loss(torch.nn.BCEWithLogitsLoss(reduction='sum'))
-    wanted = list(WORKLOADS) if args.workload == 'all' else [args.workload]
+    wanted = [w for w in WORKLOADS if w not in EXTRA] if args.workload == 'all' else [args.workload]
 
     state = {}
 
@@ -327,6 +336,31 @@ def main():
                                   gpu=(tuple(t.to(dev) for t in cpu_in), cpu_tg.to(dev)))
         return state['train']
 
+    def other_state(wl):
+        """train_vgd / train_itm: net, reducer and synthetic batches of that task's shapes."""
+        if wl not in state:
+            import importlib
+            from mmnas_amd.harness import BCE_Loss
+            task = wl.split('_')[1]
+            cfg = make_cfg(wl)
+            Net = importlib.import_module('mmnas.model.full_%s' % task).Net_Full
+            net = Net(cfg, init).to(dev).train()
+            dp.broadcast_parameters(net)
+            Bt, Sx, Sy = (160, 50, 36) if task == 'itm' else (B, 15, SY)
+            mk = lambda seed: tuple(t.to(dev) for t in synth_batch(cfg, Bt, Sx, Sy, VOCAB, 4, seed)[0])
+            g = torch.Generator().manual_seed(5 + rank)
+            st = dict(cfg=cfg, net=net, reducer=dp.GradReducer(list(net.parameters())), B=Bt, Sx=Sx, Sy=Sy,
+                      pos=mk(888 + 1000 * rank), neg=mk(999 + 1000 * rank), loss=BCE_Loss())
+            if task == 'vgd':
+                sc = torch.rand(Bt, Sy, generator=g)
+                st['tg'] = dict(scores=(sc / sc.sum(-1, keepdim=True)).to(dev), scores_mask=(torch.rand(Bt, Sy, generator=g) < 0.7).float().to(dev),
+                                bbox=torch.randn(Bt, Sy, 4, generator=g).to(dev),
+                                bbox_mask=((torch.rand(Bt, Sy, 1, generator=g) < 0.4).float() * torch.ones(1, 1, 4)).to(dev))
+                st['tg']['scores_mask'][:, 0] = 1
+                st['tg']['bbox_mask'][:, 0] = 1
+            state[wl] = st
+        return state[wl]
+
     def used_names(net):
         ms = net.redundant_modules
         return ([m.Used_OPS[m.active_index[0]] for m in ms[:12]], [m.Used_OPS[m.active_index[0]] for m in ms[12:]],
@@ -335,6 +369,28 @@ def main():
     def make_step(wl):
         """-> (step() -> loss, flops accumulator [1], steps-per-call)"""
         fl = [0.0]
+        if wl in EXTRA:
+            from mmnas_amd.harness import itm_triplet_step, vgd_loss
+            S = other_state(wl)
+            cfg, net, red = S['cfg'], S['net'], S['reducer']
+            ne = [n[0] for n in cfg.GENOTYPE['enc']]
+            nd = [n[0] for n in cfg.GENOTYPE['dec']]
+            passes = 3 if wl == 'train_itm' else 1
+            per = passes * step_flops(cfg, ne, nd, S['B'], S['Sx'], S['Sy'], 4)
+
+            def step():
+                if wl == 'train_itm':
+                    loss = itm_triplet_step(net, S['loss'], S['pos'], S['neg'], reducer=red)
+                else:
+                    red.begin_step()
+                    ps, pr = net(S['pos'])
+                    t = S['tg']
+                    loss = vgd_loss(ps, pr, t['scores'], t['scores_mask'], t['bbox'], t['bbox_mask'])
+                    loss.backward()
+                    red.finish()
+                fl[0] += per
+                return loss
+            return step, fl, 1
         if wl == 'train_vqa':
             S = train_state()
             cfg, net, red = S['cfg'], S['net'], S['reducer']
@@ -418,7 +474,7 @@ def main():
             'metric': METRICS[wl], 'value': world * nsteps / elapsed, 'unit': 'steps/s',
             'steps': nsteps, 'warmup': wcalls * per_call, 'ms_per_step': 1000.0 * elapsed / nsteps,
             'workload': WORKLOADS[wl],
-            'samples_per_s': world * nsteps * B / elapsed,
+            'samples_per_s': world * nsteps * (state[wl]['B'] if wl in EXTRA else B) / elapsed,
             'algorithmic_tflops_per_gpu': timed_flops / elapsed / 1e12,
             'step_frac_of_mfma_peak': timed_flops / elapsed / 1e12 / PEAK_MFMA_F32_TFLOPS,
             'final_loss': float(loss.detach()),
@@ -506,7 +562,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if not args.gemm_split else 'f32 results from bf16x%d split-operand MFMA products (experiment)' % args.gemm_split,
             'data': 'synthetic',
-            'config': {'workload': head['workload'], 'global_batch': B * world, 'parallelism': 'dp%d' % world,
+            'config': {'workload': head['workload'], 'global_batch': (state[head_wl]['B'] if head_wl in EXTRA else B) * world, 'parallelism': 'dp%d' % world,
                        'grad_allreduce': ('rccl' if backend == 'nccl' else backend) if world > 1 else 'none',
                        'rccl_ranks': dist.get_world_size() if world > 1 else 1,
                        'rccl_env': {k: v for k, v in os.environ.items() if k.startswith(('NCCL_', 'RCCL_'))},

@@ -213,10 +213,18 @@ int mmnas_attflat_pool_fwd(const float* logits, const float* x, const uint8_t* m
 int mmnas_attflat_pool_bwd(const float* probs, const float* x, const uint8_t* mask, const float* dpooled,
                            float* dlogits, float* dx, int B, int S, int d, int G, void* stream);
 
-/* Data path: box-geometry relation features of the loaders (relation_embedding, load_data_vqa.py:224-239,
- * load_data_vgd.py:7-33), batched: bbox [B,S,4] (x1,y1,x2,y2), nobj [B] valid boxes per sample (NULL = S)
+/* Data path: box-geometry relation features of the loaders (relation_embedding, load_data_vqa.py:7-33 =
+ * load_data_vgd.py:7-33; pinned by tests/golden/loader.npz), batched: bbox [B,S,4] (x1,y1,x2,y2), nobj [B] valid boxes per sample (NULL = S)
  * -> out [B,S,S,4] = (log max(|dcx|/w_i,1e-3), log max(|dcy|/h_i,1e-3), log(w_i/w_j), log(h_i/h_j)), zero padded. */
 int mmnas_relation_embedding(const float* bbox, const int* nobj, float* out, int B, int S, void* stream);
+
+/* Data path: token-relation features of the loaders (semantic_embedding, load_data_vqa.py:36-58), batched:
+ * ques_ix [B,S] int64 token indices, nwords [B] = min(#words, S) per question, emb [V,E] the GloVe table ->
+ * out [B,S,S,3] = (|g_i - g_j|_2, <g_i,g_j> / (sqrt|g_i| sqrt|g_j| + 1e-6), |i-j| / nwords), zero for i or j >= nwords.
+ * S <= 64, E <= 320.  (64 x 301 floats of LDS per workgroup exceed the 64 KB default only for S > 54: the launch asks
+ * for what it needs.) */
+int mmnas_semantic_embedding(const long* ques_ix, const int* nwords, const float* emb, float* out, int B, int S,
+                             int E, long V, void* stream);
 
 /* Supernet plumbing: out [rows, width] = one-hot rows, out[r, idx_host[r]] = 1 (idx_host is a HOST array, read at
  * call time and passed in the kernel arguments; rows <= 128).  Writes the alpha_gate block of all MixedOps after

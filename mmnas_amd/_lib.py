@@ -132,6 +132,7 @@ SYMBOLS = {
     'mmnas_attflat_pool_fwd': (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),
     'mmnas_attflat_pool_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),
     'mmnas_relation_embedding': (_i, [_fp, _fp, _fp, _i, _i, _fp]),
+    'mmnas_semantic_embedding': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_long, _fp]),
     'mmnas_onehot_rows': (_i, [_fp, _i, _i, C.POINTER(C.c_int), _fp]),
     'mmnas_mixed_sum_ws_floats': (_sz, []),
     'mmnas_mixed_sum_fwd': (_i, [C.POINTER(_fp), _i, _fp, _fp, _sz, _fp]),

@@ -209,6 +209,67 @@ extern "C" int mmnas_relation_embedding(const float* bbox, const int* nobj, floa
 }
 
 // ------------------------------------------------------------------------------------------
+// Data path: the token-relation features of the loaders (semantic_embedding, load_data_vqa.py:36-58), batched on the
+// GPU from the token indices and the GloVe table (the reference builds a [14,14,3] tensor per sample on the CPU):
+//   g_i = emb[ques_ix[b,i]] for the first n = nwords[b] (<= S) tokens,
+//   out[b,i,j] = ( |g_i - g_j|_2,  <g_i, g_j> / (sqrt|g_i| sqrt|g_j| + 1e-6),  |i - j| / n ),  zero for i or j >= n
+// (the reference divides by the square ROOTS of the norms: kept).  One workgroup per sample; rows staged in LDS.
+// ------------------------------------------------------------------------------------------
+namespace mmnas {
+constexpr int SE_MAXS = 64, SE_MAXE = 320;
+__global__ void __launch_bounds__(256) semantic_embedding_kernel(const long* __restrict__ ques, const int* __restrict__ nwords,
+                                                                 const float* __restrict__ emb, float* __restrict__ out, int S,
+                                                                 int E, long V) {
+  extern __shared__ float g[];          // [S][E + 1] rows, then [S] sqrt-norms
+  const int b = blockIdx.x, tid = threadIdx.x, ld = E + 1;
+  float* sn = g + (size_t)S * ld;
+  const int n = min(max(nwords[b], 0), S);
+  for (int i = tid; i < n * E; i += 256) {
+    const int r = i / E, c = i - r * E;
+    long t = ques[(size_t)b * S + r];
+    if (t < 0 || t >= V) t = 0;
+    g[r * ld + c] = emb[t * E + c];
+  }
+  __syncthreads();
+  for (int r = tid >> 6; r < n; r += 4) {   // one wave per row: squared norm
+    float s = 0.f;
+    for (int c = tid & 63; c < E; c += 64) { const float v = g[r * ld + c]; s += v * v; }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) sn[r] = sqrtf(sqrtf(s));   // sqrt(|g_r|_2)
+  }
+  __syncthreads();
+  for (int e = tid; e < S * S; e += 256) {
+    const int i = e / S, j = e - i * S;
+    float l2 = 0.f, cs = 0.f, ps = 0.f;
+    if (i < n && j < n) {
+      float d2 = 0.f, dot = 0.f;
+      for (int c = 0; c < E; ++c) {
+        const float a = g[i * ld + c], bb = g[j * ld + c];
+        const float d = a - bb;
+        d2 += d * d;
+        dot += a * bb;
+      }
+      l2 = sqrtf(d2);
+      cs = dot / (sn[i] * sn[j] + 1e-6f);
+      ps = fabsf((float)(i - j)) / (float)n;
+    }
+    float* o = out + (((size_t)b * S + i) * S + j) * 3;
+    o[0] = l2; o[1] = cs; o[2] = ps;
+  }
+}
+}  // namespace mmnas
+
+extern "C" int mmnas_semantic_embedding(const long* ques_ix, const int* nwords, const float* emb, float* out, int B, int S,
+                                        int E, long V, void* stream) {
+  MMNAS_REQUIRE(ques_ix && nwords && emb && out && B > 0, MMNAS_E_ARG, "semantic_embedding: bad arguments");
+  MMNAS_REQUIRE(S >= 1 && S <= SE_MAXS && E >= 1 && E <= SE_MAXE && V >= 1, MMNAS_E_SHAPE,
+                "semantic_embedding: S=%d (<= %d) E=%d (<= %d)", S, SE_MAXS, E, SE_MAXE);
+  const size_t lds = ((size_t)S * (E + 1) + S) * sizeof(float);
+  MMNAS_LAUNCH(semantic_embedding_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, ques_ix, nwords, emb, out, S, E, V);
+  return check_launch("semantic_embedding");
+}
+
+// ------------------------------------------------------------------------------------------
 // Supernet plumbing: write the binary gates of all nodes (MixedOp.binarize, mixed.py:131-158: alpha_gate = one-hot
 // of the sampled operator) in one launch whose indices travel in the kernel arguments -- no host->device copy,
 // hence no stream synchronisation, per NAS step.

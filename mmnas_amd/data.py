@@ -11,11 +11,16 @@ only the small tensors cross PCIe and the copies overlap the previous step.
     batch uploads 52 MB of features + 6 KB of boxes instead of 52 MB + 10 MB.
   * `DevicePrefetcher`: pinned staging buffers + a copy stream; batch i+1 is uploaded while step i computes.
 
-PARITY UNPINNED for the loader restatements: the reference's loader modules import `en_vectors_web_lg` / `spacy`
-at module level and cannot be imported in the build container; they are restated from the source text and covered
-by their own known-answer tests (tests/test_data.py).  Tokenisation (`proc_ques`, needs the spaCy vocabulary) and
-the answer scoring are out of scope.
+  * `tokenize`: `proc_ques` (load_data_vqa.py:278-296); `semantic_relations_on_device`: `semantic_embedding`
+    (load_data_vqa.py:36-58) for a whole batch on the GPU from the token indices and the GloVe table.
+
+Parity PINNED: the reference's loader modules import `en_vectors_web_lg` / `spacy` at module level and cannot be
+imported, so tests/golden/make_golden.py compiles the functions themselves out of the loader's source (`ast`) in the
+build container and stores their outputs on deterministic inputs (tests/golden/loader.npz); tests/test_data.py checks
+every function here against them.  The spaCy vocabulary itself and the answer scoring stay out of scope.
 """
+import re
+
 import numpy as np
 import torch
 
@@ -62,6 +67,23 @@ def collate_regions(samples):
             'bbox_feat': np.stack([s['bbox_feat'] for s in samples]),
             'bbox': np.stack([s['bbox'] for s in samples]),
             'nobj': np.asarray([s['nobj'] for s in samples], dtype=np.int32)}
+
+
+def tokenize(question, token_to_ix, max_token=14):
+    """proc_ques (load_data_vqa.py:278-296): lower-case, strip punctuation, '-' and '/' become spaces, unknown words map
+    to token_to_ix['UNK'], zero padding.  Returns (ques_ix int64 [max_token], min(#words, max_token))."""
+    words = re.sub(r"([.,'!?\"()*#:;])", '', question.lower()).replace('-', ' ').replace('/', ' ').split()
+    ix = np.zeros(max_token, np.int64)
+    for i, w in enumerate(words[:max_token]):
+        ix[i] = token_to_ix.get(w, token_to_ix['UNK'])
+    return ix, min(len(words), max_token)
+
+
+def semantic_relations_on_device(ques_ix, nwords, emb):
+    """[B,S] token indices + [B] word counts + the [V,300] GloVe table (device tensors) -> the loaders' zero-padded
+    [B,S,S,3] token-relation tensor (semantic_embedding, load_data_vqa.py:36-58), on the GPU."""
+    from . import ops
+    return ops.semantic_embedding(ques_ix, nwords, emb)
 
 
 def relations_on_device(bbox, nobj):

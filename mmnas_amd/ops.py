@@ -1014,7 +1014,10 @@ def head_record(att_x, att_y, ln, proj, training):
     if not _sinked((first, last)):
         return None, None
     hd, params = _cached_record(proj, (training,), first, lambda: _head_record(att_x, att_y, ln, proj, training))
-    if hd is not None and hd.drop_p > 0:
+    if hd is None:
+        return None, None
+    hd = L.Head.from_buffer_copy(hd)   # a private copy per call: several forwards may be alive before one backward (ITM triplets)
+    if hd.drop_p > 0:
         hd.sx.seed = next_seed()
         hd.sy.seed = next_seed()
     return hd, params
@@ -1145,6 +1148,19 @@ def relation_embedding(bbox, nobj=None):
     out = torch.empty(B, S, S, 4, dtype=torch.float32, device=bbox.device)
     n = None if nobj is None else nobj.to(device=bbox.device, dtype=torch.int32).contiguous()
     L.check(L.lib().mmnas_relation_embedding(L.fptr(bbox), L.ptr(n), L.fptr(out), B, S, L.stream()))
+    return out
+
+
+def semantic_embedding(ques_ix, nwords, emb):
+    """Token-relation features of the loaders (semantic_embedding, load_data_vqa.py:36-58), batched on the GPU:
+    ques_ix [B,S] int64, nwords [B] (min(#words, S) per question), emb [V,E] float32 -> [B,S,S,3]."""
+    ques_ix = ques_ix.contiguous()
+    emb = _f32c(emb)
+    B, S = ques_ix.shape
+    n = nwords.to(device=ques_ix.device, dtype=torch.int32).contiguous()
+    out = torch.empty(B, S, S, 3, dtype=torch.float32, device=ques_ix.device)
+    L.check(L.lib().mmnas_semantic_embedding(L.ptr(ques_ix), L.ptr(n), L.fptr(emb), L.fptr(out), B, S, emb.shape[1], emb.shape[0],
+                                             L.stream()))
     return out
 
 

@@ -1,0 +1,161 @@
+"""The other BASELINE configurations at FULL size, where the oracle is too slow to be the checker: properties the
+reference has by construction (samples are independent, the loss is a sum over samples, padding is inert).
+  configs[2] arch step : Net_Search, MODE 'full', B=64, 100 regions, HSIZE 256 (search_vqa.py:317-331)
+  configs[3] VGD       : Net_Full(arch/mmnas_vgd.json) + the VGD loss, B=64, 100 regions, 15 tokens, HSIZE 512
+  configs[4] ITM       : Net_Full(arch/mmnas_itm.json), hard-negative triplet step with BCE_Loss, B=160, 36 regions,
+                         50 tokens, HSIZE 512 (fp32: the reference's own precision)
+Every step goes through the step harness (mmnas_amd/harness.py), i.e. the code the bench times."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+T = torch.from_numpy
+
+
+def _init(c):
+    return {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+            'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
+
+
+def _grad_dict(net):
+    return {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+
+def _additive(g_all, g_lo, g_hi, tol=2e-3):
+    gmax = max(float(v.abs().max()) for v in g_all.values())
+    bad = []
+    for k, v in g_all.items():
+        lo, hi = g_lo.get(k), g_hi.get(k)
+        s = (lo if lo is not None else 0) + (hi if hi is not None else 0)
+        err = float((v - s).abs().max())
+        if err > tol * max(float(v.abs().max()), 1e-3 * gmax):
+            bad.append((k, err, float(v.abs().max())))
+    assert not bad, bad[:6]
+
+
+def test_supernet_arch_step_full_size():
+    from mmnas.model.hygr_vqa import Net_Search
+    from mmnas.model.mixed import MixedOp
+    B = 64
+    c = cases.net_case('vqa', None, 21, search=True, HSIZE=256, B=B, Sx=14, Sy=100, token_size=2000, ans_size=3129)
+    net = Net_Search(c['cfg'], _init(c))
+    net.load_state_dict({k: T(v) for k, v in c['P'].items()})
+    net = net.to(DEV).train()
+    plan = cases.search_plan(np.random.RandomState(8), 'full')
+    flat = plan['enc'] + plan['dec']
+    inp = [T(a).to(DEV) for a in c['inputs']]
+    tgt = T(c['target']).to(DEV)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+
+    def run(sel):
+        MixedOp.MODE = 'full'
+        try:
+            net.set_sampled(flat)
+            net.zero_grad(set_to_none=True)
+            out = net(tuple(t[sel] for t in inp))
+            bce(out, tgt[sel], reduction='sum').backward()
+        finally:
+            MixedOp.MODE = None
+        gates = torch.stack([torch.nn.functional.pad(m.alpha_gate.grad, (0, 4 - m.n_choices)) for m in net.redundant_modules])
+        return out.detach(), gates.clone()
+
+    full = torch.arange(B, device=DEV)
+    out, g_all = run(full)
+    assert torch.isfinite(out).all() and torch.isfinite(g_all).all() and float(g_all.abs().max()) > 0
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to(DEV)
+    out_p, g_p = run(perm)
+    scale = float(out.abs().max())
+    assert float((out_p - out[perm]).abs().max()) <= 2e-5 * scale          # samples are independent
+    assert float((g_p - g_all).abs().max()) <= 2e-3 * float(g_all.abs().max())    # the gate gradient is a sum over samples
+    _, g_lo = run(full[:B // 2])
+    _, g_hi = run(full[B // 2:])
+    assert float((g_lo + g_hi - g_all).abs().max()) <= 2e-3 * float(g_all.abs().max())
+    # the fused path of the harness (gated-sum kernel, gate-gradient block) gives the same gate gradients
+    from mmnas_amd.harness import SearchLoop
+    loop = SearchLoop(net)
+    try:
+        loop.arch_step(tuple(inp), tgt, optimize=False, plan=flat)
+        gg, _ = net._flat_grads
+        assert float((gg - g_all).abs().max()) <= 2e-3 * float(g_all.abs().max())
+    finally:
+        loop.reducer.fg.disable_sinks()
+
+
+def test_vgd_full_size():
+    from mmnas.model.full_vgd import Net_Full
+    from mmnas_amd.harness import vgd_loss
+    B = 64
+    c = cases.net_case('vgd', 'mmnas_vgd', 22, HSIZE=512, B=B, Sx=15, Sy=100, token_size=2000, ans_size=3129)
+    net = Net_Full(c['cfg'], _init(c))
+    net.load_state_dict({k: T(v) for k, v in c['P'].items()})
+    net = net.to(DEV).train()
+    inp = [T(a).to(DEV) for a in c['inputs']]
+    t = {k: T(v).to(DEV) for k, v in cases.vgd_targets(c, 23).items()}
+
+    def run(sel, avg=True):
+        net.zero_grad(set_to_none=True)
+        ps, pr = net(tuple(x[sel] for x in inp))
+        loss = vgd_loss(ps, pr, t['scores'][sel], t['scores_mask'][sel], t['bbox'][sel], t['bbox_mask'][sel], loss_avg=avg)
+        loss.backward()
+        return ps.detach(), pr.detach(), float(loss.detach()), _grad_dict(net)
+
+    full = torch.arange(B, device=DEV)
+    ps, pr, loss, _ = run(full)
+    assert np.isfinite(loss) and torch.isfinite(ps).all() and torch.isfinite(pr).all()
+    assert float((ps.exp().sum(-1) - 1).abs().max()) < 1e-4           # log-softmax scores (full_vgd.py:110-112)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(4)).to(DEV)
+    ps_p, pr_p, _, _ = run(perm)
+    assert float((ps_p - ps[perm]).abs().max()) <= 2e-5 * float(ps.abs().max())
+    assert float((pr_p - pr[perm]).abs().max()) <= 2e-5 * float(pr.abs().max())
+    # without the per-batch averaging (LOSS_AVG divides by mask counts of the WHOLE batch) the loss is a sum over samples
+    _, _, _, g_all = run(full, avg=False)
+    _, _, _, g_lo = run(full[:B // 2], avg=False)
+    _, _, _, g_hi = run(full[B // 2:], avg=False)
+    _additive(g_all, g_lo, g_hi)
+
+
+def test_itm_triplet_step_full_size():
+    from mmnas.model.full_itm import Net_Full
+    from mmnas.utils.itm_loss import BCE_Loss
+    from mmnas_amd import dp
+    from mmnas_amd.harness import itm_triplet_step
+    B = 160
+    c = cases.net_case('itm', 'mmnas_itm', 24, HSIZE=512, B=B, Sx=50, Sy=36, token_size=2000, ans_size=1)
+    neg = cases.net_case('itm', 'mmnas_itm', 25, HSIZE=512, B=B, Sx=50, Sy=36, token_size=2000, ans_size=1)
+    net = Net_Full(c['cfg'], _init(c))
+    net.load_state_dict({k: T(v) for k, v in c['P'].items()})
+    net = net.to(DEV).train()
+    pos = [T(a).to(DEV) for a in c['inputs']]
+    ng = [T(a).to(DEV) for a in neg['inputs']]
+    loss_fn = BCE_Loss()
+
+    def run(sel):
+        net.zero_grad(set_to_none=True)
+        loss = itm_triplet_step(net, loss_fn, tuple(x[sel] for x in pos), tuple(x[sel] for x in ng))
+        return float(loss.detach()), _grad_dict(net)
+
+    full = torch.arange(B, device=DEV)
+    loss, g_all = run(full)
+    assert np.isfinite(loss) and all(torch.isfinite(v).all() for v in g_all.values())
+    l_lo, g_lo = run(full[:B // 2])
+    l_hi, g_hi = run(full[B // 2:])
+    assert abs(l_lo + l_hi - loss) <= 1e-4 * abs(loss)
+    _additive(g_all, g_lo, g_hi)
+    # the same step through the data-parallel reducer (flat gradient buffer, backbone / head chains taken three times
+    # per backward: the sinks ACCUMULATE over the three forwards)
+    red = dp.GradReducer(list(net.parameters()))
+    try:
+        loss_r = itm_triplet_step(net, loss_fn, tuple(pos), tuple(ng), reducer=red)
+        torch.cuda.synchronize()
+        assert abs(float(loss_r.detach()) - loss) <= 1e-5 * abs(loss)
+        gmax = max(float(v.abs().max()) for v in g_all.values())
+        named = dict(net.named_parameters())
+        for k, v in g_all.items():
+            err = float((named[k].grad - v).abs().max())
+            assert err <= 1e-4 * max(float(v.abs().max()), 1e-3 * gmax), (k, err)
+    finally:
+        red.fg.disable_sinks()

@@ -73,3 +73,53 @@ def test_prefetcher_and_relations_on_the_gpu():
             assert rel_err(rel[b], exp) < 1e-4
         seen += 1
     assert seen == 5
+
+
+# ---- the loader functions against the reference's own outputs (tests/golden/loader.npz) ----------------------------
+def test_host_functions_vs_reference_loader():
+    from tests.golden import cases
+    from tests.util import load
+    npz = load('loader.npz')
+    for i in range(3):
+        want = npz['pad|%d|out' % i]
+        assert np.array_equal(data.pad_rows(npz['pad|%d|in' % i], want.shape[0]), want)
+    for i in range(2):
+        out = data.bbox_features(npz['bboxfeat|%d|bbox' % i], tuple(npz['bboxfeat|%d|shape' % i]))
+        assert np.array_equal(out, npz['bboxfeat|%d|out' % i])
+    tok = {w: i for i, w in enumerate(cases.LOADER_VOCAB)}
+    for i, q in enumerate(cases.LOADER_QUESTIONS):
+        ix, n = data.tokenize(q, tok, 14)
+        assert np.array_equal(ix, npz['sem|%d|ques_ix' % i])
+        assert n == npz['sem|%d|out' % i].shape[0]
+
+
+@pytest.mark.gpu
+def test_device_relation_kernels_vs_reference_loader():
+    """relation_embedding / semantic_embedding of load_data_vqa.py:7-58 on the GPU, batched and zero-padded as
+    DataSet.__getitem__ does (load_data_vqa.py:221-239), against the reference functions' own outputs."""
+    from tests.golden import cases
+    from tests.util import load
+    npz = load('loader.npz')
+    # boxes: four samples of 7 / 36 / 100 / 1 objects in one padded batch
+    S = 100
+    bbox = np.zeros((4, S, 4), np.float32)
+    nobj = []
+    for i in range(4):
+        b = npz['rel|%d|bbox' % i]
+        bbox[i, :b.shape[0]] = b
+        nobj.append(b.shape[0])
+    rel = data.relations_on_device(torch.from_numpy(bbox).cuda(), torch.tensor(nobj, dtype=torch.int32).cuda()).cpu().numpy()
+    for i, n in enumerate(nobj):
+        want = np.zeros((S, S, 4), np.float32)
+        want[:n, :n] = npz['rel|%d|out' % i]
+        assert np.allclose(rel[i], want, rtol=2e-5, atol=2e-5), i
+    # questions
+    tok = {w: i for i, w in enumerate(cases.LOADER_VOCAB)}
+    ixs, ns = zip(*[data.tokenize(q, tok, 14) for q in cases.LOADER_QUESTIONS])
+    emb = torch.from_numpy(npz['sem|emb']).cuda()
+    out = data.semantic_relations_on_device(torch.from_numpy(np.stack(ixs)).cuda(), torch.tensor(ns, dtype=torch.int32).cuda(), emb)
+    out = out.cpu().numpy()
+    for i, n in enumerate(ns):
+        want = np.zeros((14, 14, 3), np.float32)
+        want[:n, :n] = npz['sem|%d|out' % i]
+        assert np.allclose(out[i], want, rtol=2e-5, atol=2e-5), i
