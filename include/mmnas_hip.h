@@ -415,7 +415,7 @@ int mmnas_mlp_op_bwd(const mmnas_mlp_op* op, void* stream);
  *   ACCUMULATED as by the per-operator calls.
  *   use_side_stream != 0 (bwd): the call's stream carries only the data-gradient chain; weight-gradient products,
  *   LayerNorm parameter reductions and the relation-bias backward run on a library-owned side stream behind one
- *   event per operator.  mmnas_chain_join(main, waiting) makes `waiting` wait for everything issued to main's side
+ *   event per operator (use_side_stream == 2: only the relation-bias backward moves).  mmnas_chain_join(main, waiting) makes `waiting` wait for everything issued to main's side
  *   stream so far -- call it (with waiting = main) before anything reads the parameter gradients.
  * ------------------------------------------------------------------------------------------ */
 #define MMNAS_CHAIN_MAX_OPS 64

@@ -10,6 +10,7 @@
 namespace mmnas {
 
 constexpr int MAXC = MMNAS_MIXED_MAX;
+static_assert(MAXC == 8, "mixed_sum_reduce_kernel assumes 8 candidate slots");
 
 struct MixArgs {
   const float* o[MAXC];
@@ -67,13 +68,29 @@ __global__ void __launch_bounds__(256) mixed_sum_bwd_kernel(MixArgs a, const flo
     part[(size_t)blockIdx.x * MAXC + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// dgate[j] += sum over workgroups (fixed order: bitwise reproducible)
-__global__ void __launch_bounds__(64) mixed_sum_reduce_kernel(const float* __restrict__ part, int nwg, int n, float* __restrict__ dgate) {
-  const int j = threadIdx.x;
-  if (j >= n) return;
-  float t = 0.f;
-  for (int b = 0; b < nwg; ++b) t += part[(size_t)b * MAXC + j];
-  dgate[j] += t;
+// dgate[j] += sum over workgroups, in a fixed order (bitwise reproducible): 256 threads = 8 candidates x 32 strided
+// partial sums, then a fixed-order tree through LDS.  (A single thread per candidate walking all 2048 partials was a
+// chain of 2048 dependent loads: 105 us per node, a fifth of the architecture step.)
+__global__ void __launch_bounds__(256) mixed_sum_reduce_kernel(const float* __restrict__ part, int nwg, int n, float* __restrict__ dgate) {
+  __shared__ float red[32][MAXC + 1];
+  const int j = threadIdx.x & (MAXC - 1), g = threadIdx.x / MAXC;   // MAXC = 8: 32 groups
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  int b = g;
+  for (; b + 96 < nwg; b += 128) {
+    t0 += part[(size_t)b * MAXC + j];
+    t1 += part[(size_t)(b + 32) * MAXC + j];
+    t2 += part[(size_t)(b + 64) * MAXC + j];
+    t3 += part[(size_t)(b + 96) * MAXC + j];
+  }
+  for (; b < nwg; b += 32) t0 += part[(size_t)b * MAXC + j];
+  red[g][j] = (t0 + t1) + (t2 + t3);
+  __syncthreads();
+  if (threadIdx.x < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += red[i][threadIdx.x];
+    dgate[threadIdx.x] += t;
+  }
 }
 
 // one thread per node (row): 'full'-mode architecture gradient + Adam
@@ -144,7 +161,7 @@ extern "C" int mmnas_mixed_sum_bwd(const float* const* outs_host, int n, const f
   const int g = mix_grid(count / 4);
   ProfScope ps(MMNAS_K_ROWOPS, 2.0 * n * count, 4.0 * (n + 2) * count, (hipStream_t)stream, "mixed_sum_bwd");
   MMNAS_LAUNCH(mixed_sum_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, a, gate, dout, d_active, active, ws, count / 4);
-  MMNAS_LAUNCH(mixed_sum_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)ws, g, n, dgate);
+  MMNAS_LAUNCH(mixed_sum_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, g, n, dgate);
   return check_launch("mixed_sum_bwd");
 }
 

@@ -148,6 +148,7 @@ namespace mmnas {
 // backward).  The caller decides when and on which stream they run (SideQueue::flush).
 struct SideQueue {
   std::vector<std::function<int(hipStream_t)>> work;
+  bool rel_only = false;   // queue only the relation-bias backward; the weight gradients stay paired on the main stream
   // everything `main` has been given so far finishes first; then the queued launches run on `side`
   int flush(hipStream_t main, hipStream_t side, hipEvent_t ev) {
     if (work.empty()) return MMNAS_OK;
@@ -169,7 +170,8 @@ struct SideQueue {
 // whole relation-bias backward (~40 % of an operator's backward time, read by nothing before the optimizer / the
 // gradient exchange) are queued.
 static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* sq) {
-  const bool side = sq != nullptr;
+  const bool side = sq != nullptr && !sq->rel_only;
+  const bool side_rel = sq != nullptr;
   int rc = att_check(op, "att_op_bwd");
   if (rc) return rc;
   MMNAS_REQUIRE(op->xq && op->xkv && op->Wq && op->Wk && op->Wv && op->Wm && op->save && op->ws && op->dy &&
@@ -282,7 +284,7 @@ static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* s
       return mmnas_rel_fused_bwd(o.rel, o.Wy, o.by, o.Wr, o.br, dbiasT, o.dWy, o.dby, o.dWr, o.dbr, relws, o.B, o.Sq, o.Sk,
                                  o.C, o.R, o.H, s);
     };
-    if (side) { sq->work.push_back(relb); return MMNAS_OK; }
+    if (side_rel) { sq->work.push_back(relb); return MMNAS_OK; }
     return relb(stream);
   }
   if (rel)   // (a materialised relation tensor's own gradient may feed the caller: main stream)
@@ -388,7 +390,7 @@ extern "C" int mmnas_mlp_op_fwd(const mmnas_mlp_op* op, void* stream) {
 
 namespace mmnas {
 static int mlp_bwd_impl(const mmnas_mlp_op* op, hipStream_t stream, SideQueue* sq) {
-  const bool side = sq != nullptr;
+  const bool side = sq != nullptr && !sq->rel_only;
   int rc = mlp_check(op, "mlp_op_bwd");
   if (rc) return rc;
   MMNAS_REQUIRE(op->x && op->save && op->ws && op->dy && op->dx, MMNAS_E_ARG, "mlp_op_bwd: null pointer");
@@ -643,6 +645,7 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
   hipStream_t side = sc ? sc->side : nullptr;
   if (sc) sc->used = true;
   SideQueue q;
+  q.rel_only = c->use_side_stream == 2;
   SideQueue* sq = sc ? &q : nullptr;
   // When the queued parameter-gradient work is released: MMNAS_SIDE_FLUSH=op -> behind every operator (it then competes
   // with the data-gradient chain for the CUs); default -> once behind the decoder and once behind the encoder, so it

@@ -778,7 +778,8 @@ def side_stream_enabled():
     paired ones save, and workgroups of the deferred products delay the short, latency-bound encoder / LSTM kernels they
     were meant to fill the gaps of (6.99 -> 7.05 ms released per operator, 7.35 ms released per phase)."""
     import os
-    return os.environ.get('MMNAS_SIDE_STREAM', '0') == '1'
+    v = os.environ.get('MMNAS_SIDE_STREAM', '0')
+    return 2 if v == 'rel' else int(v == '1')   # 'rel': only the relation-bias backward (parameter gradients only) moves
 
 
 _side_pending = []          # arenas / inputs the side stream may still be reading (released by join_side_stream)

@@ -1,28 +1,40 @@
 #!/bin/bash
 # Regenerates everything under profiles/ for one round on a GPU box (run from the repo root):
-#   bash tools/refresh_profiles.sh r01
-# bench lines (with the CPU baseline for the headline workload), rocprofv3 --kernel-trace --stats summaries of the
-# same command, and the two --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a pass) behind roofline.traffic.
-# Raw traces stay in /tmp; only the summaries are written to profiles/.
+#   bash tools/refresh_profiles.sh r02
+# rocprofv3 --kernel-trace --stats summaries of the bench command per workload, one-step kernel timelines, the two
+# --pmc passes behind roofline.traffic (FETCH_SIZE / WRITE_SIZE cannot share a pass), the MFMA / LDS counter passes, and
+# the bench lines themselves (the default line with its CPU baselines last: it reads the traffic files written before).
+# Raw traces stay in /tmp; only summaries are written to profiles/.  Counters are collected with --kernel-trace only.
 set -u
-R=${1:-r01}
+R=${1:-r02}
 ROOT=$PWD
 export TMPDIR=/tmp
 W=/tmp/mmnas_prof
 rm -rf $W; mkdir -p $W profiles
-for wl in train_vqa search_vqa; do
+for wl in search_vqa arch_vqa train_vqa; do
   cmd="bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline"
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace_$wl -o t -- python3 $ROOT/$cmd > $W/trace_$wl.log 2>&1)
   python3 tools/summarize_prof.py $W/trace_$wl profiles/${R}_$wl 23 \
     "rocprofv3 --kernel-trace --stats -- python3 $cmd  (3 warm-up + 10 timed + 10 roofline-pass steps)"
+  marker=onehot_rows; [ $wl = train_vqa ] && marker=row_is_zero
+  python3 tools/step_timeline.py $W/trace_$wl $marker > profiles/${R}_timeline_$wl.txt
   [ -n "${SKIP_PMC:-}" ] && continue
+  [ $wl = arch_vqa ] && continue
+  small="bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-prof"
   for c in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d $W/pmc_${wl}_$c -o t -- python3 $ROOT/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-prof > $W/pmc_${wl}_$c.log 2>&1)
+    (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d $W/pmc_${wl}_$c -o t -- python3 $ROOT/$small > $W/pmc_${wl}_$c.log 2>&1)
   done
   python3 tools/pmc_traffic.py $W/pmc_${wl}_FETCH_SIZE $W/pmc_${wl}_WRITE_SIZE profiles/${R}_traffic_$wl.json
+  (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace -d $W/pmc_${wl}_mfma -o t -- python3 $ROOT/$small > $W/pmc_${wl}_mfma.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $W/pmc_${wl}_lds -o t -- python3 $ROOT/$small > $W/pmc_${wl}_lds.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace -d $W/pmc_${wl}_gui -o t -- python3 $ROOT/$small > $W/pmc_${wl}_gui.log 2>&1)
+  python3 tools/pmc_counters.py profiles/${R}_pmc_$wl.json $W/pmc_${wl}_mfma $W/pmc_${wl}_lds $W/pmc_${wl}_gui
 done
-# bench lines last: they read the traffic files written above
-python3 bench.py --workload train_vqa | grep '^{' | tail -1 > profiles/${R}_bench_train_vqa.json
-python3 bench.py --workload search_vqa --no-cpu-baseline | grep '^{' | tail -1 > profiles/${R}_bench_search_vqa.json
-ls -la profiles/
-for f in $W/*.log; do echo "== $f"; tail -n 3 $f; done
+python3 bench.py > $W/bench_all.log 2> $W/bench_all.err
+grep '^{' $W/bench_all.log | tail -1 > profiles/${R}_bench.json
+for wl in train_vgd train_itm; do
+  python3 bench.py --workload $wl --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > profiles/${R}_bench_$wl.json
+done
+mkdir -p gpurun_out/profiles_$R && cp profiles/${R}_* gpurun_out/profiles_$R/   # (gpurun merges only gpurun_out/ back)
+ls -la profiles/ | grep $R
+for f in $W/*.log; do echo "== $f"; tail -n 2 $f | cut -c1-300; done
