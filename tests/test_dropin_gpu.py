@@ -87,7 +87,8 @@ def _w_reference_loop(rank):
     net_optim = WarmupOptimizer(4e-4, torch.optim.Adam(ddp.module.net_parameters(), lr=0, betas=(0.9, 0.98), eps=1e-9),
                                 epoch_steps=10, warmup=True)
     alpha_optim = torch.optim.Adam(ddp.module.alpha_prob_parameters(), 0.1, betas=(0.0, 0.999))
-    inp, tgt = batch(rank)
+    _, tgt = batch(rank)
+    inp = tuple(T(a) for a in cs[rank]['inputs'])       # CPU tensors, as the reference's loader yields them: DDP moves them
     named = dict(ddp.module.named_parameters())          # (before unused_modules_off() hides the idle candidates)
 
     # ---- network step, search_vqa.py:279-300 (sampling replaced by an injected sample, as in the goldens) ----

@@ -30,6 +30,10 @@ for wl in search_vqa arch_vqa train_vqa; do
   (cd /tmp && rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace -d $W/pmc_${wl}_gui -o t -- python3 $ROOT/$small > $W/pmc_${wl}_gui.log 2>&1)
   python3 tools/pmc_counters.py profiles/${R}_pmc_$wl.json $W/pmc_${wl}_mfma $W/pmc_${wl}_lds $W/pmc_${wl}_gui
 done
+if [ -z "${SKIP_PMC:-}" ]; then
+  (cd /tmp && GEMM_PMC_SWEEP=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $W/sweep -o t -- python3 $ROOT/tools/gemm_pmc.py > $W/sweep.log 2>&1)
+  python3 tools/traffic_sweep.py $W/sweep > profiles/${R}_gemm_traffic_sweep.txt
+fi
 python3 bench.py > $W/bench_all.log 2> $W/bench_all.err
 grep '^{' $W/bench_all.log | tail -1 > profiles/${R}_bench.json
 for wl in train_vgd train_itm; do
