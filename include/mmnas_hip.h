@@ -367,6 +367,10 @@ typedef struct mmnas_plan {
   size_t save_bytes, ws_fwd_bytes, ws_bwd_bytes;
 } mmnas_plan;
 
+/* Sequences of <= 16 rows (the language stream: 14 tokens) with heads of 64 and d in {256, 512} run SelfAtt as ONE launch
+ * forward (small.hip) instead of projection / core / merge / LayerNorm launches; the saved block is the same.
+ * mmnas_set_small_ops(0) forces the general path (returns the previous setting; default on, env MMNAS_SMALL_OPS). */
+int mmnas_set_small_ops(int on);
 int mmnas_att_op_plan(const mmnas_att_op* op, mmnas_plan* plan);   /* host only */
 int mmnas_att_op_fwd(const mmnas_att_op* op, void* stream);
 int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream);
@@ -527,7 +531,7 @@ int mmnas_sumsq(const float* g, size_t n, float* out, void* stream);
  * flops / bytes; mmnas_prof_collect() synchronises the events, sums per class and resets.
  * ------------------------------------------------------------------------------------------ */
 enum { MMNAS_K_GEMM = 0, MMNAS_K_MHA_FWD = 1, MMNAS_K_MHA_BWD = 2, MMNAS_K_REL_FWD = 3, MMNAS_K_REL_BWD = 4,
-       MMNAS_K_ROWOPS = 5, MMNAS_K_LSTM = 6, MMNAS_K_COUNT = 7 };
+       MMNAS_K_ROWOPS = 5, MMNAS_K_LSTM = 6, MMNAS_K_SMALL = 7 /* fused short-sequence operators */, MMNAS_K_COUNT = 8 };
 typedef struct mmnas_prof_stat { double ms, flops, bytes; long launches; } mmnas_prof_stat;
 int mmnas_prof_enable(int on);
 int mmnas_prof_collect(mmnas_prof_stat* stats /* [MMNAS_K_COUNT] */);

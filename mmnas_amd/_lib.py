@@ -94,7 +94,7 @@ class ProfStat(C.Structure):
     _fields_ = [('ms', C.c_double), ('flops', C.c_double), ('bytes', C.c_double), ('launches', C.c_long)]
 
 
-K_NAMES = ['gemm', 'mha_fwd', 'mha_bwd', 'rel_fwd', 'rel_bwd', 'rowops', 'lstm']
+K_NAMES = ['gemm', 'mha_fwd', 'mha_bwd', 'rel_fwd', 'rel_bwd', 'rowops', 'lstm', 'small_ops']
 
 
 class Segment(C.Structure):
@@ -114,6 +114,7 @@ SYMBOLS = {
     'mmnas_lstm_fwd': (_i, [_fp] * 9 + [_i, _i, _i, _i, _fp]),
     'mmnas_lstm_bwd': (_i, [_fp] * 7 + [_i, _i, _i, _fp]),
     'mmnas_lstm_seq_supported': (_i, [_i, _i]),
+    'mmnas_set_small_ops': (_i, [_i]),
     'mmnas_lstm_seq_fwd': (_i, [_fp] * 7 + [_i, _i, _i, _fp]),
     'mmnas_lstm_seq_bwd': (_i, [_fp] * 5 + [_i, _i, _i, _fp]),
     'mmnas_lstm_seq_timed_out': (_i, [_fp]),

@@ -186,7 +186,8 @@ __device__ __forceinline__ void split_store_t(unsigned* dst, const float4 e, con
 // v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate per instruction), fp32 accumulation as before:
 //   NS = 2: x = h + l  (16 mantissa bits kept), products hh + hl + lh            -- "bf16x3"
 //   NS = 3: x = h + m + l (all 24 bits),        products hh + hm + mh + mm + hl + lh -- "bf16x6", fp32-grade
-// (the dropped cross terms are below 2^-16 resp. 2^-24 of |a||b|).  Off unless asked for: see Tuning::split.
+// (the dropped cross terms are below 2^-16 resp. 2^-24 of |a||b|).  NS = 3 is the default path (every shape measured is
+// faster than on the fp32 MFMA and the error against fp64 is not larger); NS = 0 / 2 by MMNAS_GEMM_SPLIT: Tuning::split.
 template <int BM, int BN, int NS>
 struct GemmShape {
   static constexpr int RSW = NS ? NS * 16 + 4 : LDK;   // LDS row stride in 4-byte words
@@ -308,8 +309,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[NA], rb[NB];
-    float4 ra2[NA], rb2[NB];   // second register stage (PF == 2; dead otherwise)
+    float4 rA[2][NA], rB[2][NB];   // register stages of operand prefetch (the second one: PF == 2; dead otherwise)
 
     // FAST path: per-thread byte offsets of its loads inside the operand (k = 0), ~0u when the row is
     // outside the matrix (the buffer range check then returns zeros)
@@ -353,7 +353,9 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
 
     // unit q of the tile: segment q / ntk, K-tile q % ntk; `live` false (FAST path only): every offset is put out of
     // range, the buffer bounds check answers with zeros and no memory request is made -- a branch-free "no load"
-    auto gload_to = [&](int q, bool live, float4 (&ra)[NA], float4 (&rb)[NB]) {
+    auto gload_to = [&](int q, bool live, const int st) __attribute__((always_inline)) {
+      float4* const ra = rA[st];
+      float4* const rb = rB[st];
       const int seg = q / p.ntk;
       const int kt = q - seg * p.ntk;
       const float* __restrict__ Ap = seg == 0 ? Aseg[0] : (seg == 1 ? Aseg[1] : Aseg[2]);
@@ -436,9 +438,11 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         rb[i] = v4;
       }
     };
-    auto gload = [&](int q) { gload_to(q, true, ra, rb); };
+    auto gload = [&](int q) __attribute__((always_inline)) { gload_to(q, true, 0); };
 
-    auto lstore_from = [&](int buf, const float4 (&ra)[NA], const float4 (&rb)[NB]) {
+    auto lstore_from = [&](int buf, const int st) __attribute__((always_inline)) {
+      const float4* const ra = rA[st];
+      const float4* const rb = rB[st];
       float* a = As + buf * A_SZ;
       float* b = Bs + buf * B_SZ;
       if (NS) {
@@ -483,9 +487,9 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         }
       }
     };
-    auto lstore = [&](int buf) { lstore_from(buf, ra, rb); };
+    auto lstore = [&](int buf) __attribute__((always_inline)) { lstore_from(buf, 0); };
 
-    auto mfma_block = [&](int buf) {
+    auto mfma_block = [&](int buf) __attribute__((always_inline)) {
       const float* a = As + buf * A_SZ;
       const float* b = Bs + buf * B_SZ;
       if (NS) {
@@ -551,19 +555,19 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     if (PF == 2) {
       // two register stages: while tile t is multiplied out of LDS, tile t+1 sits in (or is arriving into) one stage
       // and the loads of tile t+2 are issued into the other; the loop is unrolled by two so the stages are static
-      gload_to(q0, true, ra, rb);
-      gload_to(q0 + 1, nq > 1, ra2, rb2);
-      lstore_from(0, ra, rb);
+      gload_to(q0, true, 0);
+      gload_to(q0 + 1, nq > 1, 1);
+      lstore_from(0, 0);
       __syncthreads();
       for (int t = 0; t < nq; t += 2) {
-        gload_to(q0 + t + 2, t + 2 < nq, ra, rb);
+        gload_to(q0 + t + 2, t + 2 < nq, 0);
         mfma_block(0);
         if (t + 1 >= nq) break;
-        lstore_from(1, ra2, rb2);
+        lstore_from(1, 1);
         __syncthreads();
-        gload_to(q0 + t + 3, t + 3 < nq, ra2, rb2);
+        gload_to(q0 + t + 3, t + 3 < nq, 1);
         mfma_block(1);
-        if (t + 2 < nq) lstore_from(0, ra, rb);
+        if (t + 2 < nq) lstore_from(0, 0);
         __syncthreads();
       }
       __syncthreads();
@@ -766,7 +770,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
 }
 
 template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1>
-__global__ void __launch_bounds__(256, NS == 3 ? (BM == 128 ? 1 : 3) : (BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64)) gemm_kernel(const GemmK p) {
+__global__ void __launch_bounds__(256, NS ? (BM == 128 ? 1 : 3) : (BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64)) gemm_kernel(const GemmK p) {
   __shared__ __attribute__((aligned(16))) float As[2 * GemmShape<BM, BN, NS>::A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[2 * GemmShape<BM, BN, NS>::B_SZ];
   __shared__ int s_old;
@@ -818,7 +822,7 @@ __device__ __forceinline__ void aux_reduce_body(const AuxReduceK& a, int job, fl
 }
 
 template <int BM, int BN, int NS, int PF = 1>
-__global__ void __launch_bounds__(256, NS == 3 ? 3 : MMNAS_OCC64) gemm_pair_kernel(const GemmK q0, const GemmK q1, const int nwg0,
+__global__ void __launch_bounds__(256, NS ? 3 : MMNAS_OCC64) gemm_pair_kernel(const GemmK q0, const GemmK q1, const int nwg0,
                                                                                     const int nwg0p, const AuxReduceK aux,
                                                                                     const int naux8) {
   __shared__ __attribute__((aligned(16))) float As[2 * GemmShape<BM, BN, NS>::A_SZ];
@@ -850,11 +854,11 @@ static int env_int(const char* name, int dflt) {
 //   MMNAS_GEMM_WGS=n       co-resident workgroup budget (default 1024 for 64^2 tiles, 512 for 128^2)
 //   MMNAS_GEMM_MIN_UNITS=n fewest K-tiles a workgroup is given (default 4)
 //   MMNAS_GEMM_GM=n        row-panels per tile-order block (default 8)     MMNAS_GEMM_XCD=0 identity workgroup mapping
-//   MMNAS_GEMM_SPLIT=0|3|6 products on the fp32 MFMA (default) / as 3 / 6 bf16 MFMA products of split operands
+//   MMNAS_GEMM_SPLIT=0|3|6 products on the fp32 MFMA / as 3 / 6 (default: fp32-grade) bf16 MFMA products of split operands
 //   MMNAS_GEMM_PAIR=0      mmnas_gemm_pair launches its two products separately
 //   MMNAS_GEMM_PF=1|2      K-tiles of operand loads in flight ahead of the MFMA block (64^2 fp32 buffer-load path)
 struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split, pair, split_slots, split_p, pf, wide_min; bool loaded; };
-static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 0, 1, 0, 24, 2, 200, false};
+static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 3, 1, 0, 24, 2, 200, false};
 static void load_tuning() {
   g_tune.tile = env_int("MMNAS_GEMM_TILE", 0);
   g_tune.generic = getenv("MMNAS_GEMM_GENERIC") != nullptr;
@@ -864,7 +868,7 @@ static void load_tuning() {
   if (g_tune.min_units < 1) g_tune.min_units = 1;
   g_tune.gm = env_int("MMNAS_GEMM_GM", 0);
   g_tune.xcd = env_int("MMNAS_GEMM_XCD", 1);
-  const int sp = env_int("MMNAS_GEMM_SPLIT", 0);
+  const int sp = env_int("MMNAS_GEMM_SPLIT", 6);
   g_tune.split = sp == 3 ? 2 : (sp == 6 ? 3 : 0);   // number of bf16 parts per operand
   g_tune.pair = env_int("MMNAS_GEMM_PAIR", 1);
   g_tune.split_slots = env_int("MMNAS_GEMM_SPLIT_SLOTS", 0);
@@ -900,6 +904,15 @@ static int get_workspace(hipStream_t st, SkWorkspace* out) {
     it = g_ws.emplace(key, w).first;
   }
   *out = it->second;
+  return MMNAS_OK;
+}
+
+// the same workspace for the other kernels of the library that hand partial results between workgroups (small.hip)
+int sk_workspace(hipStream_t st, float** ws, size_t* ws_floats, int** cnt, int* ncnt) {
+  SkWorkspace w;
+  const int rc = get_workspace(st, &w);
+  if (rc) return rc;
+  *ws = w.ws; *ws_floats = WS_SLOT_FLOATS; *cnt = w.cnt; *ncnt = MAX_CNT_TILES;
   return MMNAS_OK;
 }
 

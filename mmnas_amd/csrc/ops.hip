@@ -62,6 +62,10 @@ static AttLayout att_layout(const mmnas_att_op* op) {
   return L;
 }
 
+// small.hip: one-launch forms for short sequences
+bool sa_small_applies(const mmnas_att_op* op);
+int sa_small_fwd(const mmnas_att_op* op, float* Q, float* K, float* V, float* att, float* stats, float* z, hipStream_t st);
+
 static int att_check(const mmnas_att_op* op, const char* who) {
   MMNAS_REQUIRE(op, MMNAS_E_ARG, "%s: null descriptor", who);
   MMNAS_REQUIRE(op->B > 0 && op->Sq > 0 && op->Sk > 0 && op->d > 0 && op->di > 0, MMNAS_E_SHAPE,
@@ -103,6 +107,7 @@ extern "C" int mmnas_att_op_fwd(const mmnas_att_op* op, void* stream) {
   if (fl & MMNAS_F_MASK) MMNAS_REQUIRE(op->mask, MMNAS_E_ARG, "att_op_fwd: MASK without mask");
   AttLayout L = att_layout(op);
   const int d = op->d, di = op->di;
+  if (sa_small_applies(op)) return sa_small_fwd(op, L.Q, L.K, L.V, L.att, L.stats, L.z, (hipStream_t)stream);
 
   mmnas_gemm_desc g;
   gemm_init(g, MMNAS_GEMM_NT, di, d, d, d, di);

@@ -24,7 +24,7 @@ def _check(d, world, steps=2, warmup=1):
     assert d['unit'] == 'steps/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
     assert d['value'] > 0 and abs(d['value'] - world * 1000.0 / d['ms_per_step']) < 1e-6 * d['value']
     assert d['final_loss'] == d['final_loss'] and abs(d['final_loss']) < 1e9
-    assert d['config']['global_batch'] == 64 * world and d['dtype'] == 'f32'
+    assert d['config']['global_batch'] == 64 * world and d['dtype'].startswith('f32')
     r = d['roofline']
     assert r['bound'] == 'mfma' and 0 < r['frac'] < 1 and r['unit'] == 'TFLOP/s' and r['achieved'] > 0
 

@@ -69,7 +69,8 @@ def gemm_tuning():
 @pytest.mark.parametrize('M,N,K', [(896, 512, 512), (300, 192, 160), (64, 64, 32), (21, 3129, 1024),
                                    (130, 1, 64), (257, 130, 100), (6400, 256, 256)])
 @pytest.mark.parametrize('tile', [0, 64, 128])
-def test_gemm_layouts(layout, M, N, K, tile, gemm_tuning):
+@pytest.mark.parametrize('mode', [6, 0])     # the default bf16x6 products and the fp32-MFMA kernels
+def test_gemm_layouts(layout, M, N, K, tile, mode, gemm_tuning):
     from mmnas_amd import ops
     import mmnas_amd._lib as L
     if tile and (M * N > 400000):
@@ -89,7 +90,7 @@ def test_gemm_layouts(layout, M, N, K, tile, gemm_tuning):
         lda, ldb = M, N
     Ad, Bd = g(A), g(B)
     Cd = torch.zeros(M, N, device=DEV)
-    gemm_tuning(tile=tile or None)
+    gemm_tuning(tile=tile or None, split=mode)
     split = 1
     if layout == 'TN' and K >= 256:
         split = 3
@@ -104,7 +105,7 @@ def test_gemm_layouts(layout, M, N, K, tile, gemm_tuning):
 @pytest.mark.parametrize('mode,tol', [(3, 2e-5), (6, 3e-6)])
 @pytest.mark.parametrize('tile', [0, 128])
 def test_gemm_bf16_split_modes(layout, M, N, K, mode, tol, tile, gemm_tuning):
-    """Opt-in MMNAS_GEMM_SPLIT modes: operands split into 2 / 3 bf16 parts, 3 / 6 bf16-MFMA products, fp32 accumulate.
+    """MMNAS_GEMM_SPLIT modes (6 = the default): operands split into 2 / 3 bf16 parts, 3 / 6 bf16-MFMA products, fp32 accumulate.
     Bounds (max-norm relative, against fp64): 2^-16-class for bf16x3, fp32-class for bf16x6 -- both far inside the
     1e-3 parity tolerance.  Operand scales spread over 2^+-20 to exercise the exponent range the parts share with fp32."""
     from mmnas_amd import ops
@@ -129,6 +130,38 @@ def test_gemm_bf16_split_modes(layout, M, N, K, mode, tol, tile, gemm_tuning):
     ops.gemm(lay, [dict(M=M, A=[g(A)], B=[g(B)], C=C)], N, K, lda, ldb, N, accumulate=(layout == 'TN'))
     err = rel_err(C.cpu().numpy(), ref.numpy())
     assert err < tol, err
+
+
+@pytest.mark.parametrize('layout,M,N,K', [('NT', 6400, 256, 256), ('NT', 6400, 1024, 256), ('NN', 6400, 256, 1024),
+                                          ('TN', 256, 1024, 6400), ('NT', 6400, 2048, 512), ('NN', 6400, 512, 2048),
+                                          ('TN', 2048, 512, 6400), ('NT', 896, 512, 512)])
+def test_default_products_are_fp32_grade(layout, M, N, K, gemm_tuning):
+    """The default GEMM path (6 bf16-MFMA products of exactly split operands, dropped terms < 2^-24 |a||b|) against the
+    fp32-MFMA path on the workloads' shapes, both measured against fp64: max-norm and RMS error are not larger (10 %
+    slack for the different summation order)."""
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    rs = np.random.RandomState(M + 3 * N + 7 * K)
+    td = lambda a: torch.from_numpy(a).double()
+    if layout == 'NT':
+        A, B = rnd(rs, M, K), rnd(rs, N, K)
+        ref, lda, ldb = td(A) @ td(B).t(), K, K
+    elif layout == 'NN':
+        A, B = rnd(rs, M, K), rnd(rs, K, N)
+        ref, lda, ldb = td(A) @ td(B), K, N
+    else:
+        A, B = rnd(rs, K, M), rnd(rs, K, N)
+        ref, lda, ldb = td(A).t() @ td(B), M, N
+    lay = {'NT': L.GEMM_NT, 'NN': L.GEMM_NN, 'TN': L.GEMM_TN}[layout]
+    err = {}
+    for mode in (0, 6):
+        gemm_tuning(split=mode)
+        C = torch.zeros(M, N, device=DEV)
+        ops.gemm(lay, [dict(M=M, A=[g(A)], B=[g(B)], C=C)], N, K, lda, ldb, N, accumulate=(layout == 'TN'))
+        d = C.cpu().double() - ref
+        err[mode] = (float(d.abs().max() / ref.abs().max()), float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()))
+    assert err[6][0] <= 1.1 * err[0][0] + 1e-8 and err[6][1] <= 1.1 * err[0][1] + 1e-9, err
+    assert err[6][0] < 3e-6, err
 
 
 @pytest.mark.parametrize('mode', [3, 6])

@@ -1,0 +1,73 @@
+"""Short-sequence operators (small.hip): the one-launch forms that the language stream's operators take (S <= 16, heads
+of 64, d in {256, 512}) against the fp64 oracle and against the general multi-launch path on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mmnas_oracle as O   # noqa: F401  (oracle_runner needs the package importable)
+from tests import oracle_runner as R
+from tests.golden import cases
+from tests.test_ops_gpu import _drop_sites, run_hip_op
+from tests.util import TOL, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(got, ref, tol=TOL, floor=1e-4):
+    # (a gradient that is mathematically zero -- dWq / dWk with a single key: the softmax is constant -- is rounding
+    #  noise on both sides: it is measured against the operator's gradient scale)
+    gscale = max(np.abs(ref[k]).max() for k in ref if k != 'out')
+    for k in ref:
+        den = max(np.abs(ref[k]).max(), floor * (gscale if k != 'out' else 1.0))
+        e = float(np.abs(got[k].astype(np.float64) - ref[k]).max() / den)
+        assert e <= tol, (k, e)
+
+
+@pytest.fixture
+def small_ops():
+    from mmnas_amd import _lib as L
+    lib = L.lib()
+    prev = lib.mmnas_set_small_ops(1)
+    yield lib
+    lib.mmnas_set_small_ops(prev)
+
+
+@pytest.mark.parametrize('name', ['self_att_64'])
+@pytest.mark.parametrize('dims', [dict(B=64, Sx=14, Sy=3, HSIZE=256), dict(B=5, Sx=16, Sy=3, HSIZE=512),
+                                  dict(B=7, Sx=5, Sy=3, HSIZE=256), dict(B=2, Sx=1, Sy=3, HSIZE=512)])
+@pytest.mark.parametrize('nr', [(True, True), (False, False), (True, False)])
+def test_short_sequence_op_vs_oracle(name, dims, nr, small_ops):
+    case = cases.op_case(name, nr[0], nr[1], 99 + dims['Sx'], dims)
+    got = run_hip_op(case)
+    ref = R.run_oracle_op(case, dtype=torch.float64)
+    _check(got, ref, floor=1e-2 if dims['Sx'] == 1 else 1e-4)
+    small_ops.mmnas_set_small_ops(0)
+    gen = run_hip_op(case)
+    gscale = max(np.abs(gen[k]).max() for k in gen if k != 'out')
+    for k in got:          # same arithmetic up to summation order
+        den = max(np.abs(gen[k]).max(), 1e-2 * (gscale if k != 'out' else 1.0))
+        assert np.abs(got[k] - gen[k]).max() / den <= (1e-4 if dims['Sx'] == 1 else 2e-5), k
+
+
+@pytest.mark.parametrize('name', ['self_att_64'])
+@pytest.mark.parametrize('dims', [dict(B=9, Sx=14, Sy=3, HSIZE=256), dict(B=3, Sx=16, Sy=3, HSIZE=512)])
+def test_short_sequence_op_dropout_replay(name, dims, small_ops, monkeypatch):
+    from mmnas_amd import ops
+    seed, p = 0x1234ABCD0F0F0F0F, 0.1
+    monkeypatch.setattr(ops, 'next_seed', lambda: seed)
+    case = cases.op_case(name, True, True, 4242, dims)
+    got = run_hip_op(case, train=True, drop_p=p)
+    case['cfg'].DROPOUT_R = 0.0
+    ref = R.run_oracle_op(case, drops=_drop_sites(case, seed, p), dtype=torch.float64)
+    _check(got, ref)
+    ref0 = R.run_oracle_op(case, dtype=torch.float64)
+    assert rel_err(got['out'], ref0['out']) > 1e-2
+
+
+def test_fully_padded_sample_is_uniform_attention(small_ops):
+    """masked_fill(-1e9) semantics (modules.py:194): a sample whose keys are all padding attends uniformly."""
+    case = cases.op_case('self_att_64', True, True, 5, dict(B=4, Sx=14, Sy=3, HSIZE=256))
+    case['x_mask'][1, ...] = True
+    got = run_hip_op(case)
+    ref = R.run_oracle_op(case, dtype=torch.float64)
+    _check(got, ref)

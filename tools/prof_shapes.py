@@ -6,7 +6,7 @@
 import collections
 import sys
 
-KINDS = ['gemm', 'mha_fwd', 'mha_bwd', 'rel_fwd', 'rel_bwd', 'rowops']
+KINDS = ['gemm', 'mha_fwd', 'mha_bwd', 'rel_fwd', 'rel_bwd', 'rowops', 'lstm', 'small_ops']
 
 
 def main():
