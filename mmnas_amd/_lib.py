@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libmmnas_hip.so')
+LIB_PATH = os.environ.get('MMNAS_LIB_PATH') or os.path.join(_HERE, 'lib', 'libmmnas_hip.so')   # (override: tuning builds)
 
 F_NORM, F_RESIDUAL, F_MASK, F_REL, F_SELF, F_TRAIN, F_RELRAW = 1, 2, 4, 8, 16, 32, 64
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2

@@ -92,6 +92,9 @@ __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; 
 #ifndef MMNAS_OCC64
 #define MMNAS_OCC64 4
 #endif
+#ifndef MMNAS_OCC_NS
+#define MMNAS_OCC_NS 3      // workgroups per CU of the 64^2 split-operand kernels
+#endif
 #ifndef MMNAS_OCC128
 #define MMNAS_OCC128 2
 #endif
@@ -770,7 +773,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
 }
 
 template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1>
-__global__ void __launch_bounds__(256, NS ? (BM == 128 ? 1 : 3) : (BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64)) gemm_kernel(const GemmK p) {
+__global__ void __launch_bounds__(256, NS ? (BM == 128 ? (BN == 64 ? 2 : 1) : MMNAS_OCC_NS) : (BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64)) gemm_kernel(const GemmK p) {
   __shared__ __attribute__((aligned(16))) float As[2 * GemmShape<BM, BN, NS>::A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[2 * GemmShape<BM, BN, NS>::B_SZ];
   __shared__ int s_old;
@@ -822,7 +825,7 @@ __device__ __forceinline__ void aux_reduce_body(const AuxReduceK& a, int job, fl
 }
 
 template <int BM, int BN, int NS, int PF = 1>
-__global__ void __launch_bounds__(256, NS ? 3 : MMNAS_OCC64) gemm_pair_kernel(const GemmK q0, const GemmK q1, const int nwg0,
+__global__ void __launch_bounds__(256, NS ? MMNAS_OCC_NS : MMNAS_OCC64) gemm_pair_kernel(const GemmK q0, const GemmK q1, const int nwg0,
                                                                                     const int nwg0p, const AuxReduceK aux,
                                                                                     const int naux8) {
   __shared__ __attribute__((aligned(16))) float As[2 * GemmShape<BM, BN, NS>::A_SZ];
@@ -857,8 +860,8 @@ static int env_int(const char* name, int dflt) {
 //   MMNAS_GEMM_SPLIT=0|3|6 products on the fp32 MFMA / as 3 / 6 (default: fp32-grade) bf16 MFMA products of split operands
 //   MMNAS_GEMM_PAIR=0      mmnas_gemm_pair launches its two products separately
 //   MMNAS_GEMM_PF=1|2      K-tiles of operand loads in flight ahead of the MFMA block (64^2 fp32 buffer-load path)
-struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split, pair, split_slots, split_p, pf, wide_min; bool loaded; };
-static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 3, 1, 0, 24, 2, 200, false};
+struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split, pair, split_slots, split_p, pf, wide_min, split_minwg; bool loaded; };
+static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 3, 1, 0, 24, 2, 200, 256, false};
 static void load_tuning() {
   g_tune.tile = env_int("MMNAS_GEMM_TILE", 0);
   g_tune.generic = getenv("MMNAS_GEMM_GENERIC") != nullptr;
@@ -874,6 +877,7 @@ static void load_tuning() {
   g_tune.split_slots = env_int("MMNAS_GEMM_SPLIT_SLOTS", 0);
   g_tune.split_p = env_int("MMNAS_GEMM_SPLIT_P", 24);           // K-tiles per split-K piece
   if (g_tune.split_p < 1) g_tune.split_p = 1;
+  g_tune.split_minwg = env_int("MMNAS_GEMM_SPLIT_MINWG", 256);  // fewest split-K pieces in total (x tiles) when pieces of split_p would be fewer
   g_tune.pf = env_int("MMNAS_GEMM_PF", 2) == 1 ? 1 : 2;            // register stages of operand prefetch (64^2 fp32 path)
   g_tune.wide_min = env_int("MMNAS_GEMM_WIDE_MIN", 200);         // fewest 128x64 tiles for that shape to be chosen
   g_tune.loaded = true;
@@ -1025,7 +1029,7 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
   if (g_tune.tile == 64 || g_tune.tile == 12864) big = false;
   // 128 x 64 tiles (each wave two 32x32 MFMA tiles down the rows): 1.33x the products per operand byte and per barrier
   // of 64^2 -- for plain products on the buffer-load path whose rows fill the chip anyway (experiment: MMNAS_GEMM_TILE=12864)
-  bool wide = !big && g_tune.tile == 12864 && !accumulate && fast && g_tune.split == 0;
+  bool wide = !big && g_tune.tile == 12864 && !accumulate && fast && g_tune.split != 2;
   if (wide) {
     long n = 0;
     for (int g = 0; g < d->ngroups; ++g) n += (long)cdiv(d->g[g].M, 128) * cdiv(d->N, 64);
@@ -1058,7 +1062,7 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
     if (g_tune.split_slots > 0) want = g_tune.split_slots / k.ntiles;
     else {
       want = (k.T + g_tune.split_p / 2) / g_tune.split_p;
-      if ((long)want * k.ntiles < 512) want = (512 + k.ntiles - 1) / k.ntiles;
+      if ((long)want * k.ntiles < g_tune.split_minwg) want = (g_tune.split_minwg + k.ntiles - 1) / k.ntiles;
     }
     if (want < 1) want = 1;
     if (want > k.T / min_units) want = k.T / min_units;
@@ -1131,7 +1135,7 @@ static int launch_plan(GemmPlan& pl, hipStream_t st) {
     if (ns == 3) return launch<128, 128, true, 3>(k, pl.layout, pl.nwg, st);
     return pl.fast ? launch<128, 128, true, 0>(k, pl.layout, pl.nwg, st) : launch<128, 128, false, 0>(k, pl.layout, pl.nwg, st);
   }
-  if (pl.wide) return launch<128, 64, true, 0, 2>(k, pl.layout, pl.nwg, st);
+  if (pl.wide) return ns == 3 ? launch<128, 64, true, 3>(k, pl.layout, pl.nwg, st) : launch<128, 64, true, 0, 2>(k, pl.layout, pl.nwg, st);
   if (ns == 2) return launch<64, 64, true, 2>(k, pl.layout, pl.nwg, st);
   if (ns == 3) return launch<64, 64, true, 3>(k, pl.layout, pl.nwg, st);
   if (pl.fast && g_tune.pf == 2) return launch<64, 64, true, 0, 2>(k, pl.layout, pl.nwg, st);

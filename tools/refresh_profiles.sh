@@ -39,6 +39,10 @@ grep '^{' $W/bench_all.log | tail -1 > profiles/${R}_bench.json
 for wl in train_vgd train_itm; do
   python3 bench.py --workload $wl --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > profiles/${R}_bench_$wl.json
 done
+# the same steps with the matrix products on the fp32 MFMA (MMNAS_GEMM_SPLIT=0) and as 3 bf16 products (experiment)
+for sp in 0 3; do for wl in search_vqa train_vqa; do
+  python3 bench.py --workload $wl --no-cpu-baseline --gemm-split $sp 2>/dev/null | grep '^{' | tail -1 > profiles/${R}_bench_${wl}_gemm_split$sp.json
+done; done
 mkdir -p gpurun_out/profiles_$R && cp profiles/${R}_* gpurun_out/profiles_$R/   # (gpurun merges only gpurun_out/ back)
 ls -la profiles/ | grep $R
 for f in $W/*.log; do echo "== $f"; tail -n 2 $f | cut -c1-300; done
