@@ -780,6 +780,12 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
   }
 }
 
+// (Measured and removed in round 2: the same kernel on EIGHT waves -- wave = (query block, key half), two tiles per wave,
+//  two waves per SIMD sharing one K / V image, 16-column half transpositions to fit 152 KB of LDS.  With LDS float
+//  atomics for the dK / dV accumulators 118 us against this kernel's 51 us (B = 64, H = 4, S = 100); with two-turn
+//  barrier-separated read-modify-writes 60 us.  The second wave per SIMD buys less than its duplicate operand loads,
+//  half-lane LDS stores and extra barriers cost.  tools/mha_bench.py times the attention kernels alone.)
+
 static int fill(const mmnas_mha_desc* d, MhaK& k, bool bwd) {
   MMNAS_REQUIRE(d, MMNAS_E_ARG, "mha: null descriptor");
   MMNAS_REQUIRE(d->B > 0 && d->H > 0 && d->Sq > 0 && d->Sk > 0, MMNAS_E_SHAPE, "mha: B=%d H=%d Sq=%d Sk=%d", d->B,

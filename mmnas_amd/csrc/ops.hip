@@ -566,7 +566,7 @@ static int chain_layout(const mmnas_chain* c, ChainLayout& L) {
 }
 
 // ---- side stream + events, one set per (device, main stream) ----
-struct SideCtx { hipStream_t side; hipEvent_t ev[MMNAS_CHAIN_MAX_OPS + 2]; bool used; };
+struct SideCtx { hipStream_t side; hipStream_t enc; hipEvent_t ev[MMNAS_CHAIN_MAX_OPS + 2]; hipEvent_t ovl[4]; bool used; };
 static std::mutex g_side_mu;
 static std::map<std::pair<int, hipStream_t>, SideCtx> g_side;
 
@@ -588,9 +588,41 @@ static SideCtx* side_ctx(hipStream_t main, bool create) {
               : hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking)) != hipSuccess) return nullptr;
     for (auto& e : s.ev)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    // the language stream's own stream (chain overlap): highest priority -- its launches are a handful of workgroups on
+    // a latency-bound chain and must not queue behind the image stream's thousand-workgroup launches
+    if ((prio ? hipStreamCreateWithPriority(&s.enc, hipStreamNonBlocking, greatest)
+              : hipStreamCreateWithFlags(&s.enc, hipStreamNonBlocking)) != hipSuccess) return nullptr;
+    for (auto& e : s.ovl)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
     it = g_side.emplace(key, s).first;
   }
   return &it->second;
+}
+
+// Encoder / decoder overlap.  The language stream's operators run on 896 rows: 56-224 workgroups per launch, ~10 us
+// each whatever they compute, on a quarter of the CUs.  The image-stream operators in front of the FIRST guided
+// operator do not read the language state, so forward they run beside the encoder, and backward the encoder's
+// operators run beside theirs (every guided operator's gradient has reached the language state by then).
+// MEASURED: no gain (5.746 vs 5.738 ms per supernet step, 12.15 vs 12.15 ms per training step).  A language-stream launch
+// is resident on every CU for its whole latency-bound duration, and its LDS / wave slots cost the image stream's
+// GEMM one of its three workgroups per CU meanwhile: in the trace the co-running kernels take 1.3-1.5x their solo time
+// (GEMM 26.6 -> 39.6 us, attention 22 -> 32 us), which returns what the overlap saves.  Off by default
+// (MMNAS_CHAIN_OVERLAP=1 enables it); kept because the fork / join structure is what a multi-stream caller needs.
+static bool chain_overlap_on() {
+  static const int on = [] { const char* e = getenv("MMNAS_CHAIN_OVERLAP"); return e && e[0] ? atoi(e) : 0; }();
+  return on != 0;
+}
+static int first_guided(const mmnas_chain* c) {
+  for (int i = 0; i < c->n_ops; ++i)
+    if (c->ops[i].kind == MMNAS_CHAIN_ATT && !(c->ops[i].att.flags & MMNAS_F_SELF)) return i;
+  return c->n_ops;
+}
+static int ev_fork(hipStream_t from, hipStream_t to, hipEvent_t e) {
+  if (hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) {
+    set_error("chain: event record / wait failed");
+    return MMNAS_E_LAUNCH;
+  }
+  return MMNAS_OK;
 }
 
 }  // namespace mmnas
@@ -609,31 +641,53 @@ extern "C" int mmnas_chain_fwd(const mmnas_chain* c, void* stream) {
   int rc = chain_check(c, "chain_fwd");
   if (rc) return rc;
   MMNAS_REQUIRE(c->x_in && c->y_in && c->x_out && c->y_out && c->arena, MMNAS_E_ARG, "chain_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
   ChainLayout L;
   if ((rc = chain_layout(c, L))) return rc;
   char* base = (char*)c->arena;
   const float* cur_x = c->x_in;
   const float* cur_y = c->y_in;
   const size_t nx = (size_t)c->B * c->Sx * c->d * sizeof(float), ny = (size_t)c->B * c->Sy * c->d * sizeof(float);
-  for (int i = 0; i < c->n_ops; ++i) {
+  auto run = [&](int i, hipStream_t s) -> int {
     const mmnas_chain_op& o = c->ops[i];
     mmnas_att_op a; mmnas_mlp_op m;
     chain_op_setup(c, i, a, m);
     const float* cur = o.on_y ? cur_y : cur_x;
     float* out = i == L.last_x ? c->x_out : (i == L.last_y ? c->y_out : (float*)(base + L.y[i]));
+    int r;
     if (o.kind == MMNAS_CHAIN_ATT) {
       a.xq = cur;
       a.xkv = (a.flags & MMNAS_F_SELF) ? cur : cur_x;   // guided: keys / values from the FINAL language state
       a.y = out; a.save = base + L.save[i]; a.ws = base + L.ws[i];
-      if ((rc = mmnas_att_op_fwd(&a, stream))) return rc;
+      if ((r = mmnas_att_op_fwd(&a, s))) return r;
     } else {
       m.x = cur; m.y = out; m.save = base + L.save[i]; m.ws = base + L.ws[i];
-      if ((rc = mmnas_mlp_op_fwd(&m, stream))) return rc;
+      if ((r = mmnas_mlp_op_fwd(&m, s))) return r;
     }
     if (o.on_y) cur_y = out; else cur_x = out;
+    return MMNAS_OK;
+  };
+  const int G = first_guided(c);
+  const bool ovl = chain_overlap_on() && !c->use_side_stream && L.last_x >= 0 && L.first_y >= 0 && G > L.first_y;
+  if (!ovl) {
+    for (int i = 0; i < c->n_ops; ++i)
+      if ((rc = run(i, st))) return rc;
+  } else {
+    SideCtx* sc = side_ctx(st, true);
+    MMNAS_REQUIRE(sc, MMNAS_E_LAUNCH, "chain_fwd: cannot create the encoder stream");
+    if ((rc = ev_fork(st, sc->enc, sc->ovl[0]))) return rc;
+    // encoder operators [first_x, last_x] on their own stream, the decoder's [first_y, G) on the caller's: issued alternately
+    int ie = L.first_x, id = L.first_y;
+    while (ie <= L.last_x || id < G) {
+      if (ie <= L.last_x && (rc = run(ie++, sc->enc))) return rc;
+      if (id < G && (rc = run(id++, st))) return rc;
+    }
+    if ((rc = ev_fork(sc->enc, st, sc->ovl[1]))) return rc;   // the final language state exists from here on
+    for (int i = G; i < c->n_ops; ++i)
+      if ((rc = run(i, st))) return rc;
   }
-  if (L.last_x < 0 && hipMemcpyAsync(c->x_out, c->x_in, nx, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return MMNAS_E_LAUNCH;
-  if (L.last_y < 0 && hipMemcpyAsync(c->y_out, c->y_in, ny, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return MMNAS_E_LAUNCH;
+  if (L.last_x < 0 && hipMemcpyAsync(c->x_out, c->x_in, nx, hipMemcpyDeviceToDevice, st) != hipSuccess) return MMNAS_E_LAUNCH;
+  if (L.last_y < 0 && hipMemcpyAsync(c->y_out, c->y_in, ny, hipMemcpyDeviceToDevice, st) != hipSuccess) return MMNAS_E_LAUNCH;
   return MMNAS_OK;
 }
 
@@ -668,40 +722,68 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
     return oy ? c->y_in : c->x_in;
   };
   const float* x_final = L.last_x >= 0 ? c->x_out : c->x_in;
-  const float* cur_dy = c->dy_out;
-  for (int i = c->n_ops - 1; i >= 0; --i) {
+  // one operator's backward on stream s: gradient of its output in, gradient of its input out (returned through *dxo)
+  auto run = [&](int i, hipStream_t s, const float* dyi, const float** dxo) -> int {
     const mmnas_chain_op& o = c->ops[i];
-    if (sq && i == L.last_x && (rc = q.flush(st, side, sc->ev[0]))) return rc;   // the decoder's parameter-gradient work
-    if (!o.on_y && i == L.last_x) {   // entering the encoder: its output gradient = head's + the guided operators'
-      if (c->dx_out && L.n_guided) {
-        float* g0 = (float*)(base + L.encdy);
-        if ((rc = mmnas_drop_add(c->dx_out, dpre, g0, ex, 0.f, 0, 0, stream))) return rc;
-        cur_dy = g0;
-      } else cur_dy = c->dx_out ? c->dx_out : dpre;
-      MMNAS_REQUIRE(c->dx_out || L.n_guided, MMNAS_E_ARG, "chain_bwd: no gradient reaches the encoder (dx_out NULL, no guided operator)");
-    }
     mmnas_att_op a; mmnas_mlp_op m;
     chain_op_setup(c, i, a, m);
     float* dx = i == L.first_x ? c->dx_in : (i == L.first_y ? c->dy_in : (float*)(base + L.dx[i]));
+    int r;
     if (o.kind == MMNAS_CHAIN_ATT) {
       const bool self = a.flags & MMNAS_F_SELF;
       a.xq = input_of(i);
       a.xkv = self ? a.xq : x_final;
       a.save = base + L.save[i]; a.ws = base + L.ws[i];
-      a.dy = cur_dy; a.dxq = dx;
+      a.dy = dyi; a.dxq = dx;
       a.dxkv = self ? nullptr : (float*)(base + L.tmp[i]);
       a.drel = nullptr;
-      if ((rc = att_bwd_impl(&a, st, sq))) return rc;
-      if (!self && (rc = mmnas_drop_add(a.dxkv, dpre, dpre, ex, 0.f, 0, 0, stream))) return rc;
+      if ((r = att_bwd_impl(&a, s, sq))) return r;
+      if (!self && (r = mmnas_drop_add(a.dxkv, dpre, dpre, ex, 0.f, 0, 0, s))) return r;
     } else {
       m.x = input_of(i); m.save = base + L.save[i]; m.ws = base + L.ws[i];
-      m.dy = cur_dy; m.dx = dx;
-      if ((rc = mlp_bwd_impl(&m, st, sq))) return rc;
+      m.dy = dyi; m.dx = dx;
+      if ((r = mlp_bwd_impl(&m, s, sq))) return r;
     }
-    if (sq && per_op && (rc = q.flush(st, side, sc->ev[i + 1]))) return rc;
-    cur_dy = dx;
+    *dxo = dx;
+    return MMNAS_OK;
+  };
+  // entering the encoder: its output gradient = head's + the guided operators'
+  auto encoder_dy = [&](hipStream_t s, const float** out) -> int {
+    MMNAS_REQUIRE(c->dx_out || L.n_guided, MMNAS_E_ARG, "chain_bwd: no gradient reaches the encoder (dx_out NULL, no guided operator)");
+    if (c->dx_out && L.n_guided) {
+      float* g0 = (float*)(base + L.encdy);
+      const int r = mmnas_drop_add(c->dx_out, dpre, g0, ex, 0.f, 0, 0, s);
+      if (r) return r;
+      *out = g0;
+    } else *out = c->dx_out ? c->dx_out : dpre;
+    return MMNAS_OK;
+  };
+  const int G = first_guided(c);
+  const bool ovl = chain_overlap_on() && !c->use_side_stream && L.last_x >= 0 && L.first_y >= 0 && G > L.first_y;
+  const float* cur_dy = c->dy_out;
+  if (!ovl) {
+    for (int i = c->n_ops - 1; i >= 0; --i) {
+      if (sq && i == L.last_x && (rc = q.flush(st, side, sc->ev[0]))) return rc;   // the decoder's parameter-gradient work
+      if (!c->ops[i].on_y && i == L.last_x && (rc = encoder_dy(st, &cur_dy))) return rc;
+      if ((rc = run(i, st, cur_dy, &cur_dy))) return rc;
+      if (sq && per_op && (rc = q.flush(st, side, sc->ev[i + 1]))) return rc;
+    }
+    if (sq && (rc = q.flush(st, side, sc->ev[1]))) return rc;
+  } else {
+    SideCtx* oc = side_ctx(st, true);
+    MMNAS_REQUIRE(oc, MMNAS_E_LAUNCH, "chain_bwd: cannot create the encoder stream");
+    for (int i = c->n_ops - 1; i >= G; --i)        // every guided operator is in here: the language state's gradient completes
+      if ((rc = run(i, st, cur_dy, &cur_dy))) return rc;
+    if ((rc = ev_fork(st, oc->enc, oc->ovl[2]))) return rc;
+    const float* enc_dy = nullptr;
+    if ((rc = encoder_dy(oc->enc, &enc_dy))) return rc;
+    int ie = L.last_x, id = G - 1;
+    while (ie >= L.first_x || id >= L.first_y) {    // encoder on its stream beside the decoder's leading operators
+      if (ie >= L.first_x && (rc = run(ie--, oc->enc, enc_dy, &enc_dy))) return rc;
+      if (id >= L.first_y && (rc = run(id--, st, cur_dy, &cur_dy))) return rc;
+    }
+    if ((rc = ev_fork(oc->enc, st, oc->ovl[3]))) return rc;
   }
-  if (sq && (rc = q.flush(st, side, sc->ev[1]))) return rc;
   if (L.first_y < 0 && hipMemcpyAsync(c->dy_in, c->dy_out, ey * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return MMNAS_E_LAUNCH;
   if (L.first_x < 0) {
     const float* g0 = c->dx_out;
