@@ -500,7 +500,11 @@ def main():
                                'launches_per_step': gm['launches'] / psteps,
                                'share_of_step_time': gm['ms'] * 1e-3 / prof_elapsed}
             if args.gemm_split:
-                rec['roofline']['peak_note'] = 'fp32 MFMA dense peak (the reference arithmetic type); see `executed` for the bf16 pipe'
+                rec['roofline']['peak_note'] = ('`peak` / `frac`: fp32 MFMA dense peak (the reference arithmetic type; a frac > 1 would be '
+                                                'possible here because the products run on the bf16 pipe); `peak_bf16_div%d` / `frac_bf16_div%d`: '
+                                                'the bf16 dense peak divided by the %d bf16 products per fp32 product') % ((args.gemm_split,) * 3)
+                rec['roofline']['peak_bf16_div%d' % args.gemm_split] = PEAK_MFMA_BF16_TFLOPS / args.gemm_split
+                rec['roofline']['frac_bf16_div%d' % args.gemm_split] = ach * args.gemm_split / PEAK_MFMA_BF16_TFLOPS
                 rec['roofline']['executed'] = {'mfma_tflops': ach * args.gemm_split, 'peak': PEAK_MFMA_BF16_TFLOPS,
                                                'frac': ach * args.gemm_split / PEAK_MFMA_BF16_TFLOPS,
                                                'note': '%d bf16 MFMA products per algorithmic fp32 product' % args.gemm_split}
@@ -568,7 +572,7 @@ def main():
             'metric': head['metric'], 'value': head['value'], 'unit': 'steps/s',
             'n_gpus': world, 'steps': head['steps'], 'warmup': head['warmup'], 'ms_per_step': head['ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {0: 'f32', 6: 'f32 (matrix products as 6 bf16-MFMA products of exactly split fp32 operands, fp32 accumulate: fp32-grade)',
+            'dtype': {0: 'f32', 6: 'f32 (bf16x6 split-operand MFMA, fp32 accumulate)',
                       3: 'f32 results from bf16x3 split-operand MFMA products (EXPERIMENT: 2^-16-class products)'}[args.gemm_split],
             'data': 'synthetic',
             'config': {'workload': head['workload'], 'global_batch': (state[head_wl]['B'] if head_wl in EXTRA else B) * world, 'parallelism': 'dp%d' % world,

@@ -27,6 +27,9 @@ def _check(d, world, steps=2, warmup=1):
     assert d['config']['global_batch'] == 64 * world and d['dtype'].startswith('f32')
     r = d['roofline']
     assert r['bound'] == 'mfma' and 0 < r['frac'] < 1 and r['unit'] == 'TFLOP/s' and r['achieved'] > 0
+    # default products = 6 bf16 MFMA products per fp32 product: priced against the fp32 MFMA peak AND the bf16 peak / 6
+    assert 'bf16x6' in d['dtype'] and r['peak'] == 157.3 and abs(r['peak_bf16_div6'] - 2500.0 / 6) < 1e-6
+    assert abs(r['frac_bf16_div6'] - r['achieved'] / r['peak_bf16_div6']) < 1e-9 and r['executed']['mfma_tflops'] > r['achieved']
 
 
 @pytest.mark.parametrize('workload', ['train_vqa', 'search_vqa', 'arch_vqa'])
