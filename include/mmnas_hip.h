@@ -446,6 +446,11 @@ int mmnas_chain_plan(const mmnas_chain* c, size_t* arena_bytes);   /* host only 
 int mmnas_chain_fwd(const mmnas_chain* c, void* stream);
 int mmnas_chain_bwd(const mmnas_chain* c, void* stream);
 int mmnas_chain_join(void* main_stream, void* waiting_stream);
+/* Encoder / decoder overlap inside mmnas_chain_fwd/bwd: the language-stream operators on their own (high-priority)
+ * stream beside the image-stream operators that precede the first guided operator; joined before the call returns its
+ * last launch.  Measured: no gain on MI355X, so off by default (env MMNAS_CHAIN_OVERLAP=1 or this
+ * call enable it; returns the previous setting).  Results are identical either way. */
+int mmnas_set_chain_overlap(int on);
 
 /* ------------------------------------------------------------------------------------------
  * Answer head: AttFlat over the language state + AttFlat over the image state, their sum, LayerNorm and the answer

@@ -608,9 +608,10 @@ static SideCtx* side_ctx(hipStream_t main, bool create) {
 // GEMM one of its three workgroups per CU meanwhile: in the trace the co-running kernels take 1.3-1.5x their solo time
 // (GEMM 26.6 -> 39.6 us, attention 22 -> 32 us), which returns what the overlap saves.  Off by default
 // (MMNAS_CHAIN_OVERLAP=1 enables it); kept because the fork / join structure is what a multi-stream caller needs.
+static int g_chain_overlap = -1;   // -1: not read yet (MMNAS_CHAIN_OVERLAP, default 0); mmnas_set_chain_overlap() overrides
 static bool chain_overlap_on() {
-  static const int on = [] { const char* e = getenv("MMNAS_CHAIN_OVERLAP"); return e && e[0] ? atoi(e) : 0; }();
-  return on != 0;
+  if (g_chain_overlap < 0) { const char* e = getenv("MMNAS_CHAIN_OVERLAP"); g_chain_overlap = (e && e[0] ? atoi(e) : 0) ? 1 : 0; }
+  return g_chain_overlap != 0;
 }
 static int first_guided(const mmnas_chain* c) {
   for (int i = 0; i < c->n_ops; ++i)
@@ -626,6 +627,12 @@ static int ev_fork(hipStream_t from, hipStream_t to, hipEvent_t e) {
 }
 
 }  // namespace mmnas
+
+extern "C" int mmnas_set_chain_overlap(int on) {
+  const int prev = mmnas::chain_overlap_on() ? 1 : 0;
+  mmnas::g_chain_overlap = on ? 1 : 0;
+  return prev;
+}
 
 extern "C" int mmnas_chain_plan(const mmnas_chain* c, size_t* arena_bytes) {
   int rc = chain_check(c, "chain_plan");

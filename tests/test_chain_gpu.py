@@ -101,6 +101,30 @@ def test_chain_equals_per_operator_path_supernet_weight_step(task, monkeypatch):
         _compare(got, ref)
 
 
+@pytest.mark.parametrize('task,search', [('vqa', True), ('vqa', False), ('vgd', True)])
+def test_chain_encoder_decoder_overlap_gives_the_same_result(task, search, monkeypatch):
+    """mmnas_set_chain_overlap(1): the language stream's operators on their own stream beside the image stream's leading
+    operators (fork / join by events) -- the same kernels on the same data."""
+    from mmnas_amd import _lib as L
+    lib = L.lib()
+    for seed in (3, 4, 5):      # sampled architectures with 0, 1, ... image operators in front of the first guided one
+        plan = None
+        if search:
+            pl = cases.search_plan(np.random.RandomState(seed), None)
+            plan = pl['enc'] + pl['dec']
+        arch = None if search else 'mmnas_' + task
+        ref = _run(task, arch, search, True, False, monkeypatch, plan=plan)
+        prev = lib.mmnas_set_chain_overlap(1)
+        try:
+            got = _run(task, arch, search, True, False, monkeypatch, plan=plan)
+        finally:
+            lib.mmnas_set_chain_overlap(prev)
+        assert ref[2] == 1 and got[2] == 1
+        _compare(got, ref)
+        if not search:
+            break
+
+
 def test_chain_is_skipped_without_gradient_sinks_and_in_arch_mode(monkeypatch):
     """No flat gradient buffer attached (plain autograd use) or MODE 'full': the per-operator path serves the call."""
     from mmnas_amd import ops
