@@ -205,7 +205,7 @@ struct GemmShape {
 template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1>
 __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const int nwg, const int koff,
                                           float* __restrict__ As, float* __restrict__ Bs, int& s_old) {
-  static_assert(PF == 1 || (PF == 2 && FAST && NS == 0), "the two-stage prefetch exists for the fp32 buffer-load path");
+  static_assert(PF == 1 || (PF == 2 && FAST && (NS == 0 || NS == 3)), "the two-stage prefetch exists for the buffer-load path (fp32 and bf16x6)");
   static_assert(NS == 0 || (FAST && BK == 32), "the bf16-split path exists for the buffer-load path only");
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   // split rows: NS parts of 32 bf16 (64 B) + 16 B pad -> 144 / 208 B, an odd number of 16-B words (conflict-free b128)
@@ -1137,7 +1137,7 @@ static int launch_plan(GemmPlan& pl, hipStream_t st) {
   }
   if (pl.wide) return ns == 3 ? launch<128, 64, true, 3>(k, pl.layout, pl.nwg, st) : launch<128, 64, true, 0, 2>(k, pl.layout, pl.nwg, st);
   if (ns == 2) return launch<64, 64, true, 2>(k, pl.layout, pl.nwg, st);
-  if (ns == 3) return launch<64, 64, true, 3>(k, pl.layout, pl.nwg, st);
+  if (ns == 3) return g_tune.pf == 2 ? launch<64, 64, true, 3, 2>(k, pl.layout, pl.nwg, st) : launch<64, 64, true, 3>(k, pl.layout, pl.nwg, st);
   if (pl.fast && g_tune.pf == 2) return launch<64, 64, true, 0, 2>(k, pl.layout, pl.nwg, st);
   return pl.fast ? launch<64, 64, true, 0>(k, pl.layout, pl.nwg, st) : launch<64, 64, false, 0>(k, pl.layout, pl.nwg, st);
 }
@@ -1181,7 +1181,10 @@ int gemm_pair_aux(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, co
   dim3 grid(naux8 + nwg0p + p1.nwg), block(256);
   switch (g_tune.split) {
     case 2: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8); break;
-    case 3: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8); break;
+    case 3:
+      if (g_tune.pf == 2) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
+      else MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
+      break;
     default:
       if (g_tune.pf == 2) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 0, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
       else MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 0>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
