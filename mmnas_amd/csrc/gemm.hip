@@ -134,6 +134,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // l = bf16(x - h - m); the subtractions are exact
 template <int NS>
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& w0, unsigned& w1, unsigned& w2) {
+#ifdef MMNAS_DBG_NOCONV   // timing experiment only (wrong results): what the conversion VALU costs
+  w0 = __float_as_uint(x0); w1 = __float_as_uint(x1); w2 = w0 ^ w1;
+  return;
+#endif
   f32x2 r = {x0, x1};
   const bf16x2 h = __builtin_convertvector(r, bf16x2);
   w0 = __builtin_bit_cast(unsigned, h);
