@@ -613,6 +613,10 @@ static bool chain_overlap_on() {
   if (g_chain_overlap < 0) { const char* e = getenv("MMNAS_CHAIN_OVERLAP"); g_chain_overlap = (e && e[0] ? atoi(e) : 0) ? 1 : 0; }
   return g_chain_overlap != 0;
 }
+static bool head_overlap_on() {
+  static const int on = [] { const char* e = getenv("MMNAS_HEAD_OVERLAP"); return e && e[0] ? atoi(e) : 0; }();
+  return on != 0;
+}
 static int first_guided(const mmnas_chain* c) {
   for (int i = 0; i < c->n_ops; ++i)
     if (c->ops[i].kind == MMNAS_CHAIN_ATT && !(c->ops[i].att.flags & MMNAS_F_SELF)) return i;
@@ -874,27 +878,36 @@ extern "C" int mmnas_head_fwd(const mmnas_head* hd, void* stream) {
   const bool drop = (hd->flags & MMNAS_F_TRAIN) && hd->drop_p > 0.f;
   const int B = hd->B, d = hd->d, MID = hd->MID, G = hd->G, OUT = hd->OUT;
   mmnas_gemm_desc g;
+  hipStream_t st = (hipStream_t)stream;
+  // The two AttFlat branches are independent chains of four small launches each.  MMNAS_HEAD_OVERLAP=1 runs the
+  // language side's on the second stream beside the image side's, joined where the image side's merge adds its result.
+  // MEASURED: slower (supernet step 5.61 -> 5.70 ms, two alternations): each cross-stream event wait costs more than the
+  // ~10 us launch it hides.  Off by default -- the third form of stream overlap tried on this path, none of which paid.
+  SideCtx* oc = head_overlap_on() ? side_ctx(st, true) : nullptr;
+  if (oc && (rc = ev_fork(st, oc->enc, oc->ovl[0]))) return rc;
   for (int k = 0; k < 2; ++k) {
     const mmnas_attflat_side& sd = k ? hd->sy : hd->sx;
     const HeadSideLayout& s = L.s[k];
     MMNAS_REQUIRE(sd.x && sd.W1 && sd.W2 && sd.Wm, MMNAS_E_ARG, "head_fwd: side %d null pointer", k);
+    void* const ks = (oc && k == 0) ? (void*)oc->enc : stream;
     const int M = B * sd.S;
     // h = drop(relu(x W1^T + b1))                                   (FC, modules.py:13-31)
     gemm_init(g, MMNAS_GEMM_NT, MID, d, d, d, MID);
     g.g[0].M = M; g.g[0].A[0] = sd.x; g.g[0].B[0] = sd.W1; g.g[0].bias = sd.b1; g.g[0].C = s.h; g.relu = 1;
     if (drop) { g.drop_p = hd->drop_p; g.drop_seed = sd.seed; g.drop_site = 0; }
-    if ((rc = mmnas_gemm(&g, stream))) return rc;
+    if ((rc = mmnas_gemm(&g, ks))) return rc;
     // glimpse logits = h W2^T + b2                                   (MLP.linear, modules.py:34-41)
     gemm_init(g, MMNAS_GEMM_NT, G, MID, MID, MID, G);
     g.g[0].M = M; g.g[0].A[0] = s.h; g.g[0].B[0] = sd.W2; g.g[0].bias = sd.b2; g.g[0].C = s.logit;
-    if ((rc = mmnas_gemm(&g, stream))) return rc;
+    if ((rc = mmnas_gemm(&g, ks))) return rc;
     // masked softmax over the sequence + weighted sum                (modules.py:78-84)
-    if ((rc = mmnas_attflat_pool_fwd(s.logit, sd.x, sd.mask, s.probs, s.pooled, B, sd.S, d, G, stream))) return rc;
+    if ((rc = mmnas_attflat_pool_fwd(s.logit, sd.x, sd.mask, s.probs, s.pooled, B, sd.S, d, G, ks))) return rc;
     // merge; the image side adds the language side's result (x_out + y_out, hygr_vqa.py:116)
     gemm_init(g, MMNAS_GEMM_NT, OUT, G * d, G * d, G * d, OUT);
     g.g[0].M = B; g.g[0].A[0] = s.pooled; g.g[0].B[0] = sd.Wm; g.g[0].bias = sd.bm; g.g[0].C = k ? L.sum : L.xo;
     if (k) { g.g[0].residual = L.xo; g.ldres = OUT; }
-    if ((rc = mmnas_gemm(&g, stream))) return rc;
+    if (k && oc && (rc = ev_fork(oc->enc, st, oc->ovl[1]))) return rc;   // the language side's result exists from here on
+    if ((rc = mmnas_gemm(&g, ks))) return rc;
   }
   if ((rc = mmnas_layernorm_fwd(L.sum, hd->ln_a, hd->ln_b, L.xy, B, OUT, hd->eps, stream))) return rc;
   gemm_init(g, MMNAS_GEMM_NT, hd->ANS, OUT, OUT, OUT, hd->ANS);
@@ -925,10 +938,14 @@ extern "C" int mmnas_head_bwd(const mmnas_head* hd, void* stream) {
   if ((rc = layernorm_bwd_deferred(L.sum, hd->ln_a, L.dxy, L.dsum, hd->dln_a, hd->dln_b, nullptr, nullptr, L.lnws, 0.f, 0, 0, B, OUT,
                                    hd->eps, st, &lnred)))
     return rc;
+  SideCtx* oc = head_overlap_on() ? side_ctx(st, true) : nullptr;
+  if (oc && (rc = ev_fork(st, oc->enc, oc->ovl[2]))) return rc;   // the sum's gradient is complete: both sides start
   for (int k = 1; k >= 0; --k) {
     const mmnas_attflat_side& sd = k ? hd->sy : hd->sx;
     const HeadSideLayout& s = L.s[k];
     MMNAS_REQUIRE(sd.x && sd.dx && sd.dW1 && sd.dW2 && sd.dWm, MMNAS_E_ARG, "head_bwd: side %d null pointer", k);
+    hipStream_t st = (oc && k == 0) ? oc->enc : (hipStream_t)stream;   // (shadows: the language side on the second stream)
+    void* const stream = (void*)st;
     const int M = B * sd.S;
     // merge: the sum's gradient reaches both sides unchanged
     gemm_init(w, MMNAS_GEMM_TN, G * d, B, OUT, G * d, G * d);
@@ -956,5 +973,6 @@ extern "C" int mmnas_head_bwd(const mmnas_head* hd, void* stream) {
     g.g[0].residual = s.dxpool; g.ldres = d;
     if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
   }
+  if (oc && (rc = ev_fork(oc->enc, st, oc->ovl[3]))) return rc;
   return MMNAS_OK;
 }
