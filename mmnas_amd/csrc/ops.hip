@@ -883,23 +883,34 @@ extern "C" int mmnas_head_fwd(const mmnas_head* hd, void* stream) {
   // language side's on the second stream beside the image side's, joined where the image side's merge adds its result.
   // MEASURED: slower (supernet step 5.61 -> 5.70 ms, two alternations): each cross-stream event wait costs more than the
   // ~10 us launch it hides.  Off by default -- the third form of stream overlap tried on this path, none of which paid.
+  // Default: one stream, and the two sides' glimpse-logit products share a launch (two groups of one grouped GEMM).
   SideCtx* oc = head_overlap_on() ? side_ctx(st, true) : nullptr;
   if (oc && (rc = ev_fork(st, oc->enc, oc->ovl[0]))) return rc;
+  const mmnas_attflat_side* sides[2] = {&hd->sx, &hd->sy};
+  for (int k = 0; k < 2; ++k)
+    MMNAS_REQUIRE(sides[k]->x && sides[k]->W1 && sides[k]->W2 && sides[k]->Wm, MMNAS_E_ARG, "head_fwd: side %d null pointer", k);
+  auto side_stream = [&](int k) -> void* { return (oc && k == 0) ? (void*)oc->enc : stream; };
+  // h = drop(relu(x W1^T + b1))                                   (FC, modules.py:13-31; own dropout seed per side)
   for (int k = 0; k < 2; ++k) {
-    const mmnas_attflat_side& sd = k ? hd->sy : hd->sx;
-    const HeadSideLayout& s = L.s[k];
-    MMNAS_REQUIRE(sd.x && sd.W1 && sd.W2 && sd.Wm, MMNAS_E_ARG, "head_fwd: side %d null pointer", k);
-    void* const ks = (oc && k == 0) ? (void*)oc->enc : stream;
-    const int M = B * sd.S;
-    // h = drop(relu(x W1^T + b1))                                   (FC, modules.py:13-31)
+    const mmnas_attflat_side& sd = *sides[k];
     gemm_init(g, MMNAS_GEMM_NT, MID, d, d, d, MID);
-    g.g[0].M = M; g.g[0].A[0] = sd.x; g.g[0].B[0] = sd.W1; g.g[0].bias = sd.b1; g.g[0].C = s.h; g.relu = 1;
+    g.g[0].M = B * sd.S; g.g[0].A[0] = sd.x; g.g[0].B[0] = sd.W1; g.g[0].bias = sd.b1; g.g[0].C = L.s[k].h; g.relu = 1;
     if (drop) { g.drop_p = hd->drop_p; g.drop_seed = sd.seed; g.drop_site = 0; }
-    if ((rc = mmnas_gemm(&g, ks))) return rc;
-    // glimpse logits = h W2^T + b2                                   (MLP.linear, modules.py:34-41)
-    gemm_init(g, MMNAS_GEMM_NT, G, MID, MID, MID, G);
-    g.g[0].M = M; g.g[0].A[0] = s.h; g.g[0].B[0] = sd.W2; g.g[0].bias = sd.b2; g.g[0].C = s.logit;
-    if ((rc = mmnas_gemm(&g, ks))) return rc;
+    if ((rc = mmnas_gemm(&g, side_stream(k)))) return rc;
+  }
+  // glimpse logits = h W2^T + b2                                   (MLP.linear, modules.py:34-41)
+  gemm_init(g, MMNAS_GEMM_NT, G, MID, MID, MID, G);
+  for (int k = 0; k < 2; ++k) {
+    const mmnas_attflat_side& sd = *sides[k];
+    mmnas_gemm_group& gg = g.g[oc ? 0 : k];
+    gg.M = B * sd.S; gg.A[0] = L.s[k].h; gg.B[0] = sd.W2; gg.bias = sd.b2; gg.C = L.s[k].logit;
+    if (oc && (rc = mmnas_gemm(&g, side_stream(k)))) return rc;
+  }
+  if (!oc) { g.ngroups = 2; if ((rc = mmnas_gemm(&g, stream))) return rc; }
+  for (int k = 0; k < 2; ++k) {
+    const mmnas_attflat_side& sd = *sides[k];
+    const HeadSideLayout& s = L.s[k];
+    void* const ks = side_stream(k);
     // masked softmax over the sequence + weighted sum                (modules.py:78-84)
     if ((rc = mmnas_attflat_pool_fwd(s.logit, sd.x, sd.mask, s.probs, s.pooled, B, sd.S, d, G, ks))) return rc;
     // merge; the image side adds the language side's result (x_out + y_out, hygr_vqa.py:116)
