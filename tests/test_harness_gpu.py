@@ -194,10 +194,25 @@ def test_flat_adam_dense_mode_is_torch_adam_with_zero_gradients():
                 assert rel_err(ps[i].detach().cpu().numpy(), ref[i].detach().numpy()) < 2e-5, (mode, step, i)
 
 
-def test_itm_triplet_step_vs_reference():
+@pytest.mark.parametrize('products', [6, 0, 3])
+def test_itm_triplet_step_vs_reference(products, monkeypatch):
+    """BASELINE configs[4] (train_itm.py:380-391) against the reference's own step.  products: the default 6 bf16-MFMA
+    products per fp32 product, the fp32 MFMA, and -- the reference runs this configuration in fp16 -- the 3-product form
+    (16 mantissa bits of every operand kept, fp32 accumulation: finer than fp16's 11 bits), all at the same 1e-3 tolerance."""
+    import mmnas_amd._lib as L
     from mmnas.model.full_itm import Net_Full
     from mmnas.utils.itm_loss import BCE_Loss
     from mmnas_amd.harness import itm_triplet_step
+    monkeypatch.setenv('MMNAS_GEMM_SPLIT', str(products))
+    L.lib().mmnas_gemm_reload_tuning()
+    try:
+        _itm_triplet_check(Net_Full, BCE_Loss, itm_triplet_step)
+    finally:
+        monkeypatch.delenv('MMNAS_GEMM_SPLIT')
+        L.lib().mmnas_gemm_reload_tuning()
+
+
+def _itm_triplet_check(Net_Full, BCE_Loss, itm_triplet_step):
     npz = load('losses.npz')
     c = cases.net_case('itm', 'mmnas_itm', 9201)
     neg = cases.net_case('itm', 'mmnas_itm', 9202)

@@ -43,6 +43,8 @@ done
 for sp in 0 3; do for wl in search_vqa train_vqa; do
   python3 bench.py --workload $wl --no-cpu-baseline --gemm-split $sp 2>/dev/null | grep '^{' | tail -1 > profiles/${R}_bench_${wl}_gemm_split$sp.json
 done; done
+# BASELINE configs[4] (the reference runs it in fp16): also as 3 bf16 products per fp32 product (16 mantissa bits kept)
+python3 bench.py --workload train_itm --no-cpu-baseline --gemm-split 3 2>/dev/null | grep '^{' | tail -1 > profiles/${R}_bench_train_itm_gemm_split3.json
 mkdir -p gpurun_out/profiles_$R && cp profiles/${R}_* gpurun_out/profiles_$R/   # (gpurun merges only gpurun_out/ back)
 ls -la profiles/ | grep $R
 for f in $W/*.log; do echo "== $f"; tail -n 2 $f | cut -c1-300; done
