@@ -367,7 +367,7 @@ typedef struct mmnas_plan {
   size_t save_bytes, ws_fwd_bytes, ws_bwd_bytes;
 } mmnas_plan;
 
-/* Sequences of <= 16 rows (the language stream: 14 tokens) with heads of 64 and d in {256, 512} run SelfAtt as ONE launch
+/* Sequences of <= 16 rows (the language stream: 14 tokens) with heads of 64, d in {256, 512} and B*H <= 256 run SelfAtt as ONE launch
  * forward (small.hip) instead of projection / core / merge / LayerNorm launches; the saved block is the same.
  * mmnas_set_small_ops(0) forces the general path (returns the previous setting; default on, env MMNAS_SMALL_OPS). */
 int mmnas_set_small_ops(int on);
