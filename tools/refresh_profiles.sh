@@ -19,18 +19,23 @@ for wl in search_vqa arch_vqa train_vqa; do
   marker=onehot_rows; [ $wl = train_vqa ] && marker=row_is_zero
   python3 tools/step_timeline.py $W/trace_$wl $marker > profiles/${R}_timeline_$wl.txt
   [ -n "${SKIP_PMC:-}" ] && continue
-  [ $wl = arch_vqa ] && continue
   small="bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-prof"
   for c in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d $W/pmc_${wl}_$c -o t -- python3 $ROOT/$small > $W/pmc_${wl}_$c.log 2>&1)
   done
   python3 tools/pmc_traffic.py $W/pmc_${wl}_FETCH_SIZE $W/pmc_${wl}_WRITE_SIZE profiles/${R}_traffic_$wl.json
+  [ $wl = arch_vqa ] && continue
   (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace -d $W/pmc_${wl}_mfma -o t -- python3 $ROOT/$small > $W/pmc_${wl}_mfma.log 2>&1)
   (cd /tmp && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $W/pmc_${wl}_lds -o t -- python3 $ROOT/$small > $W/pmc_${wl}_lds.log 2>&1)
   (cd /tmp && rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace -d $W/pmc_${wl}_gui -o t -- python3 $ROOT/$small > $W/pmc_${wl}_gui.log 2>&1)
   python3 tools/pmc_counters.py profiles/${R}_pmc_$wl.json $W/pmc_${wl}_mfma $W/pmc_${wl}_lds $W/pmc_${wl}_gui
 done
 if [ -z "${SKIP_PMC:-}" ]; then
+  small="bench.py --workload bilevel_vqa --steps 6 --warmup 6 --no-cpu-baseline --no-prof"   # (one round = 5 weight + 1 arch steps)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d $W/pmc_bilevel_vqa_$c -o t -- python3 $ROOT/$small > $W/pmc_bilevel_vqa_$c.log 2>&1)
+  done
+  python3 tools/pmc_traffic.py $W/pmc_bilevel_vqa_FETCH_SIZE $W/pmc_bilevel_vqa_WRITE_SIZE profiles/${R}_traffic_bilevel_vqa.json
   (cd /tmp && GEMM_PMC_SWEEP=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $W/sweep -o t -- python3 $ROOT/tools/gemm_pmc.py > $W/sweep.log 2>&1)
   python3 tools/traffic_sweep.py $W/sweep > profiles/${R}_gemm_traffic_sweep.txt
 fi
