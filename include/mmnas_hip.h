@@ -441,6 +441,10 @@ typedef struct mmnas_chain {
   const float* dx_out; const float* dy_out;
   float* dx_in; float* dy_in;
   int use_side_stream, reserved;
+  /* bwd, optional: marks[i] != NULL is a hipEvent_t recorded on the issuing stream right after operator i's backward
+   * launches -- a data-parallel reducer waits on it to start a bucket's all-reduce while the operators in front of i
+   * (issued later) still run.  NULL: no marks. */
+  void* const* marks;
 } mmnas_chain;
 int mmnas_chain_plan(const mmnas_chain* c, size_t* arena_bytes);   /* host only */
 int mmnas_chain_fwd(const mmnas_chain* c, void* stream);

@@ -71,7 +71,8 @@ class Chain(C.Structure):
     _fields_ = [('n_ops', C.c_int), ('ops', C.POINTER(ChainOp)), ('B', C.c_int), ('Sx', C.c_int), ('Sy', C.c_int),
                 ('d', C.c_int), ('x_in', _fp), ('y_in', _fp), ('x_mask', _fp), ('y_mask', _fp), ('x_rel', _fp),
                 ('y_rel', _fp), ('arena', _fp), ('x_out', _fp), ('y_out', _fp), ('dx_out', _fp), ('dy_out', _fp),
-                ('dx_in', _fp), ('dy_in', _fp), ('use_side_stream', C.c_int), ('reserved', C.c_int)]
+                ('dx_in', _fp), ('dy_in', _fp), ('use_side_stream', C.c_int), ('reserved', C.c_int),
+                ('marks', C.c_void_p)]
 
 
 CHAIN_MAX_OPS = 64

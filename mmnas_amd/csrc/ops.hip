@@ -756,6 +756,10 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
       if ((r = mlp_bwd_impl(&m, s, sq))) return r;
     }
     *dxo = dx;
+    if (c->marks && c->marks[i] && hipEventRecord((hipEvent_t)c->marks[i], s) != hipSuccess) {
+      set_error("chain_bwd: cannot record the mark event of operator %d", i);
+      return MMNAS_E_LAUNCH;
+    }
     return MMNAS_OK;
   };
   // entering the encoder: its output gradient = head's + the guided operators'

@@ -40,10 +40,10 @@ def _align(n, a=64):
 class _Sink:
     """Handle a parameter carries (`p._mmnas_sink`) while its gradient lives in a flat buffer: the HIP
     backward kernels accumulate straight into `view` (mmnas_amd.ops._grad_bufs) and call `done()`."""
-    __slots__ = ('view', 'index', 'callback', 'ready_cb')
+    __slots__ = ('view', 'index', 'callback', 'ready_cb', 'owner')
 
-    def __init__(self, view, index, callback, ready_cb=None):
-        self.view, self.index, self.callback, self.ready_cb = view, index, callback, ready_cb
+    def __init__(self, view, index, callback, ready_cb=None, owner=None):
+        self.view, self.index, self.callback, self.ready_cb, self.owner = view, index, callback, ready_cb, owner
 
     def done(self):
         """One operator has enqueued its contribution (a parameter shared by several operators gets several)."""
@@ -116,17 +116,50 @@ class FlatGrads:
             n += bool(self.adopt(i))
         return n
 
-    def enable_sinks(self, callback=None, ready_cb=None):
+    def enable_sinks(self, callback=None, ready_cb=None, owner=None):
         """Let the operators' backward kernels write parameter gradients directly into the views
         (no per-operator zero-fill, no autograd accumulate kernel).  `callback(i)` fires when one operator has
         enqueued its share of params[i]'s gradient, `ready_cb(i)` when the whole gradient has been (see _Sink)."""
         for i, (p, v) in enumerate(zip(self.params, self.views)):
-            p._mmnas_sink = _Sink(v, i, callback, ready_cb)
+            p._mmnas_sink = _Sink(v, i, callback, ready_cb, owner)
 
     def disable_sinks(self):
         for p in self.params:
             if hasattr(p, '_mmnas_sink'):
                 del p._mmnas_sink
+
+
+def _chain_marks(red, op_params, bucket_of, buckets):
+    """Events for ops.BackboneFn.backward, which issues the whole backbone's backward in ONE native call (operators in
+    reverse index order): for every bucket whose still-missing gradients all belong to chain operators, an event behind
+    the operator that issues the bucket's LAST gradient.  The chain records it there (mmnas_chain.marks); the bucket's
+    all-reduce then waits on it instead of on the end of the call, i.e. it overlaps the backward of the operators in
+    front.  Returns one entry per operator (None = no mark), or None when there is nothing to mark."""
+    if not (red.comm and red.is_cuda):
+        return None
+    index = red.fg.index
+    last_op = {}                      # param index -> the operator (smallest index = issued last) that completes it
+    for i, ps in enumerate(op_params):
+        for p in ps:
+            j = index.get(id(p))
+            if j is not None and (j not in last_op or i < last_op[j]):
+                last_op[j] = i
+    marks = [None] * len(op_params)
+    any_mark = False
+    for b in buckets:
+        if red._launched[b]:
+            continue
+        pend = red._pending_params(b)
+        if not pend or any(j not in last_op for j in pend):
+            continue                  # (a stem parameter is still missing: the bucket completes later, through its hook)
+        i = min(last_op[j] for j in pend)
+        if marks[i] is None:
+            marks[i] = torch.cuda.Event()
+            marks[i].record(torch.cuda.current_stream())   # (creates the handle; the chain records it again in place)
+        red._mark_ev[b] = marks[i]
+        any_mark = True
+    red.marks_made = getattr(red, 'marks_made', 0) + sum(m is not None for m in marks)
+    return marks if any_mark else None
 
 
 class GradReducer:
@@ -173,7 +206,14 @@ class GradReducer:
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
         if self.is_cuda:
             # HIP backward kernels add straight into the flat buffer; the backbone chain reports its parameters itself
-            self.fg.enable_sinks(None, self._arrived if self.comm else None)
+            self.fg.enable_sinks(None, self._arrived if self.comm else None, self if self.comm else None)
+        self._mark_ev = {}
+
+    def _pending_params(self, b):
+        return [i for i in self.buckets[b][2] if not self._seen[i]]
+
+    def chain_marks(self, op_params):
+        return _chain_marks(self, op_params, self.bucket_of, range(len(self.buckets)))
 
     def _arrived(self, i):
         if self._seen[i]:
@@ -200,8 +240,10 @@ class GradReducer:
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
         if self.is_cuda:
             from . import ops
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
+            ev = self._mark_ev.pop(b, None)      # recorded inside the backbone chain, behind the bucket's last operator
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
             ops.side_stream_barrier(self.comm_stream)   # weight gradients the backbone chain put on its side stream
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
@@ -215,6 +257,7 @@ class GradReducer:
         self.fg.attach()
         if not self.comm:
             return
+        self._mark_ev = {}
         self._pending = [len(idxs) for (_, _, idxs) in self.buckets]
         self._seen = [False] * len(self.fg.params)
         self._launched = [False] * len(self.buckets)
@@ -345,7 +388,8 @@ class SupernetReducer:
             for i, p in enumerate(fg.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))   # (see GradReducer: the only arrival signal)
         if self.is_cuda:
-            self.fg.enable_sinks(None, self._arrived if self.comm else None)   # (see GradReducer)
+            self.fg.enable_sinks(None, self._arrived if self.comm else None, self if self.comm else None)   # (see GradReducer)
+        self._mark_ev = {}
 
     # -- weight step --------------------------------------------------------------------------------------------
     def begin_weight_step(self):
@@ -382,10 +426,17 @@ class SupernetReducer:
             self._pending[b] = len(idxs)
             armed.update(idxs)
         self._armed = armed
+        self._mark_ev = {}
         self._launched = [False] * self.n_buckets
         self._works = []
         if self.staging is None:
             self.staging = [torch.empty(max(c, 64), dtype=torch.float32, device=self.fg.flat.device) for c in self.cap]
+
+    def _pending_params(self, b):
+        return [i for i in self._armed if self.bucket_of_param.get(i) == b]
+
+    def chain_marks(self, op_params):
+        return _chain_marks(self, op_params, self.bucket_of_param, range(self.n_buckets))
 
     def exchanged_segments(self):
         """(offset, n) runs of the flat buffer that travel in this step's exchange (all buckets)."""
@@ -419,8 +470,10 @@ class SupernetReducer:
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
         if self.is_cuda:
             from . import ops
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
+            ev = self._mark_ev.pop(b, None)      # recorded inside the backbone chain, behind the bucket's last operator
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
             ops.side_stream_barrier(self.comm_stream)   # weight gradients the backbone chain put on its side stream
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)

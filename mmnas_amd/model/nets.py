@@ -86,7 +86,7 @@ class _Backbone(nn.Module):
             return None
         if MixedOp.MODE is not None:
             return None
-        records, params = [], []
+        records, params, op_params = [], [], []
         for on_y, cells in ((0, self.cells_enc), (1, self.cells_dec)):
             rel = y_rel_embed if on_y else x_rel_embed
             for cell in cells:
@@ -124,11 +124,12 @@ class _Backbone(nn.Module):
                         return None
                     records.append(rec)
                     params += used
+                    op_params.append(used)
         if not records or len(records) > 64:
             return None
         xr = x_rel_embed.raw if isinstance(x_rel_embed, RelHandle) else None
         yr = y_rel_embed.raw if isinstance(y_rel_embed, RelHandle) else None
-        return ops.backbone_chain(x, y, x_mask, y_mask, xr, yr, records, params)
+        return ops.backbone_chain(x, y, x_mask, y_mask, xr, yr, records, params, op_params)
 
     def forward(self, x, y, x_mask, y_mask, x_rel_embed, y_rel_embed):
         out = self._chain(x, y, x_mask, y_mask, x_rel_embed, y_rel_embed)

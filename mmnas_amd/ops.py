@@ -912,7 +912,7 @@ class BackboneFn(torch.autograd.Function):
     are not autograd inputs of this node."""
 
     @staticmethod
-    def forward(ctx, x, y, x_mask, y_mask, x_rel, y_rel, records, params):
+    def forward(ctx, x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None):
         lib = L.lib()
         x, y = _f32c(x), _f32c(y)
         B, Sx, d = x.shape
@@ -934,6 +934,7 @@ class BackboneFn(torch.autograd.Function):
         ch.arena, ch.x_out, ch.y_out = L.ptr(arena), L.fptr(x_out), L.fptr(y_out)
         L.check(lib.mmnas_chain_fwd(C.byref(ch), L.stream()))
         ctx.keep = (ch, arr, arena, x, y, xm, ym, xr, yr, x_out, y_out, params)
+        ctx.op_params = op_params
         return x_out, y_out
 
     @staticmethod
@@ -948,7 +949,19 @@ class BackboneFn(torch.autograd.Function):
         ch.dx_out, ch.dy_out, ch.dx_in, ch.dy_in = L.fptr(dx_out), L.fptr(dy_out), L.fptr(dx_in), L.fptr(dy_in)
         side = side_stream_enabled()
         ch.use_side_stream = int(side)
+        # a data-parallel reducer gets events recorded INSIDE the call, behind the operator that completes each of its
+        # buckets, so that the bucket's all-reduce overlaps the backward of the operators issued after it
+        marks = marr = None
+        owner = getattr(params[0]._mmnas_sink, 'owner', None) if params else None
+        if owner is not None and ctx.op_params is not None and not side:
+            marks = owner.chain_marks(ctx.op_params)
+        if marks is not None:
+            marr = (C.c_void_p * len(marks))(*[(ev.cuda_event if ev is not None else None) for ev in marks])
+            ch.marks = C.cast(marr, C.c_void_p)
+        else:
+            ch.marks = None
         L.check(lib.mmnas_chain_bwd(C.byref(ch), L.stream()))
+        ch.marks = None
         ctx.keep = None
         if side:
             # the side stream still reads the arena and the saved inputs: keep them until the join at the end of
@@ -959,11 +972,11 @@ class BackboneFn(torch.autograd.Function):
                 torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
         for p in params:      # data-parallel reducers learn that these gradients have been enqueued
             p._mmnas_sink.ready()
-        return dx_in, dy_in, None, None, None, None, None, None
+        return dx_in, dy_in, None, None, None, None, None, None, None
 
 
-def backbone_chain(x, y, x_mask, y_mask, x_rel, y_rel, records, params):
-    return BackboneFn.apply(x, y, x_mask, y_mask, x_rel, y_rel, records, params)
+def backbone_chain(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None):
+    return BackboneFn.apply(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params)
 
 
 class HeadFn(torch.autograd.Function):

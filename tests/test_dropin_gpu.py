@@ -191,6 +191,9 @@ for it in range(2):
     assert any(red._launched), 'no bucket was launched from the backward thread'
     red.finish()
 torch.cuda.synchronize()
+# (the backbone is ONE native call: buckets completed inside it wait on events the chain records behind their last
+#  operator, not on the end of the call)
+assert getattr(red, 'marks_made', 0) >= 2, getattr(red, 'marks_made', 0)
 for k, p in net.named_parameters():
     if k in plain:
         assert float((p.grad - plain[k]).abs().max()) <= 1e-5 * float(plain[k].abs().max() + 1e-12), k
@@ -221,7 +224,7 @@ r = loop.reducer
 assert r.comm and r.n_buckets == 3
 loss = loop.weight_step(inp, tgt, optimize=False, plan=flat)
 torch.cuda.synchronize()
-assert all(r._launched)
+assert all(r._launched) and getattr(r, 'marks_made', 0) >= 1, getattr(r, 'marks_made', 0)
 named = dict(net.named_parameters())
 top = max(float(g.abs().max()) for g in plain.values())
 for k, g in plain.items():      # (the loop's net takes the backbone / head chains, `ref` the per-operator path: same
