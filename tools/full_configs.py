@@ -2,7 +2,7 @@
 B=4 S_y=36): forward + backward run, outputs and gradients finite, timing."""
 import importlib, sys, time
 import numpy as np, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.golden import cases
 T = torch.from_numpy
 for task, arch, kw in (('vgd', 'mmnas_vgd', dict(B=64, Sx=15, Sy=100)), ('itm', 'mmnas_itm', dict(B=160, Sx=50, Sy=36)),
