@@ -1,6 +1,6 @@
 """Full-size sanity of the other configs (BASELINE C4 mmnas_vgd B=64 S_x=15; C5 mmnas_itm B=160 S_y=36 S_x=50; C1 mcan
 B=4 S_y=36): forward + backward run, outputs and gradients finite, timing."""
-import importlib, sys, time
+import importlib, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.golden import cases
