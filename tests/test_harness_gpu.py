@@ -67,6 +67,48 @@ def test_bilevel_trajectory_vs_reference_loop():
         loop.reducer.fg.disable_sinks()
 
 
+def test_default_products_follow_the_fp32_mfma_through_a_bilevel_run(monkeypatch):
+    """Twelve optimizer steps of the bilevel loop (10 weight steps with clip + Adam, 2 'full' arch steps, dropout on with
+    fixed seeds) with the default 6-product arithmetic and with the fp32 MFMA, from the same initial state: the loss
+    sequences stay together (the products agree to fp32 rounding; what differs is summation order, which Adam's
+    normalisation amplifies slowly)."""
+    import mmnas_amd._lib as L
+    from mmnas.model.hygr_vqa import Net_Search
+    from mmnas_amd import ops
+    from mmnas_amd.harness import SearchLoop
+    c = cases.net_case('vqa', None, 1234, search=True, HSIZE=256, B=8, Sx=14, Sy=20)
+    inp = tuple(T(a).to(DEV) for a in c['inputs']); tgt = T(c['target']).to(DEV)
+    plans = [cases.search_plan(np.random.RandomState(100 + i), 'full' if i % 6 == 5 else None) for i in range(12)]
+    runs = {}
+    for mode in (6, 0):
+        monkeypatch.setenv('MMNAS_GEMM_SPLIT', str(mode))
+        L.lib().mmnas_gemm_reload_tuning()
+        c['cfg'].DROPOUT_R = 0.1
+        net = _build(Net_Search, c)
+        loop = SearchLoop(net, net_lr=1e-4, alpha_lr=0.05)
+        ops.manual_seed(4321)
+        losses = []
+        try:
+            for i, pl in enumerate(plans):
+                step = loop.arch_step if i % 6 == 5 else loop.weight_step
+                losses.append(float(step(inp, tgt, plan=_plan_list(pl)).detach()))
+            torch.cuda.synchronize()
+            runs[mode] = (np.array(losses), {k: p.detach().cpu().numpy().copy() for k, p in net.named_parameters()})
+        finally:
+            loop.reducer.fg.disable_sinks()
+    monkeypatch.delenv('MMNAS_GEMM_SPLIT')
+    L.lib().mmnas_gemm_reload_tuning()
+    la, lb = runs[6][0], runs[0][0]
+    assert np.all(np.isfinite(la)) and np.abs(la - lb).max() <= 2e-4 * np.abs(lb).max(), (la, lb)
+    # parameters: L2 over everything (a maximum would pick the parameters whose gradient is mathematically zero --
+    # the softmax-shift-invariant logit biases -- which Adam moves by +-lr per step in the direction of rounding noise)
+    keys = [k for k in c['P'] if 'alpha' not in k]
+    moved = np.sqrt(sum(float(((runs[0][1][k] - c['P'][k]).astype(np.float64) ** 2).sum()) for k in keys))
+    apart = np.sqrt(sum(float(((runs[6][1][k] - runs[0][1][k]).astype(np.float64) ** 2).sum()) for k in keys))
+    assert moved > 0 and apart <= 0.05 * moved, (moved, apart)     # (measured 1.8 %: two runs of ONE arithmetic with
+                                                                   #  different summation orders part as much)
+
+
 def test_arch_step_fused_path_matches_per_module_path():
     """SearchLoop.arch_step (gated-sum kernel + gate-gradient block + fused alpha Adam) against the reference-shaped
     per-module sequence on the same net: MixedOp.set_arch_param_grad + torch.optim.Adam."""
