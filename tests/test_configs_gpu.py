@@ -115,7 +115,11 @@ def test_vgd_full_size():
     _, _, _, g_all = run(full, avg=False)
     _, _, _, g_lo = run(full[:B // 2], avg=False)
     _, _, _, g_hi = run(full[B // 2:], avg=False)
-    _additive(g_all, g_lo, g_hi)
+    # (the GEMM schedule -- whole tiles / streamed tail / split-K pieces -- depends on the row count, so the half batches
+    #  sum in another order than the full one; through 30 LayerNorm'd layers and their ReLU gates that is 1-5e-3 of a
+    #  gradient at this size: 2e-3 held with the default products, 5e-3 measured on the fp32 MFMA.  A batch-dependence
+    #  bug would be O(1).)
+    _additive(g_all, g_lo, g_hi, tol=1e-2)
 
 
 def test_itm_triplet_step_full_size():
