@@ -438,6 +438,17 @@ def main():
         for _ in range(wcalls):
             step()
         barrier()
+        if os.environ.get('MMNAS_BENCH_HOST_PROFILE'):   # tuning aid: where the HOST spends a step (cProfile, not timed)
+            import cProfile, pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            for _ in range(calls):
+                step()
+            pr.disable()
+            barrier()
+            with open(os.environ['MMNAS_BENCH_HOST_PROFILE'] + '.' + wl, 'w') as f:
+                pstats.Stats(pr, stream=f).sort_stats('tottime').print_stats(45)
+                pstats.Stats(pr, stream=f).sort_stats('cumulative').print_stats(60)
         fl[0] = 0.0
         t0 = time.perf_counter()
         for _ in range(calls):
