@@ -174,7 +174,9 @@ struct SideQueue {
 // data-gradient products, the attention core; the weight-gradient products, the LayerNorm parameter reduction and the
 // whole relation-bias backward (~40 % of an operator's backward time, read by nothing before the optimizer / the
 // gradient exchange) are queued.
-static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* sq) {
+// acc_kv (guided operators inside the backbone chain): the key / value source's gradient is ADDED to *dxkv (the chain's
+// running sum over the guided operators) instead of overwriting it -- saves the chain a buffer and an add launch each.
+static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* sq, bool acc_kv = false) {
   const bool side = sq != nullptr && !sq->rel_only;
   const bool side_rel = sq != nullptr;
   int rc = att_check(op, "att_op_bwd");
@@ -266,6 +268,7 @@ static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* s
     g.g[0].M = Mk; g.g[0].C = op->dxkv;
     g.g[0].A[0] = L.dK; g.g[0].B[0] = op->Wk;
     g.g[0].A[1] = L.dV; g.g[0].B[1] = op->Wv;
+    if (acc_kv) g.accumulate = 1;
     if (side) {
       if ((rc = mmnas_gemm(&g, stream))) return rc;
     } else if ((rc = mmnas_gemm_pair(&g, &w2, stream))) return rc;
@@ -556,7 +559,7 @@ static int chain_layout(const mmnas_chain* c, ChainLayout& L) {
     L.ws[i] = take(pl.ws_bwd_bytes);
     L.dx[i] = take(n);
     const bool guided = o.kind == MMNAS_CHAIN_ATT && !(a.flags & MMNAS_F_SELF);
-    L.tmp[i] = guided ? take(nx) : 0;
+    L.tmp[i] = 0;   // (guided operators add their key / value gradient straight into dpre)
     L.n_guided += guided;
   }
   L.dpre = take(nx);
@@ -746,10 +749,9 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
       a.xkv = self ? a.xq : x_final;
       a.save = base + L.save[i]; a.ws = base + L.ws[i];
       a.dy = dyi; a.dxq = dx;
-      a.dxkv = self ? nullptr : (float*)(base + L.tmp[i]);
+      a.dxkv = self ? nullptr : dpre;     // guided: added into the running sum (zeroed above)
       a.drel = nullptr;
-      if ((r = att_bwd_impl(&a, s, sq))) return r;
-      if (!self && (r = mmnas_drop_add(a.dxkv, dpre, dpre, ex, 0.f, 0, 0, s))) return r;
+      if ((r = att_bwd_impl(&a, s, sq, !self))) return r;
     } else {
       m.x = input_of(i); m.save = base + L.save[i]; m.ws = base + L.ws[i];
       m.dy = dyi; m.dx = dx;
