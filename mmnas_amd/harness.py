@@ -115,6 +115,41 @@ class ArchAdam:
             m.alpha_version += 1                          # (the update wrote through the flat block: drop the sampling cache)
 
 
+class TrainLoop:
+    """The fixed-architecture training loop body of train_vqa.py:291-311 (train_vgd.py / train_itm.py use the same
+    statements around their own losses) for one data-parallel rank: zero_grad, forward, loss, backward with the
+    bucketed gradient exchange, clip_grad_norm_, warm-up Adam step -- the clip and the update as two launches over the
+    flat buffers.  `decay(r)` is the epoch-boundary learning-rate decay (train_vqa.py:285-287)."""
+
+    def __init__(self, net, loss_fn=None, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, clip=1.0, epoch_steps=1000, warmup=True,
+                 group=None, bucket_mb=64.0, force_collectives=False):
+        self.net = net
+        self.loss_fn = fused_loss(loss_fn if loss_fn is not None else nn.BCEWithLogitsLoss(reduction='sum'))
+        self.reducer = dp.GradReducer(list(net.parameters()), bucket_mb=bucket_mb, group=group,
+                                      force_collectives=force_collectives)
+        # every parameter of a fixed architecture receives a gradient, so "absent gradients" never occur; 'zero' keeps
+        # the arithmetic of the reference's `0 * sum(p.sum())` line (train_vqa.py:299) for parameters an architecture
+        # leaves unused
+        self.net_optim = WarmupOptimizer(lr, FlatAdam(self.reducer.fg.params, betas=betas, eps=eps, grads=self.reducer.fg,
+                                                      absent_grads='zero'),
+                                         epoch_steps=epoch_steps, warmup=warmup, max_norm=clip if clip and clip > 0 else None)
+        self.steps = 0
+
+    def step(self, inputs, target, optimize=True):
+        red = self.reducer
+        red.begin_step()
+        loss = self.loss_fn(self.net(inputs), target)
+        loss.backward()
+        red.finish()
+        if optimize:
+            self.net_optim.step()
+        self.steps += 1
+        return loss
+
+    def decay(self, decay_r):
+        self.net_optim.decay(decay_r)
+
+
 class SearchLoop:
     """The bilevel NAS loop body of search_vqa.py:279-337 for one data-parallel rank."""
 

@@ -274,6 +274,19 @@ def traj_setup(seed=9100):
     return c, c2, plans
 
 
+# ---- the fixed-architecture training loop (make_golden.gen_train_traj; train_vqa.py:291-311) -------------------------
+TRAIN_HYPER = dict(lr=0.002, betas=(0.9, 0.98), eps=1e-9, clip=1.0, epoch_steps=1, decay_r=0.2)
+TRAIN_FULL_KEYS = ('proj.bias', 'proj_norm.a_2', 'linear_y_rel.weight', 'imgfeat_linear.bias', 'lstm.bias_hh_l0',
+                   'backnone.cells_enc.0.dag.0.0.ln.a_2', 'backnone.cells_dec.0.dag.0.0.mhatt.linear_merge.weight')
+
+
+def train_traj_setup(seed=9300):
+    """Weights + two batches (steps alternate between them) for arch/mmnas_vqa.json."""
+    c = net_case('vqa', 'mmnas_vqa', seed)
+    c2 = net_case('vqa', 'mmnas_vqa', seed + 1)    # only its inputs / target are used
+    return c, c2
+
+
 # ---- loader functions (make_golden.gen_loader) ---------------------------------------------------------------------
 LOADER_VOCAB = ['PAD', 'UNK', 'what', 'is', 'the', 'man', 'holding', 'color', 'of', 'cat', 'how', 'many', 'dogs',
                 'are', 'there', 'in', 'this', 'picture', 'on', 'table', 'a', 'red', 'ball', 'left', 'right', 'side']

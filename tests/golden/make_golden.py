@@ -388,6 +388,61 @@ def _inject(mops, flat_plan, MixedOp, mode):
                 prm.grad = None
 
 
+def gen_train_traj():
+    """The reference's fixed-architecture training statements (train_vqa.py:291-311) on the reference Net_Full with the
+    reference WarmupOptimizer over torch Adam: zero_grad, forward, loss (+ the `0 * sum` line), backward, clip_grad_norm_,
+    step -- four steps over two alternating batches (the warm-up rate changes every step: epoch_steps = 1), decay(0.2) as
+    at an epoch of NET_LR_DECAY_LIST (train_vqa.py:285-287), a fifth step.  Dropout 0, single process."""
+    from mmnas.utils.optimizer import WarmupOptimizer
+    import torch.optim as Optim
+    out = {}
+    c, c2 = cases.train_traj_setup()
+    init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+            'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
+    net = full_vqa.Net_Full(c['cfg'], init)
+    net.train()
+    load_state(net, c['P'])
+    H = cases.TRAIN_HYPER
+    net_optim = WarmupOptimizer(H['lr'], Optim.Adam(net.parameters(), lr=0, betas=H['betas'], eps=H['eps']), H['epoch_steps'],
+                                warmup=True)
+    loss_fn = torch.nn.BCEWithLogitsLoss(reduction='sum')
+    batches = [(tuple(T(a) for a in c['inputs']), T(c['target'])), (tuple(T(a) for a in c2['inputs']), T(c2['target']))]
+    P0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    losses, gnorms, rates = [], [], []
+
+    def step(i):
+        inp, tgt = batches[i % 2]
+        net_optim.zero_grad()
+        loss = loss_fn(net(inp), tgt)
+        loss += 0 * sum(p.sum() for p in net.parameters())
+        loss.backward()
+        losses.append(loss.item())
+        gnorms.append(float(torch.nn.utils.clip_grad_norm_(net.parameters(), H['clip'])))
+        net_optim.step()
+        rates.append(net_optim._rate)
+
+    def snapshot(tag):
+        sd = net.state_dict()
+        keys = sorted(sd)
+        out['train|%s|keys' % tag] = np.array(keys)
+        out['train|%s|delta_norm' % tag] = np.array([float((sd[k].double() - P0[k].double()).norm()) for k in keys])
+        for k in cases.TRAIN_FULL_KEYS:
+            out['train|%s|P:%s' % (tag, k)] = sd[k].detach().numpy().copy()
+
+    for i in range(4):
+        step(i)
+        if i in (0, 3):
+            snapshot('s%d' % (i + 1))
+    net_optim.decay(H['decay_r'])
+    step(4)
+    snapshot('s5')
+    out['train|losses'] = np.array(losses)
+    out['train|grad_norms'] = np.array(gnorms)
+    out['train|rates'] = np.array(rates)
+    np.savez_compressed(os.path.join(HERE, 'train_traj.npz'), **out)
+    print('train_traj.npz', len(out), 'arrays; losses', losses)
+
+
 def gen_traj():
     """Capture (v): the reference's own statement sequence (search_vqa.py:279-337) on the reference Net_Search with the
     reference WarmupOptimizer (mmnas/utils/optimizer.py) over torch Adam: weight step, weight step (another sample),
@@ -569,6 +624,6 @@ def gen_losses():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['ops', 'ops_shapes', 'prims', 'mixed', 'nets', 'traj', 'loader', 'losses']
+    which = sys.argv[1:] or ['ops', 'ops_shapes', 'prims', 'mixed', 'nets', 'traj', 'train_traj', 'loader', 'losses']
     for w in which:
         globals()['gen_' + w]()

@@ -67,6 +67,35 @@ def test_bilevel_trajectory_vs_reference_loop():
         loop.reducer.fg.disable_sinks()
 
 
+def test_training_loop_trajectory_vs_reference_loop():
+    """tests/golden/train_traj.npz: the reference's own train_vqa.py statements (Net_Full + WarmupOptimizer + torch Adam +
+    clip_grad_norm_), five steps with a decay before the last, replayed through harness.TrainLoop = GradReducer + FlatAdam."""
+    from mmnas.model.full_vqa import Net_Full
+    from mmnas_amd.harness import TrainLoop
+    from tests.test_oracle_golden2 import check_train_trajectory
+    c, c2 = cases.train_traj_setup()
+    H = cases.TRAIN_HYPER
+    net = _build(Net_Full, c)
+    loop = TrainLoop(net, lr=H['lr'], betas=H['betas'], eps=H['eps'], clip=H['clip'], epoch_steps=H['epoch_steps'], warmup=True)
+    try:
+        batches = [(tuple(T(a).to(DEV) for a in c['inputs']), T(c['target']).to(DEV)),
+                   (tuple(T(a).to(DEV) for a in c2['inputs']), T(c2['target']).to(DEV))]
+        named = dict(net.named_parameters())
+        res = {'losses': [], 'gnorms': [], 'rates': [], 'snap': {}, 'P0': {k: T(v) for k, v in c['P'].items()}}
+        for i in range(5):
+            if i == 4:
+                loop.decay(H['decay_r'])
+            loss = loop.step(*batches[i % 2])
+            res['losses'].append(float(loss.detach()))
+            res['gnorms'].append(loop.net_optim.optimizer.grad_norm())
+            res['rates'].append(loop.net_optim._rate)
+            if i in (0, 3, 4):
+                res['snap']['s%d' % (i + 1)] = {k: named[k].detach().cpu().clone() for k in named}
+        check_train_trajectory(res)
+    finally:
+        loop.reducer.fg.disable_sinks()
+
+
 def test_default_products_follow_the_fp32_mfma_through_a_bilevel_run(monkeypatch):
     """Twelve optimizer steps of the bilevel loop (10 weight steps with clip + Adam, 2 'full' arch steps, dropout on with
     fixed seeds) with the default 6-product arithmetic and with the fp32 MFMA, from the same initial state: the loss

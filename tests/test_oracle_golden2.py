@@ -111,6 +111,65 @@ def check_trajectory(res, tol_loss=2e-4, tol_delta=2e-2):
         assert torch.equal(res['snap']['a'][k], res['snap']['w2'][k]), k
 
 
+def oracle_train_trajectory():
+    """The oracle's restatement of train_vqa.py:291-311 (zero_grad, forward, BCE sum, backward, clip, warm-up Adam step),
+    five steps with a decay(0.2) before the last -- see make_golden.gen_train_traj."""
+    c, c2 = cases.train_traj_setup()
+    H = cases.TRAIN_HYPER
+    cfg = c['cfg']
+    P = {k: T(v).clone() for k, v in c['P'].items()}
+    adam = O.Adam(P, H['betas'], H['eps'])
+    batches = [(tuple(T(a) for a in c['inputs']), T(c['target'])), (tuple(T(a) for a in c2['inputs']), T(c2['target']))]
+    res = {'losses': [], 'gnorms': [], 'rates': [], 'snap': {}, 'P0': {k: T(v) for k, v in c['P'].items()}}
+    lr_base = H['lr']
+    for i in range(5):
+        if i == 4:
+            lr_base *= H['decay_r']
+        inp, tgt = batches[i % 2]
+        Q = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+        loss = O.bce_with_logits_sum(O.net_forward('vqa', Q, cfg, inp, genotype=c['genotype']), tgt)
+        loss.backward()
+        res['losses'].append(float(loss.detach()))
+        grads = {k: q.grad for k, q in Q.items() if q.grad is not None}
+        res['gnorms'].append(O.clip_grad_norm(list(grads.values()), H['clip']))
+        rate = O.warmup_rate(lr_base, i + 1, H['epoch_steps'])
+        res['rates'].append(rate)
+        adam.step(grads, rate)
+        if i in (0, 3, 4):
+            res['snap']['s%d' % (i + 1)] = {k: v.clone() for k, v in P.items()}
+    return res
+
+
+def check_train_trajectory(res, tol_loss=2e-4, tol_delta=2e-2, tol_near=0.3):
+    """Shared with the GPU replay (tests/test_harness_gpu.py); tolerances as for check_trajectory, except that the
+    round-off-driven AttFlat hidden biases (NEAR_INVARIANT) have five steps instead of two to drift: 13 % measured for
+    the fp64-free oracle against the reference at step 4."""
+    npz = load('train_traj.npz')
+    for i, (a, b) in enumerate(zip(res['losses'], npz['train|losses'])):
+        assert abs(a - b) <= tol_loss * abs(b), ('loss', i, a, b)
+    assert rel_err(np.array(res['gnorms']), npz['train|grad_norms']) < 1e-3
+    assert np.allclose(np.array(res['rates']), npz['train|rates'], rtol=1e-12, atol=0)
+    for tag in ('s1', 's4', 's5'):
+        keys = [str(k) for k in npz['train|%s|keys' % tag]]
+        dn = npz['train|%s|delta_norm' % tag]
+        snap = res['snap'][tag]
+        assert set(keys) == set(snap.keys())
+        for k, n in zip(keys, dn):
+            if k in SHIFT_INVARIANT:
+                continue
+            mine = float((snap[k].double() - res['P0'][k].double()).norm())
+            tol = tol_near if k in NEAR_INVARIANT else tol_delta
+            assert abs(mine - n) <= tol * n + 1e-7, (tag, k, mine, n)
+        for k in cases.TRAIN_FULL_KEYS:
+            want = npz['train|%s|P:%s' % (tag, k)]
+            d0 = np.abs(want - res['P0'][k].numpy()).max()
+            assert np.abs(snap[k].numpy() - want).max() <= 5e-2 * d0 + 1e-7, (tag, k)
+
+
+def test_oracle_training_loop_vs_reference_trajectory():
+    check_train_trajectory(oracle_train_trajectory())
+
+
 def test_reference_loop_moves_unsampled_candidates():
     """The property the ADVICE review pointed at: under the reference loop a candidate that was sampled at step 1 but
     not at step 2 still moves at step 2 (zero gradient, stale momentum) -- its delta norm grows between w1 and w2."""
@@ -213,13 +272,13 @@ def test_golden_recipe_regenerates_bit_exact(tmp_path):
     code = ("import sys; sys.path.insert(0, %r)\n"
             "import tests.golden.make_golden as mg\n"
             "mg.HERE = %r\n"
-            "for w in ('prims', 'mixed', 'traj', 'loader', 'losses'):\n"
+            "for w in ('prims', 'mixed', 'traj', 'train_traj', 'loader', 'losses'):\n"
             "    getattr(mg, 'gen_' + w)()\n" % (REPO, str(tmp_path)))
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
     r = subprocess.run([sys.executable, '-c', code], cwd=str(tmp_path), env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    for w in ('prims', 'mixed', 'traj', 'loader', 'losses'):
+    for w in ('prims', 'mixed', 'traj', 'train_traj', 'loader', 'losses'):
         new = np.load(os.path.join(str(tmp_path), w + '.npz'))
         old = np.load(os.path.join(GOLDEN, w + '.npz'))
         assert sorted(new.files) == sorted(old.files), w
