@@ -133,6 +133,55 @@ class FlatAdam:
         """Total gradient norm of the last clipped step (device -> host; diagnostics only)."""
         return float(self._sumsq.sqrt())
 
+    # -- checkpoints: torch.optim.Adam's format, so that the reference's `'net_optim': net_optim.optimizer.state_dict()`
+    #    (search_vqa.py:342-346, train_vqa.py:314-319) and its resume path interchange with a torch Adam's files ----------
+    def state_dict(self):
+        state = {}
+        for i, (p, o) in enumerate(zip(self.params, self.fg.offsets)):
+            k = self.global_step if self.absent_grads == 'zero' else self.steps[i]
+            if k == 0:
+                continue            # torch Adam creates a parameter's state at its first step
+            n = p.numel()
+            state[i] = {'step': torch.tensor(float(k)),
+                        'exp_avg': self.m[o:o + n].view_as(p).clone(),
+                        'exp_avg_sq': self.v[o:o + n].view_as(p).clone()}
+        group = {'lr': self.param_groups[0]['lr'], 'betas': tuple(self.betas), 'eps': self.eps,
+                 'weight_decay': self.weight_decay, 'amsgrad': False, 'maximize': False, 'foreach': None,
+                 'capturable': False, 'differentiable': False, 'fused': None, 'params': list(range(len(self.params)))}
+        return {'state': state, 'param_groups': [group]}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        groups = sd['param_groups']
+        order = [i for g in groups for i in g['params']]
+        if len(order) != len(self.params):
+            raise ValueError('FlatAdam.load_state_dict: %d parameters in the file, %d here' % (len(order), len(self.params)))
+        g0 = groups[0]
+        self.param_groups[0]['lr'] = g0.get('lr', self.param_groups[0]['lr'])
+        self.betas, self.eps = tuple(g0.get('betas', self.betas)), g0.get('eps', self.eps)
+        self.weight_decay = g0.get('weight_decay', self.weight_decay)
+        self.m.zero_()
+        self.v.zero_()
+        self.steps = [0] * len(self.params)
+        steps = []
+        for pos, key in enumerate(order):
+            st = sd['state'].get(key)
+            if st is None:
+                continue
+            p, o = self.params[pos], self.fg.offsets[pos]
+            n = p.numel()
+            self.m[o:o + n].copy_(st['exp_avg'].reshape(-1).to(self.m.device, torch.float32))
+            self.v[o:o + n].copy_(st['exp_avg_sq'].reshape(-1).to(self.v.device, torch.float32))
+            k = int(float(st['step']))
+            self.steps[pos] = k
+            steps.append(k)
+        if self.absent_grads == 'zero':
+            if steps and min(steps) != max(steps):
+                raise ValueError("FlatAdam(absent_grads='zero') keeps ONE step count; the file holds %d..%d (written by a loop "
+                                 "without the reference's `0 * sum` lines?): load it into absent_grads='skip'" % (min(steps), max(steps)))
+            self.global_step = steps[0] if steps else 0
+
+
 
 class WarmupOptimizer:
     """mmnas/utils/optimizer.py restated: lr warm-up over three epochs, decay(), set_start_step()."""

@@ -146,3 +146,51 @@ def test_supernet_step_with_reducer_and_fused_optimizer():
     finally:
         MixedOp.MODE = None
         red.fg.disable_sinks()
+
+
+@pytest.mark.parametrize('mode', ['zero', 'skip'])
+def test_flat_adam_checkpoint_interchanges_with_torch_adam(mode):
+    """state_dict() is torch.optim.Adam's format (what the reference saves as 'net_optim', search_vqa.py:342-346): a
+    torch Adam loads it and continues exactly as the FlatAdam does, and the other way round."""
+    import io
+    from mmnas_amd.optim import FlatAdam
+    rs = np.random.RandomState(5)
+    shapes = [(7, 5), (13,), (4, 3, 2), (64,)]
+    init = [rs.standard_normal(sh).astype(np.float32) for sh in shapes]
+    grads = [[rs.standard_normal(sh).astype(np.float32) for sh in shapes] for _ in range(4)]
+
+    def mk():
+        return [torch.nn.Parameter(torch.from_numpy(a.copy()).to(DEV)) for a in init]
+
+    def give(ps, gs, skip_last):
+        for j, (p, g) in enumerate(zip(ps, gs)):
+            if skip_last and j == len(ps) - 1:
+                p.grad = None if mode == 'skip' else torch.zeros_like(p)
+            else:
+                p.grad = torch.from_numpy(g).to(DEV)
+
+    # two steps on the FlatAdam, checkpoint, then two more on (a) the same FlatAdam, (b) a torch Adam loaded from the
+    # file, (c) a fresh FlatAdam loaded from what that torch Adam saves
+    pa = mk()
+    fa = FlatAdam(pa, lr=0.01, betas=(0.9, 0.98), eps=1e-9, absent_grads=mode)
+    for t in range(2):
+        fa.zero_grad()
+        give(pa, grads[t], skip_last=(t == 1 and mode == 'skip'))
+        fa.step()
+    buf = io.BytesIO()
+    torch.save(fa.state_dict(), buf)
+    buf.seek(0)
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    ta = torch.optim.Adam(pb, lr=0.01, betas=(0.9, 0.98), eps=1e-9)
+    ta.load_state_dict(torch.load(buf))
+    pc = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    fc = FlatAdam(pc, lr=0.5, betas=(0.5, 0.5), eps=1.0, absent_grads=mode)     # (hyper-parameters come from the file)
+    fc.load_state_dict(ta.state_dict())
+    for t in (2, 3):
+        fa.zero_grad(); give(pa, grads[t], False); fa.step()
+        ta.zero_grad(); give(pb, grads[t], False); ta.step()
+        fc.zero_grad(); give(pc, grads[t], False); fc.step()
+    for a, b, c in zip(pa, pb, pc):
+        assert rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 2e-6
+        assert rel_err(c.detach().cpu().numpy(), b.detach().cpu().numpy()) < 2e-6
+
