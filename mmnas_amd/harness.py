@@ -114,6 +114,44 @@ class ArchAdam:
             m.alpha_prob.grad = pg[i, :m.n_choices]
             m.alpha_version += 1                          # (the update wrote through the flat block: drop the sampling cache)
 
+    # torch.optim.Adam's checkpoint format over alpha_prob_parameters() in module order (search_vqa.py:350: the reference
+    # saves `alpha_optim.state_dict()` beside the network's)
+    def state_dict(self):
+        state = {}
+        mods = self.net.redundant_modules
+        if self.steps:
+            for i, m in enumerate(mods):
+                n = m.n_choices
+                state[i] = {'step': torch.tensor(float(self.steps)), 'exp_avg': self.m[i, :n].clone(),
+                            'exp_avg_sq': self.v[i, :n].clone()}
+        group = {'lr': self.lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': 0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'params': list(range(len(mods)))}
+        return {'state': state, 'param_groups': [group]}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        mods = self.net.redundant_modules
+        g0 = sd['param_groups'][0]
+        order = [i for g in sd['param_groups'] for i in g['params']]
+        if len(order) != len(mods):
+            raise ValueError('ArchAdam.load_state_dict: %d parameters in the file, %d alpha blocks here' % (len(order), len(mods)))
+        self.lr, self.betas, self.eps = g0.get('lr', self.lr), tuple(g0.get('betas', self.betas)), g0.get('eps', self.eps)
+        self.m.zero_()
+        self.v.zero_()
+        steps = set()
+        for pos, key in enumerate(order):
+            st = sd['state'].get(key)
+            if st is None:
+                continue
+            n = mods[pos].n_choices
+            self.m[pos, :n].copy_(st['exp_avg'].to(self.m.device, torch.float32))
+            self.v[pos, :n].copy_(st['exp_avg_sq'].to(self.v.device, torch.float32))
+            steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise ValueError('ArchAdam keeps one step count for all alpha blocks; the file holds %s' % sorted(steps))
+        self.steps = steps.pop() if steps else 0
+
 
 class TrainLoop:
     """The fixed-architecture training loop body of train_vqa.py:291-311 (train_vgd.py / train_itm.py use the same

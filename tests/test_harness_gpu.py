@@ -228,6 +228,42 @@ def test_alpha_full_step_kernel_vs_torch_adam():
             assert bool(torch.all(torch.isinf(prob[i, n:]))), 'padding columns must stay -inf'
 
 
+def test_alpha_optimizer_checkpoint_is_torch_adams():
+    """ArchAdam.state_dict() loads into torch.optim.Adam(net.alpha_prob_parameters()) -- what search_vqa.py:350 saves --
+    and back; both continue with the same update."""
+    from mmnas.model.hygr_vqa import Net_Search
+    from mmnas_amd.harness import SearchLoop
+    c = cases.net_case('vqa', None, 77, search=True, HSIZE=64)
+    inp = tuple(T(a).to(DEV) for a in c['inputs']); tgt = T(c['target']).to(DEV)
+    net = _build(Net_Search, c)
+    loop = SearchLoop(net)
+    try:
+        plans = [cases.search_plan(np.random.RandomState(40 + i), 'full') for i in range(3)]
+        for pl in plans[:2]:
+            loop.arch_step(inp, tgt, plan=_plan_list(pl))
+        sd = loop.alpha_optim.state_dict()
+        alphas = [p.detach().clone().requires_grad_(True) for p in net.alpha_prob_parameters()]
+        ta = torch.optim.Adam(alphas, lr=0.1, betas=(0.0, 0.999))
+        ta.load_state_dict(sd)
+        assert ta.state_dict()['state'][0]['step'] == 2
+        # third step on both: the torch side takes the gradients the fused step exposes as alpha_prob.grad
+        loop.arch_step(inp, tgt, plan=_plan_list(plans[2]))
+        for a, p in zip(alphas, net.alpha_prob_parameters()):
+            a.grad = p.grad.detach().clone()
+        ta.step()
+        for a, p in zip(alphas, net.alpha_prob_parameters()):
+            assert rel_err(p.detach().cpu().numpy(), a.detach().cpu().numpy()) < 1e-5
+        # and back: a fresh ArchAdam resumes from the torch optimizer's file
+        from mmnas_amd.harness import ArchAdam
+        fresh = ArchAdam(net, lr=0.5, betas=(0.5, 0.5))
+        fresh.load_state_dict(ta.state_dict())
+        assert fresh.steps == 3 and fresh.lr == 0.1 and fresh.betas == (0.0, 0.999)
+        assert rel_err(fresh.m.cpu().numpy(), loop.alpha_optim.m.cpu().numpy()) < 1e-5
+        assert rel_err(fresh.v.cpu().numpy(), loop.alpha_optim.v.cpu().numpy()) < 1e-5
+    finally:
+        loop.reducer.fg.disable_sinks()
+
+
 def test_flat_adam_dense_mode_is_torch_adam_with_zero_gradients():
     """absent_grads='zero': what the reference loop amounts to (search_vqa.py:285-300) -- parameters without a gradient
     are stepped with a zero gradient, one global step count; 'skip' mode freezes them."""
