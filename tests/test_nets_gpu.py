@@ -248,3 +248,47 @@ def test_full_size_net_properties():
     with torch.no_grad():
         out_j = net((inp[0], inp[1], T(y2).to(DEV), inp[3], T(x2).to(DEV)))
     assert float((out_j - out).abs().max()) <= 1e-5 * scale
+
+
+def test_search_result_round_trips_through_the_arch_json_into_net_full(tmp_path):
+    """search_vqa.py:363-386 writes {'epochN': net.genotype()} to arch/<version>.json, train_vqa.py:185 reads it back as
+    __C.GENOTYPE and builds Net_Full from it.  Here: the supernet's argmax architecture goes through that file; the
+    Net_Full built from it, given the supernet's weights of the chosen candidates, computes what the supernet computes
+    with those candidates sampled."""
+    import json
+    import re
+    from mmnas.model.full_vqa import Net_Full
+    from mmnas.model.hygr_vqa import Net_Search
+    from mmnas.utils.ops_adapter import OpsAdapter
+    c = cases.net_case('vqa', None, 4711, search=True, HSIZE=128, B=3, Sx=6, Sy=9)
+    init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+            'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
+    sup = Net_Search(c['cfg'], init)
+    sup.load_state_dict({k: T(v) for k, v in c['P'].items()})
+    sup = sup.to(DEV).eval()
+    geno = sup.genotype()
+    path = tmp_path / 'arch.json'
+    json.dump({'epoch7': geno}, open(path, 'w'))
+    cfg = cases.small_cfg(HSIZE=128)
+    cfg.GENOTYPE = json.load(open(path))['epoch7']
+    used = OpsAdapter().Used_OPS
+    choice = {kind: [used[kind].index(n[0]) for n in cfg.GENOTYPE[kind]] for kind in ('enc', 'dec')}
+    full = Net_Full(cfg, init)
+    sd = {}
+    for k, v in sup.state_dict().items():
+        if 'alpha' in k or k.startswith('linear_x_rel.'):   # (hygr_vqa.py:103 embeds the question-side relations, which no
+            continue                                          #  encoder candidate reads; full_vqa.py has no such layer)
+        m = re.match(r'(backnone\.cells_(enc|dec)\.0\.dag\.(\d+)\.0)\.candidate_ops\.(\d+)\.(.*)', k)
+        if m is None:
+            sd[k] = v
+        elif int(m.group(4)) == choice[m.group(2)][int(m.group(3))]:
+            sd[m.group(1) + '.' + m.group(5)] = v
+    missing = full.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    full = full.to(DEV).eval()
+    inp = tuple(T(a).to(DEV) for a in c['inputs'])
+    sup.set_sampled([([a], [i for i in range(len(used[kind]) - 1) if i != a]) for kind in ('enc', 'dec') for a in choice[kind]])
+    with torch.no_grad():
+        ys, yf = sup(inp), full(inp)
+    assert rel_err(yf.cpu().numpy(), ys.cpu().numpy()) < 1e-5
+
