@@ -79,6 +79,28 @@ def tokenize(question, token_to_ix, max_token=14):
     return ix, min(len(words), max_token)
 
 
+_ANS_SCORE = (0.0, 0.3, 0.6, 0.9)
+
+
+def answer_targets(answer_lists, ans_to_ix, normalize=None):
+    """DataSet.proc_ans / get_score (load_data_vqa.py:299-333) for a batch: [B, len(ans_to_ix)] float32 soft targets
+    from each question's annotator answers (count -> 0 / .3 / .6 / .9 / 1).  `normalize` is the answer normaliser the
+    loader applies first (the reference's `preprocess_answer`, the VQA evaluation script's table-driven clean-up, is
+    not part of this package: pass it in, or pass already-normalised strings)."""
+    out = np.zeros((len(answer_lists), len(ans_to_ix)), np.float32)
+    for b, answers in enumerate(answer_lists):
+        counts = {}
+        for a in answers:
+            if normalize is not None:
+                a = normalize(a)
+            counts[a] = counts.get(a, 0) + 1
+        for a, n in counts.items():
+            j = ans_to_ix.get(a)
+            if j is not None:
+                out[b, j] = _ANS_SCORE[n] if n < 4 else 1.0
+    return out
+
+
 def semantic_relations_on_device(ques_ix, nwords, emb):
     """[B,S] token indices + [B] word counts + the [V,300] GloVe table (device tensors) -> the loaders' zero-padded
     [B,S,S,3] token-relation tensor (semantic_embedding, load_data_vqa.py:36-58), on the GPU."""

@@ -515,6 +515,19 @@ def vgd_loss(pred_scores, pred_reg, scores, scores_mask, bbox, bbox_mask, lam=0.
     return ls + lam * lr, ls, lr
 
 
+def answer_target(answers, ans_to_ix):
+    """DataSet.proc_ans with get_score (load_data_vqa.py:299-333): soft target over the answer vocabulary from the
+    annotators' (already normalised) answers -- 0 / .3 / .6 / .9 / 1 for 0 / 1 / 2 / 3 / >= 4 occurrences."""
+    out = np.zeros(len(ans_to_ix), np.float32)
+    counts = {}
+    for a in answers:
+        counts[a] = counts.get(a, 0) + 1
+    for a, n in counts.items():
+        if a in ans_to_ix:
+            out[ans_to_ix[a]] = (0.0, 0.3, 0.6, 0.9)[n] if n < 4 else 1.0
+    return out
+
+
 def warmup_rate(lr_base, step, epoch_steps, warmup=True):
     """WarmupOptimizer.rate (mmnas/utils/optimizer.py:24-42)."""
     if warmup:

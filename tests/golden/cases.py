@@ -274,6 +274,17 @@ def traj_setup(seed=9100):
     return c, c2, plans
 
 
+# ---- answer targets (make_golden.gen_loader: proc_ans / get_score, load_data_vqa.py:299-333) ---------------------------
+LOADER_ANSWERS = ['yes', 'no', 'red', 'blue', '2', 'frisbee', 'left', 'tennis', 'white']
+LOADER_ANSWER_SETS = (
+    ['yes'] * 10,
+    ['red'] * 3 + ['blue'] * 2 + ['white'] + ['maroon'] * 4,              # 'maroon' is not in the answer vocabulary
+    ['2'] * 1 + ['frisbee'] * 4 + ['left'] * 5,
+    ['purple'] * 10,                                                      # nothing in the vocabulary: all-zero target
+    ['no'] * 2 + ['yes'] * 3 + ['tennis'] * 1 + ['white'] * 4,
+)
+
+
 # ---- the fixed-architecture training loop (make_golden.gen_train_traj; train_vqa.py:291-311) -------------------------
 TRAIN_HYPER = dict(lr=0.002, betas=(0.9, 0.98), eps=1e-9, clip=1.0, epoch_steps=1, decay_r=0.2)
 TRAIN_FULL_KEYS = ('proj.bias', 'proj_norm.a_2', 'linear_y_rel.weight', 'imgfeat_linear.bias', 'lstm.bias_hh_l0',

@@ -541,8 +541,19 @@ def _extract_functions(path, names):
 def gen_loader():
     """Loader-side functions of mmnas/loader/load_data_vqa.py:7-58,252-296 on deterministic inputs."""
     ns = _extract_functions(os.path.join(REF, 'mmnas', 'loader', 'load_data_vqa.py'),
-                            {'relation_embedding', 'semantic_embedding', 'proc_img_feat', 'proc_bbox_feat', 'proc_ques'})
+                            {'relation_embedding', 'semantic_embedding', 'proc_img_feat', 'proc_bbox_feat', 'proc_ques',
+                             'get_score', 'proc_ans'})
     out = {}
+    # answer targets: proc_ans counts the ten annotators' (normalised) answers and maps the counts through get_score.
+    # The normaliser `preprocess_answer` (mmnas/utils/answer_punct.py: the VQA evaluation script's punctuation / article
+    # tables) is outside the path; the fixtures use already-normalised strings, so it is the identity here.
+    ns['preprocess_answer'] = lambda a: a
+
+    class _Self:
+        get_score = staticmethod(lambda occur: ns['get_score'](None, occur))
+    a2i = {a: i for i, a in enumerate(cases.LOADER_ANSWERS)}
+    for i, answers in enumerate(cases.LOADER_ANSWER_SETS):
+        out['ans|%d|out' % i] = ns['proc_ans'](_Self(), {'answers': [{'answer': a} for a in answers]}, a2i)
     for i, (n, seed) in enumerate(((7, 1), (36, 2), (100, 3), (1, 4))):
         bbox = cases.loader_boxes(n, seed)
         out['rel|%d|bbox' % i] = bbox

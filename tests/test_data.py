@@ -93,6 +93,18 @@ def test_host_functions_vs_reference_loader():
         assert n == npz['sem|%d|out' % i].shape[0]
 
 
+def test_answer_targets_vs_reference_loader():
+    from tests.golden import cases
+    from tests.util import load
+    npz = load('loader.npz')
+    a2i = {a: i for i, a in enumerate(cases.LOADER_ANSWERS)}
+    out = data.answer_targets(list(cases.LOADER_ANSWER_SETS), a2i)
+    for i in range(len(cases.LOADER_ANSWER_SETS)):
+        assert np.array_equal(out[i], npz['ans|%d|out' % i]), i
+    up = data.answer_targets([[a.upper() for a in s] for s in cases.LOADER_ANSWER_SETS], a2i, normalize=str.lower)
+    assert np.array_equal(up, out)
+
+
 @pytest.mark.gpu
 def test_device_relation_kernels_vs_reference_loader():
     """relation_embedding / semantic_embedding of load_data_vqa.py:7-58 on the GPU, batched and zero-padded as

@@ -248,6 +248,13 @@ def test_pad_and_bbox_features_pinned():
         assert np.array_equal(out, npz['bboxfeat|%d|out' % i])
 
 
+def test_answer_targets_pinned():
+    npz = load('loader.npz')
+    a2i = {a: i for i, a in enumerate(cases.LOADER_ANSWERS)}
+    for i, answers in enumerate(cases.LOADER_ANSWER_SETS):
+        assert np.array_equal(O.answer_target(answers, a2i), npz['ans|%d|out' % i]), i
+
+
 def test_tokenize_and_semantic_embedding_pinned():
     npz = load('loader.npz')
     tok = {w: i for i, w in enumerate(cases.LOADER_VOCAB)}
