@@ -89,6 +89,16 @@ def itm_triplet_step(net, loss_fn, pos, neg, reducer=None, optim=None):
     return loss
 
 
+def hard_negative_indices(scores, neg_idx, hard_size):
+    """The selection step of the ITM hard-negative mining pass (train_itm.py:349-353): `scores` are the net's matching
+    scores of every anchor against its NEG_RANDSIZE random candidates (flattened), `neg_idx` [N, NEG_RANDSIZE] the
+    candidates' dataset indices; returns [N, hard_size] -- per anchor the indices of its highest-scoring candidates."""
+    scores = scores.view(-1, neg_idx.shape[1])
+    top = torch.argsort(scores, dim=-1, descending=True)[:, :hard_size]
+    rows = torch.arange(top.size(0), device=top.device).unsqueeze(1).expand_as(top)
+    return neg_idx.to(scores.device)[rows, top]
+
+
 class ArchAdam:
     """alpha_optim of search_vqa.py:194 (torch.optim.Adam over alpha_prob_parameters, lr 0.1, betas (0, 0.999)) fused
     with Net_Search.set_arch_param_grad() for ALPHA_BINARY_MODE 'full': one kernel over the [n_nodes, width] blocks."""

@@ -93,6 +93,16 @@ def test_host_functions_vs_reference_loader():
         assert n == npz['sem|%d|out' % i].shape[0]
 
 
+def test_hard_negative_selection():
+    """train_itm.py:349-353 on a small case worked out by hand: per anchor the dataset indices of the best-scoring
+    candidates, best first."""
+    from mmnas_amd.harness import hard_negative_indices
+    scores = torch.tensor([0.1, 0.9, 0.5, 0.3,   0.7, 0.2, 0.8, 0.4])
+    neg_idx = torch.tensor([[10, 11, 12, 13], [20, 21, 22, 23]])
+    assert hard_negative_indices(scores, neg_idx, 2).tolist() == [[11, 12], [22, 20]]
+    assert hard_negative_indices(scores.view(2, 4), neg_idx, 4).tolist() == [[11, 12, 13, 10], [22, 20, 23, 21]]
+
+
 def test_answer_targets_vs_reference_loader():
     from tests.golden import cases
     from tests.util import load
