@@ -178,6 +178,10 @@ __global__ void __launch_bounds__(256, 1) lstm_seq_fwd_kernel(const LstmSeqK p) 
     }
     if (t + 1 < T) step_barrier(cnt, (unsigned)(t + 1) * nub, tmo);
   }
+  // A step barrier of this launch gave up (a workgroup was not resident): the states behind it are garbage.  Make that
+  // visible where nobody polls the timeout word -- a NaN in the output sequence reaches the loss.
+  if (tid == 0 && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+    p.out[((size_t)n0 * T + (T - 1)) * H + u0] = __builtin_nanf("");
 }
 
 // ---------------------------------------------------------------------------------------------- backward
@@ -270,6 +274,9 @@ __global__ void __launch_bounds__(512, 1) lstm_seq_bwd_kernel(const LstmSeqK p) 
     }
     if (t > 0) step_barrier(cnt, (unsigned)(T - t) * nub, tmo);
   }
+  // (as in the forward kernel: a timed-out launch poisons the gate gradients, i.e. every LSTM / embedding gradient)
+  if (tid == 0 && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+    st_sc1(p.DG + (size_t)n0 * T * K + u0, __builtin_nanf(""));
 }
 
 // ---- per-(device, stream) sync words: LSTM_MAX_SB counters + a timeout word (64 words) ----
@@ -309,9 +316,66 @@ static void launch_bwd(const LstmSeqK& k, dim3 grid, hipStream_t st) {
 
 using namespace mmnas;
 
-extern "C" int mmnas_lstm_seq_supported(int H, int B) {
-  return (H == 64 || H == 128 || H == 256 || H == 512) && B >= 1 && (B + SB_BWD - 1) / SB_BWD <= LSTM_MAX_SB;
+namespace mmnas {
+// Workgroups of the two kernels the device holds at once, per hidden size (0: no device / query failed).  The step
+// barriers spin on the other unit workgroups of a sample block, so a grid beyond this number would rely on dispatch
+// order: the entry points cut the batch into launches of whole sample blocks that fit (the blocks are independent; the
+// ITM batch of 160 at H = 512 is 320 workgroups per pass).  One block per CU is taken off
+// the occupancy query when it reports more than one (ROCm 7.2 over-reports by one for SGPR-heavy kernels,
+// MI355X_MICROARCH.md "Residency and cooperative launch").
+template <int H>
+static void resident_query(int* fwd, int* bwd) {
+  static int cache[2] = {-1, -1};
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (cache[0] < 0) {
+    cache[0] = cache[1] = 0;
+    int dev = 0, cus = 0, nf = 0, nb = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, lstm_seq_fwd_kernel<H, SB_FWD>, 256, 0) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm_seq_bwd_kernel<H, SB_BWD>, 512, 0) == hipSuccess) {
+      cache[0] = (nf > 1 ? nf - 1 : nf) * cus;
+      cache[1] = (nb > 1 ? nb - 1 : nb) * cus;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  *fwd = cache[0]; *bwd = cache[1];
 }
+}  // namespace mmnas
+
+extern "C" int mmnas_lstm_seq_supported(int H, int B) {
+  if (!((H == 64 || H == 128 || H == 256 || H == 512) && B >= 1 && (B + SB_BWD - 1) / SB_BWD <= LSTM_MAX_SB)) return 0;
+  int rf = 0, rb = 0;
+  switch (H) {
+    case 64: resident_query<64>(&rf, &rb); break;
+    case 128: resident_query<128>(&rf, &rb); break;
+    case 256: resident_query<256>(&rf, &rb); break;
+    default: resident_query<512>(&rf, &rb); break;
+  }
+  // (no device: nothing can be launched anyway.)  One sample block's workgroups must be resident together; more samples
+  // than fit one launch are run as several (lstm_chunk)
+  return rf >= H / 8 && rb >= H / 16;
+}
+
+namespace mmnas {
+// samples per launch: whole sample blocks of SB whose (units x blocks) grid is resident at once
+static int lstm_chunk(int H, int B, bool bwd) {
+  int rf = 0, rb = 0;
+  switch (H) {
+    case 64: resident_query<64>(&rf, &rb); break;
+    case 128: resident_query<128>(&rf, &rb); break;
+    case 256: resident_query<256>(&rf, &rb); break;
+    default: resident_query<512>(&rf, &rb); break;
+  }
+  const int per_block = bwd ? H / 16 : H / 8, sb = bwd ? SB_BWD : SB_FWD;
+  int blocks = (bwd ? rb : rf) / per_block;
+  if (blocks < 1) blocks = 1;
+  if (blocks > LSTM_MAX_SB) blocks = LSTM_MAX_SB;
+  const int n = blocks * sb;
+  return n < B ? n : B;
+}
+}  // namespace mmnas
 
 extern "C" int mmnas_lstm_seq_fwd(const float* xp, const float* bhh, const float* Whh, float* Hprev, float* Cs, float* Gall,
                                   float* out, int T, int B, int H, void* stream) {
@@ -319,20 +383,29 @@ extern "C" int mmnas_lstm_seq_fwd(const float* xp, const float* bhh, const float
   MMNAS_REQUIRE(T >= 1 && mmnas_lstm_seq_supported(H, B), MMNAS_E_SHAPE, "lstm_seq_fwd: T=%d B=%d H=%d unsupported", T, B, H);
   MMNAS_REQUIRE((((uintptr_t)Whh | (uintptr_t)Hprev) & 15) == 0, MMNAS_E_ARG, "lstm_seq_fwd: W_hh / state buffers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  LstmSeqK k;
-  memset(&k, 0, sizeof(k));
-  k.xp = xp; k.bhh = bhh; k.Whh = Whh; k.Hprev = Hprev; k.Cs = Cs; k.Gall = Gall; k.out = out;
-  k.T = T; k.B = B; k.H = H; k.nsb = (B + SB_FWD - 1) / SB_FWD;
-  int rc = lstm_sync_words(st, &k.cnt);
+  unsigned* words = nullptr;
+  int rc = lstm_sync_words(st, &words);
   if (rc) return rc;
-  if (hipMemsetAsync(k.cnt, 0, 256, st) != hipSuccess) { set_error("lstm_seq_fwd: memset failed"); return MMNAS_E_LAUNCH; }
-  const dim3 grid(H / 8, k.nsb);
-  ProfScope ps(MMNAS_K_LSTM, 2.0 * T * B * 4.0 * H * H, 4.0 * (4.0 * H * H + 7.0 * T * B * H), st, "lstm_seq_fwd");
-  switch (H) {
-    case 64: launch_fwd<64>(k, grid, st); break;
-    case 128: launch_fwd<128>(k, grid, st); break;
-    case 256: launch_fwd<256>(k, grid, st); break;
-    default: launch_fwd<512>(k, grid, st); break;
+  const int chunk = lstm_chunk(H, B, false);
+  for (int b0 = 0; b0 < B; b0 += chunk) {   // (one launch for every batch of the VQA / VGD configurations)
+    const int nb = B - b0 < chunk ? B - b0 : chunk;
+    const size_t r0 = (size_t)b0 * T;
+    LstmSeqK k;
+    memset(&k, 0, sizeof(k));
+    k.xp = xp + r0 * 4 * H; k.bhh = bhh; k.Whh = Whh; k.Hprev = Hprev + r0 * H; k.Cs = Cs + r0 * H; k.Gall = Gall + r0 * 4 * H;
+    k.out = out + r0 * H;
+    k.T = T; k.B = nb; k.H = H; k.nsb = (nb + SB_FWD - 1) / SB_FWD;
+    k.cnt = words;
+    // counters and, on the first launch only, the timeout word (a later launch must not clear an earlier one's report)
+    if (hipMemsetAsync(k.cnt, 0, b0 == 0 ? 256 : LSTM_MAX_SB * sizeof(unsigned), st) != hipSuccess) { set_error("lstm_seq_fwd: memset failed"); return MMNAS_E_LAUNCH; }
+    const dim3 grid(H / 8, k.nsb);
+    ProfScope ps(MMNAS_K_LSTM, 2.0 * T * nb * 4.0 * H * H, 4.0 * (4.0 * H * H + 7.0 * T * nb * H), st, "lstm_seq_fwd");
+    switch (H) {
+      case 64: launch_fwd<64>(k, grid, st); break;
+      case 128: launch_fwd<128>(k, grid, st); break;
+      case 256: launch_fwd<256>(k, grid, st); break;
+      default: launch_fwd<512>(k, grid, st); break;
+    }
   }
   return check_launch("lstm_seq_fwd");
 }
@@ -343,20 +416,28 @@ extern "C" int mmnas_lstm_seq_bwd(const float* dout, const float* Whh, const flo
   MMNAS_REQUIRE(T >= 1 && mmnas_lstm_seq_supported(H, B), MMNAS_E_SHAPE, "lstm_seq_bwd: T=%d B=%d H=%d unsupported", T, B, H);
   MMNAS_REQUIRE(((uintptr_t)DG & 15) == 0, MMNAS_E_ARG, "lstm_seq_bwd: DG must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  LstmSeqK k;
-  memset(&k, 0, sizeof(k));
-  k.Whh = Whh; k.Cs = const_cast<float*>(Cs); k.Gall = const_cast<float*>(Gall); k.dout = dout; k.DG = DG;
-  k.T = T; k.B = B; k.H = H; k.nsb = (B + SB_BWD - 1) / SB_BWD;
-  int rc = lstm_sync_words(st, &k.cnt);
+  unsigned* words = nullptr;
+  int rc = lstm_sync_words(st, &words);
   if (rc) return rc;
-  if (hipMemsetAsync(k.cnt, 0, 256, st) != hipSuccess) { set_error("lstm_seq_bwd: memset failed"); return MMNAS_E_LAUNCH; }
-  const dim3 grid(H / 16, k.nsb);
-  ProfScope ps(MMNAS_K_LSTM, 2.0 * T * B * 4.0 * H * H, 4.0 * (4.0 * H * H + 12.0 * T * B * H), st, "lstm_seq_bwd");
-  switch (H) {
-    case 64: launch_bwd<64>(k, grid, st); break;
-    case 128: launch_bwd<128>(k, grid, st); break;
-    case 256: launch_bwd<256>(k, grid, st); break;
-    default: launch_bwd<512>(k, grid, st); break;
+  const int chunk = lstm_chunk(H, B, true);
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int nb = B - b0 < chunk ? B - b0 : chunk;
+    const size_t r0 = (size_t)b0 * T;
+    LstmSeqK k;
+    memset(&k, 0, sizeof(k));
+    k.Whh = Whh; k.Cs = const_cast<float*>(Cs) + r0 * H; k.Gall = const_cast<float*>(Gall) + r0 * 4 * H; k.dout = dout + r0 * H;
+    k.DG = DG + r0 * 4 * H;
+    k.T = T; k.B = nb; k.H = H; k.nsb = (nb + SB_BWD - 1) / SB_BWD;
+    k.cnt = words;
+    if (hipMemsetAsync(k.cnt, 0, b0 == 0 ? 256 : LSTM_MAX_SB * sizeof(unsigned), st) != hipSuccess) { set_error("lstm_seq_bwd: memset failed"); return MMNAS_E_LAUNCH; }
+    const dim3 grid(H / 16, k.nsb);
+    ProfScope ps(MMNAS_K_LSTM, 2.0 * T * nb * 4.0 * H * H, 4.0 * (4.0 * H * H + 12.0 * T * nb * H), st, "lstm_seq_bwd");
+    switch (H) {
+      case 64: launch_bwd<64>(k, grid, st); break;
+      case 128: launch_bwd<128>(k, grid, st); break;
+      case 256: launch_bwd<256>(k, grid, st); break;
+      default: launch_bwd<512>(k, grid, st); break;
+    }
   }
   return check_launch("lstm_seq_bwd");
 }

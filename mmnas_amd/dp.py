@@ -40,10 +40,31 @@ def _align(n, a=64):
 class _Sink:
     """Handle a parameter carries (`p._mmnas_sink`) while its gradient lives in a flat buffer: the HIP
     backward kernels accumulate straight into `view` (mmnas_amd.ops._grad_bufs) and call `done()`."""
-    __slots__ = ('view', 'index', 'callback', 'ready_cb', 'owner')
+    __slots__ = ('view', 'index', 'callback', 'ready_cb', 'owner', 'fg', 'uses', 'gen')
 
-    def __init__(self, view, index, callback, ready_cb=None, owner=None):
+    def __init__(self, view, index, callback, ready_cb=None, owner=None, fg=None):
         self.view, self.index, self.callback, self.ready_cb, self.owner = view, index, callback, ready_cb, owner
+        # live section nodes (ops.BackboneFn / HeadFn forwards whose backward has not run yet) that add into this view
+        # in the current step; `gen` ties the count to the step it was made in (FlatGrads.zero() starts a new one)
+        self.fg, self.uses, self.gen = fg, 0, -1
+
+    def live(self):
+        if self.fg is not None and self.gen != self.fg.gen:
+            self.gen, self.uses = self.fg.gen, 0
+        return self.uses
+
+    def acquire(self):
+        """A section forward that will run a backward has taken this parameter (train_itm.py:380-391: three forwards
+        share every weight before the one backward)."""
+        self.live()
+        self.uses += 1
+
+    def release(self):
+        """That section's backward has enqueued its share.  True when it was the last live one: the parameter's WHOLE
+        gradient of this step is now enqueued."""
+        if self.live() > 0:
+            self.uses -= 1
+        return self.uses == 0
 
     def done(self):
         """One operator has enqueued its contribution (a parameter shared by several operators gets several)."""
@@ -75,6 +96,7 @@ class FlatGrads:
         # dirty[i]: the view of params[i] may hold non-zero data (it has been attached as p.grad, or a gradient was
         # copied into it) since the last zero().  FlatAdam's dense mode relies on "not dirty => all zeros".
         self.dirty = [False] * len(self.params)
+        self.gen = 0   # step generation: bumped by zero(); _Sink.live() keys its live-node count on it
 
     def attach(self, which=None):
         """Point p.grad at its view (all parameters, or the given subset; others get grad=None)."""
@@ -94,6 +116,7 @@ class FlatGrads:
     def zero(self):
         self.flat.zero_()
         self.dirty = [False] * len(self.params)
+        self.gen += 1
 
     def adopt(self, i):
         """Bring a gradient that was produced OUTSIDE the flat buffer into it: the driver called `net.zero_grad()` /
@@ -121,7 +144,7 @@ class FlatGrads:
         (no per-operator zero-fill, no autograd accumulate kernel).  `callback(i)` fires when one operator has
         enqueued its share of params[i]'s gradient, `ready_cb(i)` when the whole gradient has been (see _Sink)."""
         for i, (p, v) in enumerate(zip(self.params, self.views)):
-            p._mmnas_sink = _Sink(v, i, callback, ready_cb, owner)
+            p._mmnas_sink = _Sink(v, i, callback, ready_cb, owner, self)
 
     def disable_sinks(self):
         for p in self.params:

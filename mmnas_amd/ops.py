@@ -906,6 +906,31 @@ def chain_mlp_record(on_y, weights, biases, ln, norm, residual, drop_p, training
     return rec, params
 
 
+def _acquire_sinks(ctx, params):
+    """Section forward (BackboneFn / HeadFn): when a backward will follow, count this node as a live user of every
+    parameter's gradient sink.  Several forwards may precede one backward (train_itm.py:380-391 runs three); a
+    parameter's gradient is complete -- `ready()` for a data-parallel reducer -- only when the LAST of them has run
+    its backward, not the first."""
+    ctx.uniq = list({id(p): p for p in params}.values())   # (the shared relation stem appears once per relation operator)
+    if not any(ctx.needs_input_grad[:2]):
+        return False
+    for p in ctx.uniq:
+        p._mmnas_sink.acquire()
+    return True
+
+
+def _last_live(ctx, params):
+    """True when this node is the only live user left of every one of its parameters."""
+    return not ctx.counted or all(p._mmnas_sink.live() <= 1 for p in ctx.uniq)
+
+
+def _release_sinks(ctx, params):
+    for p in ctx.uniq:
+        s = p._mmnas_sink
+        if not ctx.counted or s.release():
+            s.ready()
+
+
 class BackboneFn(torch.autograd.Function):
     """Backbone_*.forward (hygr_vqa.py:45-52) through mmnas_chain_fwd/bwd.  Parameter gradients go straight into the
     flat gradient buffer (every parameter of the chain has an attached sink: checked by the caller), so the parameters
@@ -935,6 +960,7 @@ class BackboneFn(torch.autograd.Function):
         L.check(lib.mmnas_chain_fwd(C.byref(ch), L.stream()))
         ctx.keep = (ch, arr, arena, x, y, xm, ym, xr, yr, x_out, y_out, params)
         ctx.op_params = op_params
+        ctx.counted = _acquire_sinks(ctx, params)
         return x_out, y_out
 
     @staticmethod
@@ -953,7 +979,9 @@ class BackboneFn(torch.autograd.Function):
         # buckets, so that the bucket's all-reduce overlaps the backward of the operators issued after it
         marks = marr = None
         owner = getattr(params[0]._mmnas_sink, 'owner', None) if params else None
-        if owner is not None and ctx.op_params is not None and not side:
+        # (marks only from the LAST live node over these parameters: with several forwards before one backward -- the ITM
+        #  triplet step -- an earlier node's gradients are a third of the bucket's, not all of it)
+        if owner is not None and ctx.op_params is not None and not side and _last_live(ctx, params):
             marks = owner.chain_marks(ctx.op_params)
         if marks is not None:
             marr = (C.c_void_p * len(marks))(*[(ev.cuda_event if ev is not None else None) for ev in marks])
@@ -970,8 +998,7 @@ class BackboneFn(torch.autograd.Function):
             if not _side_join_queued[0]:
                 _side_join_queued[0] = True
                 torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
-        for p in params:      # data-parallel reducers learn that these gradients have been enqueued
-            p._mmnas_sink.ready()
+        _release_sinks(ctx, params)   # data-parallel reducers learn which gradients are now completely enqueued
         return dx_in, dy_in, None, None, None, None, None, None, None
 
 
@@ -1004,6 +1031,7 @@ class HeadFn(torch.autograd.Function):
         hd.arena, hd.logits = L.ptr(arena), L.fptr(logits)
         L.check(lib.mmnas_head_fwd(C.byref(hd), L.stream()))
         ctx.keep = (hd, arena, x, y, xm, ym, params)
+        ctx.counted = _acquire_sinks(ctx, params)
         return logits
 
     @staticmethod
@@ -1016,8 +1044,7 @@ class HeadFn(torch.autograd.Function):
         hd.dlogits, hd.sx.dx, hd.sy.dx = L.fptr(dlogits), L.fptr(dx), L.fptr(dy)
         L.check(L.lib().mmnas_head_bwd(C.byref(hd), L.stream()))
         ctx.keep = None
-        for p in params:
-            p._mmnas_sink.ready()
+        _release_sinks(ctx, params)
         return dx, dy, None, None, None, None
 
 

@@ -51,12 +51,25 @@ def test_bench_default_line_is_the_supernet_weight_step_with_sub_records():
     d = _json_line(p.stdout)
     _check(d, 1, steps=6)
     assert d['metric'].startswith('supernet fwd+bwd steps/sec') and 'WEIGHT step' in d['config']['workload']
-    assert set(d['sub']) == {'arch_step', 'bilevel', 'train_vqa'}
-    for r in [d] + list(d['sub'].values()):
+    main = {'arch_step', 'bilevel', 'train_vqa'}
+    n1 = {'search_vqa_stream', 'search_vqa_dropin', 'search_vqa_dp1', 'train_vqa_dp1'}     # N = 1 only: short records
+    assert set(d['sub']) == main | n1
+    for r in [d] + [d['sub'][k] for k in main]:
         assert r['value'] > 0 and 0 < r['roofline']['frac'] < 1
+        assert r['repeats'] == 5 and r['value_min'] <= r['value'] <= r['value_max']   # median of five timed blocks
         cb = r['cpu_baseline']
         assert cb['kind'] == 'port' and cb['value'] > 0 and cb['cores'] >= 1 and cb['unit'] == 'steps/s'
     assert d['sub']['bilevel']['steps'] == 6
+    for k in n1:
+        r = d['sub'][k]
+        assert r.get('error') is None and r['value'] > 0 and r['host_issue_ms_per_step'] > 0 and r['library_launches_per_step'] > 100, (k, r)
+    # the exchange machinery really ran: RCCL, one rank, collectives forced
+    for k in ('search_vqa_dp1', 'train_vqa_dp1'):
+        assert d['sub'][k]['config'] == {'grad_allreduce': 'rccl', 'rccl_ranks': 1, 'force_collectives': True}
+        assert 0.9 < d['sub'][k]['ms_per_step_vs_plain'] < 1.5
+    assert d['sub']['search_vqa_stream']['ms_per_step_vs_plain'] < 1.25
+    tp = d['roofline']['traffic_pmc']
+    assert tp is None or 'source_commit' in tp
 
 
 def test_bench_gpus_flag_must_match_the_launch():

@@ -256,3 +256,29 @@ def test_single_process_is_a_noop():
     net(torch.ones(2, 4)).sum().backward()
     red.finish()
     assert net.weight.grad is not None and torch.allclose(net.weight.grad, torch.full((3, 4), 2.0))
+
+
+def test_sink_live_count_several_forwards_one_backward():
+    """train_itm.py:380-391 runs three forwards before the one backward, so three section nodes (ops.BackboneFn / HeadFn)
+    hold every parameter.  A sink reports the parameter's gradient as complete only when the LAST of them has released it
+    (the first to finish holds a third of it), and a new step (FlatGrads.zero) forgets nodes that never ran a backward."""
+    from mmnas_amd import dp
+    ps = [torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(3, 2))]
+    fg = dp.FlatGrads(ps)
+    arrived = []
+    fg.enable_sinks(None, arrived.append, None)
+    s0, s1 = ps[0]._mmnas_sink, ps[1]._mmnas_sink
+    for _ in range(3):
+        s0.acquire()
+    s1.acquire()
+    assert s0.live() == 3 and s1.live() == 1
+    assert not s0.release() and not s0.release()
+    assert s1.release()
+    assert s0.live() == 1
+    assert s0.release() and s0.live() == 0
+    s0.acquire()                 # a forward whose backward never runs (an evaluation pass under grad mode) ...
+    fg.zero()                    # ... is forgotten when the next step begins
+    assert s0.live() == 0
+    s0.acquire()
+    assert s0.release()
+    assert s0.release()          # (an unmatched release -- a node that did not count itself -- stays at zero)

@@ -125,6 +125,58 @@ def _w_supernet(rank):
     assert torch.equal(red.fg.flat[mask], local[mask])   # ... and stay untouched
 
 
-@pytest.mark.parametrize('fn', ['_w_full', '_w_supernet'])
+def _w_itm_triplet(rank):
+    """the ITM triplet step runs three forwards before one backward, so three BackboneFn and three
+    HeadFn nodes add into the same gradient views.  A bucket must be all-reduced after the LAST of them, not the first
+    (which holds a third of the gradient): two ranks, small buckets, against the mean of plain per-rank gradients."""
+    from mmnas_amd import dp, ops
+    from mmnas_amd.harness import BCE_Loss, itm_triplet_step
+    from mmnas.model.full_itm import Net_Full
+    pos = [cases.net_case('itm', 'mmnas_itm', 600 + r, HSIZE=64, B=3, Sx=6, Sy=9) for r in range(WORLD)]
+    neg = [cases.net_case('itm', 'mmnas_itm', 650 + r, HSIZE=64, B=3, Sx=6, Sy=9) for r in range(WORLD)]
+    c0 = pos[0]
+    c0['cfg'].DROPOUT_R = 0.0
+    init = {'token_size': c0['token_size'], 'ans_size': c0['ans_size'],
+            'pretrained_emb': np.zeros((c0['token_size'], c0['cfg'].WORD_EMBED_SIZE), np.float32)}
+
+    def build():
+        net = Net_Full(c0['cfg'], init)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in c0['P'].items()})
+        return net.cuda().train()
+
+    tup = lambda c: tuple(torch.from_numpy(a).cuda() for a in c['inputs'])
+    ref = build()
+    want = None
+    for r in range(WORLD):       # plain autograd, per-operator path, no reducer
+        ref.zero_grad()
+        itm_triplet_step(ref, BCE_Loss(), tup(pos[r]), tup(neg[r]))
+        g = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in ref.named_parameters()}
+        want = g if want is None else {k: want[k] + g[k] for k in g}
+    scale = max(float(v.abs().max()) for v in want.values()) / WORLD
+    net = build()
+    red = dp.GradReducer(list(net.parameters()), bucket_mb=0.05)
+    assert len(red.buckets) >= 3
+    early = []
+    launch = red._launch
+
+    def checked_launch(b):       # every launch from the backward thread: no live section node may still hold the bucket
+        if not red._launched[b]:
+            early.extend((b, i) for i in red.buckets[b][2] if red.fg.params[i]._mmnas_sink.live() > 0)
+        launch(b)
+    red._launch = checked_launch
+    for step in range(4):
+        itm_triplet_step(net, BCE_Loss(), tup(pos[rank]), tup(neg[rank]), reducer=red)
+        torch.cuda.synchronize()
+        assert not early, early[:6]
+        bad = []
+        for k, p in net.named_parameters():
+            err = float((p.grad - want[k] / WORLD).abs().max())
+            if not err <= 1e-4 * max(float(want[k].abs().max()) / WORLD, 1e-3 * scale):
+                bad.append((step, k, err, float(want[k].abs().max()) / WORLD))
+        assert not bad, bad[:8]
+    assert getattr(red, 'marks_made', 0) > 0     # the chain path ran and placed its bucket events (once per step)
+
+
+@pytest.mark.parametrize('fn', ['_w_full', '_w_supernet', '_w_itm_triplet'])
 def test_two_ranks_on_one_gpu(fn):
     mp.spawn(_entry, args=(fn, _free_port()), nprocs=WORLD, join=True)

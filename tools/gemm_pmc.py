@@ -35,6 +35,14 @@ if __name__ == '__main__':
                 go('NT', 6400, 2048, 512, 64, reps=4)
                 go('NT', 6400, 512, 512, 64, reps=4)
         sys.exit(0)
+    if os.environ.get('GEMM_PMC_LAYOUTS'):   # the three operand layouts on the supernet / training shapes (LDS counters)
+        for d in (256, 512):
+            go('NT', 6400, d, d, 64, reps=4)
+            go('NT', 6400, 4 * d, d, 64, reps=4)
+            go('NN', 6400, d, 4 * d, 64, reps=4)
+            go('TN', d, 4 * d, 6400, 64, reps=4, acc=True)
+        go('NT', 8192, 2048, 2048, 128, reps=4)
+        sys.exit(0)
     for tile in (64, 128):
         go('NT', 8192, 2048, 2048, tile)
         go('NT', 6400, 2048, 512, tile)

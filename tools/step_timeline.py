@@ -19,8 +19,10 @@ def main():
     f = root if root.endswith('.csv') else sorted(glob.glob(os.path.join(root, '**', '*kernel_trace.csv'), recursive=True))[0]
     rows = []
     for r in csv.DictReader(open(f)):
+        # (queue / stream id in the name column's tail when the trace has one: launches of a communication stream show as q1, q2 ...)
+        q = r.get('Queue_Id') or r.get('Stream_Id') or ''
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1),
-                     r['Kernel_Name']))
+                     r['Kernel_Name'] if not q else r['Kernel_Name'].split('(')[0] + ' @q' + str(q)))
     rows.sort()
     starts = [i for i, r in enumerate(rows) if marker in r[3]]
     if len(starts) < 3:
