@@ -250,6 +250,18 @@ int mmnas_onehot_rows(float* out, int rows, int width, const int* idx_host, void
  * ------------------------------------------------------------------------------------------ */
 #define MMNAS_MIXED_MAX 8
 size_t mmnas_mixed_sum_ws_floats(void);   /* host only */
+/* Node epilogue of the architecture step in one pass: out[M,d] = sum_j gate[j] * LN_j(z_j), LN_j the candidate's own
+ * LayerNorm (modules.py:52-56; ln_a[j] == NULL: z_j is taken as the candidate's output as it stands) -- replaces the n
+ * LayerNorm launches at the end of the n candidate operators plus the gated sum (mixed.py:59-68); the candidates' outputs
+ * themselves are never stored.  z / ln_a / ln_b: HOST arrays of n device pointers (n <= MMNAS_MIXED_MAX, d <= 1024);
+ * z[j] == NULL: candidate j of the node was not evaluated (mode 'two') -- no term in the sum, no gate gradient.
+ * bwd: dgate[j] += <dout, LN_j(z_j)> (recomputed from z_j), d_active = gate[active] * dout (NULL: skip);
+ * ws: mmnas_mixed_sum_ws_floats() floats. */
+int mmnas_node_mix_fwd(const float* const* z, const float* const* ln_a, const float* const* ln_b, int n, const float* gate,
+                       float* out, int M, int d, float eps, void* stream);
+int mmnas_node_mix_bwd(const float* const* z, const float* const* ln_a, const float* const* ln_b, int n, const float* gate,
+                       const float* dout, float* d_active, int active, float* dgate, float* ws, int M, int d, float eps,
+                       void* stream);
 int mmnas_mixed_sum_fwd(const float* const* outs_host, int n, const float* gate, float* out, size_t count,
                         void* stream);
 int mmnas_mixed_sum_bwd(const float* const* outs_host, int n, const float* gate, const float* dout,
@@ -261,6 +273,14 @@ int mmnas_alpha_full_step(float* prob, const float* gate_grad, float* m, float* 
  * int64 token indices -- straight into the (already zeroed or accumulating) gradient buffer instead of a dense
  * [V, E] temporary.  Indices outside [0, V) are ignored. */
 int mmnas_embedding_bwd(const long* idx, const float* dy, float* dW, long n_tok, int E, long V, void* stream);
+/* The same with a fixed summation order (token order, no atomics) and a scale: dW[idx[t]] += scale * dy[t].  For the
+ * data-parallel exchange of the embedding gradient (mmnas_amd/dp.py RowExchange: ranks all-gather (idx, dy) -- ~1 MB --
+ * instead of all-reducing the dense [V, E] table -- 24 MB, what DDP does at search_vqa.py:292 -- and every rank applies all
+ * of them itself): the ranks' tables stay bitwise identical.  E <= 1024.  ws: mmnas_embedding_bwd_det_ws_floats(n_tok, E)
+ * floats of scratch (per-chunk partial rows). */
+size_t mmnas_embedding_bwd_det_ws_floats(long n_tok, int E);   /* host only */
+int mmnas_embedding_bwd_det(const long* idx, const float* dy, float* dW, float* ws, long n_tok, int E, long V, float scale,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Relation bias of RelMHAtt (modules.py:231-235):
@@ -422,12 +442,17 @@ int mmnas_mlp_op_bwd(const mmnas_mlp_op* op, void* stream);
  *   event per operator (use_side_stream == 2: only the relation-bias backward moves).  mmnas_chain_join(main, waiting) makes `waiting` wait for everything issued to main's side
  *   stream so far -- call it (with waiting = main) before anything reads the parameter gradients.
  * ------------------------------------------------------------------------------------------ */
-#define MMNAS_CHAIN_MAX_OPS 64
+#define MMNAS_CHAIN_MAX_OPS 128
 enum { MMNAS_CHAIN_ATT = 0, MMNAS_CHAIN_MLP = 1 };
 typedef struct mmnas_chain_op {
   int kind, on_y;
   mmnas_att_op att;
   mmnas_mlp_op mlp;
+  /* mixed chains (mmnas_chain.mixed = 1; MixedOp.forward in modes 'full' / 'two', mixed.py:59-68): consecutive operators
+   * with the same `node` are the evaluated candidates of one supernet node -- all read the node's input, the node's
+   * output is sum_j gate[node][cand_j] * output_j.  Exactly one of them has detached = 0: the sampled candidate, the only
+   * one differentiated; the others contribute their output to the sum and to the gate gradients only. */
+  int node, cand, detached, reserved;
 } mmnas_chain_op;
 typedef struct mmnas_chain {
   int n_ops;
@@ -445,6 +470,12 @@ typedef struct mmnas_chain {
    * launches -- a data-parallel reducer waits on it to start a bucket's all-reduce while the operators in front of i
    * (issued later) still run.  NULL: no marks. */
   void* const* marks;
+  /* architecture step: gate / dgate = the [n_nodes, gate_width] blocks of the nodes' binary gates and of their gradients
+   * (row = node, column = candidate; dgate[node][cand] += <d node output, candidate output>).  Candidates' LayerNorms
+   * and the gated sum run as one kernel per node and direction (mmnas_node_mix_fwd/bwd). */
+  int mixed, gate_width;
+  const float* gate;
+  float* dgate;
 } mmnas_chain;
 int mmnas_chain_plan(const mmnas_chain* c, size_t* arena_bytes);   /* host only */
 int mmnas_chain_fwd(const mmnas_chain* c, void* stream);

@@ -64,7 +64,8 @@ class MlpOp(C.Structure):
 
 
 class ChainOp(C.Structure):
-    _fields_ = [('kind', C.c_int), ('on_y', C.c_int), ('att', AttOp), ('mlp', MlpOp)]
+    _fields_ = [('kind', C.c_int), ('on_y', C.c_int), ('att', AttOp), ('mlp', MlpOp),
+                ('node', C.c_int), ('cand', C.c_int), ('detached', C.c_int), ('reserved', C.c_int)]
 
 
 class Chain(C.Structure):
@@ -72,10 +73,10 @@ class Chain(C.Structure):
                 ('d', C.c_int), ('x_in', _fp), ('y_in', _fp), ('x_mask', _fp), ('y_mask', _fp), ('x_rel', _fp),
                 ('y_rel', _fp), ('arena', _fp), ('x_out', _fp), ('y_out', _fp), ('dx_out', _fp), ('dy_out', _fp),
                 ('dx_in', _fp), ('dy_in', _fp), ('use_side_stream', C.c_int), ('reserved', C.c_int),
-                ('marks', C.c_void_p)]
+                ('marks', C.c_void_p), ('mixed', C.c_int), ('gate_width', C.c_int), ('gate', _fp), ('dgate', _fp)]
 
 
-CHAIN_MAX_OPS = 64
+CHAIN_MAX_OPS = 128
 
 
 class AttFlatSide(C.Structure):
@@ -142,6 +143,10 @@ SYMBOLS = {
     'mmnas_mixed_sum_bwd': (_i, [C.POINTER(_fp), _i, _fp, _fp, _fp, _i, _fp, _fp, _sz, _fp]),
     'mmnas_alpha_full_step': (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _f, _f, _f, _f, _i, _fp]),
     'mmnas_embedding_bwd': (_i, [_fp, _fp, _fp, C.c_long, _i, C.c_long, _fp]),
+    'mmnas_node_mix_fwd': (_i, [_fp, _fp, _fp, _i, _fp, _fp, _i, _i, _f, _fp]),
+    'mmnas_node_mix_bwd': (_i, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _f, _fp]),
+    'mmnas_embedding_bwd_det': (_i, [_fp, _fp, _fp, _fp, C.c_long, _i, C.c_long, _f, _fp]),
+    'mmnas_embedding_bwd_det_ws_floats': (_sz, [C.c_long, _i]),
     'mmnas_rel_fused_supported': (_i, [_i, _i, _i]),
     'mmnas_rel_fused_fwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     'mmnas_rel_fused_bwd_ws_floats': (_sz, [_i, _i, _i]),

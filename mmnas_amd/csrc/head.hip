@@ -310,6 +310,86 @@ __global__ void __launch_bounds__(256) embedding_bwd_kernel(const long* __restri
 }
 }  // namespace mmnas
 
+namespace mmnas {
+// The same scatter-add with a FIXED summation order and no atomics, in two levels (the padding token alone is half of a
+// batch's tokens: one workgroup adding ~450 rows one after the other took 180 us):
+//   1. chunks of 64 tokens: workgroup t owns token t's row inside its chunk if t is the first token of the chunk holding
+//      it, and writes the sum of the chunk's rows with that index, in token order, to part[t];
+//   2. workgroup t owns the row globally if t is the first token of the whole batch holding it, and adds the chunk sums
+//      part[first token of the row in chunk c], c ascending, onto dW (scaled).
+// Used by the data-parallel exchange of the embedding gradient (dp.RowExchange): every rank applies the gathered
+// (index, dy) pairs of all ranks itself, and the ranks' tables must stay bitwise identical -- which float atomics do not
+// promise.  One wave's ballot over a chunk's 64 indices finds the owners.
+__global__ void __launch_bounds__(256) embedding_bwd_det1_kernel(const long* __restrict__ idx, const float* __restrict__ dy,
+                                                                 float* __restrict__ part, int n_tok, int E, long V) {
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const long row = idx[t];
+  if (row < 0 || row >= V) return;
+  const int c0 = t & ~63, j = c0 + lane;
+  // (every wave forms the chunk's match mask itself: no LDS, no barrier)
+  unsigned long long mm = __ballot(j < n_tok && idx[j] == row);
+  if (mm & ((1ull << (t - c0)) - 1ull)) return;          // an earlier token of the chunk owns the row
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};                    // columns tid, tid + 256, ... (E <= 1024)
+  while (mm) {
+    const float* src = dy + (size_t)(c0 + __builtin_ctzll(mm)) * E;
+    mm &= mm - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (tid + 256 * k < E) acc[k] += src[tid + 256 * k];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (tid + 256 * k < E) part[(size_t)t * E + tid + 256 * k] = acc[k];
+}
+
+__global__ void __launch_bounds__(256) embedding_bwd_det2_kernel(const long* __restrict__ idx, const float* __restrict__ part,
+                                                                 float* __restrict__ dW, int n_tok, int E, long V, float scale) {
+  __shared__ int first_of[4];
+  __shared__ int earlier;
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long row = idx[t];
+  if (row < 0 || row >= V) return;
+  if (tid == 0) earlier = 0;
+  __syncthreads();
+  for (int j = tid; j < t; j += 256)
+    if (idx[j] == row) earlier = 1;   // (benign race: every writer stores 1)
+  __syncthreads();
+  if (earlier) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int base = t & ~63; base < n_tok; base += 256) {   // four chunks per round, one per wave
+    const int j = base + 64 * wave + lane;
+    const unsigned long long mm = __ballot(j < n_tok && idx[j] == row);
+    if (lane == 0) first_of[wave] = mm ? base + 64 * wave + __builtin_ctzll(mm) : -1;
+    __syncthreads();
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+      const int f = first_of[w];
+      if (f < 0) continue;
+      const float* src = part + (size_t)f * E;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (tid + 256 * k < E) acc[k] += src[tid + 256 * k];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (tid + 256 * k < E) dW[row * E + tid + 256 * k] += acc[k] * scale;
+}
+}  // namespace mmnas
+
+extern "C" size_t mmnas_embedding_bwd_det_ws_floats(long n_tok, int E) { return (size_t)(n_tok > 0 ? n_tok : 0) * (size_t)(E > 0 ? E : 0); }
+
+extern "C" int mmnas_embedding_bwd_det(const long* idx, const float* dy, float* dW, float* ws, long n_tok, int E, long V, float scale,
+                                       void* stream) {
+  MMNAS_REQUIRE(idx && dy && dW && ws && n_tok > 0 && E > 0 && V > 0, MMNAS_E_ARG, "embedding_bwd_det: bad arguments");
+  MMNAS_REQUIRE(E <= 1024 && n_tok < (1l << 30), MMNAS_E_SHAPE, "embedding_bwd_det: E=%d (<= 1024) n_tok=%ld", E, n_tok);
+  hipStream_t st = (hipStream_t)stream;
+  MMNAS_LAUNCH(embedding_bwd_det1_kernel, dim3((unsigned)n_tok), dim3(256), 0, st, idx, dy, ws, (int)n_tok, E, V);
+  MMNAS_LAUNCH(embedding_bwd_det2_kernel, dim3((unsigned)n_tok), dim3(256), 0, st, idx, (const float*)ws, dW, (int)n_tok, E, V, scale);
+  return check_launch("embedding_bwd_det");
+}
+
 extern "C" int mmnas_embedding_bwd(const long* idx, const float* dy, float* dW, long n_tok, int E, long V, void* stream) {
   MMNAS_REQUIRE(idx && dy && dW && n_tok > 0 && E > 0 && V > 0, MMNAS_E_ARG, "embedding_bwd: bad arguments");
   MMNAS_LAUNCH(embedding_bwd_kernel, dim3((unsigned)cdiv(n_tok * E, 256)), dim3(256), 0, (hipStream_t)stream, idx, dy, dW, n_tok, E, V);

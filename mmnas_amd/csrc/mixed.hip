@@ -5,6 +5,7 @@
 //   * the architecture-parameter update of all nodes in one launch: dL/dalpha from dL/dgate (mixed.py:171-198,
 //     'full' mode) followed by the Adam step of alpha_optim (search_vqa.py:194,331-332).
 // HBM-bound streaming kernels (one pass over the candidate outputs).
+#include <string.h>
 #include "common.h"
 
 namespace mmnas {
@@ -93,6 +94,146 @@ __global__ void __launch_bounds__(256) mixed_sum_reduce_kernel(const float* __re
   }
 }
 
+// ---- node epilogue of the architecture step: every candidate's LayerNorm AND the gated sum in one pass ----
+// A supernet node in modes 'full' / 'two' evaluates n candidates on the same input; each ends in its own LayerNorm
+// (modules.py:52-56, wrapper :266-268) and the node's output is sum_j gate_j LN_j(z_j) (mixed.py:59-68).  As separate
+// launches that is n LayerNorm kernels (read z_j, write y_j) plus the gated sum (read every y_j, write out): 2n + 1
+// passes over [M, d] and n + 1 launches per node, 30 nodes per step.  Here: one wave per row reads the n pre-LayerNorm
+// rows, normalises each in registers and writes only the node output -- n + 1 passes, one launch; the candidates' own
+// outputs y_j are never stored.  The backward needs them once more for the gate gradients <dout, y_j>: it recomputes
+// them from z_j the same way.  A candidate without LayerNorm (or one whose kernel normalised already) passes
+// ln_a = NULL and its output as z.
+struct NodeMixArgs {
+  const float* z[MAXC];
+  const float* a[MAXC];
+  const float* b[MAXC];
+  int n;
+};
+
+template <int NV>
+__device__ __forceinline__ void node_ln_row(float4 (&v)[NV], const float* __restrict__ a, const float* __restrict__ b, int lane, int d,
+                                            float eps) {
+  // (the arithmetic of ln_fwd_kernel, rowops.hip, operation for operation)
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum(s) / (float)d;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < d) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+  }
+  const float sd = sqrtf(wave_sum(ss) / (float)(d - 1));
+  const float inv = 1.0f / (sd + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < d) {
+      const float4 av = *reinterpret_cast<const float4*>(a + c);
+      const float4 bv = *reinterpret_cast<const float4*>(b + c);
+      v[i].x = av.x * v[i].x * inv + bv.x; v[i].y = av.y * v[i].y * inv + bv.y;
+      v[i].z = av.z * v[i].z * inv + bv.z; v[i].w = av.w * v[i].w * inv + bv.w;
+    }
+  }
+}
+
+template <int NV>
+__global__ void __launch_bounds__(256) node_mix_fwd_kernel(NodeMixArgs p, const float* __restrict__ gate, float* __restrict__ out,
+                                                           int M, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float4 acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 v[MAXC][NV];
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j)     // every candidate's row in flight before the first reduction
+    if (j < p.n && p.z[j]) {         // (z == NULL: a candidate of the node that was not evaluated -- mode 'two')
+      const float* zr = p.z[j] + (size_t)row * d;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        v[j][i] = (c < d) ? *reinterpret_cast<const float4*>(zr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j)
+    if (j < p.n && p.z[j]) {
+      if (p.a[j]) node_ln_row<NV>(v[j], p.a[j], p.b[j], lane, d, eps);
+      const float g = gate[j];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) { acc[i].x += g * v[j][i].x; acc[i].y += g * v[j][i].y; acc[i].z += g * v[j][i].z; acc[i].w += g * v[j][i].w; }
+    }
+  float* o = out + (size_t)row * d;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < d) *reinterpret_cast<float4*>(o + c) = acc[i];
+  }
+}
+
+// part[blockIdx.x][j] = sum over this workgroup's rows of <dout, LN_j(z_j)>; d_active = gate[active] * dout
+template <int NV>
+__global__ void __launch_bounds__(256) node_mix_bwd_kernel(NodeMixArgs p, const float* __restrict__ gate, const float* __restrict__ dout,
+                                                           float* __restrict__ d_active, int active, float* __restrict__ part,
+                                                           int M, int d, float eps) {
+  __shared__ float red[4][MAXC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float s[MAXC];
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) s[j] = 0.f;
+  const float ga = d_active ? gate[active] : 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    float4 g4[NV];
+    const float* dr = dout + (size_t)row * d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      g4[i] = (c < d) ? *reinterpret_cast<const float4*>(dr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 v[MAXC][NV];
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j)
+      if (j < p.n && p.z[j]) {
+        const float* zr = p.z[j] + (size_t)row * d;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int c = (lane + 64 * i) * 4;
+          v[j][i] = (c < d) ? *reinterpret_cast<const float4*>(zr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    if (d_active) {
+      float* ar = d_active + (size_t)row * d;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) *reinterpret_cast<float4*>(ar + c) = make_float4(ga * g4[i].x, ga * g4[i].y, ga * g4[i].z, ga * g4[i].w);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j)
+      if (j < p.n && p.z[j]) {
+        if (p.a[j]) node_ln_row<NV>(v[j], p.a[j], p.b[j], lane, d, eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          s[j] += (g4[i].x * v[j][i].x + g4[i].y * v[j][i].y) + (g4[i].z * v[j][i].z + g4[i].w * v[j][i].w);
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) {
+    const float t = wave_sum(s[j]);
+    if (lane == 0) red[wave][j] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < MAXC)
+    part[(size_t)blockIdx.x * MAXC + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // one thread per node (row): 'full'-mode architecture gradient + Adam
 __global__ void alpha_full_step_kernel(float* __restrict__ prob, const float* __restrict__ gate_grad, float* __restrict__ m,
                                        float* __restrict__ v, float* __restrict__ prob_grad, int rows, int width, float lr,
@@ -174,4 +315,60 @@ extern "C" int mmnas_alpha_full_step(float* prob, const float* gate_grad, float*
   MMNAS_LAUNCH(alpha_full_step_kernel, dim3(cdiv(rows, 64)), dim3(64), 0, (hipStream_t)stream, prob, gate_grad, m, v, prob_grad,
                rows, width, lr, beta1, beta2, eps, c1, c2s);
   return check_launch("alpha_full_step");
+}
+
+
+namespace mmnas {
+static int node_args(NodeMixArgs& a, const float* const* z, const float* const* ln_a, const float* const* ln_b, int n, int d, const char* who) {
+  MMNAS_REQUIRE(z && n >= 1 && n <= MAXC, MMNAS_E_SHAPE, "%s: 1..%d candidates, got %d", who, MAXC, n);
+  MMNAS_REQUIRE(d >= 4 && d % 4 == 0 && d <= 1024, MMNAS_E_SHAPE, "%s: d=%d (multiple of 4, <= 1024)", who, d);
+  memset(&a, 0, sizeof(a));
+  a.n = n;
+  for (int j = 0; j < n; ++j) {
+    a.z[j] = z[j];
+    a.a[j] = ln_a ? ln_a[j] : nullptr;
+    a.b[j] = ln_b ? ln_b[j] : nullptr;
+    MMNAS_REQUIRE(((uintptr_t)a.z[j] & 15) == 0, MMNAS_E_ARG, "%s: candidate %d: unaligned input", who, j);   // (NULL: not evaluated)
+    MMNAS_REQUIRE(!a.a[j] || (a.b[j] && (((uintptr_t)a.a[j] | (uintptr_t)a.b[j]) & 15) == 0), MMNAS_E_ARG, "%s: candidate %d: LayerNorm parameters", who, j);
+    if (d < 2) MMNAS_REQUIRE(!a.a[j], MMNAS_E_SHAPE, "%s: LayerNorm needs d >= 2", who);
+  }
+  return MMNAS_OK;
+}
+}  // namespace mmnas
+
+extern "C" int mmnas_node_mix_fwd(const float* const* z, const float* const* ln_a, const float* const* ln_b, int n, const float* gate,
+                                  float* out, int M, int d, float eps, void* stream) {
+  NodeMixArgs a;
+  int rc = node_args(a, z, ln_a, ln_b, n, d, "mmnas_node_mix_fwd");
+  if (rc) return rc;
+  MMNAS_REQUIRE(gate && out && M >= 0, MMNAS_E_ARG, "mmnas_node_mix_fwd: null pointer");
+  if (M == 0) return MMNAS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MMNAS_K_ROWOPS, (2.0 * n + 8.0 * n) * M * d, 4.0 * (n + 1) * M * d, st, "node_mix_fwd");
+  const dim3 grid(cdiv(M, 4)), block(256);
+  if (d <= 256) MMNAS_LAUNCH((node_mix_fwd_kernel<1>), grid, block, 0, st, a, gate, out, M, d, eps);
+  else if (d <= 512) MMNAS_LAUNCH((node_mix_fwd_kernel<2>), grid, block, 0, st, a, gate, out, M, d, eps);
+  else MMNAS_LAUNCH((node_mix_fwd_kernel<4>), grid, block, 0, st, a, gate, out, M, d, eps);
+  return check_launch("node_mix_fwd");
+}
+
+extern "C" int mmnas_node_mix_bwd(const float* const* z, const float* const* ln_a, const float* const* ln_b, int n, const float* gate,
+                                  const float* dout, float* d_active, int active, float* dgate, float* ws, int M, int d, float eps,
+                                  void* stream) {
+  NodeMixArgs a;
+  int rc = node_args(a, z, ln_a, ln_b, n, d, "mmnas_node_mix_bwd");
+  if (rc) return rc;
+  MMNAS_REQUIRE(gate && dout && dgate && ws && M >= 0, MMNAS_E_ARG, "mmnas_node_mix_bwd: null pointer");
+  MMNAS_REQUIRE(!d_active || (active >= 0 && active < n), MMNAS_E_ARG, "mmnas_node_mix_bwd: active index out of range");
+  if (M == 0) return MMNAS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int g = cdiv(M, 4);
+  if (g > 2048) g = 2048;
+  ProfScope ps(MMNAS_K_ROWOPS, (2.0 * n + 8.0 * n) * M * d, 4.0 * (n + 2) * M * d, st, "node_mix_bwd");
+  const dim3 grid(g), block(256);
+  if (d <= 256) MMNAS_LAUNCH((node_mix_bwd_kernel<1>), grid, block, 0, st, a, gate, dout, d_active, active, ws, M, d, eps);
+  else if (d <= 512) MMNAS_LAUNCH((node_mix_bwd_kernel<2>), grid, block, 0, st, a, gate, dout, d_active, active, ws, M, d, eps);
+  else MMNAS_LAUNCH((node_mix_bwd_kernel<4>), grid, block, 0, st, a, gate, dout, d_active, active, ws, M, d, eps);
+  MMNAS_LAUNCH(mixed_sum_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, g, n, dgate);
+  return check_launch("node_mix_bwd");
 }

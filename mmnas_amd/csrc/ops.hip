@@ -94,7 +94,18 @@ extern "C" int mmnas_att_op_plan(const mmnas_att_op* op, mmnas_plan* plan) {
   return MMNAS_OK;
 }
 
+namespace mmnas {
+// defer_ln (mixed chains): with NORM the operator stops behind its residual sum z (saved block) and writes no output --
+// the node epilogue (mmnas_node_mix_fwd) normalises every candidate of the node and forms the gated sum in one pass.
+// *ln_done tells the caller whether the output was normalised here after all (the one-launch short-sequence kernel).
+static int att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_ln, bool* ln_done);
+}
 extern "C" int mmnas_att_op_fwd(const mmnas_att_op* op, void* stream) {
+  bool done;
+  return mmnas::att_fwd_impl(op, stream, false, &done);
+}
+static int mmnas::att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_ln, bool* ln_done) {
+  *ln_done = true;
   int rc = att_check(op, "att_op_fwd");
   if (rc) return rc;
   MMNAS_REQUIRE(op->xq && op->xkv && op->Wq && op->Wk && op->Wv && op->Wm && op->y && op->save, MMNAS_E_ARG,
@@ -143,6 +154,7 @@ extern "C" int mmnas_att_op_fwd(const mmnas_att_op* op, void* stream) {
   if (drop) { g.drop_p = op->drop_p; g.drop_site = 1; g.drop_seed = op->seed; }
   if ((rc = mmnas_gemm(&g, stream))) return rc;
 
+  if (norm && defer_ln) { *ln_done = false; return MMNAS_OK; }
   if (norm) return mmnas_layernorm_fwd(L.z, op->ln_a, op->ln_b, op->y, (int)L.Mq, d, op->eps, stream);
   return MMNAS_OK;
 }
@@ -364,7 +376,15 @@ extern "C" int mmnas_mlp_op_plan(const mmnas_mlp_op* op, mmnas_plan* plan) {
   return MMNAS_OK;
 }
 
+namespace mmnas {
+static int mlp_fwd_impl(const mmnas_mlp_op* op, void* stream, bool defer_ln, bool* ln_done);
+}
 extern "C" int mmnas_mlp_op_fwd(const mmnas_mlp_op* op, void* stream) {
+  bool done;
+  return mmnas::mlp_fwd_impl(op, stream, false, &done);
+}
+static int mmnas::mlp_fwd_impl(const mmnas_mlp_op* op, void* stream, bool defer_ln, bool* ln_done) {
+  *ln_done = true;
   int rc = mlp_check(op, "mlp_op_fwd");
   if (rc) return rc;
   MMNAS_REQUIRE(op->x && op->y && op->save, MMNAS_E_ARG, "mlp_op_fwd: null pointer");
@@ -392,6 +412,7 @@ extern "C" int mmnas_mlp_op_fwd(const mmnas_mlp_op* op, void* stream) {
     if ((rc = mmnas_gemm(&g, stream))) return rc;
     in = L.h[i + 1];
   }
+  if (norm && defer_ln) { *ln_done = false; return MMNAS_OK; }
   if (norm) return mmnas_layernorm_fwd(L.z, op->ln_a, op->ln_b, op->y, op->M, d, op->eps, stream);
   return MMNAS_OK;
 }
@@ -499,6 +520,9 @@ struct ChainLayout {
       tmp[MMNAS_CHAIN_MAX_OPS];
   size_t dpre, encdy, total;
   int last_x, last_y, first_x, first_y, n_guided;
+  // mixed chains: per node (indexed by the node's first operator) the node output and the sampled candidate's output
+  // gradient; one scratch block for the gate-gradient partials
+  size_t nout[MMNAS_CHAIN_MAX_OPS], ndact[MMNAS_CHAIN_MAX_OPS], mixws;
 };
 
 static int chain_check(const mmnas_chain* c, const char* who) {
@@ -513,6 +537,26 @@ static int chain_check(const mmnas_chain* c, const char* who) {
     else MMNAS_REQUIRE(!seen_y, MMNAS_E_ARG, "%s: encoder operators must precede the decoder's (operator %d)", who, i);
     if (o.kind == MMNAS_CHAIN_ATT && !(o.att.flags & MMNAS_F_SELF))
       MMNAS_REQUIRE(o.on_y, MMNAS_E_ARG, "%s: operator %d: guided attention needs the decoder stream", who, i);
+  }
+  if (c->mixed) {
+    MMNAS_REQUIRE(c->gate && c->gate_width >= 1 && c->gate_width <= MMNAS_MIXED_MAX, MMNAS_E_ARG, "%s: mixed chain without a gate block (width %d)", who, c->gate_width);
+    MMNAS_REQUIRE(!c->use_side_stream, MMNAS_E_ARG, "%s: mixed chains run on one stream", who);
+    MMNAS_REQUIRE(c->d <= 1024, MMNAS_E_SHAPE, "%s: mixed chains need d <= 1024", who);
+    int node = -1, live = 0, count = 0;
+    for (int i = 0; i < c->n_ops; ++i) {
+      const mmnas_chain_op& o = c->ops[i];
+      if (o.node != node) {
+        MMNAS_REQUIRE(o.node == node + 1, MMNAS_E_ARG, "%s: operator %d: node %d after node %d", who, i, o.node, node);
+        MMNAS_REQUIRE(node < 0 || live == 1, MMNAS_E_ARG, "%s: node %d has %d differentiated candidates (exactly one)", who, node, live);
+        node = o.node; live = 0; count = 0;
+      } else {
+        MMNAS_REQUIRE(o.on_y == c->ops[i - 1].on_y, MMNAS_E_ARG, "%s: node %d mixes the two streams", who, node);
+      }
+      MMNAS_REQUIRE(o.cand >= 0 && o.cand < c->gate_width, MMNAS_E_ARG, "%s: operator %d: candidate %d outside the gate row", who, i, o.cand);
+      MMNAS_REQUIRE(++count <= MMNAS_MIXED_MAX, MMNAS_E_SHAPE, "%s: node %d has more than %d candidates", who, node, MMNAS_MIXED_MAX);
+      live += o.detached ? 0 : 1;
+    }
+    MMNAS_REQUIRE(live == 1, MMNAS_E_ARG, "%s: node %d has %d differentiated candidates (exactly one)", who, node, live);
   }
   return MMNAS_OK;
 }
@@ -558,12 +602,28 @@ static int chain_layout(const mmnas_chain* c, ChainLayout& L) {
     L.save[i] = take(pl.save_bytes);
     L.ws[i] = take(pl.ws_bwd_bytes);
     L.dx[i] = take(n);
-    const bool guided = o.kind == MMNAS_CHAIN_ATT && !(a.flags & MMNAS_F_SELF);
+    const bool guided = o.kind == MMNAS_CHAIN_ATT && !(a.flags & MMNAS_F_SELF) && !(c->mixed && o.detached);
     L.tmp[i] = 0;   // (guided operators add their key / value gradient straight into dpre)
     L.n_guided += guided;
   }
   L.dpre = take(nx);
   L.encdy = take(nx);
+  L.mixws = 0;
+  if (c->mixed) {
+    for (int i = 0; i < c->n_ops; ++i) {
+      const bool first = i == 0 || c->ops[i].node != c->ops[i - 1].node;
+      L.nout[i] = first ? take(c->ops[i].on_y ? ny : nx) : 0;
+      L.ndact[i] = first ? take(c->ops[i].on_y ? ny : nx) : 0;
+    }
+    L.mixws = take(mmnas_mixed_sum_ws_floats() * sizeof(float));
+    // (streams' first / last markers refer to NODES here: the first operator of the first / last node of a stream)
+    L.last_x = L.last_y = L.first_x = L.first_y = -1;
+    for (int i = 0; i < c->n_ops; ++i) {
+      if (!(i == 0 || c->ops[i].node != c->ops[i - 1].node)) continue;
+      if (c->ops[i].on_y) { if (L.first_y < 0) L.first_y = i; L.last_y = i; }
+      else { if (L.first_x < 0) L.first_x = i; L.last_x = i; }
+    }
+  }
   L.total = off;
   return MMNAS_OK;
 }
@@ -651,6 +711,182 @@ extern "C" int mmnas_chain_plan(const mmnas_chain* c, size_t* arena_bytes) {
   return MMNAS_OK;
 }
 
+namespace mmnas {
+// ---- mixed chains: the architecture step (MixedOp modes 'full' / 'two') ----
+// Per node: every evaluated candidate's forward up to its pre-LayerNorm sum, then ONE epilogue launch that normalises
+// all of them and forms the gated node output (mmnas_node_mix_fwd).  Backward: one launch turns the node's output
+// gradient into the gate gradients of all candidates (their outputs recomputed from the saved sums) and the sampled
+// candidate's output gradient; only that candidate's backward runs.
+struct NodeView { int first, n, active; const float* z[MMNAS_MIXED_MAX]; const float* a[MMNAS_MIXED_MAX]; const float* b[MMNAS_MIXED_MAX]; int cand[MMNAS_MIXED_MAX]; };
+
+// z / LayerNorm pointers of operator i (buffers from the arena): what the node epilogue reads for this candidate
+static void chain_cand_view(const mmnas_chain* c, const ChainLayout& L, int i, bool ln_done, const float** z, const float** la, const float** lb) {
+  char* base = (char*)c->arena;
+  const mmnas_chain_op& o = c->ops[i];
+  mmnas_att_op a; mmnas_mlp_op m;
+  chain_op_setup(c, i, a, m);
+  const bool norm = (o.kind == MMNAS_CHAIN_ATT ? a.flags : m.flags) & MMNAS_F_NORM;
+  if (!norm || ln_done) { *z = (const float*)(base + L.y[i]); *la = nullptr; *lb = nullptr; return; }
+  if (o.kind == MMNAS_CHAIN_ATT) {
+    a.save = base + L.save[i]; a.ws = nullptr;
+    *z = att_layout(&a).z; *la = a.ln_a; *lb = a.ln_b;
+  } else {
+    m.save = base + L.save[i]; m.ws = nullptr;
+    *z = mlp_layout(&m).z; *la = m.ln_a; *lb = m.ln_b;
+  }
+}
+
+// whether operator i's forward normalises its own output even when asked to defer (the one-launch short-sequence kernel)
+static bool chain_ln_done_in_op(const mmnas_chain* c, int i) {
+  const mmnas_chain_op& o = c->ops[i];
+  if (o.kind != MMNAS_CHAIN_ATT) return false;
+  mmnas_att_op a; mmnas_mlp_op m;
+  chain_op_setup(c, i, a, m);
+  return sa_small_applies(&a);
+}
+
+static int chain_fwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayout& L) {
+  char* base = (char*)c->arena;
+  const float* cur_x = c->x_in;
+  const float* cur_y = c->y_in;
+  const size_t nx = (size_t)c->B * c->Sx * c->d * sizeof(float), ny = (size_t)c->B * c->Sy * c->d * sizeof(float);
+  int rc;
+  for (int i0 = 0; i0 < c->n_ops;) {
+    int i1 = i0;
+    while (i1 < c->n_ops && c->ops[i1].node == c->ops[i0].node) ++i1;
+    const bool oy = c->ops[i0].on_y;
+    const float* cur = oy ? cur_y : cur_x;
+    const float* z[MMNAS_MIXED_MAX]; const float* la[MMNAS_MIXED_MAX]; const float* lb[MMNAS_MIXED_MAX];
+    float gate_order[MMNAS_MIXED_MAX];
+    (void)gate_order;
+    float eps = 1e-6f;
+    for (int i = i0; i < i1; ++i) {
+      const mmnas_chain_op& o = c->ops[i];
+      mmnas_att_op a; mmnas_mlp_op m;
+      chain_op_setup(c, i, a, m);
+      bool ln_done = true;
+      if (o.kind == MMNAS_CHAIN_ATT) {
+        a.xq = cur;
+        a.xkv = (a.flags & MMNAS_F_SELF) ? cur : cur_x;
+        a.y = (float*)(base + L.y[i]); a.save = base + L.save[i]; a.ws = base + L.ws[i];
+        if ((rc = att_fwd_impl(&a, st, true, &ln_done))) return rc;
+        if (a.flags & MMNAS_F_NORM) eps = a.eps;
+      } else {
+        m.x = cur; m.y = (float*)(base + L.y[i]); m.save = base + L.save[i]; m.ws = base + L.ws[i];
+        if ((rc = mlp_fwd_impl(&m, st, true, &ln_done))) return rc;
+        if (m.flags & MMNAS_F_NORM) eps = m.eps;
+      }
+      chain_cand_view(c, L, i, ln_done, &z[i - i0], &la[i - i0], &lb[i - i0]);
+    }
+    // the gate values of the node's candidates, in operator order: a row of the [n_nodes, width] block picked apart
+    // by candidate index -- the kernel reads gate[j] for operator j, so the operators are passed in candidate order
+    const float* zs[MMNAS_MIXED_MAX] = {nullptr}; const float* as[MMNAS_MIXED_MAX] = {nullptr}; const float* bs[MMNAS_MIXED_MAX] = {nullptr};
+    int width = 0;
+    for (int i = i0; i < i1; ++i) {
+      const int k = c->ops[i].cand;
+      zs[k] = z[i - i0]; as[k] = la[i - i0]; bs[k] = lb[i - i0];
+      if (k + 1 > width) width = k + 1;
+    }
+    // (candidates of the node that were not evaluated -- mode 'two' -- stay NULL: no term in the sum, no gate gradient)
+    float* out = i0 == L.last_x ? c->x_out : (i0 == L.last_y ? c->y_out : (float*)(base + L.nout[i0]));
+    const int M = c->B * (oy ? c->Sy : c->Sx);
+    if ((rc = mmnas_node_mix_fwd(zs, as, bs, width, c->gate + (size_t)c->ops[i0].node * c->gate_width, out, M, c->d, eps, st))) return rc;
+    if (oy) cur_y = out; else cur_x = out;
+    i0 = i1;
+  }
+  if (L.last_x < 0 && hipMemcpyAsync(c->x_out, c->x_in, nx, hipMemcpyDeviceToDevice, st) != hipSuccess) return MMNAS_E_LAUNCH;
+  if (L.last_y < 0 && hipMemcpyAsync(c->y_out, c->y_in, ny, hipMemcpyDeviceToDevice, st) != hipSuccess) return MMNAS_E_LAUNCH;
+  return MMNAS_OK;
+}
+
+static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayout& L) {
+  MMNAS_REQUIRE(c->dgate, MMNAS_E_ARG, "chain_bwd: mixed chain without a gate-gradient block");
+  char* base = (char*)c->arena;
+  const size_t ex = (size_t)c->B * c->Sx * c->d, ey = (size_t)c->B * c->Sy * c->d;
+  float* dpre = (float*)(base + L.dpre);
+  int rc;
+  if (L.n_guided && hipMemsetAsync(dpre, 0, ex * sizeof(float), st) != hipSuccess) return MMNAS_E_LAUNCH;
+  // node starts in order
+  int starts[MMNAS_CHAIN_MAX_OPS + 1], nn = 0;
+  for (int i = 0; i < c->n_ops; ++i)
+    if (i == 0 || c->ops[i].node != c->ops[i - 1].node) starts[nn++] = i;
+  starts[nn] = c->n_ops;
+  auto node_out = [&](int i0) -> const float* { return i0 == L.last_x ? c->x_out : (i0 == L.last_y ? c->y_out : (const float*)(base + L.nout[i0])); };
+  auto input_of = [&](int k) -> const float* {   // input of node k = output of the previous node on its stream
+    const bool oy = c->ops[starts[k]].on_y;
+    for (int j = k - 1; j >= 0; --j)
+      if ((bool)c->ops[starts[j]].on_y == oy) return node_out(starts[j]);
+    return oy ? c->y_in : c->x_in;
+  };
+  const float* x_final = L.last_x >= 0 ? c->x_out : c->x_in;
+  const float* cur_dy = c->dy_out;
+  for (int k = nn - 1; k >= 0; --k) {
+    const int i0 = starts[k], i1 = starts[k + 1];
+    const bool oy = c->ops[i0].on_y;
+    if (!oy && i0 == L.last_x) {   // entering the encoder: its output gradient = the head's + the guided operators'
+      MMNAS_REQUIRE(c->dx_out || L.n_guided, MMNAS_E_ARG, "chain_bwd: no gradient reaches the encoder (dx_out NULL, no guided operator)");
+      if (c->dx_out && L.n_guided) {
+        float* g0 = (float*)(base + L.encdy);
+        if ((rc = mmnas_drop_add(c->dx_out, dpre, g0, ex, 0.f, 0, 0, st))) return rc;
+        cur_dy = g0;
+      } else cur_dy = c->dx_out ? c->dx_out : dpre;
+    }
+    const float* zs[MMNAS_MIXED_MAX] = {nullptr}; const float* as[MMNAS_MIXED_MAX] = {nullptr}; const float* bs[MMNAS_MIXED_MAX] = {nullptr};
+    int width = 0, act = -1, act_op = -1;
+    float eps = 1e-6f;
+    for (int i = i0; i < i1; ++i) {
+      const int kc = c->ops[i].cand;
+      chain_cand_view(c, L, i, chain_ln_done_in_op(c, i), &zs[kc], &as[kc], &bs[kc]);
+      if (kc + 1 > width) width = kc + 1;
+      if (!c->ops[i].detached) { act = kc; act_op = i; }
+      const mmnas_chain_op& o = c->ops[i];
+      if (o.kind == MMNAS_CHAIN_ATT) { if (o.att.flags & MMNAS_F_NORM) eps = o.att.eps; }
+      else if (o.mlp.flags & MMNAS_F_NORM) eps = o.mlp.eps;
+    }
+    const float* nin = input_of(k);
+    float* dact = (float*)(base + L.ndact[i0]);
+    const int M = c->B * (oy ? c->Sy : c->Sx);
+    const size_t grow = (size_t)c->ops[i0].node * c->gate_width;
+    if ((rc = mmnas_node_mix_bwd(zs, as, bs, width, c->gate + grow, cur_dy, dact, act, c->dgate + grow, (float*)(base + L.mixws), M, c->d, eps, st)))
+      return rc;
+    // the sampled candidate's backward
+    const mmnas_chain_op& o = c->ops[act_op];
+    mmnas_att_op a; mmnas_mlp_op m;
+    chain_op_setup(c, act_op, a, m);
+    float* dx = i0 == L.first_x ? c->dx_in : (i0 == L.first_y ? c->dy_in : (float*)(base + L.dx[act_op]));
+    if (o.kind == MMNAS_CHAIN_ATT) {
+      const bool self = a.flags & MMNAS_F_SELF;
+      a.xq = nin;
+      a.xkv = self ? nin : x_final;
+      a.save = base + L.save[act_op]; a.ws = base + L.ws[act_op];
+      a.dy = dact; a.dxq = dx;
+      a.dxkv = self ? nullptr : dpre;
+      a.drel = nullptr;
+      if ((rc = att_bwd_impl(&a, st, nullptr, !self))) return rc;
+    } else {
+      m.x = nin; m.save = base + L.save[act_op]; m.ws = base + L.ws[act_op];
+      m.dy = dact; m.dx = dx;
+      if ((rc = mlp_bwd_impl(&m, st, nullptr))) return rc;
+    }
+    cur_dy = dx;
+    if (c->marks && c->marks[act_op] && hipEventRecord((hipEvent_t)c->marks[act_op], st) != hipSuccess) {
+      set_error("chain_bwd: cannot record the mark event of operator %d", act_op);
+      return MMNAS_E_LAUNCH;
+    }
+  }
+  if (L.first_y < 0 && hipMemcpyAsync(c->dy_in, c->dy_out, ey * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return MMNAS_E_LAUNCH;
+  if (L.first_x < 0) {
+    const float* g0 = c->dx_out;
+    if (c->dx_out && L.n_guided) {
+      if ((rc = mmnas_drop_add(c->dx_out, dpre, c->dx_in, ex, 0.f, 0, 0, st))) return rc;
+      g0 = nullptr;
+    } else if (!c->dx_out) g0 = dpre;
+    if (g0 && hipMemcpyAsync(c->dx_in, g0, ex * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return MMNAS_E_LAUNCH;
+  }
+  return MMNAS_OK;
+}
+}  // namespace mmnas
+
 extern "C" int mmnas_chain_fwd(const mmnas_chain* c, void* stream) {
   int rc = chain_check(c, "chain_fwd");
   if (rc) return rc;
@@ -658,6 +894,7 @@ extern "C" int mmnas_chain_fwd(const mmnas_chain* c, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   ChainLayout L;
   if ((rc = chain_layout(c, L))) return rc;
+  if (c->mixed) return chain_fwd_mixed(c, st, L);
   char* base = (char*)c->arena;
   const float* cur_x = c->x_in;
   const float* cur_y = c->y_in;
@@ -713,6 +950,7 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   ChainLayout L;
   if ((rc = chain_layout(c, L))) return rc;
+  if (c->mixed) return chain_bwd_mixed(c, st, L);
   SideCtx* sc = c->use_side_stream ? side_ctx(st, true) : nullptr;
   MMNAS_REQUIRE(!c->use_side_stream || sc, MMNAS_E_LAUNCH, "chain_bwd: cannot create the side stream");
   hipStream_t side = sc ? sc->side : nullptr;
@@ -736,6 +974,8 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
     return oy ? c->y_in : c->x_in;
   };
   const float* x_final = L.last_x >= 0 ? c->x_out : c->x_in;
+  const int G = first_guided(c);
+  const bool ovl = chain_overlap_on() && !c->use_side_stream && L.last_x >= 0 && L.first_y >= 0 && G > L.first_y;
   // one operator's backward on stream s: gradient of its output in, gradient of its input out (returned through *dxo)
   auto run = [&](int i, hipStream_t s, const float* dyi, const float** dxo) -> int {
     const mmnas_chain_op& o = c->ops[i];
@@ -758,7 +998,9 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
       if ((r = mlp_bwd_impl(&m, s, sq))) return r;
     }
     *dxo = dx;
-    if (c->marks && c->marks[i] && hipEventRecord((hipEvent_t)c->marks[i], s) != hipSuccess) {
+    // (encoder / decoder overlap: an event behind operator i on ONE of the two streams says nothing about the operators
+    //  with larger indices still running on the other -- the marks are recorded behind the join below instead)
+    if (!ovl && c->marks && c->marks[i] && hipEventRecord((hipEvent_t)c->marks[i], s) != hipSuccess) {
       set_error("chain_bwd: cannot record the mark event of operator %d", i);
       return MMNAS_E_LAUNCH;
     }
@@ -775,8 +1017,6 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
     } else *out = c->dx_out ? c->dx_out : dpre;
     return MMNAS_OK;
   };
-  const int G = first_guided(c);
-  const bool ovl = chain_overlap_on() && !c->use_side_stream && L.last_x >= 0 && L.first_y >= 0 && G > L.first_y;
   const float* cur_dy = c->dy_out;
   if (!ovl) {
     for (int i = c->n_ops - 1; i >= 0; --i) {
@@ -800,6 +1040,12 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
       if (id >= L.first_y && (rc = run(id--, st, cur_dy, &cur_dy))) return rc;
     }
     if ((rc = ev_fork(oc->enc, st, oc->ovl[3]))) return rc;
+    if (c->marks)
+      for (int i = 0; i < c->n_ops; ++i)
+        if (c->marks[i] && hipEventRecord((hipEvent_t)c->marks[i], st) != hipSuccess) {
+          set_error("chain_bwd: cannot record the mark event of operator %d", i);
+          return MMNAS_E_LAUNCH;
+        }
   }
   if (L.first_y < 0 && hipMemcpyAsync(c->dy_in, c->dy_out, ey * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return MMNAS_E_LAUNCH;
   if (L.first_x < 0) {

@@ -89,39 +89,68 @@ __global__ void dropout_mask_kernel(float* out, size_t n, DropCfg c) {
     out[i] = c.thresh ? drop_mult(c, (uint32_t)i) : 1.0f;
 }
 
-__global__ void pack_kernel(const mmnas_segment* segs, float* staging, float scale, int direction) {
-  const mmnas_segment s = segs[blockIdx.y];
+// Gather / scatter of gradient segments (DDP's bucket copies).  One 1-D grid over all segments: segment sizes differ by
+// 100x (a candidate's 1 MB of weights beside the 24 MB embedding table), so the work is cut into equal pieces of
+// PACK_PIECE floats and each workgroup takes pieces round-robin; a piece never crosses a segment (pieces are counted per
+// segment).  (Round 2 launched 64 workgroups per segment: the largest segment set the kernel's duration, 50 us for a
+// 24 MB bucket.)
+constexpr int PACK_PIECE = 8192;   // floats per piece: 8 float4 per thread
+__device__ __forceinline__ void pack_piece(const mmnas_segment s, float* staging, size_t piece, float scale, int direction) {
   float* stg = staging + s.offset;
-  const size_t n4 = (((uintptr_t)s.ptr & 15) == 0 && ((uintptr_t)stg & 15) == 0) ? (s.n >> 2) : 0;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  float4* p4 = reinterpret_cast<float4*>(s.ptr);
-  float4* s4 = reinterpret_cast<float4*>(stg);
-  for (size_t i = t0; i < n4; i += stride) {
-    if (direction == 0) { float4 v = p4[i]; v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; s4[i] = v; }
-    else { float4 v = s4[i]; v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; p4[i] = v; }
-  }
-  for (size_t i = (n4 << 2) + t0; i < s.n; i += stride) {
-    if (direction == 0) stg[i] = s.ptr[i] * scale; else s.ptr[i] = stg[i] * scale;
+  const size_t lo = piece * PACK_PIECE, hi = lo + PACK_PIECE < s.n ? lo + PACK_PIECE : s.n;
+  if ((((uintptr_t)s.ptr | (uintptr_t)stg) & 15) == 0) {
+    float4* p4 = reinterpret_cast<float4*>(s.ptr);
+    float4* s4 = reinterpret_cast<float4*>(stg);
+    const size_t l4 = lo >> 2, h4 = hi >> 2;
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {   // all loads of the piece in flight before the first store
+      const size_t i = l4 + threadIdx.x + 256 * k;
+      if (i < h4) v[k] = direction == 0 ? p4[i] : s4[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const size_t i = l4 + threadIdx.x + 256 * k;
+      if (i < h4) {
+        float4 w = v[k];
+        w.x *= scale; w.y *= scale; w.z *= scale; w.w *= scale;
+        if (direction == 0) s4[i] = w; else p4[i] = w;
+      }
+    }
+    for (size_t i = (h4 << 2) + threadIdx.x; i < hi; i += 256) {
+      if (direction == 0) stg[i] = s.ptr[i] * scale; else s.ptr[i] = stg[i] * scale;
+    }
+  } else {
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+      if (direction == 0) stg[i] = s.ptr[i] * scale; else s.ptr[i] = stg[i] * scale;
+    }
   }
 }
 
+// piece q of the whole table -> (segment, piece inside it); nseg <= 96: a linear walk of per-segment piece counts
+template <typename Table>
+__device__ __forceinline__ void pack_body(const Table& segs, int nseg, size_t npieces, float* staging, float scale, int direction) {
+  if (npieces == 0)   // (table on the device: the launcher could not count)
+    for (int k = 0; k < nseg; ++k) npieces += (segs[k].n + PACK_PIECE - 1) / PACK_PIECE;
+  for (size_t q = blockIdx.x; q < npieces; q += gridDim.x) {
+    size_t rest = q;
+    int k = 0;
+    for (; k < nseg; ++k) {
+      const size_t np = (segs[k].n + PACK_PIECE - 1) / PACK_PIECE;
+      if (rest < np) break;
+      rest -= np;
+    }
+    if (k < nseg) pack_piece(segs[k], staging, rest, scale, direction);
+  }
+}
+
+__global__ void pack_kernel(const mmnas_segment* segs, int nseg, size_t npieces, float* staging, float scale, int direction) {
+  pack_body(segs, nseg, npieces, staging, scale, direction);
+}
+
 struct PackArgs { mmnas_segment s[96]; };
-__global__ void pack_args_kernel(PackArgs a, float* staging, float scale, int direction) {
-  const mmnas_segment s = a.s[blockIdx.y];
-  float* stg = staging + s.offset;
-  const size_t n4 = (((uintptr_t)s.ptr & 15) == 0 && ((uintptr_t)stg & 15) == 0) ? (s.n >> 2) : 0;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  float4* p4 = reinterpret_cast<float4*>(s.ptr);
-  float4* s4 = reinterpret_cast<float4*>(stg);
-  for (size_t i = t0; i < n4; i += stride) {
-    if (direction == 0) { float4 v = p4[i]; v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; s4[i] = v; }
-    else { float4 v = s4[i]; v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; p4[i] = v; }
-  }
-  for (size_t i = (n4 << 2) + t0; i < s.n; i += stride) {
-    if (direction == 0) stg[i] = s.ptr[i] * scale; else s.ptr[i] = stg[i] * scale;
-  }
+__global__ void pack_args_kernel(PackArgs a, int nseg, size_t npieces, float* staging, float scale, int direction) {
+  pack_body(a.s, nseg, npieces, staging, scale, direction);
 }
 
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1,
@@ -198,11 +227,14 @@ extern "C" int mmnas_dropout_mask(float* out, size_t n, float p, uint64_t seed, 
   return check_launch("dropout_mask");
 }
 
+static int pack_grid(size_t npieces) { return (int)(npieces < 2048 ? (npieces ? npieces : 1) : 2048); }
+
 extern "C" int mmnas_pack_segments(const mmnas_segment* segs, int nseg, float* staging, float scale,
                                    int direction, void* stream) {
   if (nseg <= 0) return MMNAS_OK;
   MMNAS_REQUIRE(segs && staging, MMNAS_E_ARG, "mmnas_pack_segments: null pointer");
-  MMNAS_LAUNCH(pack_kernel, dim3(64, nseg), dim3(256), 0, (hipStream_t)stream, segs, staging, scale, direction);
+  // (the table lives on the device: the kernel counts the pieces itself)
+  MMNAS_LAUNCH(pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, segs, nseg, (size_t)0, staging, scale, direction);
   return check_launch("pack_segments");
 }
 
@@ -215,7 +247,9 @@ extern "C" int mmnas_pack_segments_host(const mmnas_segment* segs_host, int nseg
     PackArgs a;
     memset(&a, 0, sizeof(a));
     memcpy(a.s, segs_host + base, (size_t)n * sizeof(mmnas_segment));
-    MMNAS_LAUNCH(pack_args_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, a, staging, scale, direction);
+    size_t npieces = 0;
+    for (int k = 0; k < n; ++k) npieces += (a.s[k].n + PACK_PIECE - 1) / PACK_PIECE;
+    MMNAS_LAUNCH(pack_args_kernel, dim3(pack_grid(npieces)), dim3(256), 0, (hipStream_t)stream, a, n, npieces, staging, scale, direction);
   }
   return check_launch("pack_segments_host");
 }

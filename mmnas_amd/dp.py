@@ -19,6 +19,7 @@ What is different from DDP, and why:
 Gradients are AVERAGED over ranks, as DDP does; the loss keeps reduction='sum' per rank.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -185,6 +186,110 @@ def _chain_marks(red, op_params, bucket_of, buckets):
     return marks if any_mark else None
 
 
+def _row_sparse_index(fg, comm, is_cuda):
+    """Index (in fg.params) of the parameter whose gradient is exchanged as rows, or None.  The nets tag their word
+    embedding (`weight._mmnas_row_sparse`): its gradient is the ~900 rows of the batch's tokens inside a 24 MB table, it
+    completes LAST in backward (nothing is left to overlap a dense all-reduce with) and is half of everything the
+    d = 256 supernet exchanges per step.  Only the first parameter of the flat buffer is taken (a bucket then simply
+    starts behind it)."""
+    if not (comm and is_cuda and fg.params) or os.environ.get('MMNAS_DP_ROWS', '1') == '0':   # (0: dense, for A/B runs)
+        return None
+    return 0 if getattr(fg.params[0], '_mmnas_row_sparse', False) else None
+
+
+class RowExchange:
+    """Data-parallel exchange of a row-sparse gradient (nn.Embedding.weight): instead of all-reducing the dense [V, E]
+    table (DDP, search_vqa.py:292), every rank all-gathers the batch's token indices and output-gradient rows (~1 MB per
+    rank) and adds ALL ranks' rows, scaled by 1 / world, into its own (zeroed) gradient view with a fixed summation order
+    (mmnas_embedding_bwd_det) -- so the ranks' results are bitwise equal, as an all-reduce's are.  Runs on the reducer's
+    communication stream from inside ops.EmbeddingFn.backward.  A gradient that reaches the parameter any other way
+    (a dense autograd gradient) is caught at finish() and all-reduced densely."""
+
+    def __init__(self, red, index):
+        self.red, self.i = red, index
+        self.done = False
+        self._keep = []
+        self._idx = {}
+
+    def begin(self):
+        self.done = False
+        self._keep = []
+        self._idx = {}
+
+    def gather_indices(self, idx):
+        """Forward (ops.EmbeddingFn.forward): the ranks' token indices are exchanged while the step computes, so that
+        only the gradient rows are left for the end of backward.  Returns a key for exchange()."""
+        red = self.red
+        idx_l = idx.reshape(-1).contiguous()
+        world = dist.get_world_size(red.group)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        cs = red.comm_stream
+        with torch.cuda.stream(cs):
+            cs.wait_event(ev)
+            ip = [torch.empty_like(idx_l) for _ in range(world)]
+            dist.all_gather(ip, idx_l, group=red.group)
+            idx_all = torch.cat(ip) if world > 1 else ip[0]
+        idx_l.record_stream(cs)
+        key = len(self._idx)
+        self._idx[key] = (idx_l, ip, idx_all)
+        return key
+
+    def exchange(self, idx, dy, key=None):
+        from . import _lib as L
+        red = self.red
+        view = red.fg.views[self.i]
+        V, E = view.shape
+        if key is None or key not in self._idx:
+            key = self.gather_indices(idx)
+        idx_l, ip, idx_all = self._idx.pop(key)
+        dy_l = dy.reshape(-1, E).contiguous()
+        world = dist.get_world_size(red.group)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        cs = red.comm_stream
+        with torch.cuda.stream(cs):
+            cs.wait_event(ev)
+            gp = [torch.empty_like(dy_l) for _ in range(world)]
+            dist.all_gather(gp, dy_l, group=red.group)
+            dy_all = torch.cat(gp) if world > 1 else gp[0]
+            ws = torch.empty(idx_all.numel() * E, dtype=torch.float32, device=dy_all.device)
+            L.check(L.lib().mmnas_embedding_bwd_det(L.ptr(idx_all), L.fptr(dy_all), L.fptr(view), L.fptr(ws), idx_all.numel(), E, V,
+                                                    1.0 / world, cs.cuda_stream))
+        dy_l.record_stream(cs)
+        # (several calls per step -- the ITM triplet step embeds three captions -- simply accumulate, in call order on
+        #  every rank.)  Held until finish(): the communication stream still reads them
+        self._keep.append((idx_l, dy_l, idx_all, dy_all, ip, gp, ws))
+        red.fg.dirty[self.i] = True
+        self.done = True
+
+    def finish(self):
+        """Called by the reducer's finish, before it joins the communication stream.  Dense fallback when the gradient
+        did not come through exchange() this step."""
+        red = self.red
+        if not self.done:
+            red.fg.adopt(self.i)
+            view = red.fg.views[self.i]
+            if red.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                with torch.cuda.stream(red.comm_stream):
+                    red.comm_stream.wait_event(ev)
+                    _all_reduce_avg(view, red.group, red.world)
+            else:
+                _all_reduce_avg(view, red.group, red.world)
+        self._keep = []
+        self._idx = {}
+
+
+def _all_reduce_avg(t, group, world):
+    if _has_avg(group):
+        dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t.mul_(1.0 / world)
+
+
 class GradReducer:
     """Bucketed, backward-overlapped all-reduce of a fixed parameter set (Net_Full training)."""
 
@@ -196,6 +301,8 @@ class GradReducer:
         self.comm = self.world > 1 or (force_collectives and dist.is_initialized())
         self.is_cuda = self.fg.flat.is_cuda
         self.fg.attach()
+        ri = _row_sparse_index(self.fg, self.comm, self.is_cuda)
+        self.row_exchange = RowExchange(self, ri) if ri is not None else None
         # buckets over the flat buffer, filled in REVERSE parameter order (~ backward order)
         cap = int(bucket_mb * (1 << 20) / 4)
         self.buckets = []  # (lo, hi, [param indices])
@@ -203,6 +310,8 @@ class GradReducer:
         cur = []
         lo = hi
         for i in reversed(range(len(self.fg.params))):
+            if i == ri:
+                continue          # (index 0: the last bucket starts behind it)
             lo = self.fg.offsets[i]
             cur.append(i)
             if hi - lo >= cap:
@@ -242,6 +351,8 @@ class GradReducer:
         if self._seen[i]:
             return
         self._seen[i] = True
+        if i not in self.bucket_of:      # the row-exchanged parameter: RowExchange.exchange() / .finish() move it
+            return
         self.fg.adopt(i)   # (a gradient autograd accumulated outside the flat buffer: see FlatGrads.adopt)
         b = self.bucket_of[i]
         self._pending[b] -= 1
@@ -285,12 +396,16 @@ class GradReducer:
         self._seen = [False] * len(self.fg.params)
         self._launched = [False] * len(self.buckets)
         self._works = []
+        if self.row_exchange is not None:
+            self.row_exchange.begin()
 
     def finish(self):
         """Call after backward: flush buckets whose gradients never arrived, wait for all collectives."""
         if not self.comm:
             self.fg.adopt_strays()
             return
+        if self.row_exchange is not None:
+            self.row_exchange.finish()
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self.fg.adopt_strays(self.buckets[b][2])
@@ -345,6 +460,8 @@ class SupernetReducer:
         self.is_cuda = self.fg.flat.is_cuda
         self._active = None
         fg = self.fg
+        ri = _row_sparse_index(fg, self.comm, self.is_cuda)
+        self.row_exchange = RowExchange(self, ri) if ri is not None else None
 
         def span(params):   # contiguous by construction
             if not params:
@@ -361,6 +478,8 @@ class SupernetReducer:
         runs = []   # maximal runs of consecutive shared parameters of the same kind: (is_head, [param indices])
         for p in self.shared:
             i = fg.index[id(p)]
+            if i == ri:
+                continue          # exchanged as rows (RowExchange), not as part of a bucket
             h = id(p) in head_ids
             if runs and runs[-1][0] == h and runs[-1][1][-1] == i - 1:
                 runs[-1][1].append(i)
@@ -452,6 +571,8 @@ class SupernetReducer:
         self._mark_ev = {}
         self._launched = [False] * self.n_buckets
         self._works = []
+        if self.row_exchange is not None:
+            self.row_exchange.begin()
         if self.staging is None:
             self.staging = [torch.empty(max(c, 64), dtype=torch.float32, device=self.fg.flat.device) for c in self.cap]
 
@@ -502,6 +623,15 @@ class SupernetReducer:
                 self.comm_stream.wait_event(ev)
                 self._pack(segs, stg, 0)
                 w = dist.all_reduce(stg, op=op, group=self.group, async_op=True)
+                if avg and os.environ.get('MMNAS_DP_EARLY_SCATTER', '0') == '1':
+                    # Optional (MMNAS_DP_EARLY_SCATTER=1): scatter the averaged gradients back as soon as THIS bucket's
+                    # all-reduce ends (RCCL: wait() only makes the communication stream wait), leaving only the last
+                    # bucket's scatter behind the end of backward.  Measured in a one-rank group: +0.06 ms per step --
+                    # the scatter kernels then run beside the backward's single-round GEMM launches and cost them more
+                    # than the ~20 us they take off the tail.  Off by default.
+                    w.wait()
+                    self._pack(segs, stg, 1)
+                    w = None
         else:
             self._pack(segs, stg, 0)
             w = dist.all_reduce(stg, op=op, group=self.group, async_op=True)
@@ -516,11 +646,15 @@ class SupernetReducer:
         for i in list(self._armed):          # gradients that never arrived through a hook (e.g. produced under no hook)
             self.fg.adopt(i)
         self._armed = set()
+        if self.row_exchange is not None:
+            self.row_exchange.finish()
         for b in range(self.n_buckets):
             self._launch(b)
         if self.is_cuda:
             with torch.cuda.stream(self.comm_stream):
                 for w, b, stg, need_div in self._works:
+                    if w is None:
+                        continue             # (scattered back right behind its all-reduce: _launch)
                     w.wait()
                     self._pack(self._segs[b], stg, 1, 1.0 / self.world if need_div else 1.0)
             torch.cuda.current_stream().wait_stream(self.comm_stream)

@@ -12,7 +12,7 @@ implementation:
         included (zero gradient, decaying moments, stale-momentum motion) -- is kept by FlatAdam(absent_grads='zero');
       - gradients live in one flat buffer (dp.SupernetReducer); clip_grad_norm_ + Adam are two kernels (optim.FlatAdam);
       - the arch step's alpha gradient + alpha_optim.step() are one kernel (ArchAdam, mode 'full').
-    Pinned against the reference loop itself by tests/golden/traj.npz (tests/test_traj_gpu.py).
+    Pinned against the reference loop itself by tests/golden/traj.npz (tests/test_harness_gpu.py::test_bilevel_trajectory_vs_reference_loop).
   * itm_triplet_step -- train_itm.py:380-391: three forwards (positive, negative caption, negative image), BCE_Loss.
   * BCE_Loss -- mmnas/utils/itm_loss.py:4-24.  vgd_loss -- train_vgd.py:316-333.
 """
@@ -204,9 +204,8 @@ class SearchLoop:
     def __init__(self, net, loss_fn=None, net_lr=4e-4, net_betas=(0.9, 0.98), net_eps=1e-9, clip=1.0, epoch_steps=1000,
                  warmup=True, alpha_lr=0.1, alpha_betas=(0.0, 0.999), alpha_every=5, arch_mode='full', group=None,
                  absent_grads='zero', n_buckets=3, force_collectives=False):
-        if arch_mode != 'full':
-            raise NotImplementedError("SearchLoop fuses the architecture update for ALPHA_BINARY_MODE 'full' (the shipped "
-                                      "setting, search_vqa.py:151); drive mode 'two' through MixedOp's own methods")
+        if arch_mode not in ('full', 'two'):
+            raise ValueError("ALPHA_BINARY_MODE is 'full' or 'two' (search_vqa.py:151), got %r" % (arch_mode,))
         self.net = net
         self.loss_fn = fused_loss(loss_fn if loss_fn is not None else nn.BCEWithLogitsLoss(reduction='sum'))
         dense = absent_grads == 'zero'
@@ -216,7 +215,14 @@ class SearchLoop:
         self.net_optim = WarmupOptimizer(net_lr, FlatAdam(self.reducer.fg.params, betas=net_betas, eps=net_eps,
                                                           grads=self.reducer.fg, absent_grads=absent_grads),
                                          epoch_steps=epoch_steps, warmup=warmup, max_norm=clip if clip and clip > 0 else None)
-        self.alpha_optim = ArchAdam(net, alpha_lr, alpha_betas)
+        # 'full' (the shipped setting): alpha gradient + Adam as one kernel over the [n_nodes, width] blocks.  'two': the
+        # reference's own statements -- MixedOp.set_arch_param_grad over the sampled pair, torch Adam on the alpha
+        # parameters, rescale_updated_arch_param (search_vqa.py:330-334, mixed.py:179-208)
+        if arch_mode == 'full':
+            self.alpha_optim = ArchAdam(net, alpha_lr, alpha_betas)
+        else:
+            net._flat_alphas()          # (the parameters' storage moves into the flat blocks before Adam sees them)
+            self.alpha_optim = torch.optim.Adam(list(net.alpha_prob_parameters()), alpha_lr, betas=tuple(alpha_betas))
         self.alpha_every = alpha_every
         self.arch_mode = arch_mode
         self.steps = 0
@@ -256,7 +262,14 @@ class SearchLoop:
             loss = self.loss_fn(net(inputs), target)
             loss.backward()
             red.reduce_alpha_gate_grads()
-            if optimize:
+            if self.arch_mode == 'two':
+                for m in net.redundant_modules:      # (the script's net.zero_grad() before backward, search_vqa.py:328)
+                    m.alpha_prob.grad = None
+                net.set_arch_param_grad()
+                if optimize:
+                    self.alpha_optim.step()
+                    net.rescale_updated_arch_param()
+            elif optimize:
                 self.alpha_optim.step()
         finally:
             MixedOp.MODE = None

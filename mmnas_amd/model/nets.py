@@ -84,9 +84,40 @@ class _Backbone(nn.Module):
         from .modules import FeedForward, FeedForward_deep, GuidedAtt, RelSelfAtt, SelfAtt
         if not (ops.chain_enabled() and x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32):
             return None
-        if MixedOp.MODE is not None:
+        mixed_mode = MixedOp.MODE in ('full', 'two')
+        if MixedOp.MODE is not None and not (mixed_mode and ops.mixed_chain_enabled()):
             return None
         records, params, op_params = [], [], []
+        mops = []
+
+        def record(op, on_y, rel):
+            """(ChainOp, parameters) of one operator, or None when the chain cannot take it."""
+            t = type(op)
+            if t is SelfAtt or t is GuidedAtt or t is RelSelfAtt:
+                if t is GuidedAtt and not on_y:
+                    return None
+                rh = None
+                if t is RelSelfAtt:
+                    if not (isinstance(rel, RelHandle) and rel.fusable(op.mhatt.linear_r.weight.shape[0])):
+                        return None
+                    rh = rel
+                ps = _op_params(op)
+                if not ops._sinked(ps) or (rh is not None and not ops._sinked((rh.weight, rh.bias))):
+                    return None
+                return ops.chain_att_record_cached(op, on_y, t is not GuidedAtt, rh)
+            if t is FeedForward or t is FeedForward_deep:
+                ps = _op_params(op)
+                if not ops._sinked(ps):
+                    return None
+                m = op.mlp
+                if t is FeedForward:
+                    ws, bs = [m.fc.linear.weight, m.linear.weight], [m.fc.linear.bias, m.linear.bias]
+                else:
+                    ws = [op.fc.linear.weight, m.fc.linear.weight, m.linear.weight]
+                    bs = [op.fc.linear.bias, m.fc.linear.bias, m.linear.bias]
+                return ops.chain_mlp_record_cached(op, on_y, ws, bs)
+            return None
+
         for on_y, cells in ((0, self.cells_enc), (1, self.cells_dec)):
             rel = y_rel_embed if on_y else x_rel_embed
             for cell in cells:
@@ -94,42 +125,57 @@ class _Backbone(nn.Module):
                     if len(node) != 1:
                         return None
                     op = node[0]
+                    if mixed_mode:
+                        # architecture step: every evaluated candidate of the node, in candidate order; only the sampled
+                        # one is differentiated (mixed.py:59-68)
+                        if not isinstance(op, MixedOp) or len(op.active_index) != 1:
+                            return None
+                        k = len(mops)
+                        mops.append(op)
+                        for i in sorted(op.active_index + op.inactive_index):
+                            cand = op.candidate_ops[i]
+                            if cand is None:
+                                return None
+                            got = record(cand, on_y, rel)
+                            if got is None:
+                                return None
+                            rec, used = got
+                            rec.node, rec.cand, rec.detached = k, i, int(i != op.active_index[0])
+                            records.append(rec)
+                            if not rec.detached:
+                                params += used
+                        continue
                     if isinstance(op, MixedOp):
                         op = op.active_op
-                    t = type(op)
-                    if t is SelfAtt or t is GuidedAtt or t is RelSelfAtt:
-                        if t is GuidedAtt and not on_y:
-                            return None
-                        rh = None
-                        if t is RelSelfAtt:
-                            if not (isinstance(rel, RelHandle) and rel.fusable(op.mhatt.linear_r.weight.shape[0])):
-                                return None
-                            rh = rel
-                        ps = _op_params(op)
-                        if not ops._sinked((ps[0], ps[-1])) or (rh is not None and not ops._sinked((rh.weight, rh.bias))):
-                            return None
-                        rec, used = ops.chain_att_record_cached(op, on_y, t is not GuidedAtt, rh)
-                    elif t is FeedForward or t is FeedForward_deep:
-                        ps = _op_params(op)
-                        if not ops._sinked((ps[0], ps[-1])):
-                            return None
-                        m = op.mlp
-                        if t is FeedForward:
-                            ws, bs = [m.fc.linear.weight, m.linear.weight], [m.fc.linear.bias, m.linear.bias]
-                        else:
-                            ws = [op.fc.linear.weight, m.fc.linear.weight, m.linear.weight]
-                            bs = [op.fc.linear.bias, m.fc.linear.bias, m.linear.bias]
-                        rec, used = ops.chain_mlp_record_cached(op, on_y, ws, bs)
-                    else:
+                    got = record(op, on_y, rel)
+                    if got is None:
                         return None
+                    rec, used = got
+                    rec.node, rec.cand, rec.detached = len(records), 0, 0
                     records.append(rec)
                     params += used
                     op_params.append(used)
-        if not records or len(records) > 64:
+        mixed = None
+        if mixed_mode:
+            # the nodes' binary gates / gate gradients must be rows of two [n_nodes, width] blocks (Net_Search._flat_alphas,
+            # begin_arch_step): the chain addresses them by node index
+            g0 = mops[0].alpha_gate
+            gr0 = g0.grad
+            if gr0 is None or gr0 is not getattr(g0, '_mmnas_gate_grad', None):
+                return None
+            width = max(m.n_choices for m in mops)
+            for k, m in enumerate(mops):
+                g = m.alpha_gate
+                if (g.grad is None or g.grad is not getattr(g, '_mmnas_gate_grad', None) or
+                        g.data_ptr() != g0.data_ptr() + 4 * width * k or g.grad.data_ptr() != gr0.data_ptr() + 4 * width * k):
+                    return None
+            mixed = (g0.data_ptr(), gr0.data_ptr(), width)
+            op_params = None
+        if not records or len(records) > 128:
             return None
         xr = x_rel_embed.raw if isinstance(x_rel_embed, RelHandle) else None
         yr = y_rel_embed.raw if isinstance(y_rel_embed, RelHandle) else None
-        return ops.backbone_chain(x, y, x_mask, y_mask, xr, yr, records, params, op_params)
+        return ops.backbone_chain(x, y, x_mask, y_mask, xr, yr, records, params, op_params, mixed)
 
     def forward(self, x, y, x_mask, y_mask, x_rel_embed, y_rel_embed):
         out = self._chain(x, y, x_mask, y_mask, x_rel_embed, y_rel_embed)
@@ -171,6 +217,8 @@ class _Net(nn.Module):
         d = __C.HSIZE
         self.embedding = nn.Embedding(num_embeddings=init_dict['token_size'], embedding_dim=__C.WORD_EMBED_SIZE)
         self.embedding.weight.data.copy_(torch.from_numpy(init_dict['pretrained_emb']))
+        # its gradient is the rows of the batch's tokens: data-parallel reducers exchange those rows (dp.RowExchange)
+        self.embedding.weight._mmnas_row_sparse = True
         self.lstm = nn.LSTM(input_size=__C.WORD_EMBED_SIZE, hidden_size=d, num_layers=1, batch_first=True)
         feat = __C.FRCNFEAT_SIZE
         if __C.BBOX_FEATURE:

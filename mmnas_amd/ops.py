@@ -460,6 +460,12 @@ class EmbeddingFn(torch.autograd.Function):
     def forward(ctx, idx, weight):
         ctx.weight = weight
         ctx.save_for_backward(idx)
+        # data parallel: the ranks' token indices start travelling now (dp.RowExchange), the gradient rows follow in backward
+        ctx.rows_key = None
+        s = getattr(weight, '_mmnas_sink', None)
+        rows = getattr(s.owner, 'row_exchange', None) if s is not None and s.owner is not None else None
+        if rows is not None and rows.i == s.index and weight.grad is s.view and _sinks_on[0] and ctx.needs_input_grad[1]:
+            ctx.rows_key = rows.gather_indices(idx)
         return torch.nn.functional.embedding(idx, weight)
 
     @staticmethod
@@ -469,7 +475,13 @@ class EmbeddingFn(torch.autograd.Function):
         dy = _f32c(dy)
         idx = idx.contiguous()
         (dW,), rets, sinks = _grad_bufs([w], dy.device)
-        L.check(L.lib().mmnas_embedding_bwd(L.ptr(idx), L.fptr(dy), L.fptr(dW), idx.numel(), w.shape[1], w.shape[0], L.stream()))
+        rows = getattr(sinks[0].owner, 'row_exchange', None) if sinks and sinks[0].owner is not None else None
+        if rows is not None and rows.i == sinks[0].index:
+            # data parallel: the ranks exchange (token index, dy row) pairs -- ~1 MB -- and each adds all of them into its
+            # own table gradient, instead of all-reducing the dense 24 MB table (dp.RowExchange)
+            rows.exchange(idx, dy, ctx.rows_key)
+        else:
+            L.check(L.lib().mmnas_embedding_bwd(L.ptr(idx), L.fptr(dy), L.fptr(dW), idx.numel(), w.shape[1], w.shape[0], L.stream()))
         for sk in sinks:
             sk.done()
         return None, rets[0]
@@ -772,6 +784,14 @@ def chain_enabled():
     return os.environ.get('MMNAS_CHAIN', '1') != '0'
 
 
+def mixed_chain_enabled():
+    """Architecture step (MixedOp modes 'full' / 'two') through the backbone chain: every evaluated candidate in one native
+    call per direction, the candidates' LayerNorms and the gated sum of a node as one kernel.  MMNAS_MIXED_CHAIN=0 keeps
+    the per-candidate path (one autograd node per candidate + ops.MixedSumFn)."""
+    import os
+    return os.environ.get('MMNAS_MIXED_CHAIN', '1') != '0'
+
+
 def side_stream_enabled():
     """Weight-gradient work of the backbone chain on a second stream (MMNAS_SIDE_STREAM=1).  OFF by default: measured on
     the supernet and training steps it does not pay -- unpaired data- / weight-gradient launches cost more than the
@@ -937,7 +957,7 @@ class BackboneFn(torch.autograd.Function):
     are not autograd inputs of this node."""
 
     @staticmethod
-    def forward(ctx, x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None):
+    def forward(ctx, x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None, mixed=None):
         lib = L.lib()
         x, y = _f32c(x), _f32c(y)
         B, Sx, d = x.shape
@@ -952,6 +972,8 @@ class BackboneFn(torch.autograd.Function):
         yr = _f32c(y_rel) if y_rel is not None else None
         ch.x_in, ch.y_in, ch.x_mask, ch.y_mask = L.fptr(x), L.fptr(y), L.ptr(xm), L.ptr(ym)
         ch.x_rel, ch.y_rel = L.fptr(xr), L.fptr(yr)
+        if mixed is not None:      # architecture step: (gate block, gate-gradient block, row width) of the supernet's nodes
+            ch.mixed, ch.gate, ch.dgate, ch.gate_width = 1, mixed[0], mixed[1], mixed[2]
         sz = C.c_size_t()
         L.check(lib.mmnas_chain_plan(C.byref(ch), C.byref(sz)))   # (host arithmetic only: a few microseconds)
         arena = _bytes(sz.value, x.device)
@@ -999,11 +1021,11 @@ class BackboneFn(torch.autograd.Function):
                 _side_join_queued[0] = True
                 torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
         _release_sinks(ctx, params)   # data-parallel reducers learn which gradients are now completely enqueued
-        return dx_in, dy_in, None, None, None, None, None, None, None
+        return dx_in, dy_in, None, None, None, None, None, None, None, None
 
 
-def backbone_chain(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None):
-    return BackboneFn.apply(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params)
+def backbone_chain(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None, mixed=None):
+    return BackboneFn.apply(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params, mixed)
 
 
 class HeadFn(torch.autograd.Function):
@@ -1051,12 +1073,13 @@ class HeadFn(torch.autograd.Function):
 def head_record(att_x, att_y, ln, proj, training):
     """(Head descriptor, params) for AttFlat modules att_x / att_y, the proj_norm LayerNorm and the proj Linear; None when
     a parameter's gradient does not live in a flat buffer.  Cached on the projection module (see _cached_record)."""
-    first, last = att_x.mlp.fc.linear.weight, proj.bias
-    if not _sinked((first, last)):
+    first = att_x.mlp.fc.linear.weight
+    if not _sinked((first,)):
         return None, None
     hd, params = _cached_record(proj, (training,), first, lambda: _head_record(att_x, att_y, ln, proj, training))
-    if hd is None:
-        return None, None
+    if hd is None or not _sinked(params):   # EVERY parameter's gradient must (still) be its flat-buffer view: the cached
+        return None, None                   # descriptor holds their raw pointers
+
     hd = L.Head.from_buffer_copy(hd)   # a private copy per call: several forwards may be alive before one backward (ITM triplets)
     if hd.drop_p > 0:
         hd.sx.seed = next_seed()

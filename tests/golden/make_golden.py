@@ -79,6 +79,27 @@ def summarize(out, key, g):
         out[key + '#shape'] = np.array(g.shape, np.int64)
 
 
+def esample(t, n=64):
+    """<= n strided elements of a tensor (a fixed stride of its flattened form): element-wise anchors for tensors whose
+    full value is not stored -- a sign or permutation error that keeps the norm does not keep these."""
+    flat = np.ascontiguousarray(t.detach().numpy() if hasattr(t, 'detach') else t, dtype=np.float32).reshape(-1)
+    return flat[::max(1, flat.size // n)][:n].copy()
+
+
+def grad_samples(out, tag, net):
+    """tag + 'gs_keys' / 'gs' / 'gs_off': the strided samples of EVERY parameter gradient of the net, concatenated
+    (gs_off[i] : gs_off[i+1] is parameter gs_keys[i]'s; an absent gradient contributes nothing)."""
+    keys, parts, off = [], [], [0]
+    for k, p in sorted(net.named_parameters()):
+        if p.grad is None:
+            continue
+        sm = esample(p.grad)
+        keys.append(k); parts.append(sm); off.append(off[-1] + sm.size)
+    out[tag + 'gs_keys'] = np.array(keys)
+    out[tag + 'gs'] = np.concatenate(parts) if parts else np.zeros(0, np.float32)
+    out[tag + 'gs_off'] = np.array(off, np.int64)
+
+
 def run_ref_op(case):
     name, cfg = case['name'], case['cfg']
     op = ROA.OpsAdapter().OPS[name](cfg, norm=cfg.OPS_NORM, residual=cfg.OPS_RESIDUAL)
@@ -303,6 +324,7 @@ def gen_nets():
         out[tag + 'gradnorm_keys'] = np.array(keys)
         out[tag + 'gradnorms'] = np.array([gn[k] for k in keys], np.float64)
         out[tag + 'g:imgfeat_linear.bias'] = net.imgfeat_linear.bias.grad.numpy()
+        grad_samples(out, tag, net)
         if net.linear_y_rel.weight.grad is not None:
             out[tag + 'g:linear_y_rel.weight'] = net.linear_y_rel.weight.grad.numpy()
 
@@ -357,6 +379,7 @@ def gen_nets():
             keys = sorted(gn)
             out[tag + 'gradnorm_keys'] = np.array(keys)
             out[tag + 'gradnorms'] = np.array([gn[k] for k in keys], np.float64)
+            grad_samples(out, tag, net)
             MixedOp.MODE = None
             if task == 'vqa' and mode is None:
                 # genotype / genotype_weights for the loaded alphas (hygr_vqa.py:242-297)
@@ -489,6 +512,9 @@ def gen_traj():
         keys = sorted(k for k in sd if 'alpha' not in k)
         out['traj|%s|keys' % tag] = np.array(keys)
         out['traj|%s|delta_norm' % tag] = np.array([float((sd[k].double() - P0[k].double()).norm()) for k in keys])
+        ds = [esample(sd[k].double() - P0[k].double()) for k in keys]     # element-wise anchors of every tensor's motion
+        out['traj|%s|delta_sample' % tag] = np.concatenate(ds)
+        out['traj|%s|delta_off' % tag] = np.cumsum([0] + [d.size for d in ds]).astype(np.int64)
         for k in cases.TRAJ_FULL_KEYS:
             out['traj|%s|P:%s' % (tag, k)] = sd[k].detach().numpy().copy()
 

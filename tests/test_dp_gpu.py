@@ -61,6 +61,9 @@ def _w_full(rank):
     dp.broadcast_parameters(net)
     red = dp.GradReducer(list(net.parameters()), bucket_mb=0.05)
     assert len(red.buckets) >= 3 and red.comm_stream is not None
+    # the word embedding's gradient travels as (token, dy row) pairs, not as a dense table (dp.RowExchange)
+    assert red.row_exchange is not None and red.fg.params[red.row_exchange.i] is net.embedding.weight
+    assert all(red.row_exchange.i not in idxs for _, _, idxs in red.buckets)
     # expected: mean over ranks of the plain autograd gradients
     ref = _build_full(cs[0])
     want = None
@@ -76,6 +79,10 @@ def _w_full(rank):
         assert all(red._seen), 'a parameter never reported its gradient'
         red.finish()
         torch.cuda.synchronize()
+        assert red.row_exchange.done                       # the rows went through the exchange, not the dense fallback
+        both = [torch.empty_like(net.embedding.weight.grad) for _ in range(WORLD)]
+        dist.all_gather(both, net.embedding.weight.grad)
+        assert torch.equal(both[0], both[1])               # bitwise equal on the ranks, as an all-reduce's result is
         bad = []
         for k, p in net.named_parameters():
             err = float((p.grad - want[k] / WORLD).abs().max())
@@ -97,6 +104,7 @@ def _w_supernet(rank):
     net = Net_Search(cs[rank]['cfg'], init).cuda().train()
     dp.broadcast_parameters(net)
     red = dp.SupernetReducer(net)
+    assert red.row_exchange is not None and red.fg.params[red.row_exchange.i] is net.embedding.weight
     mixed.seed_arch_sampler(321)                 # same samples on both ranks
     MixedOp.MODE = None
     net.reset_binary_gates()
@@ -113,6 +121,15 @@ def _w_supernet(rank):
     dist.all_gather(both, local)
     mean = (both[0] + both[1]) / WORLD
     segs = red.exchanged_segments()
+    # the word embedding is not part of any bucket: its rows were exchanged inside backward (so `local` above may already
+    # hold them -- it is checked separately below)
+    rx = red.row_exchange
+    eo, en = red.fg.offsets[rx.i], net.embedding.weight.numel()
+    assert rx.done and all(not (o < eo + en and eo < o + n) for o, n in segs)
+    emb_avg = red.fg.flat[eo:eo + en].clone()
+    segs = segs + [(eo, en)]
+    mean[eo:eo + en] = emb_avg
+    local[eo:eo + en] = emb_avg
     assert sum(n for _, n in segs) >= sum(p.numel() for p in red._active)
     covered = 0
     for o, n in segs:
@@ -123,6 +140,24 @@ def _w_supernet(rank):
     for o, n in segs:
         mask[o:o + n] = False
     assert torch.equal(red.fg.flat[mask], local[mask])   # ... and stay untouched
+    # the exchanged embedding gradient = the mean of the ranks' dense embedding gradients: the same step once more with
+    # the row exchange switched off (the table's gradient then stays local: it is in no bucket)
+    red.row_exchange = None
+    red.begin_weight_step()
+    net.unused_modules_off()
+    _loss(net, cs[rank]).backward()
+    torch.cuda.synchronize()
+    mine = red.fg.flat[eo:eo + en].clone()
+    red.finish_weight_step()
+    net.unused_modules_back()
+    parts = [torch.zeros_like(mine) for _ in range(WORLD)]
+    dist.all_gather(parts, mine)
+    want = (parts[0] + parts[1]) / WORLD
+    assert float(want.abs().max()) > 0
+    assert float((emb_avg - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    both_e = [torch.zeros_like(emb_avg) for _ in range(WORLD)]
+    dist.all_gather(both_e, emb_avg)
+    assert torch.equal(both_e[0], both_e[1])             # bitwise equal on the ranks
 
 
 def _w_itm_triplet(rank):

@@ -368,3 +368,115 @@ def test_operator_backward_twice_raises_a_clear_error():
     y.backward(retain_graph=True)
     with pytest.raises(RuntimeError, match='second time'):
         y.backward()
+
+
+def test_node_mix_kernels_vs_torch():
+    """mmnas_node_mix_fwd/bwd (one pass per supernet node of the architecture step): out = sum_j gate_j LN_j(z_j) with
+    the reference's LayerNorm (unbiased std, eps on the std; modules.py:52-56), candidates without LayerNorm passed
+    through, non-binary gates; backward: every gate's <dout, LN_j(z_j)> added onto the gate-gradient row and
+    d_active = gate[active] * dout."""
+    import ctypes as C
+    from mmnas_amd import _lib as L
+    g = torch.Generator().manual_seed(7)
+    for n, M, d, active, plain in ((4, 6400, 256, 2, ()), (2, 896, 256, 0, (1,)), (4, 37, 512, 3, (0, 2)), (3, 5, 36, 1, ()), (1, 9, 1024, 0, ())):
+        z = [torch.randn(M, d, generator=g).mul_(1.5).add_(0.3).to(DEV) for _ in range(n)]
+        la = [None if j in plain else (torch.rand(d, generator=g) + 0.5).to(DEV) for j in range(n)]
+        lb = [None if j in plain else torch.randn(d, generator=g).to(DEV) for j in range(n)]
+        gate = torch.randn(n, generator=g).to(DEV)
+        dout = torch.randn(M, d, generator=g).to(DEV)
+        eps = 1e-6
+
+        def ln(x, a, b):
+            x = x.double()
+            mu = x.mean(-1, keepdim=True)
+            sd = x.std(-1, keepdim=True)          # unbiased
+            return a.double() * (x - mu) / (sd + eps) + b.double()
+        outs = [zj.double() if a is None else ln(zj, a, b) for zj, a, b in zip(z, la, lb)]
+        want = sum(gate[j].double() * outs[j] for j in range(n))
+        arr = lambda ts: (C.c_void_p * n)(*[L.fptr(t) for t in ts])
+        out = torch.empty(M, d, device=DEV)
+        L.check(L.lib().mmnas_node_mix_fwd(arr(z), arr(la), arr(lb), n, L.fptr(gate), L.fptr(out), M, d, eps, L.stream()))
+        assert rel_err(out.cpu().numpy(), want.cpu().numpy()) < 2e-6, (n, M, d)
+        dgate = torch.full((n,), 0.25, device=DEV)
+        dact = torch.empty(M, d, device=DEV)
+        ws = torch.empty(L.lib().mmnas_mixed_sum_ws_floats(), device=DEV)
+        L.check(L.lib().mmnas_node_mix_bwd(arr(z), arr(la), arr(lb), n, L.fptr(gate), L.fptr(dout), L.fptr(dact), active, L.fptr(dgate),
+                                           L.fptr(ws), M, d, eps, L.stream()))
+        wg = torch.stack([(dout.double() * o).sum() for o in outs]) + 0.25
+        assert rel_err(dgate.cpu().numpy(), wg.cpu().numpy()) < 1e-5, (n, M, d)
+        assert rel_err(dact.cpu().numpy(), (gate[active] * dout).cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize('mode', ['full', 'two'])
+def test_arch_step_through_the_mixed_chain_equals_the_per_candidate_path(mode, monkeypatch):
+    """The architecture step as ONE native call per direction (every evaluated candidate, node epilogues fused) against
+    the per-candidate path (one autograd node per candidate + the gated-sum kernels, MMNAS_MIXED_CHAIN=0): loss, the gate
+    gradients, the alpha update and every weight gradient of the sampled candidates, stem and head."""
+    from mmnas.model.hygr_vqa import Net_Search
+    from mmnas_amd.harness import SearchLoop
+    c = cases.net_case('vqa', None, 4242, search=True, B=3)
+    plan = _plan_list(cases.search_plan(np.random.RandomState(6), mode))
+    inp = tuple(T(a).to(DEV) for a in c['inputs']); tgt = T(c['target']).to(DEV)
+    res = {}
+    for chain in ('0', '1'):
+        monkeypatch.setenv('MMNAS_MIXED_CHAIN', chain)
+        net = _build(Net_Search, c)
+        loop = SearchLoop(net, arch_mode=mode)
+        try:
+            loss = loop.arch_step(inp, tgt, plan=plan)
+            torch.cuda.synchronize()
+            gg, _ = net._flat_grads
+            res[chain] = dict(loss=float(loss), gg=gg.cpu().numpy().copy(),
+                              alpha=np.stack([np.pad(m.alpha_prob.detach().cpu().numpy(), (0, 4 - m.n_choices)) for m in net.redundant_modules]),
+                              grads={k: p.grad.detach().cpu().numpy().copy() for k, p in net.named_net_parameters() if p.grad is not None})
+        finally:
+            loop.reducer.fg.disable_sinks()
+    a, b = res['0'], res['1']
+    assert abs(a['loss'] - b['loss']) < 1e-5 * abs(a['loss'])
+    assert float(np.abs(a['gg']).max()) > 0 and rel_err(b['gg'], a['gg']) < 1e-4
+    assert rel_err(b['alpha'], a['alpha']) < 1e-5
+    top = max(float(np.abs(v).max()) for v in a['grads'].values())
+    for k, v in a['grads'].items():
+        assert float(np.abs(b['grads'][k] - v).max()) <= 1e-4 * max(float(np.abs(v).max()), 1e-3 * top), k
+    nz = sum(float(np.abs(v).max()) > 0 for v in a['grads'].values())
+    assert nz > 60          # the sampled candidates, stem and head carry gradients on both paths
+
+
+def test_search_loop_mode_two_follows_the_per_module_statements():
+    """SearchLoop(arch_mode='two') (search_vqa.py:317-334 with ALPHA_BINARY_MODE 'two'): the sampled pair's gate gradients,
+    set_arch_param_grad over the pair, torch Adam and rescale_updated_arch_param -- against the same statements written out
+    on a second net through the per-module path."""
+    from mmnas.model.hygr_vqa import Net_Search
+    from mmnas.model.mixed import MixedOp
+    from mmnas_amd.harness import SearchLoop
+    c = cases.net_case('vqa', None, 4343, search=True)
+    plan = _plan_list(cases.search_plan(np.random.RandomState(8), 'two'))
+    inp = tuple(T(a).to(DEV) for a in c['inputs']); tgt = T(c['target']).to(DEV)
+    loss_fn = torch.nn.BCEWithLogitsLoss(reduction='sum')
+    net = _build(Net_Search, c)
+    opt = torch.optim.Adam(list(net.alpha_prob_parameters()), 0.1, betas=(0.0, 0.999))
+    MixedOp.MODE = 'two'
+    try:
+        net.set_sampled(plan)
+        loss_a = loss_fn(net(inp), tgt)
+        net.zero_grad()
+        loss_a.backward()
+        net.set_arch_param_grad()
+        pg_a = np.stack([np.pad(m.alpha_prob.grad.cpu().numpy(), (0, 4 - m.n_choices)) for m in net.redundant_modules])
+        opt.step()
+        net.rescale_updated_arch_param()
+        alpha_a = np.stack([np.pad(m.alpha_prob.detach().cpu().numpy(), (0, 4 - m.n_choices)) for m in net.redundant_modules])
+    finally:
+        MixedOp.MODE = None
+    net2 = _build(Net_Search, c)
+    loop = SearchLoop(net2, arch_mode='two')
+    try:
+        loss_b = loop.arch_step(inp, tgt, plan=plan)
+        pg_b = np.stack([np.pad(m.alpha_prob.grad.cpu().numpy(), (0, 4 - m.n_choices)) for m in net2.redundant_modules])
+        alpha_b = np.stack([np.pad(m.alpha_prob.detach().cpu().numpy(), (0, 4 - m.n_choices)) for m in net2.redundant_modules])
+        assert abs(float(loss_a) - float(loss_b)) < 1e-5 * abs(float(loss_a))
+        assert float(np.abs(pg_a).max()) > 0 and rel_err(pg_b, pg_a) < 1e-4
+        assert rel_err(alpha_b, alpha_a) < 1e-5
+        assert MixedOp.MODE is None
+    finally:
+        loop.reducer.fg.disable_sinks()

@@ -882,3 +882,57 @@ def test_embedding_backward_adds_rows_into_the_gradient():
         assert rel_err(mod.weight.grad.cpu().numpy(), ref.weight.grad.numpy()) < 1e-6
         if use_sink:
             assert mod.weight.grad.data_ptr() == fg.views[0].data_ptr()
+
+
+def test_embedding_backward_fixed_order_for_the_row_exchange():
+    """mmnas_embedding_bwd_det (dp.RowExchange applies every rank's (token index, dy row) pairs with it): equals the
+    scatter-add in float64, scales, ignores indices outside the table, accumulates onto what the gradient already holds,
+    and is bitwise reproducible (no atomics: the ranks' tables must stay identical)."""
+    from mmnas_amd import _lib as L
+    rs = np.random.RandomState(11)
+    for V, E, n in ((50, 300, 2000), (20000, 300, 7168), (7, 24, 3), (300, 1024, 700)):
+        idx = rs.randint(-2, V + 2, size=n).astype(np.int64)          # a few out-of-range entries
+        idx[::2] = idx[0] if 0 <= idx[0] < V else 1                   # one row hit by half of the tokens (the padding token)
+        dy = rs.randn(n, E).astype(np.float32)
+        base = rs.randn(V, E).astype(np.float32)
+        want = base.astype(np.float64)
+        ok = (idx >= 0) & (idx < V)
+        np.add.at(want, idx[ok], 0.25 * dy[ok].astype(np.float64))
+        outs = []
+        idx_d, dy_d = g(idx), g(dy)
+        for rep in range(3):
+            dW = g(base.copy())
+            junk = torch.randn(1 << 20, device=DEV)
+            ws = torch.full((L.lib().mmnas_embedding_bwd_det_ws_floats(n, E),), float('nan'), device=DEV)
+            L.check(L.lib().mmnas_embedding_bwd_det(L.ptr(idx_d), L.fptr(dy_d), L.fptr(dW), L.fptr(ws), n, E, V, 0.25, L.stream()))
+            outs.append(dW.cpu().numpy())
+            del junk
+        assert rel_err(outs[0], want) < 2e-6, (V, E, n)
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_pack_segments_balanced_over_very_uneven_segments():
+    """The gather / scatter of a gradient bucket: one 24 MB segment (the embedding table of the stem bucket) beside small
+    and unaligned ones -- every float moves exactly once in both directions, gaps stay untouched."""
+    from mmnas_amd import _lib as L
+    rs = np.random.RandomState(5)
+    sizes = [6_000_000, 3, 8191, 8192, 8193, 1_048_576, 1, 70_001]
+    gaps = [5, 1, 0, 3, 64, 2, 7, 0]
+    flat = g(rnd(rs, sum(sizes) + sum(gaps) + 8))
+    segs = (L.Segment * len(sizes))()
+    o = so = 0
+    src_off = []
+    for i, (n, gp) in enumerate(zip(sizes, gaps)):
+        segs[i].ptr, segs[i].offset, segs[i].n = flat.data_ptr() + 4 * o, so, n
+        src_off.append(o)
+        o += n + gp
+        so += n
+    stg = torch.full((so,), float('nan'), device=DEV)
+    L.check(L.lib().mmnas_pack_segments_host(segs, len(sizes), L.fptr(stg), 0.5, 0, L.stream()))
+    exp = torch.cat([flat[a:a + n] for a, n in zip(src_off, sizes)]) * 0.5
+    assert torch.equal(stg, exp)
+    before = flat.clone()
+    L.check(L.lib().mmnas_pack_segments_host(segs, len(sizes), L.fptr(stg), 4.0, 1, L.stream()))
+    for a, n, gp in zip(src_off, sizes, gaps):
+        assert torch.equal(flat[a:a + n], before[a:a + n] * 2.0)
+        assert torch.equal(flat[a + n:a + n + gp], before[a + n:a + n + gp])

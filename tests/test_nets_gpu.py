@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from tests.golden import cases
-from tests.util import TOL, load, rel_err
+from tests.util import check_grad_samples, TOL, load, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -39,6 +39,11 @@ def _check_gradnorms(npz, tag, net, skip_alpha=False):
         g = mine[k].grad
         v = 0.0 if g is None else float(g.double().norm())
         assert abs(v - n) <= 3e-3 * n + 1e-5 * big, (k, v, n)
+    # ... and element-wise on the reference's strided samples of every gradient tensor (a permutation or sign error inside
+    # a weight gradient keeps the norm)
+    grads = {k: (None if p.grad is None else p.grad.detach().cpu().numpy()) for k, p in mine.items()}
+    n_checked = check_grad_samples(npz, tag, grads, skip=(lambda k: 'alpha' in k) if skip_alpha else (lambda k: False))
+    assert n_checked > 100
 
 
 @pytest.mark.parametrize('mode', [None, 'full', 'two'])

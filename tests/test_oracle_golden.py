@@ -7,7 +7,7 @@ import torch
 from oracle import mmnas_oracle as O
 from tests import oracle_runner as R
 from tests.golden import cases
-from tests.util import TOL, golden_err, has, load, rel_err
+from tests.util import check_grad_samples, TOL, golden_err, has, load, rel_err
 
 T = torch.from_numpy
 OTOL = 2e-5  # oracle vs reference: same fp32 arithmetic, only summation order differs
@@ -147,6 +147,7 @@ def test_net_full(task, arch):
     for k, n in zip(keys, norms):
         mine = 0.0 if grads[k] is None else float(np.linalg.norm(grads[k].astype(np.float64)))
         assert abs(mine - n) <= 2e-3 * n + 1e-6 * float(np.max(npz[tag + 'gradnorms'])), (k, mine, n)
+    assert check_grad_samples(npz, tag, grads) > 100      # every gradient tensor, element-wise on strided samples
 
 
 @pytest.mark.parametrize('task,mode', [('vqa', None), ('vqa', 'full'), ('vqa', 'two'), ('vgd', None),
@@ -178,6 +179,7 @@ def test_net_search_steps(task, mode):
             continue
         mine = 0.0 if grads[k] is None else float(np.linalg.norm(grads[k].astype(np.float64)))
         assert abs(mine - n) <= 2e-3 * n + 1e-6 * float(np.max(npz[tag + 'gradnorms'])), (k, mine, n)
+    assert check_grad_samples(npz, tag, grads, skip=lambda k: 'alpha' in k) > 100
     if mode is not None:
         gg = np.stack([np.pad(grads[k], (0, 4 - grads[k].size)) for k in keys])
         assert rel_err(gg, npz[tag + 'gate_grads']) < 1e-3

@@ -13,7 +13,7 @@ import torch
 from oracle import mmnas_oracle as O
 from tests import oracle_runner as R
 from tests.golden import cases
-from tests.util import GOLDEN, REPO, load, rel_err
+from tests.util import GOLDEN, REPO, esample, load, rel_err
 
 T = torch.from_numpy
 
@@ -100,6 +100,22 @@ def check_trajectory(res, tol_loss=2e-4, tol_delta=2e-2):
             mine = float((snap[k].double() - res['P0'][k].double()).norm())
             tol = 0.1 if k in NEAR_INVARIANT else tol_delta
             assert abs(mine - n) <= tol * n + 1e-7, (tag, k, mine, n)
+        # element-wise anchors: strided samples of every tensor's motion.  A coordinate whose clipped gradient is
+        # round-off-sized takes its +-lr Adam step in a direction the summation order decides, so single coordinates may
+        # differ: per tensor at most a tenth of the samples, over all tensors at most 1 %
+        off = npz['traj|%s|delta_off' % tag]
+        ds = npz['traj|%s|delta_sample' % tag]
+        bad = total = 0
+        for i, k in enumerate(keys):
+            if k in SHIFT_INVARIANT or k in NEAR_INVARIANT:
+                continue
+            want = ds[off[i]:off[i + 1]]
+            mine = esample((snap[k].double() - res['P0'][k].double()).numpy())
+            miss = int(np.sum(np.abs(mine - want) > 5e-2 * np.abs(want).max() + 1e-7))
+            assert miss <= max(1, want.size // 10), (tag, k, miss, want.size)
+            bad += miss
+            total += want.size
+        assert total > 5000 and bad <= 0.01 * total, (tag, bad, total)
         for k in cases.TRAJ_FULL_KEYS:
             want = npz['traj|%s|P:%s' % (tag, k)]
             d0 = np.abs(want - res['P0'][k].numpy()).max()

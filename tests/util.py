@@ -48,3 +48,33 @@ def golden_err(npz, key, arr):
 
 def has(npz, key):
     return key in npz.files or (key + '#sample') in npz.files
+
+
+def esample(a, n=64):
+    """The strided element sample tests/golden/make_golden.py::esample stores (<= n elements, fixed stride)."""
+    flat = np.ascontiguousarray(np.asarray(a), dtype=np.float32).reshape(-1)
+    return flat[::max(1, flat.size // n)][:n]
+
+
+def check_grad_samples(npz, tag, grads, tol=3e-3, skip=lambda k: False):
+    """Element-wise check of EVERY parameter gradient of a network against the reference's strided samples
+    (`tag + 'gs_keys' / 'gs' / 'gs_off'`): a sign or permutation error inside a weight gradient keeps its norm, not these.
+    grads: name -> array (None / missing = no gradient).  Tolerance: `tol` of the tensor's largest sampled reference
+    element, floored at 1e-3 of the largest over all tensors (round-off-sized gradients)."""
+    keys = [str(k) for k in npz[tag + 'gs_keys']]
+    off = npz[tag + 'gs_off']
+    gs = npz[tag + 'gs']
+    top = float(np.max(np.abs(gs))) if gs.size else 0.0
+    checked = 0
+    for i, k in enumerate(keys):
+        if skip(k):
+            continue
+        ref = gs[off[i]:off[i + 1]]
+        g = grads.get(k)
+        assert g is not None, ('no gradient for', k)
+        mine = esample(g)
+        assert mine.shape == ref.shape, (k, mine.shape, ref.shape)
+        err = float(np.max(np.abs(mine.astype(np.float64) - ref)))
+        assert err <= tol * max(float(np.max(np.abs(ref))), 1e-3 * top), (k, err, float(np.max(np.abs(ref))))
+        checked += 1
+    return checked
