@@ -632,6 +632,17 @@ def main():
         order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
         elapsed, t_enqueue, timed_flops = blocks[order[len(order) // 2]]
         el_min, el_max = blocks[order[0]][0], blocks[order[-1]][0]
+        # host time of ONE call issued into an EMPTY queue (synchronise first): in the timed blocks the host runs ahead
+        # until the launch queue is full and then waits on it, so there `host_issue` approaches the GPU time of a
+        # GPU-bound step; this is what the host itself needs
+        host_alone = []
+        for _ in range(3):
+            barrier()
+            th = time.perf_counter()
+            step()
+            host_alone.append(time.perf_counter() - th)
+        barrier()
+        host_alone_ms = 1000.0 * sorted(host_alone)[1] / per_call
         # Roofline pass: the same steps repeated right after the timed region with every library launch carrying a
         # start/stop HIP event (on the launch stream).  Kept out of the timed region because the events themselves
         # cost ~9 % of the step (a completion signal per dispatch); launches, shapes and data are identical.
@@ -661,6 +672,7 @@ def main():
             'step_frac_of_mfma_peak': timed_flops / elapsed / 1e12 / PEAK_MFMA_F32_TFLOPS,
             'final_loss': float(loss.detach()),
             'host_issue_ms_per_step': 1000.0 * t_enqueue / nsteps,
+            'host_issue_ms_per_step_empty_queue': host_alone_ms,
         }
         if stats and wl in N1_SUBS:
             psteps = prof_calls * per_call

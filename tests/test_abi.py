@@ -65,6 +65,14 @@ def test_plan_functions_run_on_host():
     assert p.save_bytes >= (6400 * 2048 + 6400 * 512) * 4
 
 
+def test_host_only_entry_points_of_the_product_library():
+    """Chain / mixed-chain / head planners, scratch-size helpers and the argument checks with their messages
+    (tests/host_plan_driver.py; tests/test_asan.py runs the same driver against the AddressSanitizer build)."""
+    from tests import host_plan_driver
+    out = host_plan_driver.run()
+    assert out['mixed_chain_bytes'] > out['chain_bytes'] > 0 and out['head_bytes'] > 0
+
+
 def test_product_path_refuses_cpu_tensors():
     from mmnas_amd import _lib as L
     from mmnas.utils.ops_adapter import OpsAdapter
