@@ -598,7 +598,13 @@ __global__ void __launch_bounds__(64 * NW * QS, (NW == 4 && QS == 1) ? 2 : 1) mh
 //     summed at write-out.
 // LDS: NKB = 4: K, V 68 KB + accumulators 64 KB + transposition 16.5 KB = 148.5 KB (one workgroup per CU).
 // ------------------------------------------------------------------------------------------
-template <int NKB>
+#ifndef MMNAS_DBG_MHA
+#define MMNAS_DBG_MHA 0   // timing experiments only (wrong results): bit mask of kernel phases left out (tools/mha_phases.sh)
+#endif
+#ifndef MMNAS_MHA_VPM
+#define MMNAS_MHA_VPM 8    // vector instructions scheduled behind each MFMA of the overlapped phase (tuning)
+#endif
+template <int NKB, bool DB>   // DB: the bias gradient dZ is written (relation attention)
 __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
   constexpr int DHC = 64, LD = DHC + 4, NS = DHC / 8, JC = 2, NW = 4, KB = 32 * NKB;
   constexpr int CP = NW / NKB;   // accumulator copies (waves that meet in one key block at a step)
@@ -656,8 +662,12 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
       const size_t rr = (size_t)b * Sq + (ok ? q : Sq - 1);
 #pragma unroll
       for (int jc = 0; jc < JC; ++jc) {
+#if MMNAS_DBG_MHA & 32
+        const float qv = (float)r, gv = (float)jc;
+#else
         const float qv = p.Q[rr * p.ldq + h * p.dh + 32 * jc + l31];
         const float gv = p.dO[rr * p.ldo + h * p.dh + 32 * jc + l31];
+#endif
         qB[jc][r] = ok ? qv : 0.f;
         gB[jc][r] = ok ? gv : 0.f;
       }
@@ -670,86 +680,141 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
     for (int r = 0; r < 16; ++r) dq[jc][r] = 0.f;
   __syncthreads();
 
-  const bool has_bias = p.biasT != nullptr, has_mask = p.mask != nullptr, has_drop = p.drop.thresh != 0;
-  const bool put_dbias = p.dbiasT != nullptr;
-  const int qic = qok ? qi : Sq - 1;
-#pragma unroll 1
-  for (int s = 0; s < NKB; ++s) {
+  // Bias / mask operands and the bias-gradient stores go through buffer resources whose range check does the
+  // predication: an absent operand is a zero-length buffer (loads return 0), a lane outside the problem an out-of-range
+  // offset (loads return 0, stores are dropped).  No branch anywhere in a tile: its whole body is ONE scheduling region,
+  // which lets the S^T / dA^T products of the NEXT tile be interleaved with the softmax-backward arithmetic of this one.
+  const size_t bho = bh * (size_t)Sk * Sq;
+  const unsigned plane = (unsigned)Sk * (unsigned)Sq * 4u;
+  const __amdgpu_buffer_rsrc_t bias_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.biasT ? p.biasT + bho : p.Q), 0, p.biasT ? plane : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mask_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.mask ? p.mask + (size_t)b * Sk : (const uint8_t*)p.Q), 0, p.mask ? (unsigned)Sk : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dbias_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(DB ? p.dbiasT + bho : p.dQ), 0, DB ? plane : 0u, 0x00020000);
+  const uint32_t drop_base = (uint32_t)((bh * Sq + qi) * Sk);
+
+  // phase 1 of a tile: S^T = K Q^T and dA^T = V dO^T (64 MFMAs) + the tile's bias / mask operands
+  auto P1 = [&](int k0, f32x16& acc, f32x16& dacc, float (&bias)[16], float (&mk)[16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + acc_row(r, hh);
+      const bool okk = key < Sk && qok;
+      bias[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bias_rs, okk ? (unsigned)(key * Sq + qi) * 4u : ~0u, 0, 0));
+      mk[r] = (float)__builtin_amdgcn_raw_buffer_load_b8(mask_rs, key < Sk ? (unsigned)key : ~0u, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; dacc[r] = 0.f; }
+#if !(MMNAS_DBG_MHA & 1)
+#pragma unroll
+    for (int s8 = 0; s8 < NS; ++s8) {
+      const int fo = 8 * s8 + 4 * hh;
+      const float4 kf = *reinterpret_cast<const float4*>(Ks + (k0 + l31) * LD + fo);
+      const float4 vf = *reinterpret_cast<const float4*>(Vs + (k0 + l31) * LD + fo);
+      MFMA4(acc, kf, qfr[s8])
+      MFMA4(dacc, vf, gfr[s8])
+    }
+#else
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = qfr[r & 7].x + bias[r]; dacc[r] = gfr[r & 7].y + mk[r]; }
+#endif
+  };
+  // phase 2: softmax backward in registers; acc becomes dZ^T / sqrt(dh), dacc becomes A^T = (P o D)^T   [key][query]
+  auto P2 = [&](int k0, f32x16& acc, f32x16& dacc, const float (&bias)[16], const float (&mk)[16]) __attribute__((always_inline)) {
+#if !(MMNAS_DBG_MHA & 2)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + acc_row(r, hh);
+      const bool ok = key < Sk && qok;
+      const bool masked = mk[r] != 0.f;
+      float v = acc[r] * p.scale + bias[r];
+      v = masked ? -1e9f : v;
+      const float pr = __expf(v - m) * inv;
+      const float dm = drop_mult(p.drop, drop_base + (uint32_t)key);   // (no dropout: thresh 0, scale 1 -> multiplier 1)
+      const float dz = (ok && !masked) ? pr * (dacc[r] * dm - del) : 0.f;
+      if (DB) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz), dbias_rs, ok ? (unsigned)(key * Sq + qi) * 4u : ~0u, 0, 0);
+      acc[r] = dz * p.scale;
+      dacc[r] = ok ? pr * dm : 0.f;
+    }
+#endif
+  };
+  // phases 3 + 4: dQ += dZ K; the two tiles transposed through the wave's LDS image; dK / dV contributions into the
+  // LDS accumulators of this step's key block
+  auto P34 = [&](int k0, int cp, f32x16& acc, f32x16& dacc) __attribute__((always_inline)) {
+#if !(MMNAS_DBG_MHA & 4)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kl = k0 + acc_row(r, hh);
+#pragma unroll
+      for (int jc = 0; jc < JC; ++jc) dq[jc] = mfma32(acc[r], Ks[kl * LD + 32 * jc + l31], dq[jc]);
+    }
+#else
+    dq[0][0] += acc[3]; dq[1][1] += dacc[5];
+#endif
+#if MMNAS_DBG_MHA & 8
+    Tr[lane] = acc[0] + dacc[1];
+#else
+    // transpose the two tiles: [key][query] -> registers = query, lane = key (same-wave LDS accesses stay in order)
+    f32x16 tz, tp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Tr[acc_row(r, hh) * 33 + l31] = acc[r];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tz[r] = Tr[l31 * 33 + acc_row(r, hh)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Tr[acc_row(r, hh) * 33 + l31] = dacc[r];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tp[r] = Tr[l31 * 33 + acc_row(r, hh)];
+    // dK[key][j] += dZ[q][key] Q[q][j] / sqrt(dh),  dV[key][j] += A[q][key] dO[q][j]
+    f32x16 dkp[JC], dvp[JC];
+#pragma unroll
+    for (int jc = 0; jc < JC; ++jc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dkp[jc][r] = 0.f; dvp[jc][r] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int jc = 0; jc < JC; ++jc) {
+        dkp[jc] = mfma32(tz[r], qB[jc][r], dkp[jc]);
+        dvp[jc] = mfma32(tp[r], gB[jc][r], dvp[jc]);
+      }
+    float* dka = dKs + (size_t)(cp * KB + k0) * DHC;
+    float* dva = dVs + (size_t)(cp * KB + k0) * DHC;
+#if MMNAS_DBG_MHA & 16
+    dka[lane] = dkp[0][0] + dkp[1][3]; dva[lane] = dvp[0][1] + dvp[1][2];
+#else
+#pragma unroll
+    for (int jc = 0; jc < JC; ++jc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = acc_row(r, hh) * DHC + 32 * jc + l31;
+        dka[o] += dkp[jc][r];
+        dva[o] += dvp[jc][r];
+      }
+#endif
+#endif
+  };
+
+  // Software pipeline over the key blocks (fully unrolled: the two tile register sets alternate statically).  With one
+  // wave per SIMD nothing else hides the ~480 vector instructions of a tile's softmax backward (index hash of the dropout
+  // replay, exp, selects): issued between the 64 independent MFMAs of the next tile's first phase they cost nothing --
+  // measured 15 us of this kernel's 51 (tools/mha_phases.sh) before.
+  f32x16 tA[2], tD[2];
+  float tb[2][16], tm[2][16];
+  constexpr int NSTEP = (MMNAS_DBG_MHA & 64) ? 0 : NKB;
+  if (active && NSTEP > 0) P1(32 * (w % NKB), tA[0], tD[0], tb[0], tm[0]);
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    const int cur = s & 1, nxt = cur ^ 1;
     const int kbi = (w + s) % NKB, k0 = 32 * kbi, cp = w / NKB;
     if (active) {
-      // the tile's bias / mask operands first: their global-memory latency passes behind the 64 MFMAs below
-      float bias[16], mk[16];
+      if (s + 1 < NSTEP) P1(32 * ((w + s + 1) % NKB), tA[nxt], tD[nxt], tb[nxt], tm[nxt]);
+      P2(k0, tA[cur], tD[cur], tb[cur], tm[cur]);
+      if (s + 1 < NSTEP) {
+        // one MFMA of the next tile, then a slice of this tile's vector work, 64 times
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {   // batched, branch-free operand fetch (clamped indices)
-        const int key = min(k0 + acc_row(r, hh), Sk - 1);
-        bias[r] = has_bias ? p.biasT[(bh * Sk + key) * Sq + qic] : 0.f;
-        mk[r] = has_mask ? (float)p.mask[(size_t)b * Sk + key] : 0.f;
-      }
-      f32x16 acc, dacc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; dacc[r] = 0.f; }
-#pragma unroll
-      for (int s8 = 0; s8 < NS; ++s8) {
-        const int fo = 8 * s8 + 4 * hh;
-        const float4 kf = *reinterpret_cast<const float4*>(Ks + (k0 + l31) * LD + fo);
-        const float4 vf = *reinterpret_cast<const float4*>(Vs + (k0 + l31) * LD + fo);
-        MFMA4(acc, kf, qfr[s8])
-        MFMA4(dacc, vf, gfr[s8])
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + acc_row(r, hh);
-        const bool ok = key < Sk && qok;
-        const bool masked = mk[r] != 0.f;
-        float v = acc[r] * p.scale + bias[r];
-        if (masked) v = -1e9f;
-        const float pr = __expf(v - m) * inv;
-        const float dm = has_drop ? drop_mult(p.drop, (uint32_t)((bh * Sq + qi) * Sk + key)) : 1.f;
-        const float dz = (ok && !masked) ? pr * (dacc[r] * dm - del) : 0.f;
-        if (put_dbias && ok) p.dbiasT[(bh * Sk + key) * Sq + qi] = dz;
-        acc[r] = dz * p.scale;          // dZ^T / sqrt(dh)   [key][query]
-        dacc[r] = ok ? pr * dm : 0.f;   // A^T = (P o D)^T   [key][query]
-      }
-      // dQ += dZ K
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kl = k0 + acc_row(r, hh);
-#pragma unroll
-        for (int jc = 0; jc < JC; ++jc) dq[jc] = mfma32(acc[r], Ks[kl * LD + 32 * jc + l31], dq[jc]);
-      }
-      // transpose the two tiles: [key][query] -> registers = query, lane = key (same-wave LDS accesses stay in order)
-      f32x16 tz, tp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Tr[acc_row(r, hh) * 33 + l31] = acc[r];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tz[r] = Tr[l31 * 33 + acc_row(r, hh)];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Tr[acc_row(r, hh) * 33 + l31] = dacc[r];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tp[r] = Tr[l31 * 33 + acc_row(r, hh)];
-      // dK[key][j] += dZ[q][key] Q[q][j] / sqrt(dh),  dV[key][j] += A[q][key] dO[q][j]
-      f32x16 dkp[JC], dvp[JC];
-#pragma unroll
-      for (int jc = 0; jc < JC; ++jc)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dkp[jc][r] = 0.f; dvp[jc][r] = 0.f; }
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-#pragma unroll
-        for (int jc = 0; jc < JC; ++jc) {
-          dkp[jc] = mfma32(tz[r], qB[jc][r], dkp[jc]);
-          dvp[jc] = mfma32(tp[r], gB[jc][r], dvp[jc]);
+        for (int i = 0; i < 64; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, MMNAS_MHA_VPM, 0);
         }
-      float* dka = dKs + (size_t)(cp * KB + k0) * DHC;
-      float* dva = dVs + (size_t)(cp * KB + k0) * DHC;
-#pragma unroll
-      for (int jc = 0; jc < JC; ++jc)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o = acc_row(r, hh) * DHC + 32 * jc + l31;
-          dka[o] += dkp[jc][r];
-          dva[o] += dvp[jc][r];
-        }
+      }
+      P34(k0, cp, tA[cur], tD[cur]);
     }
     __syncthreads();
   }
@@ -889,9 +954,15 @@ extern "C" int mmnas_mha_core_bwd(const mmnas_mha_desc* d, void* stream) {
     k.nch = 1;
     const dim3 grid(k.H, k.B);
     const int nkb = cdiv(k.Sk, 32);
-    if (nkb <= 1) MMNAS_LAUNCH((mha_bwd_fused_kernel<1>), grid, dim3(256), 0, st, k);
-    else if (nkb <= 2) MMNAS_LAUNCH((mha_bwd_fused_kernel<2>), grid, dim3(256), 0, st, k);
-    else MMNAS_LAUNCH((mha_bwd_fused_kernel<4>), grid, dim3(256), 0, st, k);
+    if (k.dbiasT) {
+      if (nkb <= 1) MMNAS_LAUNCH((mha_bwd_fused_kernel<1, true>), grid, dim3(256), 0, st, k);
+      else if (nkb <= 2) MMNAS_LAUNCH((mha_bwd_fused_kernel<2, true>), grid, dim3(256), 0, st, k);
+      else MMNAS_LAUNCH((mha_bwd_fused_kernel<4, true>), grid, dim3(256), 0, st, k);
+    } else {
+      if (nkb <= 1) MMNAS_LAUNCH((mha_bwd_fused_kernel<1, false>), grid, dim3(256), 0, st, k);
+      else if (nkb <= 2) MMNAS_LAUNCH((mha_bwd_fused_kernel<2, false>), grid, dim3(256), 0, st, k);
+      else MMNAS_LAUNCH((mha_bwd_fused_kernel<4, false>), grid, dim3(256), 0, st, k);
+    }
     return check_launch("mha_core_bwd");
   }
   if (k.dh > 64) {   // several head-dim chunks: delta needs the whole row first (dh <= 64: fused into the dQ kernel)

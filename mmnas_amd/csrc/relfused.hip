@@ -14,6 +14,7 @@
 // are reductions over B*S*S = 640k elements: each workgroup stages hid / dhid of 256 elements in LDS
 // and contracts them on the fp32 MFMA (accumulating over its elements in registers), then writes one
 // partial row to a workspace that a second tiny kernel sums (no hot-address atomics, deterministic).
+#include <stdlib.h>
 #include "common.h"
 
 namespace mmnas {
@@ -425,6 +426,247 @@ rel_fused_bwd_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const float
   }
 }
 
+// Backward for H <= 4 heads (HSIZE 256: the supernet of search_*.py), round 3.  The MFMA chain
+// above multiplies mostly padding once the head count is small: the head projection (step 2) and the two parameter-
+// gradient contractions (step 5) put 4-8 heads / 5 raw channels on 16- or 32-wide tiles -- 4352 of its 5120
+// MFMA-cycles per 32 elements.  The fp32 vector pipe has the same peak as the fp32 MFMA and no padding, so here:
+//   1. hid^T[j,e]  on the MFMA as before (8 MFMAs; A = Wy|by, B = the lane's raw row);
+//   2. r[h,e]      on the VALU: lane (e, half) holds 32 of the 64 hidden values of its element; HH partial dot products
+//                  with Wr^T read as broadcast float4 from LDS, one cross-half shuffle each;
+//   3. dpre[h,e]   every lane of an element holds all HH heads;
+//   4. dhid^T[j,e] on the MFMA with the heads as the k index (HH MFMAs instead of 8-16);
+//   5. dWr, dWy    on the VALU with lane = hidden unit j: hid / dhid pass through the wave's LDS image (written [e][j],
+//                  read back row by row: conflict-free), dpre[e,:] and raw_ext[e,:] are broadcast float4 reads;
+//                  4 + 6 (HH = 4) fused multiply-adds per element and lane, HH + C + 1 accumulators per lane.
+// Per 32 elements: 768-1024 MFMA-cycles + ~2400-3400 VALU-cycles, two waves per SIMD to interleave them
+// (52 KB LDS), against 5120 MFMA-cycles.
+template <int C, int HH>
+__global__ void __launch_bounds__(256, 2)
+rel_fused_bwd_v_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const float* __restrict__ Wy,
+                       const float* __restrict__ by, const float* __restrict__ Wr, const float* __restrict__ br) {
+  static_assert(HH == 4 || HH == 8, "heads padded to 4 or 8");
+  __shared__ __attribute__((aligned(16))) float sHidAll[4][32 * RF_LDH];
+  __shared__ __attribute__((aligned(16))) float sDpreAll[4][32 * 8];
+  __shared__ __attribute__((aligned(16))) float sRawAll[4][32 * RF_CP];
+  __shared__ __attribute__((aligned(16))) float sWrT[RF_R * 8];      // Wr^T: [j][h], heads padded to 8
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  float* sHid = sHidAll[w];
+  float* sDpre = sDpreAll[w];
+  float* sRaw = sRawAll[w];
+  const int H = p.H;
+  for (int i = tid; i < RF_R * 8; i += 256) {
+    const int j = i >> 3, h = i & 7;
+    sWrT[i] = h < H ? Wr[h * RF_R + j] : 0.f;
+  }
+  // ---- per-lane constant MFMA operands ----
+  float wyA[2][4];       // step 1, A[i = j][k = c]
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int j = 32 * t + l31, c = 2 * s4 + hh;
+      wyA[t][s4] = c < C ? Wy[j * C + c] : (c == C ? by[j] : 0.f);
+    }
+  float wrK[2][HH / 2];  // step 4, A[i = j][k = h]: MFMA m covers heads 2m (lower half-wave) and 2m + 1 (upper)
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int m = 0; m < HH / 2; ++m) {
+      const int h = 2 * m + hh;
+      wrK[t][m] = h < H ? Wr[h * RF_R + 32 * t + l31] : 0.f;
+    }
+  float brv[HH];
+#pragma unroll
+  for (int h = 0; h < HH; ++h) brv[h] = h < H ? br[h] : 0.f;
+  __syncthreads();
+
+  float accWr[HH], accWy[RF_CP], accbr[HH];   // lane = hidden unit j (step 5); accbr: lane = element
+#pragma unroll
+  for (int h = 0; h < HH; ++h) { accWr[h] = 0.f; accbr[h] = 0.f; }
+#pragma unroll
+  for (int c = 0; c < RF_CP; ++c) accWy[c] = 0.f;
+
+  const unsigned SS = (unsigned)p.Sq * (unsigned)p.Sk;
+  const int nwaves = (int)gridDim.x * 4;
+  const int adv_b = nwaves / tiles_per_b, adv_t = nwaves - adv_b * tiles_per_b;
+  struct TileIn { float ex[RF_CP]; float db[HH]; };
+  // loads of one tile: the lane's raw row (gathered, 16 B) and its element's dbias of every head; issued one tile ahead
+  auto tile_load = [&](int b, int tb) __attribute__((always_inline)) {
+    TileIn t;
+    const unsigned f = (unsigned)tb * 32u + (unsigned)l31;
+    const bool ok = b < p.B && f < SS;
+    const unsigned fc = ok ? f : 0u;
+    const int bc = ok ? b : 0;
+    const unsigned k = fc / (unsigned)p.Sq, q = fc - k * (unsigned)p.Sq;
+    const float* src = p.raw + (((size_t)bc * p.Sq + q) * p.Sk + k) * C;
+#pragma unroll
+    for (int c = 0; c < RF_CP; ++c) t.ex[c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { const float v = src[c]; t.ex[c] = ok ? v : 0.f; }   // (address clamped: the load is unconditional)
+    t.ex[C] = ok ? 1.f : 0.f;
+    const float* dbp = p.dbiasT + (size_t)bc * H * SS + fc;
+#pragma unroll
+    for (int h = 0; h < HH; ++h) {
+      const float v = dbp[(size_t)(h < H ? h : 0) * SS];
+      t.db[h] = (ok && h < H) ? v : 0.f;
+    }
+    return t;
+  };
+  int tile = (int)blockIdx.x * 4 + w;
+  int cb = tile / tiles_per_b, ct = tile - cb * tiles_per_b;
+  int nb_ = cb + adv_b, nt_ = ct + adv_t;
+  if (nt_ >= tiles_per_b) { nt_ -= tiles_per_b; ++nb_; }
+  TileIn cur = tile_load(cb, ct);
+  for (; tile < ntiles; tile += nwaves) {
+    const TileIn nxt = tile_load(nb_, nt_);   // in flight during this tile's arithmetic
+    nb_ += adv_b; nt_ += adv_t;
+    if (nt_ >= tiles_per_b) { nt_ -= tiles_per_b; ++nb_; }
+    // 1. hidden layer (transposed: rows j, columns e); relu, and its gate as one bit per accumulator register
+    f32x16 hid[2];
+    unsigned gm = 0u;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hid[t][r] = 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) hid[t] = mfma32(wyA[t][s4], hh ? cur.ex[2 * s4 + 1] : cur.ex[2 * s4], hid[t]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        gm |= hid[t][r] > 0.f ? (1u << (16 * t + r)) : 0u;
+        hid[t][r] = fmaxf(hid[t][r], 0.f);
+      }
+    }
+    // 2. r[h, e]: this lane's 32 hidden values against the matching rows of Wr^T (broadcast reads: the 16-lane read
+    //    groups of ds_read_b128 sit inside one half-wave, i.e. on one address)
+    float rr[HH];
+#pragma unroll
+    for (int h = 0; h < HH; ++h) rr[h] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if ((r & 3) == 0) asm volatile("" ::: "memory");   // (a compiler fence every 4 rows keeps the 32-64 weight reads from
+                                                            //  being hoisted in front of the loop all at once: 128-256 VGPRs)
+        const float* wp = sWrT + (32 * t + acc_row(r, hh)) * 8;
+        const float4 w0 = *reinterpret_cast<const float4*>(wp);
+        rr[0] += w0.x * hid[t][r]; rr[1] += w0.y * hid[t][r]; rr[2] += w0.z * hid[t][r]; rr[3] += w0.w * hid[t][r];
+        if (HH == 8) {
+          const float4 w1 = *reinterpret_cast<const float4*>(wp + 4);
+          rr[4] += w1.x * hid[t][r]; rr[5] += w1.y * hid[t][r]; rr[6] += w1.z * hid[t][r]; rr[7] += w1.w * hid[t][r];
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    // 3. d(log max(r, 1e-6)) / dr -- both half-waves hold every head of their element
+    float dpre[HH];
+#pragma unroll
+    for (int h = 0; h < HH; ++h) {
+      const float rv = rr[h] + __shfl_xor(rr[h], 32, 64) + brv[h];
+      dpre[h] = rv >= 1e-6f ? cur.db[h] / rv : 0.f;
+      accbr[h] += dpre[h];
+    }
+    // 5a. through the wave's LDS image: hid written [e][j] from the accumulator layout, read back with lane = j
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        *reinterpret_cast<float4*>(sHid + l31 * RF_LDH + 32 * t + 8 * u + 4 * hh) =
+            make_float4(hid[t][4 * u], hid[t][4 * u + 1], hid[t][4 * u + 2], hid[t][4 * u + 3]);
+    if (hh == 0) {
+      *reinterpret_cast<float4*>(sDpre + l31 * 8) = make_float4(dpre[0], dpre[1], dpre[2], dpre[3]);
+      if (HH == 8) *reinterpret_cast<float4*>(sDpre + l31 * 8 + 4) = make_float4(dpre[4], dpre[5], dpre[6], dpre[7]);
+      *reinterpret_cast<float4*>(sRaw + l31 * RF_CP) = make_float4(cur.ex[0], cur.ex[1], cur.ex[2], cur.ex[3]);
+      *reinterpret_cast<float4*>(sRaw + l31 * RF_CP + 4) = make_float4(cur.ex[4], cur.ex[5], cur.ex[6], cur.ex[7]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);       // (the hidden values are dead from here on: 32 registers)
+    //     dWr[h, j = lane] += sum_e dpre[h, e] hid[j, e]
+#pragma unroll 4
+    for (int e = 0; e < 32; ++e) {
+      const float hv = sHid[e * RF_LDH + lane];
+      const float4 d0 = *reinterpret_cast<const float4*>(sDpre + e * 8);
+      accWr[0] += d0.x * hv; accWr[1] += d0.y * hv; accWr[2] += d0.z * hv; accWr[3] += d0.w * hv;
+      if (HH == 8) {
+        const float4 d1 = *reinterpret_cast<const float4*>(sDpre + e * 8 + 4);
+        accWr[4] += d1.x * hv; accWr[5] += d1.y * hv; accWr[6] += d1.z * hv; accWr[7] += d1.w * hv;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // 4. gradient of the hidden layer, gated by relu' (the saved bits)
+    f32x16 dh[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dh[t][r] = 0.f;
+#pragma unroll
+      for (int m = 0; m < HH / 2; ++m) dh[t] = mfma32(wrK[t][m], hh ? dpre[2 * m + 1] : dpre[2 * m], dh[t]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dh[t][r] = (gm >> (16 * t + r)) & 1u ? dh[t][r] : 0.f;
+    }
+    // 5b. the same image again, now with dhid
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        *reinterpret_cast<float4*>(sHid + l31 * RF_LDH + 32 * t + 8 * u + 4 * hh) =
+            make_float4(dh[t][4 * u], dh[t][4 * u + 1], dh[t][4 * u + 2], dh[t][4 * u + 3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    //     dWy_ext[j = lane, c] += sum_e dhid[j, e] raw_ext[e, c]   (column C of raw_ext is 1: dby)
+#pragma unroll 4
+    for (int e = 0; e < 32; ++e) {
+      const float dv = sHid[e * RF_LDH + lane];
+      const float4 r0 = *reinterpret_cast<const float4*>(sRaw + e * RF_CP);
+      const float4 r1 = *reinterpret_cast<const float4*>(sRaw + e * RF_CP + 4);
+      accWy[0] += dv * r0.x; accWy[1] += dv * r0.y; accWy[2] += dv * r0.z; accWy[3] += dv * r0.w;
+      accWy[4] += dv * r1.x;
+      if (C + 1 > 5) accWy[5] += dv * r1.y;
+    }
+    cur = nxt;
+  }
+
+  // ---- the workgroup's partial row: the 4 waves add their accumulators in wave order through LDS (fixed order:
+  //      reproducible), the last one writes the row.  Row layout as for the MFMA kernel: [dWr: HP x R | dWy_ext: R x CP | dbr: HP]
+  __syncthreads();
+  float* srow = &sHidAll[0][0];
+  float* grow = p.part + (size_t)blockIdx.x * RF_ROW;
+  float brsum[HH];
+#pragma unroll
+  for (int h = 0; h < HH; ++h) {
+    float v = hh == 0 ? accbr[h] : 0.f;     // (both half-waves carried the same dpre: count one)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    brsum[h] = v;
+  }
+  for (int turn = 0; turn < 4; ++turn) {
+    if (w == turn) {
+      const bool first = turn == 0, last = turn == 3;
+#pragma unroll
+      for (int h = 0; h < HH; ++h) {
+        const int o1 = h * RF_R + lane;                                  // dWr[h][j]
+        const float v1 = accWr[h] + (first ? 0.f : srow[o1]);
+        if (last) grow[o1] = v1; else srow[o1] = v1;
+      }
+#pragma unroll
+      for (int c = 0; c < RF_CP; ++c) {
+        const int o2 = RF_HP * RF_R + lane * RF_CP + c;                  // dWy_ext[j][c]
+        const float v2 = (c <= C ? accWy[c] : 0.f) + (first ? 0.f : srow[o2]);
+        if (last) grow[o2] = v2; else srow[o2] = v2;
+      }
+      if (lane < RF_HP) {
+        const int o3 = RF_HP * RF_R + RF_R * RF_CP + lane;               // dbr[h]
+        float mine = 0.f;
+#pragma unroll
+        for (int h = 0; h < HH; ++h) mine = lane == h ? brsum[h] : mine;
+        const float v3 = mine + (first ? 0.f : srow[o3]);
+        if (last) grow[o3] = v3; else srow[o3] = v3;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // sum the partial rows and add into the parameter gradients (single writer per output: plain +=)
 __global__ void __launch_bounds__(1024) rel_fused_reduce_kernel(const float* __restrict__ part, int nrows, int C, int H,
                                                                 float* dWr, float* dbr, float* dWy, float* dby) {
@@ -526,10 +768,17 @@ extern "C" int mmnas_rel_fused_bwd(const float* raw, const float* Wy, const floa
   const double n = (double)B * Sq * Sk;
   ProfScope ps(MMNAS_K_REL_BWD, 2.0 * n * (RF_R * (C + 1) + 3.0 * H * RF_R + RF_R * (C + 1)), 4.0 * n * (C + H), st);
 #define RF_BWD(CC, NGG) MMNAS_LAUNCH((rel_fused_bwd_kernel<CC, NGG>), dim3(grid), dim3(256), 0, st, k, ntiles, tpb, Wy, by, Wr, br)
-  if (H <= 8) { if (C == 4) RF_BWD(4, 1); else RF_BWD(3, 1); }
+#define RF_BWDV(CC, HHH) MMNAS_LAUNCH((rel_fused_bwd_v_kernel<CC, HHH>), dim3(grid), dim3(256), 0, st, k, ntiles, tpb, Wy, by, Wr, br)
+  static const bool vpath = !(getenv("MMNAS_REL_BWD_VALU") && getenv("MMNAS_REL_BWD_VALU")[0] == '0');   // 0: the all-MFMA kernel (A/B runs)
+  // H <= 4 (HSIZE 256: the supernet): the vector-pipe kernel.  At 8 heads its 256 loop-invariant Wr^T values no longer
+  // stay in registers beside the tile state (the compiler keeps them there for 4 heads: no weight reads per tile at all)
+  // and the head projection costs the vector pipe what the 16-wide MFMA form costs the matrix pipe: the MFMA kernel stays.
+  if (H <= 4 && vpath) { if (C == 4) RF_BWDV(4, 4); else RF_BWDV(3, 4); }
+  else if (H <= 8) { if (C == 4) RF_BWD(4, 1); else RF_BWD(3, 1); }
   else if (H <= 16) { if (C == 4) RF_BWD(4, 2); else RF_BWD(3, 2); }
   else { if (C == 4) RF_BWD(4, 4); else RF_BWD(3, 4); }
 #undef RF_BWD
+#undef RF_BWDV
   MMNAS_LAUNCH(rel_fused_reduce_kernel, dim3(cdiv(RF_ROW, 64)), dim3(1024), 0, st, ws, grid, C, H, dWr, dbr, dWy, dby);
   return check_launch("rel_fused_bwd");
 }
