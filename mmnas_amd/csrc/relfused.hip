@@ -19,6 +19,8 @@
 
 namespace mmnas {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int RF_R = 64;      // REL_SIZE handled by the fused path
 constexpr int RF_CP = 8;      // raw channels padded (C + 1 <= 8: the extra column of ones yields dby)
 constexpr int RF_HP = 32;     // heads padded to one MFMA tile
@@ -438,8 +440,8 @@ rel_fused_bwd_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const float
 //   5. dWr, dWy    on the VALU with lane = hidden unit j: hid / dhid pass through the wave's LDS image (written [e][j],
 //                  read back row by row: conflict-free), dpre[e,:] and raw_ext[e,:] are broadcast float4 reads;
 //                  4 + 6 (HH = 4) fused multiply-adds per element and lane, HH + C + 1 accumulators per lane.
-// Per 32 elements: 768-1024 MFMA-cycles + ~2400-3400 VALU-cycles, two waves per SIMD to interleave them
-// (52 KB LDS), against 5120 MFMA-cycles.
+// Per 32 elements: 768 MFMA-cycles + ~2400 VALU-cycles at two waves per SIMD (52 KB LDS), against 5120 MFMA-cycles.
+// Measured (tools/rel_bench.py, B = 64, 100 x 100, 4 heads): 91 -> 76 us per backward (the reduction launch included).
 template <int C, int HH>
 __global__ void __launch_bounds__(256, 2)
 rel_fused_bwd_v_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const float* __restrict__ Wy,
@@ -538,6 +540,11 @@ rel_fused_bwd_v_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const flo
     }
     // 2. r[h, e]: this lane's 32 hidden values against the matching rows of Wr^T (broadcast reads: the 16-lane read
     //    groups of ds_read_b128 sit inside one half-wave, i.e. on one address)
+    //    (The Wr^T rows are loop invariant: for 4 heads the compiler keeps all 128 of a lane's values in registers, so the
+    //    tile loop reads no weights at all -- at the price of two waves per SIMD.  Tried and dropped: volatile reads +
+    //    three waves per SIMD (168 VGPRs: >200 spill instructions in the loop); two-wide vector types so the products
+    //    issue as v_pk_fma_f32 (97 packed instead of ~190 scalar FMAs: 79.6 vs 76.2 us -- the chain of dependent MFMA /
+    //    shuffle / LDS round trips, not the issue rate, sets the pace).)
     float rr[HH];
 #pragma unroll
     for (int h = 0; h < HH; ++h) rr[h] = 0.f;
@@ -545,8 +552,6 @@ rel_fused_bwd_v_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const flo
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if ((r & 3) == 0) asm volatile("" ::: "memory");   // (a compiler fence every 4 rows keeps the 32-64 weight reads from
-                                                            //  being hoisted in front of the loop all at once: 128-256 VGPRs)
         const float* wp = sWrT + (32 * t + acc_row(r, hh)) * 8;
         const float4 w0 = *reinterpret_cast<const float4*>(wp);
         rr[0] += w0.x * hid[t][r]; rr[1] += w0.y * hid[t][r]; rr[2] += w0.z * hid[t][r]; rr[3] += w0.w * hid[t][r];
@@ -555,7 +560,6 @@ rel_fused_bwd_v_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const flo
           rr[4] += w1.x * hid[t][r]; rr[5] += w1.y * hid[t][r]; rr[6] += w1.z * hid[t][r]; rr[7] += w1.w * hid[t][r];
         }
       }
-    __builtin_amdgcn_sched_barrier(0);
     // 3. d(log max(r, 1e-6)) / dr -- both half-waves hold every head of their element
     float dpre[HH];
 #pragma unroll
@@ -718,9 +722,9 @@ static int rf_check(const char* who, int B, int Sq, int Sk, int C, int R, int H)
 }
 
 static long rf_tiles_per_b(int Sq, int Sk) { return ((long)Sq * Sk + 31) / 32; }
-static int rf_grid(long ntiles) {   // persistent: <= 2 workgroups (8 waves) per CU, one 32-element tile per wave at a time
-  const long wgs = (ntiles + 3) / 4;
-  return (int)(wgs < 512 ? wgs : 512);
+static int rf_grid(long ntiles, int per_cu = 2) {   // persistent: 2 or 3 workgroups per CU, one 32-element tile per wave at a time
+  const long wgs = (ntiles + 3) / 4, cap = 256l * per_cu;
+  return (int)(wgs < cap ? wgs : cap);
 }
 
 }  // namespace mmnas
@@ -747,7 +751,7 @@ extern "C" int mmnas_rel_fused_fwd(const float* raw, const float* Wy, const floa
 }
 
 extern "C" size_t mmnas_rel_fused_bwd_ws_floats(int B, int Sq, int Sk) {
-  return (size_t)rf_grid((long)B * rf_tiles_per_b(Sq, Sk)) * RF_ROW;
+  return (size_t)rf_grid((long)B * rf_tiles_per_b(Sq, Sk), 2) * RF_ROW;
 }
 
 extern "C" int mmnas_rel_fused_bwd(const float* raw, const float* Wy, const float* by, const float* Wr, const float* br,
@@ -763,17 +767,18 @@ extern "C" int mmnas_rel_fused_bwd(const float* raw, const float* Wy, const floa
   const int tpb = (int)rf_tiles_per_b(Sq, Sk);
   MMNAS_REQUIRE((long)B * tpb < (1l << 30) && (long)Sq * Sk < (1l << 30), MMNAS_E_SHAPE, "rel_fused_bwd: problem too large for 32-bit tile indices");
   const int ntiles = B * tpb;
-  const int grid = rf_grid(ntiles);
+  static const bool vpath = !(getenv("MMNAS_REL_BWD_VALU") && getenv("MMNAS_REL_BWD_VALU")[0] == '0');   // 0: the all-MFMA kernel (A/B runs)
+  const bool use_v = H <= 4 && vpath;
+  const int grid = rf_grid(ntiles, 2);
   hipStream_t st = (hipStream_t)stream;
   const double n = (double)B * Sq * Sk;
   ProfScope ps(MMNAS_K_REL_BWD, 2.0 * n * (RF_R * (C + 1) + 3.0 * H * RF_R + RF_R * (C + 1)), 4.0 * n * (C + H), st);
 #define RF_BWD(CC, NGG) MMNAS_LAUNCH((rel_fused_bwd_kernel<CC, NGG>), dim3(grid), dim3(256), 0, st, k, ntiles, tpb, Wy, by, Wr, br)
 #define RF_BWDV(CC, HHH) MMNAS_LAUNCH((rel_fused_bwd_v_kernel<CC, HHH>), dim3(grid), dim3(256), 0, st, k, ntiles, tpb, Wy, by, Wr, br)
-  static const bool vpath = !(getenv("MMNAS_REL_BWD_VALU") && getenv("MMNAS_REL_BWD_VALU")[0] == '0');   // 0: the all-MFMA kernel (A/B runs)
   // H <= 4 (HSIZE 256: the supernet): the vector-pipe kernel.  At 8 heads its 256 loop-invariant Wr^T values no longer
   // stay in registers beside the tile state (the compiler keeps them there for 4 heads: no weight reads per tile at all)
   // and the head projection costs the vector pipe what the 16-wide MFMA form costs the matrix pipe: the MFMA kernel stays.
-  if (H <= 4 && vpath) { if (C == 4) RF_BWDV(4, 4); else RF_BWDV(3, 4); }
+  if (use_v) { if (C == 4) RF_BWDV(4, 4); else RF_BWDV(3, 4); }
   else if (H <= 8) { if (C == 4) RF_BWD(4, 1); else RF_BWD(3, 1); }
   else if (H <= 16) { if (C == 4) RF_BWD(4, 2); else RF_BWD(3, 2); }
   else { if (C == 4) RF_BWD(4, 4); else RF_BWD(3, 4); }

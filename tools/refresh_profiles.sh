@@ -1,12 +1,12 @@
 #!/bin/bash
 # Regenerates everything under profiles/ for one round on a GPU box (run from the repo root):
-#   bash tools/refresh_profiles.sh r02
+#   bash tools/refresh_profiles.sh r03
 # rocprofv3 --kernel-trace --stats summaries of the bench command per workload, one-step kernel timelines, the two
 # --pmc passes behind roofline.traffic (FETCH_SIZE / WRITE_SIZE cannot share a pass), the MFMA / LDS counter passes, and
 # the bench lines themselves (the default line with its CPU baselines last: it reads the traffic files written before).
 # Raw traces stay in /tmp; only summaries are written to profiles/.  Counters are collected with --kernel-trace only.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$PWD
 export TMPDIR=/tmp
 W=/tmp/mmnas_prof
@@ -30,6 +30,14 @@ for wl in search_vqa arch_vqa train_vqa; do
   (cd /tmp && rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace -d $W/pmc_${wl}_gui -o t -- python3 $ROOT/$small > $W/pmc_${wl}_gui.log 2>&1)
   python3 tools/pmc_counters.py profiles/${R}_pmc_$wl.json $W/pmc_${wl}_mfma $W/pmc_${wl}_lds $W/pmc_${wl}_gui
 done
+# the data-parallel exchange in a one-rank RCCL group, and the streamed-input step with the copy engine's rows
+for wl in search_vqa_dp1 train_vqa_dp1; do
+  (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $W/trace_$wl -o t -- python3 $ROOT/bench.py --workload $wl --steps 6 --warmup 3 --repeats 1 --no-cpu-baseline --no-prof > $W/trace_$wl.log 2>&1)
+  marker=onehot_rows; [ $wl = train_vqa_dp1 ] && marker=row_is_zero
+  python3 tools/step_timeline.py $W/trace_$wl $marker --list > profiles/${R}_timeline_$wl.txt
+done
+(cd /tmp && rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $W/trace_stream -o t -- python3 $ROOT/bench.py --workload search_vqa_stream --steps 8 --warmup 3 --repeats 1 --no-cpu-baseline --no-prof > $W/trace_stream.log 2>&1)
+python3 tools/copy_overlap.py $W/trace_stream > profiles/${R}_timeline_search_vqa_stream.txt 2>&1
 if [ -z "${SKIP_PMC:-}" ]; then
   small="bench.py --workload bilevel_vqa --steps 6 --warmup 6 --no-cpu-baseline --no-prof"   # (one round = 5 weight + 1 arch steps)
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -39,6 +47,12 @@ if [ -z "${SKIP_PMC:-}" ]; then
   (cd /tmp && GEMM_PMC_SWEEP=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $W/sweep -o t -- python3 $ROOT/tools/gemm_pmc.py > $W/sweep.log 2>&1)
   python3 tools/traffic_sweep.py $W/sweep > profiles/${R}_gemm_traffic_sweep.txt
 fi
+python3 tools/mha_bench.py > profiles/${R}_mha_microbench.txt 2>/dev/null
+python3 tools/rel_bench.py > profiles/${R}_rel_microbench.txt 2>/dev/null
+python3 tools/gemm_ab.py mmnas_amd/lib/libmmnas_hip_r2.so mmnas_amd/lib/libmmnas_hip.so > profiles/${R}_gemm_vs_round2_build.txt 2>/dev/null
+(cd /tmp && GEMM_PMC_LAYOUTS=1 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $W/pmc_gemm_lds -o t -- python3 $ROOT/tools/gemm_pmc.py > $W/pmc_gemm_lds.log 2>&1)
+(cd /tmp && GEMM_PMC_LAYOUTS=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace -d $W/pmc_gemm_mfma -o t -- python3 $ROOT/tools/gemm_pmc.py > $W/pmc_gemm_mfma.log 2>&1)
+python3 tools/pmc_counters.py profiles/${R}_pmc_gemm_layouts.json $W/pmc_gemm_lds $W/pmc_gemm_mfma
 python3 bench.py > $W/bench_all.log 2> $W/bench_all.err
 grep '^{' $W/bench_all.log | tail -1 > profiles/${R}_bench.json
 for wl in train_vgd train_itm; do
