@@ -60,7 +60,10 @@ const char* mmnas_last_error(void);
 int mmnas_dropout_mask(float* out, size_t n, float p, uint64_t seed, uint32_t site, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Grouped fp32 GEMM on v_mfma_f32_32x32x2_f32 with fused epilogue.
+ * Grouped fp32 GEMM with fused epilogue.  Default arithmetic: every fp32 product as 6 v_mfma_f32_32x32x16_bf16 products of
+ * operands split EXACTLY into three bf16 parts, fp32 accumulation (fp32-grade error, tests/test_kernels_gpu.py::
+ * test_default_products_are_fp32_grade); MMNAS_GEMM_SPLIT=0 selects v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), which
+ * shapes outside the buffer-load path (K % 32 != 0, unaligned operands) always take.
  * Replaces the mm/addmm/bmm calls behind nn.Linear in modules.py:18,38,172-175 and their
  * autograd backward.  For group g (independent problems launched together):
  *     C_g[M_g,N] = epilogue( alpha * sum_{s<nseg} op(A_{g,s}) * op(B_{g,s}) )
@@ -142,9 +145,15 @@ int mmnas_lstm_bwd(const float* dout, const float* Whh, const float* Call, const
  *   bwd: dout [B,T,H] -> DG [B,T,4H] (gradients of the pre-activations).  The caller finishes with ordinary products:
  *        dW_ih += DG^T x, dW_hh += DG^T Hprev (mmnas_gemm TN over the B*T rows), db += column sums of DG,
  *        dx = DG W_ih (mmnas_gemm NN).
- * Supported: H in {64, 128, 256, 512}, any T >= 1, B <= 960 (blocks of 32 / 16 samples run independently).
- * mmnas_lstm_seq_timed_out(stream): synchronises and returns 1 if a step hand-off of the last launch gave up waiting
- * (a workgroup was not resident: results are garbage), 0 otherwise -- tests / debugging. */
+ * Supported: H in {64, 128, 256, 512}, any T >= 1, B <= 960 (blocks of 32 / 16 samples run independently); needs a device
+ * (the query asks it how many workgroups of the two kernels it holds at once).  Residency: the step barriers spin on the
+ * other unit workgroups of a sample block, so a pass is cut into launches of whole sample blocks whose grid is resident at
+ * once (occupancy query x CU count, one block per CU taken off when the query reports more than one); every batch of the
+ * VQA / VGD configurations is one launch, the ITM batch of 160 at H = 512 two.
+ * A step hand-off that gives up waiting (a workgroup not resident after all -- e.g. a co-running kernel held its slot)
+ * sets a flag AND poisons the pass: a NaN goes into the output sequence (forward) / the gate gradients (backward), so the
+ * loss or the gradient norm shows it without anybody polling.  mmnas_lstm_seq_timed_out(stream): synchronises and returns
+ * 1 if that happened in the last pass on the stream, 0 otherwise -- tests / debugging. */
 int mmnas_lstm_seq_supported(int H, int B);
 int mmnas_lstm_seq_fwd(const float* xp, const float* bhh, const float* Whh, float* Hprev, float* Cs, float* Gall,
                        float* out, int T, int B, int H, void* stream);

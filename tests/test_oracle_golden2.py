@@ -78,7 +78,7 @@ NEAR_INVARIANT = ('attflat_x.mlp.fc.linear.bias', 'attflat_y.mlp.fc.linear.bias'
 
 
 def check_trajectory(res, tol_loss=2e-4, tol_delta=2e-2):
-    """Shared with the GPU replay (tests/test_traj_gpu.py).  Adam normalises every coordinate's first step to +-lr,
+    """Shared with the GPU replay (tests/test_harness_gpu.py::test_bilevel_trajectory_vs_reference_loop).  Adam normalises every coordinate's first step to +-lr,
     so coordinates whose gradient is round-off-sized move by a full step in a direction the summation order decides:
     parameter motion is compared as per-tensor delta norms and, for the listed small tensors, element-wise."""
     npz = load('traj.npz')

@@ -29,7 +29,10 @@ def main():
         return
     lo, hi = starts[-4], starts[-1]
     print('three steady-state steps: %.1f us each on average; copies inside them:' % ((hi - lo) / 3e3))
-    print('%10s %9s %12s %8s %8s  %s' % ('at us', 'dur us', 'bytes', 'GB/s', 'hidden', 'direction'))
+    print('(hidden = share of the copy during which a compute kernel was running; slack = how long before the first kernel of the')
+    print(' NEXT step the copy had finished -- a positive slack means the copy was not what that step waited for.  Under the')
+    print(' profiler every step has a ~0.3 ms host-side hole near its start, which is where the unhidden part of a copy falls.)')
+    print('%10s %9s %12s %8s %8s %9s  %s' % ('at us', 'dur us', 'bytes', 'GB/s', 'hidden', 'slack us', 'direction'))
     tot = hid = 0.0
     for s, e, d, nb in cps:
         if not (lo <= s < hi) or 'HOST_TO_DEVICE' not in d.upper().replace(' ', '_') and 'H2D' not in d.upper():
@@ -43,7 +46,9 @@ def main():
             ov += min(e, ke) - max(s, ks)
         dur = max(e - s, 1)
         step0 = max(x for x in starts if x <= s)
-        print('%10.1f %9.1f %12d %8.1f %8.2f  %s' % ((s - step0) / 1e3, dur / 1e3, nb, nb / dur, min(ov / dur, 1.0), d))
+        nxt = [x for x in starts if x > s]
+        slack = (nxt[0] - e) / 1e3 if nxt else float('nan')
+        print('%10.1f %9.1f %12d %8.1f %8.2f %9.1f  %s' % ((s - step0) / 1e3, dur / 1e3, nb, nb / dur, min(ov / dur, 1.0), slack, d))
         tot += dur
         hid += min(ov, dur)
     if tot:
