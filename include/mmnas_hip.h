@@ -92,7 +92,11 @@ typedef struct mmnas_gemm_group {
   const float* gate;      /* [M, ldgate] or NULL */
   float* colsum;          /* [N] or NULL: colsum[n] += sum_m C[m, n] of the values just stored (the bias gradient of the
                              layer below when C is its pre-activation gradient); not with accumulate */
+  uint64_t drop_seed;     /* != 0: this group's own dropout seed (drop_p / drop_site of the descriptor): the merge products
+                             of a supernet node's candidates share a launch but not a mask */
 } mmnas_gemm_group;
+
+#define MMNAS_GEMM_MAX_GROUPS 9   /* e.g. the nine N = K = d projections of a decoder node's three attention candidates */
 
 typedef struct mmnas_gemm_desc {
   int layout, ngroups, nseg;
@@ -104,7 +108,7 @@ typedef struct mmnas_gemm_desc {
   float drop_p;           /* 0 = no dropout */
   uint32_t drop_site;
   uint64_t drop_seed;
-  mmnas_gemm_group g[3];
+  mmnas_gemm_group g[MMNAS_GEMM_MAX_GROUPS];
 } mmnas_gemm_desc;
 
 int mmnas_gemm(const mmnas_gemm_desc* d, void* stream);

@@ -19,7 +19,10 @@ _fp = C.c_void_p  # device pointers travel as void*
 
 class GemmGroup(C.Structure):
     _fields_ = [('M', C.c_int), ('A', _fp * 3), ('B', _fp * 3), ('C', _fp), ('bias', _fp),
-                ('residual', _fp), ('gate', _fp), ('colsum', _fp)]
+                ('residual', _fp), ('gate', _fp), ('colsum', _fp), ('drop_seed', C.c_uint64)]
+
+
+GEMM_MAX_GROUPS = 9
 
 
 class GemmDesc(C.Structure):
@@ -27,7 +30,7 @@ class GemmDesc(C.Structure):
                 ('lda', C.c_int), ('ldb', C.c_int), ('ldc', C.c_int), ('ldres', C.c_int), ('ldgate', C.c_int),
                 ('relu', C.c_int), ('split_k', C.c_int), ('accumulate', C.c_int), ('reserved', C.c_int), ('alpha', C.c_float), ('gate_scale', C.c_float),
                 ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64),
-                ('g', GemmGroup * 3)]
+                ('g', GemmGroup * GEMM_MAX_GROUPS)]
 
 
 class MhaDesc(C.Structure):

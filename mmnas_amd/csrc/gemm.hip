@@ -29,6 +29,7 @@
 //     instead of split-K atomics.
 //   * workgroup -> unit-range mapping is XCD-aware: the 8 XCDs (private 4 MiB L2 each) get contiguous
 //     runs of units, so an XCD re-reads only its own A row-panels and the (small) weight matrix.
+#include <stddef.h>
 #include <string.h>
 #include <map>
 #include <mutex>
@@ -47,7 +48,10 @@ struct GemmGroupK {
   const float* residual;
   const float* gate;
   float* colsum;
+  uint32_t seed_lo, site_key;   // this group's dropout stream (DropCfg fields; the launch's when the group names no seed)
 };
+
+constexpr int MAXG = MMNAS_GEMM_MAX_GROUPS;
 
 struct GemmK {
   int ngroups, nseg, N, K;
@@ -69,7 +73,6 @@ struct GemmK {
   int avec, bvec;       // generic path: 16-byte vector loads legal for the A / B operand
   float alpha, gate_scale;
   DropCfg drop;
-  GemmGroupK g[3];
   // LSTM time-step epilogues (EPI template parameter; lstm_* entry points below).  M = batch rows.
   //   EPI 1 (forward, N = 4H with column 4j+gate = gate `gate` of unit j): pre-activations = result + residual;
   //     gates -> lg_gates[M,4H], c = f c_prev + i g -> lg_cout[M,H], h = o tanh(c) -> C[M,H] and lg_h2 (ld lg_ldh2)
@@ -83,6 +86,8 @@ struct GemmK {
   float* lg_dc;
   const float* lg_act;
   int lg_ldh2, lg_pad;
+  // (the groups last: the first three end inside the 512 bytes the warm-up loads touch)
+  GemmGroupK g[MAXG];
 };
 
 enum { MODE_TILE = 0, MODE_SPLIT = 1, MODE_STREAM = 2 };
@@ -256,22 +261,25 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
   constexpr int A_SZ = GemmShape<BM, BN, NS>::A_SZ, B_SZ = GemmShape<BM, BN, NS>::B_SZ;
   constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;   // float4 loads per thread per tile
 
-  // The kernel arguments (~400 B = 7 cache lines) live in host-visible memory: the first touch of each line
+  // The kernel arguments (~540 B = 9-10 cache lines for up to three groups) live in host-visible memory: the first touch of each line
   // is a ~1 us round trip, and the compiler reads them in dependent steps (mode -> sizes -> group -> pointers).
   // Touch every line up front so the misses overlap (measured: -3.5 us per launch).
   {
     const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr() + koff;
-    unsigned t0, t1, t2, t3, t4, t5, t6, t7;
+    unsigned t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;
     asm volatile(
-        "s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\t"
-        "s_load_dword %3, %8, 0xc0\n\ts_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\t"
-        "s_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\ts_waitcnt lgkmcnt(0)"
-        : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7)   // early-clobber: the
-                                                  // loads return while later ones are still being issued from %8
+        "s_load_dword %0, %10, 0x0\n\ts_load_dword %1, %10, 0x40\n\ts_load_dword %2, %10, 0x80\n\t"
+        "s_load_dword %3, %10, 0xc0\n\ts_load_dword %4, %10, 0x100\n\ts_load_dword %5, %10, 0x140\n\t"
+        "s_load_dword %6, %10, 0x180\n\ts_load_dword %7, %10, 0x1c0\n\ts_load_dword %8, %10, 0x200\n\t"
+        "s_load_dword %9, %10, 0x240\n\ts_waitcnt lgkmcnt(0)"
+        : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8), "=&s"(t9)   // early-clobber: the
+                                                  // loads return while later ones are still being issued from %10
         : "s"(ka)
         : "memory");
   }
-  static_assert(sizeof(GemmK) > 0x1c0 && sizeof(GemmK) <= 0x200, "update the kernel-argument warm-up loads");
+  static_assert(offsetof(GemmK, g) + 3 * sizeof(GemmGroupK) > 0x200 && offsetof(GemmK, g) + 3 * sizeof(GemmGroupK) <= 0x280,
+                "update the kernel-argument warm-up loads (header + the first three groups; further groups -- the architecture "
+                "step's node-wide launches -- take their first-touch miss)");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -318,8 +326,9 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
       u += nq;
     }
     int grp = 0;
-    if (p.ngroups > 1 && tile >= p.g[1].tile0) grp = 1;
-    if (p.ngroups > 2 && tile >= p.g[2].tile0) grp = 2;
+#pragma unroll
+    for (int g = 1; g < MAXG; ++g)
+      if (g < p.ngroups && tile >= p.g[g].tile0) grp = g;
     const GemmGroupK& G = p.g[grp];
     const int Mg = G.M;
     const int tl = tile - G.tile0;
@@ -330,6 +339,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     const float* __restrict__ const resp = G.residual;
     const float* __restrict__ const gatep = G.gate;
     float* __restrict__ const csp = G.colsum;
+    const uint32_t gseed_lo = G.seed_lo, gsite_key = G.site_key;
     const float* const Aseg[3] = {G.A[0], G.A[1], G.A[2]};
     const float* const Bseg[3] = {G.B[0], G.B[1], G.B[2]};
     // Tiles of a problem are numbered in blocks of gm row-panels x all column tiles, column by column inside a
@@ -690,6 +700,8 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     // independent loads (clamped row index instead of a branch) before any arithmetic.
     const bool has_res = resp != nullptr, has_gate = gatep != nullptr, has_acc = p.accumulate != 0;
     const bool has_drop = p.drop.thresh != 0, has_relu = p.relu != 0;
+    DropCfg gdrop = p.drop;
+    gdrop.seed_lo = gseed_lo; gdrop.site_key = gsite_key;
     // (LSTM epilogues: the extra operands into registers once, as for the group fields above)
     const float* __restrict__ const lg_cprev = EPI ? p.lg_cprev : nullptr;
     const float* __restrict__ const lg_c = EPI ? p.lg_c : nullptr;
@@ -804,7 +816,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
           const int row = rbase + (r & 3) + 8 * (r >> 2);
           float val = acc[i][j][r] * p.alpha + bv;
           if (has_relu) val = fmaxf(val, 0.f);
-          if (has_drop) val *= drop_mult(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)col);
+          if (has_drop) val *= drop_mult(gdrop, (uint32_t)row * (uint32_t)p.N + (uint32_t)col);
           if (has_gate) val = gatev[r] > 0.f ? val * p.gate_scale : 0.f;
           if (has_res) val += resv[r];
           if (has_acc) val += oldv[r];
@@ -1000,7 +1012,7 @@ struct GemmPlan {
 static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
   if (!g_tune.loaded) load_tuning();
   MMNAS_REQUIRE(d != nullptr, MMNAS_E_ARG, "mmnas_gemm: null descriptor");
-  MMNAS_REQUIRE(d->ngroups >= 1 && d->ngroups <= 3 && d->nseg >= 1 && d->nseg <= 3, MMNAS_E_ARG,
+  MMNAS_REQUIRE(d->ngroups >= 1 && d->ngroups <= MAXG && d->nseg >= 1 && d->nseg <= 3, MMNAS_E_ARG,
                 "mmnas_gemm: ngroups=%d nseg=%d out of range", d->ngroups, d->nseg);
   MMNAS_REQUIRE(d->layout >= 0 && d->layout <= 2, MMNAS_E_ARG, "mmnas_gemm: bad layout %d", d->layout);
   MMNAS_REQUIRE(d->N > 0 && d->K > 0, MMNAS_E_SHAPE, "mmnas_gemm: N=%d K=%d", d->N, d->K);
@@ -1031,6 +1043,10 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
     MMNAS_REQUIRE(s.M > 0 && s.C, MMNAS_E_ARG, "mmnas_gemm: group %d M=%d C=%p", g, s.M, (void*)s.C);
     k.g[g].M = s.M; k.g[g].C = s.C; k.g[g].bias = s.bias; k.g[g].residual = s.residual; k.g[g].gate = s.gate;
     k.g[g].colsum = s.colsum;
+    {
+      const DropCfg gd = s.drop_seed ? make_drop(d->drop_p, s.drop_seed, d->drop_site) : k.drop;
+      k.g[g].seed_lo = gd.seed_lo; k.g[g].site_key = gd.site_key;
+    }
     MMNAS_REQUIRE(!(s.colsum && accumulate), MMNAS_E_ARG, "mmnas_gemm: no column sums when accumulating onto C");
     for (int i = 0; i < 3; ++i) {
       k.g[g].A[i] = s.A[i]; k.g[g].B[i] = s.B[i];

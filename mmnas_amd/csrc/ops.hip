@@ -104,30 +104,22 @@ extern "C" int mmnas_att_op_fwd(const mmnas_att_op* op, void* stream) {
   bool done;
   return mmnas::att_fwd_impl(op, stream, false, &done);
 }
-static int mmnas::att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_ln, bool* ln_done) {
-  *ln_done = true;
-  int rc = att_check(op, "att_op_fwd");
-  if (rc) return rc;
-  MMNAS_REQUIRE(op->xq && op->xkv && op->Wq && op->Wk && op->Wv && op->Wm && op->y && op->save, MMNAS_E_ARG,
-                "att_op_fwd: null pointer");
-  const int fl = op->flags;
-  const bool norm = fl & MMNAS_F_NORM, rel = fl & MMNAS_F_REL;
+namespace mmnas {
+// The forward of an attention operator in three stages, so that a supernet node can run the same stage of all its
+// attention candidates as ONE launch (mixed chains): the Q / K / V projections as groups of one grouped product, the
+// cores one by one, the merge projections (+ output dropout + residual) as groups of one product with per-group seeds.
+static void att_qkv_groups(const mmnas_att_op* op, const AttLayout& L, mmnas_gemm_group* g) {
+  memset(g, 0, 3 * sizeof(*g));
+  g[0].M = (int)L.Mq; g[0].A[0] = op->xq;  g[0].B[0] = op->Wq; g[0].C = L.Q;
+  g[1].M = (int)L.Mk; g[1].A[0] = op->xkv; g[1].B[0] = op->Wk; g[1].C = L.K;
+  g[2].M = (int)L.Mk; g[2].A[0] = op->xkv; g[2].B[0] = op->Wv; g[2].C = L.V;
+}
+
+static int att_core_fwd(const mmnas_att_op* op, const AttLayout& L, void* stream) {
+  const int fl = op->flags, di = op->di;
+  const bool rel = fl & MMNAS_F_REL;
   const bool drop = (fl & MMNAS_F_TRAIN) && op->drop_p > 0.f;
-  if (norm) MMNAS_REQUIRE(op->ln_a && op->ln_b, MMNAS_E_ARG, "att_op_fwd: NORM without ln parameters");
-  if (rel) MMNAS_REQUIRE(op->rel && op->Wr && op->br, MMNAS_E_ARG, "att_op_fwd: REL without rel/Wr/br");
-  if (fl & MMNAS_F_MASK) MMNAS_REQUIRE(op->mask, MMNAS_E_ARG, "att_op_fwd: MASK without mask");
-  AttLayout L = att_layout(op);
-  const int d = op->d, di = op->di;
-  if (sa_small_applies(op)) return sa_small_fwd(op, L.Q, L.K, L.V, L.att, L.stats, L.z, (hipStream_t)stream);
-
-  mmnas_gemm_desc g;
-  gemm_init(g, MMNAS_GEMM_NT, di, d, d, d, di);
-  g.ngroups = 3;
-  g.g[0].M = (int)L.Mq; g.g[0].A[0] = op->xq;  g.g[0].B[0] = op->Wq; g.g[0].C = L.Q;
-  g.g[1].M = (int)L.Mk; g.g[1].A[0] = op->xkv; g.g[1].B[0] = op->Wk; g.g[1].C = L.K;
-  g.g[2].M = (int)L.Mk; g.g[2].A[0] = op->xkv; g.g[2].B[0] = op->Wv; g.g[2].C = L.V;
-  if ((rc = mmnas_gemm(&g, stream))) return rc;
-
+  int rc;
   if (rel) {
     if (fl & MMNAS_F_RELRAW) {  // lazy handle: bias straight from the raw [B,Sq,Sk,C] relations
       MMNAS_REQUIRE(op->Wy && op->by, MMNAS_E_ARG, "att_op_fwd: RELRAW without Wy/by");
@@ -138,7 +130,6 @@ static int mmnas::att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_
     }
     if (rc) return rc;
   }
-
   mmnas_mha_desc m;
   memset(&m, 0, sizeof(m));
   m.B = op->B; m.H = op->H; m.Sq = op->Sq; m.Sk = op->Sk; m.dh = op->dh;
@@ -146,11 +137,51 @@ static int mmnas::att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_
   m.Q = L.Q; m.K = L.K; m.V = L.V; m.mask = (fl & MMNAS_F_MASK) ? op->mask : nullptr; m.biasT = L.biasT;
   m.O = L.att; m.lse = L.stats;
   m.drop_p = drop ? op->drop_p : 0.f; m.drop_site = 0; m.drop_seed = op->seed;
-  if ((rc = mmnas_mha_core_fwd(&m, stream))) return rc;
+  return mmnas_mha_core_fwd(&m, stream);
+}
 
+// the merge projection as one group: C = z (NORM: the LayerNorm follows) or y; residual = the operator's input
+static void att_merge_group(const mmnas_att_op* op, const AttLayout& L, mmnas_gemm_group* g) {
+  const bool norm = op->flags & MMNAS_F_NORM;
+  memset(g, 0, sizeof(*g));
+  g->M = (int)L.Mq; g->A[0] = L.att; g->B[0] = op->Wm; g->C = norm ? L.z : op->y;
+  if (op->flags & MMNAS_F_RESIDUAL) g->residual = op->xq;
+  g->drop_seed = op->seed;
+}
+
+static int att_fwd_args(const mmnas_att_op* op) {
+  int rc = att_check(op, "att_op_fwd");
+  if (rc) return rc;
+  MMNAS_REQUIRE(op->xq && op->xkv && op->Wq && op->Wk && op->Wv && op->Wm && op->y && op->save, MMNAS_E_ARG,
+                "att_op_fwd: null pointer");
+  const int fl = op->flags;
+  if (fl & MMNAS_F_NORM) MMNAS_REQUIRE(op->ln_a && op->ln_b, MMNAS_E_ARG, "att_op_fwd: NORM without ln parameters");
+  if (fl & MMNAS_F_REL) MMNAS_REQUIRE(op->rel && op->Wr && op->br, MMNAS_E_ARG, "att_op_fwd: REL without rel/Wr/br");
+  if (fl & MMNAS_F_MASK) MMNAS_REQUIRE(op->mask, MMNAS_E_ARG, "att_op_fwd: MASK without mask");
+  return MMNAS_OK;
+}
+}  // namespace mmnas
+
+static int mmnas::att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_ln, bool* ln_done) {
+  *ln_done = true;
+  int rc = att_fwd_args(op);
+  if (rc) return rc;
+  const int fl = op->flags;
+  const bool norm = fl & MMNAS_F_NORM;
+  const bool drop = (fl & MMNAS_F_TRAIN) && op->drop_p > 0.f;
+  AttLayout L = att_layout(op);
+  const int d = op->d, di = op->di;
+  if (sa_small_applies(op)) return sa_small_fwd(op, L.Q, L.K, L.V, L.att, L.stats, L.z, (hipStream_t)stream);
+
+  mmnas_gemm_desc g;
+  gemm_init(g, MMNAS_GEMM_NT, di, d, d, d, di);
+  g.ngroups = 3;
+  att_qkv_groups(op, L, g.g);
+  if ((rc = mmnas_gemm(&g, stream))) return rc;
+  if ((rc = att_core_fwd(op, L, stream))) return rc;
   gemm_init(g, MMNAS_GEMM_NT, d, di, di, di, d);
-  g.g[0].M = (int)L.Mq; g.g[0].A[0] = L.att; g.g[0].B[0] = op->Wm; g.g[0].C = norm ? L.z : op->y;
-  if (fl & MMNAS_F_RESIDUAL) { g.g[0].residual = op->xq; g.ldres = d; }
+  att_merge_group(op, L, &g.g[0]);
+  if (fl & MMNAS_F_RESIDUAL) g.ldres = d;
   if (drop) { g.drop_p = op->drop_p; g.drop_site = 1; g.drop_seed = op->seed; }
   if ((rc = mmnas_gemm(&g, stream))) return rc;
 
@@ -760,11 +791,61 @@ static int chain_fwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
     float gate_order[MMNAS_MIXED_MAX];
     (void)gate_order;
     float eps = 1e-6f;
+    // The node's attention candidates on the general path run stage by stage, each stage ONE launch for all of them: their
+    // Q / K / V projections (up to 9 groups: same N = d_inside, K = d), their cores, their merge projections (own dropout
+    // seed per group).  3 + 3 launches -> 1 + 1 per decoder node of the VQA search space (self / relation / guided).
+    mmnas_att_op ga[MMNAS_MIXED_MAX];
+    AttLayout gl[MMNAS_MIXED_MAX];
+    int gidx[MMNAS_MIXED_MAX], ng = 0;
+    for (int i = i0; i < i1; ++i) {
+      const mmnas_chain_op& o = c->ops[i];
+      if (o.kind != MMNAS_CHAIN_ATT) continue;
+      mmnas_att_op a; mmnas_mlp_op m;
+      chain_op_setup(c, i, a, m);
+      a.xq = cur;
+      a.xkv = (a.flags & MMNAS_F_SELF) ? cur : cur_x;
+      a.y = (float*)(base + L.y[i]); a.save = base + L.save[i]; a.ws = base + L.ws[i];
+      if (sa_small_applies(&a)) continue;
+      if (ng > 0) {
+        const mmnas_att_op& f = ga[0];
+        const bool d0 = (f.flags & MMNAS_F_TRAIN) && f.drop_p > 0.f, d1 = (a.flags & MMNAS_F_TRAIN) && a.drop_p > 0.f;
+        if (a.di != f.di || ((a.flags ^ f.flags) & MMNAS_F_RESIDUAL) || d0 != d1 || (d0 && a.drop_p != f.drop_p)) continue;
+      }
+      if (3 * (ng + 1) > MMNAS_GEMM_MAX_GROUPS) continue;
+      if ((rc = att_fwd_args(&a))) return rc;
+      ga[ng] = a; gl[ng] = att_layout(&a); gidx[ng] = i; ++ng;
+    }
+    if (ng < 2) ng = 0;   // (a single one takes the per-operator route below)
+    if (ng) {
+      const mmnas_att_op& f = ga[0];
+      const bool drop = (f.flags & MMNAS_F_TRAIN) && f.drop_p > 0.f;
+      mmnas_gemm_desc g;
+      gemm_init(g, MMNAS_GEMM_NT, f.di, c->d, c->d, c->d, f.di);
+      g.ngroups = 3 * ng;
+      for (int j = 0; j < ng; ++j) att_qkv_groups(&ga[j], gl[j], g.g + 3 * j);
+      if ((rc = mmnas_gemm(&g, st))) return rc;
+      for (int j = 0; j < ng; ++j)
+        if ((rc = att_core_fwd(&ga[j], gl[j], st))) return rc;
+      gemm_init(g, MMNAS_GEMM_NT, c->d, f.di, f.di, f.di, c->d);
+      g.ngroups = ng;
+      for (int j = 0; j < ng; ++j) att_merge_group(&ga[j], gl[j], &g.g[j]);
+      if (f.flags & MMNAS_F_RESIDUAL) g.ldres = c->d;
+      if (drop) { g.drop_p = f.drop_p; g.drop_site = 1; g.drop_seed = f.seed; }
+      if ((rc = mmnas_gemm(&g, st))) return rc;
+    }
     for (int i = i0; i < i1; ++i) {
       const mmnas_chain_op& o = c->ops[i];
       mmnas_att_op a; mmnas_mlp_op m;
       chain_op_setup(c, i, a, m);
       bool ln_done = true;
+      bool staged = false;
+      for (int j = 0; j < ng; ++j) staged |= gidx[j] == i;
+      if (staged) {   // (NORM: the node epilogue normalises; otherwise the merge product wrote the output)
+        ln_done = !(a.flags & MMNAS_F_NORM);
+        if (a.flags & MMNAS_F_NORM) eps = a.eps;
+        chain_cand_view(c, L, i, ln_done, &z[i - i0], &la[i - i0], &lb[i - i0]);
+        continue;
+      }
       if (o.kind == MMNAS_CHAIN_ATT) {
         a.xq = cur;
         a.xkv = (a.flags & MMNAS_F_SELF) ? cur : cur_x;

@@ -39,7 +39,7 @@ def test_struct_sizes_are_plain_c_layouts():
     # spot-check the layouts the C side assumes (LP64): catches a field added on one side only
     assert ctypes.sizeof(L.Plan) == 24
     assert ctypes.sizeof(L.Segment) == 24
-    assert ctypes.sizeof(L.GemmGroup) == 8 + 8 * 11
+    assert ctypes.sizeof(L.GemmGroup) == 8 + 8 * 12
     assert ctypes.sizeof(L.GemmDesc) % 8 == 0 and ctypes.sizeof(L.AttOp) % 8 == 0
 
 

@@ -936,3 +936,40 @@ def test_pack_segments_balanced_over_very_uneven_segments():
     for a, n, gp in zip(src_off, sizes, gaps):
         assert torch.equal(flat[a:a + n], before[a:a + n] * 2.0)
         assert torch.equal(flat[a + n:a + n + gp], before[a + n:a + n + gp])
+
+
+@pytest.mark.parametrize('mode', [6, 0])
+def test_gemm_nine_groups_with_their_own_dropout_seeds(mode, gemm_tuning):
+    """One launch for every projection of a supernet node's attention candidates (mixed chains): up to 9 groups with
+    different row counts, operands and outputs; and the merge projections of the candidates as groups that share the
+    launch's dropout rate and site but draw from their OWN seeds (the reference's modules own their dropout)."""
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    gemm_tuning(split=mode)
+    rs = np.random.RandomState(91)
+    N, K = 256, 256
+    Ms = [6400, 6400, 6400, 6400, 6400, 6400, 6400, 896, 896]
+    A = [g(rnd(rs, M, K)) for M in Ms]
+    B = [g(rnd(rs, N, K)) for _ in Ms]
+    Cs = [torch.full((M, N), float('nan'), device=DEV) for M in Ms]
+    ops.gemm(L.GEMM_NT, [dict(M=M, A=[a], B=[b], C=c) for M, a, b, c in zip(Ms, A, B, Cs)], N, K, K, K, N)
+    for a, b, c in zip(A, B, Cs):
+        ref = a.double() @ b.double().t()
+        assert rel_err(c.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    # three merge groups: bias-free product, dropout (site 1, p = 0.1) with a seed per group, then the residual
+    p, seeds = 0.1, [0x1234567811, 0xABCDEF0122, 0x5555AAAA33]
+    res = g(rnd(rs, 6400, N))
+    Cm = [torch.empty(6400, N, device=DEV) for _ in seeds]
+    desc = ops.gemm_desc(L.GEMM_NT, [dict(M=6400, A=[A[j]], B=[B[j]], C=Cm[j], residual=res) for j in range(3)], N, K, K, K, N,
+                         drop=(p, seeds[0], 1), ldres=N)
+    for j in range(3):
+        desc.g[j].drop_seed = seeds[j]
+    import ctypes as C
+    L.check(L.lib().mmnas_gemm(C.byref(desc), L.stream()))
+    masks = []
+    for j in range(3):
+        mask = ops.dropout_mask(6400 * N, p, seeds[j], 1, DEV).view(6400, N)
+        masks.append(mask)
+        ref = (A[j].double() @ B[j].double().t()) * mask.double() + res.double()
+        assert rel_err(Cm[j].cpu().numpy(), ref.cpu().numpy()) < 1e-5, j
+    assert not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
