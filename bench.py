@@ -92,7 +92,7 @@ METRICS = {
 # ---------------------------------------------------------------------------------------------------------------------
 # launcher: --gpus N without torch.distributed.run
 # ---------------------------------------------------------------------------------------------------------------------
-def _self_spawn(n, argv):
+def _self_spawn(n, argv, script=None):
     """Start one child per GPU (fresh interpreters: nothing here has touched the GPU) and relay rank 0's line."""
     import socket
     s = socket.socket()
@@ -103,13 +103,40 @@ def _self_spawn(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, p.wait())
-    sys.stdout.write(out.decode())
+    # a rank that dies leaves the others parked in a collective: poll all of them, and once one has exited non-zero
+    # (or the whole run exceeds its limit) end the exact children started here
+    import threading
+    import time as _time
+    got = {}
+    reader = threading.Thread(target=lambda: got.setdefault('out', procs[0].stdout.read()), daemon=True)
+    reader.start()
+    limit = float(os.environ.get('MMNAS_BENCH_SPAWN_TIMEOUT', '3600'))
+    t0, rc = _time.time(), 0
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            rc = max(abs(c) for c in codes)
+            break
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad or _time.time() - t0 > limit:
+            rc = abs(bad[0]) if bad else 124
+            sys.stderr.write('bench.py: %s; stopping the other ranks\n'
+                             % ('a rank exited with %d' % rc if bad else 'no result after %.0f s' % limit))
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            break
+        _time.sleep(0.2)
+    reader.join(timeout=5)
+    sys.stdout.write(got.get('out', b'').decode())
     sys.stdout.flush()
     return rc
 

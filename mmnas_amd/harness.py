@@ -66,6 +66,8 @@ def vgd_loss(pred_scores, pred_reg, scores, scores_mask, bbox, bbox_mask, lam=0.
         ls = F.kl_div(pred_scores * scores_mask, scores * scores_mask, reduction='sum')
     lr = F.smooth_l1_loss(pred_reg * bbox_mask, bbox * bbox_mask, reduction='sum')
     if loss_avg:
+        if batch_size is None:
+            batch_size = pred_scores.shape[0]     # train_vgd.py divides by the loader's batch size
         ls = ls / (batch_size if scores_loss == 'bce' else scores_mask.sum())
         lr = lr / bbox_mask.sum()
     return ls + lam * lr

@@ -1,0 +1,61 @@
+"""Host-side behaviour of bench.py that needs no GPU."""
+import importlib.util
+import os
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_self_spawn_stops_the_other_ranks_when_one_fails(tmp_path, capfd):
+    """A rank that exits non-zero must not leave `bench.py --gpus N` waiting on ranks parked in a collective."""
+    script = tmp_path / 'rank.py'
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n"
+                      "    sys.exit(3)\n"
+                      "print('{\"rank0\": true}', flush=True)\n"
+                      "time.sleep(600)\n")
+    t0 = time.time()
+    rc = _bench()._self_spawn(2, [], script=str(script))
+    assert rc == 3
+    assert time.time() - t0 < 60
+    out = capfd.readouterr()
+    assert 'rank0' in out.out and 'stopping the other ranks' in out.err
+
+
+def test_self_spawn_relays_rank0_and_returns_zero(tmp_path, capfd):
+    script = tmp_path / 'rank.py'
+    script.write_text("import os\nif os.environ['RANK'] == '0':\n    print('{\"n\": %s}' % os.environ['WORLD_SIZE'])\n")
+    assert _bench()._self_spawn(2, [], script=str(script)) == 0
+    assert '{"n": 2}' in capfd.readouterr().out
+
+
+def test_self_spawn_has_a_wall_clock_limit(tmp_path, monkeypatch, capfd):
+    script = tmp_path / 'rank.py'
+    script.write_text("import time\ntime.sleep(600)\n")
+    monkeypatch.setenv('MMNAS_BENCH_SPAWN_TIMEOUT', '2')
+    t0 = time.time()
+    assert _bench()._self_spawn(2, [], script=str(script)) == 124
+    assert time.time() - t0 < 60
+
+
+def test_vgd_bce_loss_average_defaults_to_the_batch_rows():
+    """train_vgd.py:316-333 divides the BCE term by the batch size; left out, it is the leading dimension."""
+    import torch
+    import torch.nn.functional as F
+    from mmnas_amd.harness import vgd_loss
+    g = torch.Generator().manual_seed(5)
+    ps, pr = torch.randn(6, 10, generator=g), torch.randn(6, 10, 4, generator=g)
+    sc, bb = torch.rand(6, 10, generator=g), torch.rand(6, 10, 4, generator=g)
+    sm, bm = torch.ones(6, 10), torch.ones(6, 10, 4)
+    got = vgd_loss(ps, pr, sc, sm, bb, bm, scores_loss='bce')
+    want = F.binary_cross_entropy_with_logits(ps, sc, reduction='sum') / 6 + 0.5 * F.smooth_l1_loss(pr, bb, reduction='sum') / bm.sum()
+    assert torch.allclose(got, want)
+    assert torch.allclose(vgd_loss(ps, pr, sc, sm, bb, bm, scores_loss='bce', batch_size=3),
+                          want + F.binary_cross_entropy_with_logits(ps, sc, reduction='sum') / 6)
