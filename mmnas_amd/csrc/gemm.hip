@@ -252,13 +252,13 @@ struct GemmShape {
 // with one tile in flight every iteration waits out a full L2 / Infinity-Cache round trip, ~2x its 0.43 us of MFMA).
 template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1>
 __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const int nwg, const int koff,
-                                          float* __restrict__ As, float* __restrict__ Bs, int& s_old) {
+                                          float* __restrict__ As, float* __restrict__ Bs, float* __restrict__ As1,
+                                          float* __restrict__ Bs1, int& s_old) {
   static_assert(PF == 1 || (PF == 2 && FAST && (NS == 0 || NS == 3)), "the two-stage prefetch exists for the buffer-load path (fp32 and bf16x6)");
   static_assert(NS == 0 || (FAST && BK == 32), "the bf16-split path exists for the buffer-load path only");
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   // split rows: NS parts of 32 bf16 (64 B) + 16 B pad -> 144 / 208 B, an odd number of 16-B words (conflict-free b128)
   constexpr int RSW = GemmShape<BM, BN, NS>::RSW;
-  constexpr int A_SZ = GemmShape<BM, BN, NS>::A_SZ, B_SZ = GemmShape<BM, BN, NS>::B_SZ;
   constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;   // float4 loads per thread per tile
 
   // The kernel arguments (~540 B = 9-10 cache lines for up to three groups) live in host-visible memory: the first touch of each line
@@ -503,8 +503,8 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     auto lstore_from = [&](int buf, const int st) __attribute__((always_inline)) {
       const float4* const ra = rA[st];
       const float4* const rb = rB[st];
-      float* a = As + buf * A_SZ;
-      float* b = Bs + buf * B_SZ;
+      float* a = buf ? As1 : As;   // (the two buffers are separate LDS objects: a store into one provably does not alias
+      float* b = buf ? Bs1 : Bs;   //  a fragment read of the other)
       if (NS) {
         unsigned* ua = reinterpret_cast<unsigned*>(a);
         unsigned* ub = reinterpret_cast<unsigned*>(b);
@@ -550,8 +550,8 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     auto lstore = [&](int buf) __attribute__((always_inline)) { lstore_from(buf, 0); };
 
     auto mfma_block = [&](int buf) __attribute__((always_inline)) {
-      const float* a = As + buf * A_SZ;
-      const float* b = Bs + buf * B_SZ;
+      const float* a = buf ? As1 : As;
+      const float* b = buf ? Bs1 : Bs;
       if (NS) {
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
@@ -833,10 +833,10 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
 
 template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1>
 __global__ void __launch_bounds__(256, NS ? (BM == 128 ? (BN == 64 ? 2 : 1) : MMNAS_OCC_NS) : (BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64)) gemm_kernel(const GemmK p) {
-  __shared__ __attribute__((aligned(16))) float As[2 * GemmShape<BM, BN, NS>::A_SZ];
-  __shared__ __attribute__((aligned(16))) float Bs[2 * GemmShape<BM, BN, NS>::B_SZ];
+  __shared__ __attribute__((aligned(16))) float As[GemmShape<BM, BN, NS>::A_SZ], As1[GemmShape<BM, BN, NS>::A_SZ];
+  __shared__ __attribute__((aligned(16))) float Bs[GemmShape<BM, BN, NS>::B_SZ], Bs1[GemmShape<BM, BN, NS>::B_SZ];
   __shared__ int s_old;
-  gemm_body<BM, BN, AKC, BKC, FAST, NS, EPI, PF>(p, blockIdx.x, gridDim.x, 0, As, Bs, s_old);
+  gemm_body<BM, BN, AKC, BKC, FAST, NS, EPI, PF>(p, blockIdx.x, gridDim.x, 0, As, Bs, As1, Bs1, s_old);
 }
 
 // Two independent problems in ONE launch: the data gradient (NN) and the weight gradient (TN) of a linear layer.
@@ -887,8 +887,8 @@ template <int BM, int BN, int NS, int PF = 1>
 __global__ void __launch_bounds__(256, NS ? MMNAS_OCC_NS : MMNAS_OCC64) gemm_pair_kernel(const GemmK q0, const GemmK q1, const int nwg0,
                                                                                     const int nwg0p, const AuxReduceK aux,
                                                                                     const int naux8) {
-  __shared__ __attribute__((aligned(16))) float As[2 * GemmShape<BM, BN, NS>::A_SZ];
-  __shared__ __attribute__((aligned(16))) float Bs[2 * GemmShape<BM, BN, NS>::B_SZ];
+  __shared__ __attribute__((aligned(16))) float As[GemmShape<BM, BN, NS>::A_SZ], As1[GemmShape<BM, BN, NS>::A_SZ];
+  __shared__ __attribute__((aligned(16))) float Bs[GemmShape<BM, BN, NS>::B_SZ], Bs1[GemmShape<BM, BN, NS>::B_SZ];
   __shared__ int s_old;
   int bid = blockIdx.x;
   if (bid < naux8) {   // (a multiple of 8, so blockIdx % 8 keeps naming the XCD in the sections behind it)
@@ -897,9 +897,9 @@ __global__ void __launch_bounds__(256, NS ? MMNAS_OCC_NS : MMNAS_OCC64) gemm_pai
   }
   bid -= naux8;
   if (bid < nwg0p) {
-    if (bid < nwg0) gemm_body<BM, BN, true, false, true, NS, 0, PF>(q0, bid, nwg0, 0, As, Bs, s_old);
+    if (bid < nwg0) gemm_body<BM, BN, true, false, true, NS, 0, PF>(q0, bid, nwg0, 0, As, Bs, As1, Bs1, s_old);
   } else {
-    gemm_body<BM, BN, false, false, true, NS, 0, PF>(q1, bid - nwg0p, (int)gridDim.x - naux8 - nwg0p, (int)sizeof(GemmK), As, Bs, s_old);
+    gemm_body<BM, BN, false, false, true, NS, 0, PF>(q1, bid - nwg0p, (int)gridDim.x - naux8 - nwg0p, (int)sizeof(GemmK), As, Bs, As1, Bs1, s_old);
   }
 }
 

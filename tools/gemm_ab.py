@@ -42,10 +42,14 @@ def old_split(M, N, groups, K):
 
 def main():
     # a path prefixed with "old:" is driven with the revision-0 descriptor (no accumulate field, caller-chosen split_k)
+    # ("r2:": the round-2 descriptor -- three groups, no per-group dropout seed)
     paths = sys.argv[1:3]
     is_old = [p.startswith('old:') for p in paths]
-    libs = [C.CDLL(os.path.abspath(p[4:] if o else p)) for p, o in zip(paths, is_old)]
-    types = [desc_type(not o) for o in is_old]
+    is_r2 = [p.startswith('r2:') for p in paths]
+    libs = [C.CDLL(os.path.abspath(p.split(':', 1)[1] if (o or r) else p)) for p, o, r in zip(paths, is_old, is_r2)]
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mmnas_amd._lib import GemmDesc   # the current descriptor (include/mmnas_hip.h)
+    types = [desc_type(False) if o else (desc_type(True) if r else GemmDesc) for o, r in zip(is_old, is_r2)]
     dev = 'cuda'
     shapes = []
     for d in (512, 256):

@@ -12,14 +12,14 @@ export TMPDIR=/tmp
 W=/tmp/mmnas_prof
 rm -rf $W; mkdir -p $W profiles
 for wl in search_vqa arch_vqa train_vqa; do
-  cmd="bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline"
+  cmd="bench.py --workload $wl --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline"
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace_$wl -o t -- python3 $ROOT/$cmd > $W/trace_$wl.log 2>&1)
   python3 tools/summarize_prof.py $W/trace_$wl profiles/${R}_$wl 23 \
     "rocprofv3 --kernel-trace --stats -- python3 $cmd  (3 warm-up + 10 timed + 10 roofline-pass steps)"
   marker=onehot_rows; [ $wl = train_vqa ] && marker=row_is_zero
   python3 tools/step_timeline.py $W/trace_$wl $marker > profiles/${R}_timeline_$wl.txt
   [ -n "${SKIP_PMC:-}" ] && continue
-  small="bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-prof"
+  small="bench.py --workload $wl --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-prof"
   for c in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d $W/pmc_${wl}_$c -o t -- python3 $ROOT/$small > $W/pmc_${wl}_$c.log 2>&1)
   done
@@ -39,7 +39,7 @@ done
 (cd /tmp && rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $W/trace_stream -o t -- python3 $ROOT/bench.py --workload search_vqa_stream --steps 8 --warmup 3 --repeats 1 --no-cpu-baseline --no-prof > $W/trace_stream.log 2>&1)
 python3 tools/copy_overlap.py $W/trace_stream > profiles/${R}_timeline_search_vqa_stream.txt 2>&1
 if [ -z "${SKIP_PMC:-}" ]; then
-  small="bench.py --workload bilevel_vqa --steps 6 --warmup 6 --no-cpu-baseline --no-prof"   # (one round = 5 weight + 1 arch steps)
+  small="bench.py --workload bilevel_vqa --steps 6 --warmup 6 --repeats 1 --no-cpu-baseline --no-prof"   # (one round = 5 weight + 1 arch steps)
   for c in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d $W/pmc_bilevel_vqa_$c -o t -- python3 $ROOT/$small > $W/pmc_bilevel_vqa_$c.log 2>&1)
   done
@@ -49,7 +49,7 @@ if [ -z "${SKIP_PMC:-}" ]; then
 fi
 python3 tools/mha_bench.py > profiles/${R}_mha_microbench.txt 2>/dev/null
 python3 tools/rel_bench.py > profiles/${R}_rel_microbench.txt 2>/dev/null
-python3 tools/gemm_ab.py mmnas_amd/lib/libmmnas_hip_r2.so mmnas_amd/lib/libmmnas_hip.so > profiles/${R}_gemm_vs_round2_build.txt 2>/dev/null
+python3 tools/gemm_ab.py r2:mmnas_amd/lib/libmmnas_hip_r2.so mmnas_amd/lib/libmmnas_hip.so > profiles/${R}_gemm_vs_round2_build.txt 2>/dev/null
 (cd /tmp && GEMM_PMC_LAYOUTS=1 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $W/pmc_gemm_lds -o t -- python3 $ROOT/tools/gemm_pmc.py > $W/pmc_gemm_lds.log 2>&1)
 (cd /tmp && GEMM_PMC_LAYOUTS=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace -d $W/pmc_gemm_mfma -o t -- python3 $ROOT/tools/gemm_pmc.py > $W/pmc_gemm_mfma.log 2>&1)
 python3 tools/pmc_counters.py profiles/${R}_pmc_gemm_layouts.json $W/pmc_gemm_lds $W/pmc_gemm_mfma
