@@ -34,6 +34,8 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <algorithm>
+#include <climits>
 #include "common.h"
 
 namespace mmnas {
@@ -68,6 +70,8 @@ struct GemmK {
                         // tail tiles are streamed.  Per XCD: sk_per streaming workgroups (launched first), then full_per whole tiles
   int P;                // K-tiles per piece / work units per workgroup
   int U;                // work units in total (= ntiles * T; stream-K needs it below 2^31)
+  int gtile0[MAXG];     // first linear tile of every group (INT_MAX past ngroups): a copy of g[].tile0 inside the header's first
+  int gpad0;            // cache lines, so that the group of a tile is found without touching the group records
   float* ws;            // partial-tile slots: 2 per workgroup, BM*BN floats each
   int* cnt;             // per-tile arrival counters (zero between launches)
   int avec, bvec;       // generic path: 16-byte vector loads legal for the A / B operand
@@ -259,6 +263,7 @@ __device__ __forceinline__ void split_store_t(unsigned* dst, const float4 e, con
 
 #ifdef MMNAS_DBG_STAMP
 __device__ unsigned long long g_stamp_acc[8];
+__device__ unsigned long long g_life_acc[8];   // whole-workgroup phases: arguments, set-up, first tile in LDS, K loop, epilogue
 #endif
 
 // NS > 0: the operands are split into NS bf16 parts while they are written to LDS and the products run on
@@ -289,6 +294,12 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
   constexpr int RSW = GemmShape<BM, BN, NS>::RSW;
   constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;   // float4 loads per thread per tile
 
+#ifdef MMNAS_DBG_STAMP
+  unsigned long long life_prev = __builtin_readcyclecounter();
+#define MMNAS_LIFE(i) do { const unsigned long long c_ = __builtin_readcyclecounter(); if (threadIdx.x == 0 && bid == MMNAS_DBG_STAMP) g_life_acc[i] += c_ - life_prev; life_prev = c_; } while (0)
+#else
+#define MMNAS_LIFE(i) do { } while (0)
+#endif
   // The kernel arguments (~540 B = 9-10 cache lines for up to three groups) live in host-visible memory: the first touch of each line
   // is a ~1 us round trip, and the compiler reads them in dependent steps (mode -> sizes -> group -> pointers).
   // Touch every line up front so the misses overlap (measured: -3.5 us per launch).
@@ -309,6 +320,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
                 "update the kernel-argument warm-up loads (header + the first three groups; further groups -- the architecture "
                 "step's node-wide launches -- take their first-touch miss)");
 
+  MMNAS_LIFE(0);   // kernel-argument warm-up
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
@@ -316,47 +328,63 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
 
   // ---- this workgroup's run of work units (XCD-aware bijective remap: blocks b and b+8 share an XCD,
   //      so an XCD owns a contiguous run of units = neighbouring tiles / K-slices of few tiles) ----
+  // Every scalar of the header that the set-up and the K loop read, loaded here in ONE batch and kept: left to the compiler
+  // each branch of the set-up loads its own fields and waits for them, and under register pressure it re-loads rather than
+  // keeps them -- 19 dependent scalar-memory round trips (~200 cycles each on cache hits) stood between the kernel's first
+  // instruction and its first operand load, 3900 cycles of a workgroup's ~10000 on the supernet's products
+  // (tools/gemm_stamps.py).  The empty asm makes each value opaque, so it cannot be re-materialised by a second load.
+  struct Hdr { int N, K, lda, ldb, tiles_n, ntiles, xcd_remap, gm, ntk, T, mode, n_full, full_per, sk_per, P, U, gt[MAXG]; };
+  Hdr h;
+  h.N = p.N; h.K = p.K; h.lda = p.lda; h.ldb = p.ldb; h.tiles_n = p.tiles_n; h.ntiles = p.ntiles; h.xcd_remap = p.xcd_remap;
+  h.gm = p.gm; h.ntk = p.ntk; h.T = p.T; h.mode = p.mode; h.n_full = p.n_full; h.full_per = p.full_per; h.sk_per = p.sk_per;
+  h.P = p.P; h.U = p.U;
+#pragma unroll
+  for (int g = 0; g < MAXG; ++g) h.gt[g] = p.gtile0[g];
+  asm volatile("" : "+s"(h.N), "+s"(h.K), "+s"(h.lda), "+s"(h.ldb), "+s"(h.tiles_n), "+s"(h.ntiles), "+s"(h.xcd_remap), "+s"(h.gm),
+               "+s"(h.ntk), "+s"(h.T), "+s"(h.mode), "+s"(h.n_full), "+s"(h.full_per), "+s"(h.sk_per), "+s"(h.P));
+  static_assert(MAXG == 9, "the list of group boundaries below names nine groups");
+  asm volatile("" : "+s"(h.U), "+s"(h.gt[1]), "+s"(h.gt[2]), "+s"(h.gt[3]), "+s"(h.gt[4]), "+s"(h.gt[5]), "+s"(h.gt[6]), "+s"(h.gt[7]),
+               "+s"(h.gt[8]));
   int v;
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, in = bid >> 3;
     v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
-    if (!p.xcd_remap) v = bid;
+    if (!h.xcd_remap) v = bid;
   }
   int u = 0, uend = 1;  // MODE_TILE / MODE_SPLIT: a single piece
   int vs = v;           // MODE_STREAM: index among the streaming workgroups
   int whole = -1;       // hybrid: the whole tile of this workgroup
-  if (p.mode == MODE_STREAM) {
-    if (p.n_full > 0) {  // grid = 8 * (sk_per + full_per); bid % 8 labels the XCD, low indices start first
+  if (h.mode == MODE_STREAM) {
+    if (h.n_full > 0) {  // grid = 8 * (sk_per + full_per); bid % 8 labels the XCD, low indices start first
       const int xcd = bid & 7, li = bid >> 3;
-      if (li < p.sk_per) vs = xcd * p.sk_per + li;
-      else whole = xcd * p.full_per + (li - p.sk_per);
+      if (li < h.sk_per) vs = xcd * h.sk_per + li;
+      else whole = xcd * h.full_per + (li - h.sk_per);
     }
-    if (whole < 0) { u = vs * p.P; uend = min(p.U, u + p.P); }
+    if (whole < 0) { u = vs * h.P; uend = min(h.U, u + h.P); }
   }
 
   while (u < uend) {
     int tile, q0, nq;
-    if (p.mode == MODE_TILE || whole >= 0) {
-      tile = whole >= 0 ? whole : v; q0 = 0; nq = p.T;
+    if (h.mode == MODE_TILE || whole >= 0) {
+      tile = whole >= 0 ? whole : v; q0 = 0; nq = h.T;
       u = uend;
-    } else if (p.mode == MODE_SPLIT) {  // slice-major: neighbouring workgroups (one XCD) add into different tiles
-      const int sl = v / p.ntiles;       // and stream the same K-slice of both operands through its L2
-      tile = v - sl * p.ntiles;
-      q0 = sl * p.P;
-      nq = min(p.P, p.T - q0);
+    } else if (h.mode == MODE_SPLIT) {  // slice-major: neighbouring workgroups (one XCD) add into different tiles
+      const int sl = v / h.ntiles;       // and stream the same K-slice of both operands through its L2
+      tile = v - sl * h.ntiles;
+      q0 = sl * h.P;
+      nq = min(h.P, h.T - q0);
       u = uend;
       if (nq <= 0) break;
     } else {
-      const int tt = u / p.T;  // tile among the streamed (tail) tiles
-      tile = p.n_full + tt;
-      q0 = u - tt * p.T;       // first K-tile of the piece
-      nq = min(p.T - q0, uend - u);
+      const int tt = u / h.T;  // tile among the streamed (tail) tiles
+      tile = h.n_full + tt;
+      q0 = u - tt * h.T;       // first K-tile of the piece
+      nq = min(h.T - q0, uend - u);
       u += nq;
     }
-    int grp = 0;
+    int grp = 0;   // (gtile0 rises with the group and is INT_MAX past the last one: the group is a count, no branches)
 #pragma unroll
-    for (int g = 1; g < MAXG; ++g)
-      if (g < p.ngroups && tile >= p.g[g].tile0) grp = g;
+    for (int g = 1; g < MAXG; ++g) grp += tile >= h.gt[g] ? 1 : 0;
     const GemmGroupK& G = p.g[grp];
     const int Mg = G.M;
     const int tl = tile - G.tile0;
@@ -377,11 +405,11 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     int tile_m, tile_n;
     {
       const int tiles_m = cdiv_dev(Mg, BM);
-      const int per_block = p.gm * p.tiles_n;
+      const int per_block = h.gm * h.tiles_n;
       const int blk = tl / per_block, in = tl - blk * per_block;
-      const int rows = min(p.gm, tiles_m - blk * p.gm);   // the last block may be shorter
+      const int rows = min(h.gm, tiles_m - blk * h.gm);   // the last block may be shorter
       tile_n = in / rows;
-      tile_m = blk * p.gm + (in - tile_n * rows);
+      tile_m = blk * h.gm + (in - tile_n * rows);
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -406,15 +434,15 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         const int f = tid + 256 * i;
         if (AKC) {
           const int row = NS ? kc_row(f) : f / KQ, kq = f % KQ, gr = m0 + row;
-          offa[i] = gr < Mg ? (unsigned)(gr * p.lda + 4 * kq) * 4u : ~0u;
+          offa[i] = gr < Mg ? (unsigned)(gr * h.lda + 4 * kq) * 4u : ~0u;
         } else if (NS) {  // loads 2j / 2j+1 of a thread: rows k = 2kp, 2kp+1 of the same 4 columns (packed as bf16 pairs)
           int kp, rq;
           t_map<BM>(tid, i >> 1, kp, rq);
           const int gr = m0 + 4 * rq;
-          offa[i] = gr < Mg ? (unsigned)((2 * kp + (i & 1)) * p.lda + gr) * 4u : ~0u;
+          offa[i] = gr < Mg ? (unsigned)((2 * kp + (i & 1)) * h.lda + gr) * 4u : ~0u;
         } else {
           const int k = f / (BM / 4), rq = f - k * (BM / 4), gr = m0 + 4 * rq;
-          offa[i] = gr < Mg ? (unsigned)(k * p.lda + gr) * 4u : ~0u;
+          offa[i] = gr < Mg ? (unsigned)(k * h.lda + gr) * 4u : ~0u;
         }
       }
 #pragma unroll
@@ -422,30 +450,34 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         const int f = tid + 256 * i;
         if (BKC) {
           const int row = NS ? kc_row(f) : f / KQ, kq = f % KQ, gr = n0 + row;
-          offb[i] = gr < p.N ? (unsigned)(gr * p.ldb + 4 * kq) * 4u : ~0u;
+          offb[i] = gr < h.N ? (unsigned)(gr * h.ldb + 4 * kq) * 4u : ~0u;
         } else if (NS) {
           int kp, rq;
           t_map<BN>(tid, i >> 1, kp, rq);
           const int gr = n0 + 4 * rq;
-          offb[i] = gr < p.N ? (unsigned)((2 * kp + (i & 1)) * p.ldb + gr) * 4u : ~0u;
+          offb[i] = gr < h.N ? (unsigned)((2 * kp + (i & 1)) * h.ldb + gr) * 4u : ~0u;
         } else {
           const int k = f / (BN / 4), rq = f - k * (BN / 4), gr = n0 + 4 * rq;
-          offb[i] = gr < p.N ? (unsigned)(k * p.ldb + gr) * 4u : ~0u;
+          offb[i] = gr < h.N ? (unsigned)(k * h.ldb + gr) * 4u : ~0u;
         }
       }
-      stepa = AKC ? BK * 4u : (unsigned)p.lda * BK * 4u;
-      stepb = BKC ? BK * 4u : (unsigned)p.ldb * BK * 4u;
-      bytesa = (unsigned)(AKC ? Mg : p.K) * (unsigned)p.lda * 4u;
-      bytesb = (unsigned)(BKC ? p.N : p.K) * (unsigned)p.ldb * 4u;
+      stepa = AKC ? BK * 4u : (unsigned)h.lda * BK * 4u;
+      stepb = BKC ? BK * 4u : (unsigned)h.ldb * BK * 4u;
+      bytesa = (unsigned)(AKC ? Mg : h.K) * (unsigned)h.lda * 4u;
+      bytesb = (unsigned)(BKC ? h.N : h.K) * (unsigned)h.ldb * 4u;
     }
 
     // unit q of the tile: segment q / ntk, K-tile q % ntk; `live` false (FAST path only): every offset is put out of
     // range, the buffer bounds check answers with zeros and no memory request is made -- a branch-free "no load"
+    int seg_c = 0, kt_c = 0;   // segment / K-tile of the next unit gload_to is asked for
+    if (q0 != 0) { seg_c = q0 / h.ntk; kt_c = q0 - seg_c * h.ntk; }
     auto gload_to = [&](int q, bool live, const int st) __attribute__((always_inline)) {
       float4* const ra = rA[st];
       float4* const rb = rB[st];
-      const int seg = q / p.ntk;
-      const int kt = q - seg * p.ntk;
+      // (the calls of a tile ask for consecutive units q0, q0 + 1, ...: segment and K-tile are carried along instead of
+      //  divided out of q every time -- the scalar division cost every wave ~100 cycles per K-tile)
+      const int seg = seg_c, kt = kt_c;
+      if (++kt_c == h.ntk) { kt_c = 0; ++seg_c; }
       const float* __restrict__ Ap = seg == 0 ? Aseg[0] : (seg == 1 ? Aseg[1] : Aseg[2]);
       const float* __restrict__ Bp = seg == 0 ? Bseg[0] : (seg == 1 ? Bseg[1] : Bseg[2]);
       if (FAST) {
@@ -458,7 +490,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         for (int i = 0; i < NB; ++i) rb[i] = buf_load4(rb_src, (offb[i] == ~0u || !live) ? ~0u : offb[i] + kb);
         return;
       }
-      const int k0 = kt * BK, kend = p.K;
+      const int k0 = kt * BK, kend = h.K;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const int f = tid + 256 * i;
@@ -467,7 +499,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
           const int row = f / KQ, kq = f % KQ;
           const int gr = m0 + row, gk = k0 + 4 * kq;
           if (gr < Mg && gk < kend) {
-            const float* src = Ap + (size_t)gr * p.lda + gk;
+            const float* src = Ap + (size_t)gr * h.lda + gk;
             if (p.avec) v4 = *reinterpret_cast<const float4*>(src);
             else {
               v4.x = src[0];
@@ -480,7 +512,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
           const int k = f / (BM / 4), rq = f - k * (BM / 4);
           const int gk = k0 + k, gr = m0 + 4 * rq;
           if (gk < kend && gr < Mg) {
-            const float* src = Ap + (size_t)gk * p.lda + gr;
+            const float* src = Ap + (size_t)gk * h.lda + gr;
             if (p.avec) v4 = *reinterpret_cast<const float4*>(src);
             else {
               v4.x = src[0];
@@ -499,8 +531,8 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         if (BKC) {
           const int row = f / KQ, kq = f % KQ;
           const int gr = n0 + row, gk = k0 + 4 * kq;
-          if (gr < p.N && gk < kend) {
-            const float* src = Bp + (size_t)gr * p.ldb + gk;
+          if (gr < h.N && gk < kend) {
+            const float* src = Bp + (size_t)gr * h.ldb + gk;
             if (p.bvec) v4 = *reinterpret_cast<const float4*>(src);
             else {
               v4.x = src[0];
@@ -512,14 +544,14 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         } else {
           const int k = f / (BN / 4), rq = f - k * (BN / 4);
           const int gk = k0 + k, gr = n0 + 4 * rq;
-          if (gk < kend && gr < p.N) {
-            const float* src = Bp + (size_t)gk * p.ldb + gr;
+          if (gk < kend && gr < h.N) {
+            const float* src = Bp + (size_t)gk * h.ldb + gr;
             if (p.bvec) v4 = *reinterpret_cast<const float4*>(src);
             else {
               v4.x = src[0];
-              if (gr + 1 < p.N) v4.y = src[1];
-              if (gr + 2 < p.N) v4.z = src[2];
-              if (gr + 3 < p.N) v4.w = src[3];
+              if (gr + 1 < h.N) v4.y = src[1];
+              if (gr + 2 < h.N) v4.z = src[2];
+              if (gr + 3 < h.N) v4.w = src[3];
             }
           }
         }
@@ -646,10 +678,12 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     if (PF == 2) {
       // two register stages: while tile t is multiplied out of LDS, tile t+1 sits in (or is arriving into) one stage
       // and the loads of tile t+2 are issued into the other; the loop is unrolled by two so the stages are static
+      MMNAS_LIFE(1);   // tile / group / offset set-up
       gload_to(q0, true, 0);
       gload_to(q0 + 1, nq > 1, 1);
       lstore_from(0, 0);
       __syncthreads();
+      MMNAS_LIFE(2);   // first tile: loads -> conversion -> LDS -> barrier
 #ifdef MMNAS_DBG_STAMP   // timing experiment only: cycle stamps of one wave per phase of the first half-iteration (tools/gemm_stamps.py)
 #define MMNAS_STAMP(i) do { const unsigned long long c_ = __builtin_readcyclecounter(); stamp_acc[i] += (unsigned)(c_ - stamp_prev); stamp_prev = c_; } while (0)
       const bool stamp_on = tid == 0 && bid == MMNAS_DBG_STAMP;
@@ -690,6 +724,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
       if (stamp_on)
         for (int i = 0; i < 8; ++i) g_stamp_acc[i] += stamp_acc[i];
 #endif
+      MMNAS_LIFE(3);   // K loop
     } else {
       gload(q0);
       lstore(0);
@@ -704,10 +739,10 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     }
 
     // ---- partial tile: hand the accumulators over; the last contributor to arrive finishes the tile ----
-    const bool atomic_out = nq != p.T && p.accumulate;  // "C +=" results: a partial tile simply adds its share
-    if (nq != p.T && !atomic_out) {
-      const int t0 = (tile - p.n_full) * p.T;  // first unit of the tile in the streamed sequence
-      const int v_lo = t0 / p.P, v_hi = (t0 + p.T - 1) / p.P;  // contributors (streaming workgroup indices), inclusive
+    const bool atomic_out = nq != h.T && p.accumulate;  // "C +=" results: a partial tile simply adds its share
+    if (nq != h.T && !atomic_out) {
+      const int t0 = (tile - h.n_full) * h.T;  // first unit of the tile in the streamed sequence
+      const int v_lo = t0 / h.P, v_hi = (t0 + h.T - 1) / h.P;  // contributors (streaming workgroup indices), inclusive
       // a workgroup has at most two partial tiles: the one it starts inside (slot 2v) and the one it
       // ends inside (slot 2v+1)
       // slot image: [register pair][thread] of 8-byte words -- every store / load instruction covers 512
@@ -735,7 +770,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 #pragma unroll 1
       for (int c = v_lo; c <= v_hi; ++c) {
-        const bool head = c * p.P > t0;  // contributor c starts inside this tile
+        const bool head = c * h.P > t0;  // contributor c starts inside this tile
         const u64* src = reinterpret_cast<const u64*>(p.ws) + (size_t)(2 * c + (head ? 0 : 1)) * (BM * BN / 2) + tid;
         u64 part[TM * TN * 8];  // the whole partial in flight at once: the loads miss L2 by design (~2 us each)
 #pragma unroll
@@ -775,11 +810,11 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * WN + j * 32 + l31;
-        const bool cok = col < p.N;
-        const int colc = cok ? col : p.N - 1;
+        const bool cok = col < h.N;
+        const int colc = cok ? col : h.N - 1;
         const int rbase = m0 + wm * WM + i * 32 + 4 * hh;
         if (EPI == 1) {   // LSTM forward step: column = 4 * unit + gate; the 4 lanes of a quad hold one unit's gates
-          const int unit = col >> 2, gate = col & 3, Hn = p.N >> 2;
+          const int unit = col >> 2, gate = col & 3, Hn = h.N >> 2;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = rbase + (r & 3) + 8 * (r >> 2);
@@ -791,7 +826,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
             const int q = lane & ~3;
             const float gi = __shfl(a, q, 64), gf = __shfl(a, q + 1, 64), gg = __shfl(a, q + 2, 64), go = __shfl(a, q + 3, 64);
             if (ok) {
-              lg_gates[(size_t)row * p.N + col] = a;
+              lg_gates[(size_t)row * h.N + col] = a;
               if (gate == 0) {
                 const float c = gf * lg_cprev[(size_t)row * Hn + unit] + gi * gg;
                 const float hv = go * tanhf(c);
@@ -808,7 +843,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
           for (int r = 0; r < 16; ++r) {
             const int row = rbase + (r & 3) + 8 * (r >> 2);
             if (!(cok && row < Mg)) continue;
-            const size_t o = (size_t)row * p.N + col;
+            const size_t o = (size_t)row * h.N + col;
             const float dh = acc[i][j][r] + resp[(size_t)row * p.ldres + col];
             const float4 g4 = *reinterpret_cast<const float4*>(lg_act + 4 * o);   // i, f, g, o (activated)
             const float c = lg_c[o], cp = lg_cprev[o];
@@ -875,7 +910,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
           const int row = rbase + (r & 3) + 8 * (r >> 2);
           float val = acc[i][j][r] * p.alpha + bv;
           if (has_relu) val = fmaxf(val, 0.f);
-          if (has_drop) val *= drop_mult(gdrop, (uint32_t)row * (uint32_t)p.N + (uint32_t)col);
+          if (has_drop) val *= drop_mult(gdrop, (uint32_t)row * (uint32_t)h.N + (uint32_t)col);
           if (has_gate) val = gatev[r] > 0.f ? val * p.gate_scale : 0.f;
           if (has_res) val += resv[r];
           if (has_acc) val += oldv[r];
@@ -887,6 +922,10 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         }
       }
     }
+#ifdef MMNAS_DBG_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    MMNAS_LIFE(4);   // epilogue, stores landed
   }
 }
 
@@ -1161,7 +1200,8 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
   const int btm = wide ? 128 : bt, btn = bt;
   k.tiles_n = cdiv(d->N, btn);
   long t0 = 0;
-  for (int g = 0; g < d->ngroups; ++g) { k.g[g].tile0 = (int)t0; t0 += (long)cdiv(d->g[g].M, btm) * k.tiles_n; }
+  for (int g = 0; g < MAXG; ++g) k.gtile0[g] = INT_MAX;
+  for (int g = 0; g < d->ngroups; ++g) { k.g[g].tile0 = k.gtile0[g] = (int)t0; t0 += (long)cdiv(d->g[g].M, btm) * k.tiles_n; }
   MMNAS_REQUIRE(t0 < (1l << 30), MMNAS_E_SHAPE, "mmnas_gemm: too many output tiles");
   k.ntiles = (int)t0;
   k.gm = g_tune.gm > 0 ? g_tune.gm : 8;
@@ -1405,10 +1445,10 @@ extern "C" int mmnas_lstm_bwd(const float* dout, const float* Whh, const float* 
 
 #ifdef MMNAS_DBG_STAMP
 extern "C" int mmnas_dbg_stamps(unsigned long long* out8, int reset) {
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(mmnas::g_stamp_acc), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
-  if (reset) {
+  if (hipMemcpyFromSymbol(out8, reset & 2 ? HIP_SYMBOL(mmnas::g_life_acc) : HIP_SYMBOL(mmnas::g_stamp_acc), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset & 1) {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(mmnas::g_stamp_acc), z, sizeof(z)) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(reset & 2 ? HIP_SYMBOL(mmnas::g_life_acc) : HIP_SYMBOL(mmnas::g_stamp_acc), z, sizeof(z)) != hipSuccess) return 1;
   }
   return 0;
 }

@@ -23,22 +23,28 @@ def run(M, N, K, launches=20):
         L.check(L.lib().mmnas_gemm(C.byref(d), L.stream()))
     torch.cuda.synchronize()
     assert lib.mmnas_dbg_stamps(out, 1) == 0
+    assert lib.mmnas_dbg_stamps(out, 3) == 0
     for _ in range(launches):
         L.check(L.lib().mmnas_gemm(C.byref(d), L.stream()))
     torch.cuda.synchronize()
     assert lib.mmnas_dbg_stamps(out, 1) == 0
-    pairs = launches * (K // 64)
+    pairs = launches * max(K // 64, 1)
     print('NT %d x %d x %d (%d workgroups): cycles per pair of K-tiles' % (M, N, K, (M // 64) * (N // 64)))
     tot = 0
     for i, n in enumerate(NAMES):
         print('   %-40s %7.0f' % (n, out[i] / pairs))
         tot += out[i] / pairs
     print('   %-40s %7.0f' % ('sum', tot))
+    assert lib.mmnas_dbg_stamps(out, 2) == 0
+    life = ['kernel-argument warm-up', 'tile / group / offset set-up', 'first tile: loads -> conversion -> LDS -> barrier', 'K loop', 'epilogue, stores landed']
+    print('   workgroup lifetime, cycles per launch: ' + ', '.join('%s %.0f' % (n, out[i] / launches) for i, n in enumerate(life))
+          + '  (total %.0f)' % (sum(out[i] for i in range(5)) / launches))
 
 
 if __name__ == '__main__':
     for w in (1, 2, 3):
         run(4096 * w, 256, 2048)
+    run(64 * 38, 64, 32)
+    run(6400, 256, 32)
     run(6400, 256, 256)
-    run(6400, 256, 1024)
     run(6400, 1024, 256)
