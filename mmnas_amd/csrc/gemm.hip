@@ -1017,7 +1017,7 @@ static int env_int(const char* name, int dflt) {
 //   MMNAS_GEMM_SPLIT=0|3|6 products on the fp32 MFMA / as 3 / 6 (default: fp32-grade) bf16 MFMA products of split operands
 //   MMNAS_GEMM_PAIR=0      mmnas_gemm_pair launches its two products separately
 //   MMNAS_GEMM_PF=1|2      K-tiles of operand loads in flight ahead of the MFMA block (64^2 fp32 buffer-load path)
-struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split, pair, split_slots, split_p, pf, wide_min, split_minwg; bool loaded; };
+struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split, pair, split_slots, split_p, pf, wide_min, split_minwg, hyb_t; bool loaded; };
 static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 3, 1, 0, 24, 2, 200, 256, false};
 static void load_tuning() {
   g_tune.tile = env_int("MMNAS_GEMM_TILE", 0);
@@ -1036,6 +1036,7 @@ static void load_tuning() {
   if (g_tune.split_p < 1) g_tune.split_p = 1;
   g_tune.split_minwg = env_int("MMNAS_GEMM_SPLIT_MINWG", 256);  // fewest split-K pieces in total (x tiles) when pieces of split_p would be fewer
   g_tune.pf = env_int("MMNAS_GEMM_PF", 2) == 1 ? 1 : 2;            // register stages of operand prefetch (64^2 fp32 path)
+  g_tune.hyb_t = env_int("MMNAS_GEMM_HYB_T", 16);                // fewest K-tiles per output tile for the whole-tiles + streamed-tail hybrid
   g_tune.wide_min = env_int("MMNAS_GEMM_WIDE_MIN", 200);         // fewest 128x64 tiles for that shape to be chosen
   g_tune.loaded = true;
 }
@@ -1236,7 +1237,7 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
       nwg = S * k.ntiles;
     }
   } else if (!accumulate && sk != 0 && !big && !wide && U < (1ll << 30) && k.ntiles <= MAX_CNT_TILES && g_tune.wgs == 0 &&
-             sk == 1 && k.ntiles > 256 && k.ntiles < 8192 && k.ntiles % 256 != 0 && k.T >= 16) {
+             sk == 1 && k.ntiles > 256 && k.ntiles < 8192 && k.ntiles % 256 != 0 && k.T >= g_tune.hyb_t) {
     // Single round (every tile resident at once, 3-4 workgroups per CU) with a ragged last "layer": the first
     // floor(ntiles / 256) * 256 tiles are computed whole; the R tail tiles are streamed by ~one extra SHORT workgroup
     // per CU (R * T units cut into <= 256 runs), launched first.  Their hand-over through the workspace ends long
