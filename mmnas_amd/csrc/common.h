@@ -18,15 +18,32 @@ int check_launch(const char* what);
 #define MMNAS_REQUIRE(cond, code, ...) \
   do { if (!(cond)) { ::mmnas::set_error(__VA_ARGS__); return (code); } } while (0)
 
+// Sum / maximum over the 64 lanes of a wave (all lanes active), the same value returned to every lane.  DPP lane
+// permutations inside the vector ALU: quad swaps, half-row and row mirrors give every lane its 16-lane row's result, two row
+// broadcasts carry it across the four rows into lane 63, a readlane hands it out.  (The __shfl_xor butterfly this replaces is six
+// ds_bpermute_b32 round trips through the LDS crossbar: LayerNorm backward spent 24 of them per row.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float old, float src) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_move<0xB1, 0xf>(0.f, v);    // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E, 0xf>(0.f, v);    // quad_perm [2,3,0,1]
+  v += dpp_move<0x141, 0xf>(0.f, v);   // row_half_mirror
+  v += dpp_move<0x140, 0xf>(0.f, v);   // row_mirror
+  v += dpp_move<0x142, 0xa>(0.f, v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_move<0x143, 0xc>(0.f, v);   // row_bcast:31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  constexpr float NI = -__builtin_inff();
+  v = fmaxf(v, dpp_move<0xB1, 0xf>(NI, v));
+  v = fmaxf(v, dpp_move<0x4E, 0xf>(NI, v));
+  v = fmaxf(v, dpp_move<0x141, 0xf>(NI, v));
+  v = fmaxf(v, dpp_move<0x140, 0xf>(NI, v));
+  v = fmaxf(v, dpp_move<0x142, 0xa>(NI, v));
+  v = fmaxf(v, dpp_move<0x143, 0xc>(NI, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Row of the 32x32 MFMA accumulator held in register r of a lane in half `hh` (= lane >> 5):
