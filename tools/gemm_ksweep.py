@@ -35,14 +35,23 @@ def timed(desc, iters=40):
 
 if __name__ == '__main__':
     N = int(os.environ.get('KSWEEP_N', '64'))
+    LAY = os.environ.get('KSWEEP_LAYOUT', 'NT')   # NT: both operands K-contiguous; NN: B as [K][N]; TN: both as [K][rows]
     for w in (1, 2, 3, 4, 6):
         M = 64 * 256 * w * 64 // N
         row = []
         for K in (64, 128, 256, 512, 1024, 2048):
-            a, b, c = torch.randn(M, K, device='cuda'), torch.randn(N, K, device='cuda'), torch.zeros(M, N, device='cuda')
-            d = ops.gemm_desc(L.GEMM_NT, [dict(M=M, A=[a], B=[b], C=c)], N, K, K, K, N)
+            c = torch.zeros(M, N, device='cuda')
+            if LAY == 'NT':
+                a, b = torch.randn(M, K, device='cuda'), torch.randn(N, K, device='cuda')
+                d = ops.gemm_desc(L.GEMM_NT, [dict(M=M, A=[a], B=[b], C=c)], N, K, K, K, N)
+            elif LAY == 'NN':
+                a, b = torch.randn(M, K, device='cuda'), torch.randn(K, N, device='cuda')
+                d = ops.gemm_desc(L.GEMM_NN, [dict(M=M, A=[a], B=[b], C=c)], N, K, K, N, N)
+            else:
+                a, b = torch.randn(K, M, device='cuda'), torch.randn(K, N, device='cuda')
+                d = ops.gemm_desc(L.GEMM_TN, [dict(M=M, A=[a], B=[b], C=c)], N, K, M, N, N)
             row.append((K, timed(d)))
         (k0, t0), (k1, t1) = row[2], row[-1]
         slope = (t1 - t0) / ((k1 - k0) / 32)
-        print('N=%d  %d workgroups/CU (M=%d): ' % (N, w, M) + '  '.join('K=%d %.1f us' % kt for kt in row)
+        print('%s N=%d  %d workgroups/CU (M=%d): ' % (LAY, N, w, M) + '  '.join('K=%d %.1f us' % kt for kt in row)
               + '  | per K-tile %.3f us = %.0f cycles at 2.4 GHz, intercept %.1f us' % (slope, slope * 2400, t0 - slope * k0 / 32), flush=True)
