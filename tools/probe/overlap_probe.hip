@@ -175,6 +175,14 @@ __global__ void __launch_bounds__(512) probe(int mode, int iters, float* out) {
   else if (mode == 19) { if (wave < 4) mfma_chain(iters, out); else valu_chain<2>(iters, out); }
   else if (mode == 20) valu_chain<3>(iters, out);
   else if (mode == 21) { if (wave < 4) mfma_chain(iters, out); else valu_chain<3>(iters, out); }
+  else if (mode == 22) { if ((wave & 2) == 0) mfma_chain(iters, out); else conv_chain(iters, out); }   // waves 0,1,4,5 MFMA (SIMD 0,1 if waves go round-robin); 2,3,6,7 conversion
+  else if (mode == 23) {   // roles from the hardware SIMD id
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const unsigned simd = (hw >> 4) & 3;
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) out[512 + wave] = (float)simd;
+    if (simd < 2) mfma_chain(iters, out); else conv_chain(iters, out);
+  }
 }
 
 int main() {
@@ -188,10 +196,11 @@ int main() {
                          "4 waves: MFMA, 4 accumulators", "4 waves: each MFMA followed by a conversion slice, 1 accumulator",
                          "4 waves: each MFMA followed by a conversion slice, 2 accumulators", "4 waves: each MFMA followed by a conversion slice, 4 accumulators",
                          "4 waves: 88 v_fma_f32", "8 waves: 4 MFMA + 4 x 88 v_fma_f32", "4 waves: 88 v_cvt_pk_bf16_f32", "8 waves: 4 MFMA + 4 x 88 v_cvt_pk_bf16_f32",
-                         "4 waves: 88 x (v_and + v_lshl)", "8 waves: 4 MFMA + 4 x 88 x (v_and + v_lshl)", "4 waves: 88 v_sub_f32", "8 waves: 4 MFMA + 4 x 88 v_sub_f32"};
+                         "4 waves: 88 x (v_and + v_lshl)", "8 waves: 4 MFMA + 4 x 88 x (v_and + v_lshl)", "4 waves: 88 v_sub_f32", "8 waves: 4 MFMA + 4 x 88 v_sub_f32",
+                         "8 waves: waves 0,1,4,5 MFMA, waves 2,3,6,7 conversion", "8 waves: MFMA on hardware SIMD 0-1, conversion on SIMD 2-3"};
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int mode = 0; mode < 22; ++mode) {
+  for (int mode = 0; mode < 24; ++mode) {
     const int threads = (mode == 0 || mode == 1 || mode == 6 || (mode >= 10 && mode <= 14) || mode == 16 || mode == 18 || mode == 20) ? 256 : 512;
     probe<<<256, threads>>>(mode, 10, out);
     hipDeviceSynchronize();
@@ -202,6 +211,13 @@ int main() {
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
     printf("mode %d  %-75s %8.1f us  = %6.0f cycles per tile at 2.4 GHz\n", mode, names[mode], ms * 1e3, ms * 1e-3 * 2.4e9 / iters);
+    if (mode == 23) {
+      float hs[8];
+      hipMemcpy(hs, out + 512, sizeof(hs), hipMemcpyDeviceToHost);
+      printf("         SIMD of waves 0..7 of workgroup 0:");
+      for (int i = 0; i < 8; ++i) printf(" %d", (int)hs[i]);
+      printf("\n");
+    }
   }
   return 0;
 }
