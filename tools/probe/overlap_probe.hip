@@ -33,6 +33,29 @@ __device__ __forceinline__ void mfma_chain_n(int iters, float* out) {
 }
 __device__ __forceinline__ void mfma_chain(int iters, float* out) { mfma_chain_n<1>(iters, out); }
 
+// the same chain with the wave stepping back from the issue port between MFMAs: NOPS cycles of s_nop after each one
+template <int NOPS, int SLEEP>
+__device__ __forceinline__ void mfma_chain_yield(int iters, float* out) {
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(1.0f + threadIdx.x * 1e-3f); b[i] = (__bf16)(0.5f); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      if (SLEEP) __builtin_amdgcn_s_sleep(1);
+      else {
+        if (NOPS >= 16) asm volatile("s_nop 15");
+        if (NOPS % 16) asm volatile("s_nop %0" ::"n"((NOPS % 16) - 1));   // (one s_nop unit = 4 clocks)
+      }
+    }
+  }
+  float s = 0.f;
+  for (int r = 0; r < 16; ++r) s += acc[r];
+  if (s == 123.456f) out[threadIdx.x] = s;
+}
+
 // one wave doing both: per MFMA one slice of the conversion (8 pairs over 12 MFMAs), NACC accumulators
 template <int NACC>
 __device__ __forceinline__ void both_chain(int iters, float* out) {
@@ -150,7 +173,38 @@ __device__ __forceinline__ void lds_chain(int iters, float* out, float* lds) {
   if (s.x == 123.456f) out[threadIdx.x] = s.x;
 }
 
-__global__ void __launch_bounds__(512) probe(int mode, int iters, float* out) {
+// LDS / global traffic of one wave per "tile" without dependent chains: KIND 0: 8 ds_write_b64, 1: 12 ds_read_b128 (one wait per
+// tile), 2: 4 buffer-style global_load_dwordx4 from a 64 KB L2-resident region (one wait per tile)
+template <int KIND>
+__device__ __forceinline__ void mem_chain(int iters, float* out, float* lds, const float* gsrc) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) & 3;
+  float* base = lds + w * 2048;
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+    if (KIND == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) *reinterpret_cast<volatile f2*>(base + ((lane * 2 + k * 128) & 2047)) = f2{(float)it, (float)k};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if (KIND == 1) {
+      f4 v[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) v[k] = *reinterpret_cast<volatile f4*>(base + ((lane * 4 + k * 256) & 2047));
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc += v[k];
+    } else {
+      f4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const volatile f4*>(gsrc + ((size_t)blockIdx.x * 4096 + (size_t)((it * 4 + k) & 3) * 1024 + w * 256 + lane * 4));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc += v[k];
+    }
+  }
+  if (acc.x == 123.456f) out[threadIdx.x] = acc.x + acc.y;
+}
+
+__global__ void __launch_bounds__(512) probe(int mode, int iters, float* out, const float* gsrc) {
   __shared__ float lds[4 * 2048];
   if (threadIdx.x < 4 * 2048 / 8) for (int i = 0; i < 8; ++i) lds[threadIdx.x * 8 + i] = 1.0f;
   __syncthreads();
@@ -176,6 +230,30 @@ __global__ void __launch_bounds__(512) probe(int mode, int iters, float* out) {
   else if (mode == 20) valu_chain<3>(iters, out);
   else if (mode == 21) { if (wave < 4) mfma_chain(iters, out); else valu_chain<3>(iters, out); }
   else if (mode == 22) { if ((wave & 2) == 0) mfma_chain(iters, out); else conv_chain(iters, out); }   // waves 0,1,4,5 MFMA (SIMD 0,1 if waves go round-robin); 2,3,6,7 conversion
+  else if (mode == 24) mem_chain<0>(iters, out, lds, gsrc);
+  else if (mode == 25) { if (wave < 4) mfma_chain(iters, out); else mem_chain<0>(iters, out, lds, gsrc); }
+  else if (mode == 26) mem_chain<1>(iters, out, lds, gsrc);
+  else if (mode == 27) { if (wave < 4) mfma_chain(iters, out); else mem_chain<1>(iters, out, lds, gsrc); }
+  else if (mode == 28) mem_chain<2>(iters, out, lds, gsrc);
+  else if (mode == 29) { if (wave < 4) mfma_chain(iters, out); else mem_chain<2>(iters, out, lds, gsrc); }
+  else if (mode == 30) { if (wave >= 4) mfma_chain(iters, out); else conv_chain(iters, out); }            // the MFMA waves are the YOUNGER ones
+  else if (mode == 31) { if (wave >= 4) mfma_chain(iters, out); else mem_chain<1>(iters, out, lds, gsrc); }
+  else if (mode == 32) { if (wave >= 4) mfma_chain(iters, out); else mem_chain<2>(iters, out, lds, gsrc); }
+  else if (mode == 33) { if (wave < 4) { __builtin_amdgcn_s_setprio(0); mfma_chain(iters, out); } else { __builtin_amdgcn_s_setprio(3); conv_chain(iters, out); } }   // conversion waves at high priority
+  else if (mode == 34) mfma_chain_yield<24, 0>(iters, out);
+  else if (mode == 35) { if (wave < 4) mfma_chain_yield<24, 0>(iters, out); else conv_chain(iters, out); }
+  else if (mode == 36) mfma_chain_yield<16, 0>(iters, out);
+  else if (mode == 37) { if (wave < 4) mfma_chain_yield<16, 0>(iters, out); else conv_chain(iters, out); }
+  else if (mode == 38) mfma_chain_yield<0, 1>(iters, out);
+  else if (mode == 39) { if (wave < 4) mfma_chain_yield<0, 1>(iters, out); else conv_chain(iters, out); }
+  else if (mode == 40) mfma_chain_yield<6, 0>(iters, out);
+  else if (mode == 41) { if (wave < 4) mfma_chain_yield<6, 0>(iters, out); else conv_chain(iters, out); }
+  else if (mode == 42) mfma_chain_yield<4, 0>(iters, out);
+  else if (mode == 43) { if (wave < 4) mfma_chain_yield<4, 0>(iters, out); else conv_chain(iters, out); }
+  else if (mode == 44) mfma_chain_yield<2, 0>(iters, out);
+  else if (mode == 45) { if (wave < 4) mfma_chain_yield<2, 0>(iters, out); else conv_chain(iters, out); }
+  else if (mode == 46) { if (wave < 4) mfma_chain_yield<6, 0>(iters, out); else mem_chain<1>(iters, out, lds, gsrc); }
+  else if (mode == 47) { if (wave < 4) mfma_chain_yield<6, 0>(iters, out); else mem_chain<2>(iters, out, lds, gsrc); }
   else if (mode == 23) {   // roles from the hardware SIMD id
     unsigned hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -197,15 +275,27 @@ int main() {
                          "4 waves: each MFMA followed by a conversion slice, 2 accumulators", "4 waves: each MFMA followed by a conversion slice, 4 accumulators",
                          "4 waves: 88 v_fma_f32", "8 waves: 4 MFMA + 4 x 88 v_fma_f32", "4 waves: 88 v_cvt_pk_bf16_f32", "8 waves: 4 MFMA + 4 x 88 v_cvt_pk_bf16_f32",
                          "4 waves: 88 x (v_and + v_lshl)", "8 waves: 4 MFMA + 4 x 88 x (v_and + v_lshl)", "4 waves: 88 v_sub_f32", "8 waves: 4 MFMA + 4 x 88 v_sub_f32",
-                         "8 waves: waves 0,1,4,5 MFMA, waves 2,3,6,7 conversion", "8 waves: MFMA on hardware SIMD 0-1, conversion on SIMD 2-3"};
+                         "8 waves: waves 0,1,4,5 MFMA, waves 2,3,6,7 conversion", "8 waves: MFMA on hardware SIMD 0-1, conversion on SIMD 2-3",
+                         "4 waves: 8 ds_write_b64 per tile", "8 waves: 4 MFMA + 4 x 8 ds_write_b64", "4 waves: 12 ds_read_b128 per tile", "8 waves: 4 MFMA + 4 x 12 ds_read_b128",
+                         "4 waves: 4 global_load_dwordx4 per tile (L2-resident)", "8 waves: 4 MFMA + 4 x 4 global_load_dwordx4",
+                         "8 waves: 4 conversion (older waves) + 4 MFMA (younger)", "8 waves: 4 x 12 ds_read_b128 (older) + 4 MFMA (younger)",
+                         "8 waves: 4 x 4 global loads (older) + 4 MFMA (younger)", "8 waves: 4 MFMA at priority 0 + 4 conversion at priority 3",
+                         "4 waves: MFMA chain, s_nop 15 + s_nop 7 (96 clocks) after each", "8 waves: 4 MFMA (96 clocks of s_nop after each) + 4 conversion",
+                         "4 waves: MFMA chain, s_nop 15 (64 clocks) after each", "8 waves: 4 MFMA (64 clocks of s_nop after each) + 4 conversion",
+                         "4 waves: MFMA chain, s_sleep 1 after each", "8 waves: 4 MFMA (s_sleep 1 after each) + 4 conversion",
+                         "4 waves: MFMA chain, s_nop 5 (24 clocks) after each", "8 waves: 4 MFMA (s_nop 5 after each) + 4 conversion",
+                         "4 waves: MFMA chain, s_nop 3 (16 clocks) after each", "8 waves: 4 MFMA (s_nop 3 after each) + 4 conversion",
+                         "4 waves: MFMA chain, s_nop 1 (8 clocks) after each", "8 waves: 4 MFMA (s_nop 1 after each) + 4 conversion",
+                         "8 waves: 4 MFMA (s_nop 5 after each) + 4 x 12 ds_read_b128", "8 waves: 4 MFMA (s_nop 5 after each) + 4 x 4 global loads"};
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int mode = 0; mode < 24; ++mode) {
-    const int threads = (mode == 0 || mode == 1 || mode == 6 || (mode >= 10 && mode <= 14) || mode == 16 || mode == 18 || mode == 20) ? 256 : 512;
-    probe<<<256, threads>>>(mode, 10, out);
+  float* gsrc; hipMalloc(&gsrc, 256 * 4096 * 4); hipMemset(gsrc, 0, 256 * 4096 * 4);
+  for (int mode = 0; mode < 48; ++mode) {
+    const int threads = (mode == 0 || mode == 1 || mode == 6 || (mode >= 10 && mode <= 14) || mode == 16 || mode == 18 || mode == 20 || mode == 24 || mode == 26 || mode == 28 || mode == 34 || mode == 36 || mode == 38 || mode == 40 || mode == 42 || mode == 44) ? 256 : 512;
+    probe<<<256, threads>>>(mode, 10, out, gsrc);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    probe<<<256, threads>>>(mode, iters, out);
+    probe<<<256, threads>>>(mode, iters, out, gsrc);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0.f;
