@@ -325,6 +325,12 @@ def main():
         sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a mislabelled number\n' % (args.gpus, world))
         sys.exit(2)
     os.environ['MMNAS_GEMM_SPLIT'] = str(args.gemm_split)       # read when the library first schedules a GEMM
+    # The contract is ONE JSON line on stdout.  Libraries of the process write there too (RCCL prints its version banner to
+    # stdout under NCCL_DEBUG=VERSION, which this pool exports -- through C stdio, i.e. behind the JSON line when stdout is a
+    # pipe): point file descriptor 1 at stderr for the whole run and keep the real stdout for the one line.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -832,9 +838,11 @@ def main():
         sub = {{'arch_vqa': 'arch_step', 'bilevel_vqa': 'bilevel'}.get(w, w): r for w, r in recs.items() if w != head_wl}
         if sub:
             out['sub'] = sub
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if world > 1 or state.get('own_group'):
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.close(real_stdout)
 
 
 if __name__ == '__main__':

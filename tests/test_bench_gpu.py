@@ -45,10 +45,13 @@ def test_bench_single_gpu(workload):
 def test_bench_default_line_is_the_supernet_weight_step_with_sub_records():
     """The driver's command (no --workload): headline = the BASELINE metric's workload, the other three under `sub`,
     every record with its own roofline and CPU baseline."""
+    env = dict(os.environ, NCCL_DEBUG='VERSION')   # (RCCL then prints a version banner to stdout from the one-rank records)
     p = subprocess.run([sys.executable, 'bench.py', '--steps', '6', '--warmup', '1', '--cpu-budget', '3'],
-                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     d = _json_line(p.stdout)
+    assert [l for l in p.stdout.splitlines() if l.strip()] == [l for l in p.stdout.splitlines() if l.startswith('{')], \
+        'stdout must carry the one JSON line and nothing else: ' + p.stdout[-500:]
     _check(d, 1, steps=6)
     assert d['metric'].startswith('supernet fwd+bwd steps/sec') and 'WEIGHT step' in d['config']['workload']
     main = {'arch_step', 'bilevel', 'train_vqa'}
