@@ -331,6 +331,8 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if os.environ.get('NCCL_DEBUG', '').upper() == 'VERSION':   # the banner itself: the version goes into the JSON line instead
+        os.environ['NCCL_DEBUG'] = 'WARN'
 
     import numpy as np
     import torch
@@ -699,6 +701,7 @@ def main():
             'steps': nsteps, 'warmup': wcalls * per_call, 'ms_per_step': 1000.0 * elapsed / nsteps,
             'repeats': len(blocks), 'value_min': world * nsteps / el_max, 'value_max': world * nsteps / el_min,
             'value_note': 'median of `repeats` timed blocks of `steps` steps each; value_min / value_max = slowest / fastest block',
+            'blocks_ms_per_step': [round(1000.0 * b[0] / nsteps, 4) for b in blocks],   # in the order they ran
             'workload': WORKLOADS[wl],
             'samples_per_s': world * nsteps * (state[wl]['B'] if wl in EXTRA else B) / elapsed,
             'algorithmic_tflops_per_gpu': timed_flops / elapsed / 1e12,
@@ -830,6 +833,7 @@ def main():
                        'grad_allreduce': ('rccl' if backend == 'nccl' else backend) if world > 1 else 'none',
                        'rccl_ranks': dist.get_world_size() if world > 1 else 1,
                        'rccl_env': {k: v for k, v in os.environ.items() if k.startswith(('NCCL_', 'RCCL_'))},
+                       'rccl_version': '.'.join(str(x) for x in torch.cuda.nccl.version()) if hasattr(torch.cuda, 'nccl') else None,
                        'optimizer_in_step': False, 'gemm_split': args.gemm_split},
         }
         for k, v in head.items():
