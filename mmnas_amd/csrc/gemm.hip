@@ -300,9 +300,10 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
 #else
 #define MMNAS_LIFE(i) do { } while (0)
 #endif
-  // The kernel arguments (~540 B = 9-10 cache lines for up to three groups) live in host-visible memory: the first touch of each line
-  // is a ~1 us round trip, and the compiler reads them in dependent steps (mode -> sizes -> group -> pointers).
-  // Touch every line up front so the misses overlap (measured: -3.5 us per launch).
+  // The kernel arguments (~1.2 KB with nine groups; the header and the first three groups are 10 cache lines) are written by the
+  // runtime just before the launch (device memory under HIP_FORCE_DEV_KERNARG=1, this image's default; host-visible memory
+  // otherwise): the first touch of each line is a miss of up to ~1 us, and the group record is read in a dependent step.
+  // Touch every line up front so the misses overlap (measured in round 2: -3.5 us per launch).
   {
     const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr() + koff;
     unsigned t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;
