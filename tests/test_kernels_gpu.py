@@ -973,3 +973,30 @@ def test_gemm_nine_groups_with_their_own_dropout_seeds(mode, gemm_tuning):
         ref = (A[j].double() @ B[j].double().t()) * mask.double() + res.double()
         assert rel_err(Cm[j].cpu().numpy(), ref.cpu().numpy()) < 1e-5, j
     assert not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
+
+
+@pytest.mark.parametrize('layout', ['NT', 'NN'])
+@pytest.mark.parametrize('ngroups', [1, 2, 5, 9])
+def test_gemm_group_of_a_tile_with_ragged_row_counts(layout, ngroups, gemm_tuning):
+    """The group a tile belongs to is found from the header's copy of the group boundaries (a count of boundaries at or
+    below the tile, INT_MAX past the last group): row counts of one row, just under / at / just over the 64- and 128-row
+    tile edges, and every number of groups up to the nine the descriptor holds."""
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    gemm_tuning(split=6)
+    rs = np.random.RandomState(17 + ngroups)
+    N, K = 192, 96
+    Ms = [1, 63, 64, 65, 127, 128, 129, 896, 6400][:ngroups] if ngroups < 9 else [129, 1, 6400, 63, 64, 896, 65, 127, 128]
+    groups, refs = [], []
+    for M in Ms:
+        a, c = g(rnd(rs, M, K)), torch.full((M, N), float('nan'), device=DEV)
+        b = g(rnd(rs, N, K)) if layout == 'NT' else g(rnd(rs, K, N))
+        bias = g(rnd(rs, N))
+        groups.append(dict(M=M, A=[a], B=[b], C=c, bias=bias))
+        refs.append(a.double() @ (b.double().t() if layout == 'NT' else b.double()) + bias.double())
+    if layout == 'NT':
+        ops.gemm(L.GEMM_NT, groups, N, K, K, K, N)
+    else:
+        ops.gemm(L.GEMM_NN, groups, N, K, K, N, N)
+    for grp, ref in zip(groups, refs):
+        assert rel_err(grp['C'].cpu().numpy(), ref.cpu().numpy()) < 1e-5, grp['M']
