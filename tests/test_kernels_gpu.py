@@ -1000,3 +1000,25 @@ def test_gemm_group_of_a_tile_with_ragged_row_counts(layout, ngroups, gemm_tunin
         ops.gemm(L.GEMM_NN, groups, N, K, K, N, N)
     for grp, ref in zip(groups, refs):
         assert rel_err(grp['C'].cpu().numpy(), ref.cpu().numpy()) < 1e-5, grp['M']
+
+
+@pytest.mark.parametrize('layout', ['NT', 'NN'])
+@pytest.mark.parametrize('wgs', [7, 33, 129])
+def test_gemm_streamed_pieces_across_k_segments(layout, wgs, gemm_tuning):
+    """Stream-K pieces that start in the middle of a K-segment and run across segment boundaries: the segment / K-tile of
+    a piece's loads is carried from its first unit (one division per piece), not divided out per tile."""
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    gemm_tuning(split=6, sk=2, min_units=1, wgs=wgs)
+    rs = np.random.RandomState(300 + wgs)
+    M, N, K = 320, 192, 160          # 5 K-tiles per segment, 3 segments: 15 units per tile, 15 tiles
+    As = [g(rnd(rs, M, K)) for _ in range(3)]
+    Bs = [g(rnd(rs, N, K)) if layout == 'NT' else g(rnd(rs, K, N)) for _ in range(3)]
+    C = torch.full((M, N), float('nan'), device=DEV)
+    if layout == 'NT':
+        ops.gemm(L.GEMM_NT, [dict(M=M, A=As, B=Bs, C=C)], N, K, K, K, N, nseg=3)
+        ref = sum(a.double() @ b.double().t() for a, b in zip(As, Bs))
+    else:
+        ops.gemm(L.GEMM_NN, [dict(M=M, A=As, B=Bs, C=C)], N, K, K, N, N, nseg=3)
+        ref = sum(a.double() @ b.double() for a, b in zip(As, Bs))
+    assert rel_err(C.cpu().numpy(), ref.cpu().numpy()) < 1e-5
