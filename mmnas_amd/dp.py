@@ -203,18 +203,24 @@ class RowExchange:
     rank) and adds ALL ranks' rows, scaled by 1 / world, into its own (zeroed) gradient view with a fixed summation order
     (mmnas_embedding_bwd_det) -- so the ranks' results are bitwise equal, as an all-reduce's are.  Runs on the reducer's
     communication stream from inside ops.EmbeddingFn.backward.  A gradient that reaches the parameter any other way
-    (a dense autograd gradient) is caught at finish() and all-reduced densely."""
+    (a dense autograd gradient) is caught at finish() and all-reduced densely.  Only a backward between the reducer's
+    begin and finish takes this path (`active`): anywhere else -- the arch step, whose weight gradients nobody reads and
+    which never joins the communication stream -- the embedding's gradient is the local scatter-add on the main stream."""
 
     def __init__(self, red, index):
         self.red, self.i = red, index
         self.done = False
+        self.active = False       # True between the reducer's begin and finish: only then does a backward take the row path
         self._keep = []
         self._idx = {}
+        self._next_key = 0
 
     def begin(self):
         self.done = False
+        self.active = True
         self._keep = []
         self._idx = {}
+        self._next_key = 0
 
     def gather_indices(self, idx):
         """Forward (ops.EmbeddingFn.forward): the ranks' token indices are exchanged while the step computes, so that
@@ -231,7 +237,8 @@ class RowExchange:
             dist.all_gather(ip, idx_l, group=red.group)
             idx_all = torch.cat(ip) if world > 1 else ip[0]
         idx_l.record_stream(cs)
-        key = len(self._idx)
+        key = self._next_key          # never reused within a step: exchange() pops entries while forwards may still add
+        self._next_key += 1
         self._idx[key] = (idx_l, ip, idx_all)
         return key
 
@@ -280,6 +287,7 @@ class RowExchange:
                 _all_reduce_avg(view, red.group, red.world)
         self._keep = []
         self._idx = {}
+        self.active = False
 
 
 def _all_reduce_avg(t, group, world):

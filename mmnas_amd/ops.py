@@ -464,7 +464,7 @@ class EmbeddingFn(torch.autograd.Function):
         ctx.rows_key = None
         s = getattr(weight, '_mmnas_sink', None)
         rows = getattr(s.owner, 'row_exchange', None) if s is not None and s.owner is not None else None
-        if rows is not None and rows.i == s.index and weight.grad is s.view and _sinks_on[0] and ctx.needs_input_grad[1]:
+        if rows is not None and rows.active and rows.i == s.index and weight.grad is s.view and _sinks_on[0] and ctx.needs_input_grad[1]:
             ctx.rows_key = rows.gather_indices(idx)
         return torch.nn.functional.embedding(idx, weight)
 
@@ -476,7 +476,7 @@ class EmbeddingFn(torch.autograd.Function):
         idx = idx.contiguous()
         (dW,), rets, sinks = _grad_bufs([w], dy.device)
         rows = getattr(sinks[0].owner, 'row_exchange', None) if sinks and sinks[0].owner is not None else None
-        if rows is not None and rows.i == sinks[0].index:
+        if rows is not None and rows.active and rows.i == sinks[0].index:
             # data parallel: the ranks exchange (token index, dy row) pairs -- ~1 MB -- and each adds all of them into its
             # own table gradient, instead of all-reducing the dense 24 MB table (dp.RowExchange)
             rows.exchange(idx, dy, ctx.rows_key)

@@ -59,3 +59,22 @@ def test_vgd_bce_loss_average_defaults_to_the_batch_rows():
     assert torch.allclose(got, want)
     assert torch.allclose(vgd_loss(ps, pr, sc, sm, bb, bm, scores_loss='bce', batch_size=3),
                           want + F.binary_cross_entropy_with_logits(ps, sc, reduction='sum') / 6)
+
+
+def test_compact_line_of_a_full_default_record_stays_small():
+    """The driver keeps ~16 KB of stdout and parses the last line: the line made from a full `--workload all` record
+    (seven sub records, kernel classes, PMC detail) must stay under the limit and keep what the driver reads."""
+    import json
+    b = _bench()
+    rec = json.load(open(os.path.join(ROOT, 'profiles', 'r03_bench.json')))
+    assert len(json.dumps(rec)) > 16000          # the record that cost round 3 its parse
+    line = json.dumps(b.compact_line(rec, 'gpurun_out/bench_full.json'), separators=(',', ':'))
+    assert len(line) < 4500 < b.LINE_LIMIT
+    d = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'sub', 'full_record'):
+        assert k in d, k
+    assert set(d['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
+    assert set(d['cpu_baseline']) >= {'value', 'unit', 'cores', 'kind', 'sample'}
+    assert set(d['sub']) == set(rec['sub']) and all('ms_per_step' in s for s in d['sub'].values())
+    assert abs(d['value'] - rec['value']) < 1e-3

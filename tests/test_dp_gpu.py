@@ -160,6 +160,51 @@ def _w_supernet(rank):
     assert torch.equal(both_e[0], both_e[1])             # bitwise equal on the ranks
 
 
+def _w_arch_then_weight(rank):
+    """the row exchange of the embedding gradient runs on the communication stream, which only the
+    weight step joins (begin_weight_step .. finish_weight_step).  An arch step in between (its weight gradients are
+    never read; search_vqa.py:331 steps alpha_optim only) must not take that path: nothing of it may still be writing
+    into the flat buffer when the next weight step zeroes it.  The weight step after an arch step must give exactly the
+    embedding gradient of the same weight step without one."""
+    from mmnas_amd.harness import SearchLoop
+    from mmnas_amd.model import mixed
+    from mmnas.model.hygr_vqa import Net_Search
+    cs = [cases.net_case('vqa', None, 900 + r, search=True, HSIZE=64, B=2) for r in range(WORLD)]
+    init = {'token_size': cs[0]['token_size'], 'ans_size': cs[0]['ans_size'],
+            'pretrained_emb': np.zeros((cs[0]['token_size'], cs[0]['cfg'].WORD_EMBED_SIZE), np.float32)}
+    cs[rank]['cfg'].DROPOUT_R = 0.0
+    torch.manual_seed(2)
+    net = Net_Search(cs[rank]['cfg'], init).cuda().train()
+    loop = SearchLoop(net, epoch_steps=10)
+    red, rx = loop.reducer, loop.reducer.row_exchange
+    assert rx is not None and not rx.active
+    inp = tuple(torch.from_numpy(a).cuda() for a in cs[rank]['inputs'])
+    tgt = torch.from_numpy(cs[rank]['target']).cuda()
+    eo, en = red.fg.offsets[rx.i], net.embedding.weight.numel()
+    mixed.seed_arch_sampler(99)
+    net.reset_binary_gates()
+    plan = [(list(m.active_index), list(m.inactive_index)) for m in net.redundant_modules]
+    loop.weight_step(inp, tgt, optimize=False, plan=plan)
+    torch.cuda.synchronize()
+    assert rx.done and not rx.active
+    want = red.fg.flat[eo:eo + en].clone()
+    assert float(want.abs().max()) > 0
+    for _ in range(4):
+        calls = []
+        orig = rx.exchange
+        rx.exchange = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        loop.arch_step(inp, tgt, optimize=False, plan=plan)
+        assert not calls and not rx._keep and not rx._idx and not rx.active      # local scatter-add, main stream
+        loop.weight_step(inp, tgt, optimize=False, plan=plan)
+        rx.exchange = orig
+        assert len(calls) == 1
+        torch.cuda.synchronize()
+        assert torch.equal(red.fg.flat[eo:eo + en], want)
+    both = [torch.zeros_like(want) for _ in range(WORLD)]
+    dist.all_gather(both, want)
+    assert torch.equal(both[0], both[1])
+
+
 def _w_itm_triplet(rank):
     """the ITM triplet step runs three forwards before one backward, so three BackboneFn and three
     HeadFn nodes add into the same gradient views.  A bucket must be all-reduced after the LAST of them, not the first
@@ -212,6 +257,6 @@ def _w_itm_triplet(rank):
     assert getattr(red, 'marks_made', 0) > 0     # the chain path ran and placed its bucket events (once per step)
 
 
-@pytest.mark.parametrize('fn', ['_w_full', '_w_supernet', '_w_itm_triplet'])
+@pytest.mark.parametrize('fn', ['_w_full', '_w_supernet', '_w_itm_triplet', '_w_arch_then_weight'])
 def test_two_ranks_on_one_gpu(fn):
     mp.spawn(_entry, args=(fn, _free_port()), nprocs=WORLD, join=True)
