@@ -1,5 +1,7 @@
 """The other BASELINE configurations at FULL size, where the oracle is too slow to be the checker: properties the
 reference has by construction (samples are independent, the loss is a sum over samples, padding is inert).
+  configs[2] weight step : Net_Search, MODE None, B=64, 100 regions, HSIZE 256 (search_vqa.py:279-292) -- the workload
+                         of BASELINE.json's metric, through SearchLoop.weight_step (chain path, flat gradient buffer)
   configs[2] arch step : Net_Search, MODE 'full', B=64, 100 regions, HSIZE 256 (search_vqa.py:317-331)
   configs[3] VGD       : Net_Full(arch/mmnas_vgd.json) + the VGD loss, B=64, 100 regions, 15 tokens, HSIZE 512
   configs[4] ITM       : Net_Full(arch/mmnas_itm.json), hard-negative triplet step with BCE_Loss, B=160, 36 regions,
@@ -35,6 +37,103 @@ def _additive(g_all, g_lo, g_hi, tol=2e-3):
         if err > tol * max(float(v.abs().max()), 1e-3 * gmax):
             bad.append((k, err, float(v.abs().max())))
     assert not bad, bad[:6]
+
+
+def test_supernet_weight_step_full_size(monkeypatch):
+    """The metric's own workload at full size (search_vqa.py:279-292; B=64, 100 x 2048 regions + 14 tokens, HSIZE 256)
+    through exactly what bench.py times: SearchLoop.weight_step -> backbone / head chains, flat gradient buffer.
+      * samples are independent: the logits of a permuted batch are the permuted logits;
+      * the loss is a sum over samples: every sampled parameter's gradient over the batch = the sum over its halves;
+      * the chain path equals the per-operator path (the drop-in modules under autograd) at this size -- also with
+        dropout 0.1, the masks replayed from the same seed (they are counter-based: seed, site, element index);
+      * the candidates the sample left out receive no gradient."""
+    from mmnas.model.hygr_vqa import Net_Search
+    from mmnas.model.mixed import MixedOp
+    from mmnas_amd import ops
+    from mmnas_amd.harness import SearchLoop, fused_loss
+    B = 64
+    c = cases.net_case('vqa', None, 31, search=True, HSIZE=256, B=B, Sx=14, Sy=100, token_size=2000, ans_size=3129)
+    c['cfg'].DROPOUT_R = 0.0
+    net = Net_Search(c['cfg'], _init(c))
+    net.load_state_dict({k: T(v) for k, v in c['P'].items()})
+    net = net.to(DEV).train()
+    plan = cases.search_plan(np.random.RandomState(9), None)
+    flat = plan['enc'] + plan['dec']
+    assert {net.redundant_modules[12 + i].Used_OPS[a[0]] for i, (a, _) in enumerate(plan['dec'])} >= {'rel_self_att_64', 'guided_att_64', 'feed_forward'}
+    inp = [T(a).to(DEV) for a in c['inputs']]
+    tgt = T(c['target']).to(DEV)
+
+    class Loss(torch.nn.Module):          # keeps the logits the harness hands to the loss
+        def __init__(self):
+            super().__init__()
+            self.inner = fused_loss(torch.nn.BCEWithLogitsLoss(reduction='sum'))
+
+        def forward(self, pred, target):
+            self.pred = pred.detach()
+            return self.inner(pred, target)
+
+    lf = Loss()
+    loop = SearchLoop(net, lf)
+    fg = loop.reducer.fg
+    names = {id(p): k for k, p in net.named_parameters()}
+
+    def run(sel, chain=True, seed=5):
+        monkeypatch.setenv('MMNAS_CHAIN', '1' if chain else '0')
+        ops.manual_seed(seed)
+        loss = loop.weight_step(tuple(t[sel] for t in inp), tgt[sel], optimize=False, plan=flat)
+        torch.cuda.synchronize()
+        return lf.pred.clone(), float(loss.detach()), fg.flat.clone()
+
+    try:
+        full = torch.arange(B, device=DEV)
+        out, loss, g_all = run(full)
+        assert np.isfinite(loss) and torch.isfinite(out).all() and torch.isfinite(g_all).all()
+        gmax = float(g_all.abs().max())
+        assert gmax > 0
+        # the sample's operators (and the stem / head) have gradients; the candidates left out have none
+        active = {id(p) for p in loop.reducer._active}
+        n_act = n_off = 0
+        for i, p in enumerate(fg.params):
+            v = g_all[fg.offsets[i]:fg.offsets[i] + p.numel()]
+            if id(p) in active:
+                n_act += 1
+            elif 'candidate_ops' in names[id(p)]:
+                assert not bool(v.any()), names[id(p)]
+                n_off += 1
+        assert n_act > 100 and n_off > 100
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to(DEV)
+        out_p, loss_p, g_p = run(perm)
+        assert float((out_p - out[perm]).abs().max()) <= 2e-5 * float(out.abs().max())
+        assert abs(loss_p - loss) <= 1e-5 * abs(loss)
+        # (another summation order inside the weight-gradient products' split-K pieces and the stream-K hand-over)
+        assert float((g_p - g_all).abs().max()) <= 2e-3 * gmax
+        _, l_lo, g_lo = run(full[:B // 2])
+        _, l_hi, g_hi = run(full[B // 2:])
+        assert abs(l_lo + l_hi - loss) <= 1e-5 * abs(loss)
+        bad = []
+        for i, p in enumerate(fg.params):
+            sl = slice(fg.offsets[i], fg.offsets[i] + p.numel())
+            err = float((g_lo[sl] + g_hi[sl] - g_all[sl]).abs().max())
+            if err > 2e-3 * max(float(g_all[sl].abs().max()), 1e-3 * gmax):
+                bad.append((names[id(p)], err, float(g_all[sl].abs().max())))
+        assert not bad, bad[:6]
+        # chain == per-operator path at this size, dropout off and on (same seed -> same masks)
+        for p_drop in (0.0, 0.1):
+            c['cfg'].DROPOUT_R = p_drop
+            for m in net.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = p_drop
+                if hasattr(m, 'dropout_r'):
+                    m.dropout_r = p_drop
+            o_c, l_c, g_c = run(full, chain=True, seed=11)
+            o_o, l_o, g_o = run(full, chain=False, seed=11)
+            if p_drop:
+                assert abs(l_c - loss) > 1e-4 * abs(loss)          # dropout really on
+            assert float((o_c - o_o).abs().max()) <= 1e-5 * float(o_o.abs().max()), p_drop
+            assert abs(l_c - l_o) <= 1e-5 * abs(l_o)
+            assert float((g_c - g_o).abs().max()) <= 2e-3 * float(g_o.abs().max()), p_drop
+    finally:
+        fg.disable_sinks()
 
 
 def test_supernet_arch_step_full_size():
