@@ -103,7 +103,10 @@ typedef struct mmnas_gemm_desc {
   int N, K;
   int lda, ldb, ldc, ldres, ldgate;
   int relu, split_k;
-  int accumulate, reserved;
+  int accumulate;
+  int b_planes;           /* != 0: B[i] of every group points at the pre-split bf16 planes of the weight matrix
+                             (mmnas_split_planes: [3][N][ldb] bf16) instead of the fp32 matrix; the planes go global -> LDS
+                             by LDS-DMA.  Layout NT with N % 64 == 0 and ldb % 8 == 0 only; same result bit for bit. */
   float alpha, gate_scale;
   float drop_p;           /* 0 = no dropout */
   uint32_t drop_site;
@@ -112,6 +115,11 @@ typedef struct mmnas_gemm_desc {
 } mmnas_gemm_desc;
 
 int mmnas_gemm(const mmnas_gemm_desc* d, void* stream);
+
+/* A weight matrix (nn.Linear.weight, modules.py:18,172-175) as three bf16 planes, planes[c * n + i] = part c of w[i]
+ * with w[i] = part0 + part1 + part2 exactly -- the split mmnas_gemm otherwise performs on every K-tile it stages; done
+ * once per optimizer step instead.  n % 8 == 0; `planes` holds 3 n bf16 (6 n bytes), 16-byte aligned. */
+int mmnas_split_planes(const float* w, void* planes, size_t n, void* stream);
 
 /* The two backward products of one linear layer -- data gradient dx = dy W (layout NN) and weight gradient
  * dW += dy^T x (layout TN, accumulate) -- which autograd issues as two independent mm calls

@@ -28,7 +28,7 @@ GEMM_MAX_GROUPS = 9
 class GemmDesc(C.Structure):
     _fields_ = [('layout', C.c_int), ('ngroups', C.c_int), ('nseg', C.c_int), ('N', C.c_int), ('K', C.c_int),
                 ('lda', C.c_int), ('ldb', C.c_int), ('ldc', C.c_int), ('ldres', C.c_int), ('ldgate', C.c_int),
-                ('relu', C.c_int), ('split_k', C.c_int), ('accumulate', C.c_int), ('reserved', C.c_int), ('alpha', C.c_float), ('gate_scale', C.c_float),
+                ('relu', C.c_int), ('split_k', C.c_int), ('accumulate', C.c_int), ('b_planes', C.c_int), ('alpha', C.c_float), ('gate_scale', C.c_float),
                 ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64),
                 ('g', GemmGroup * GEMM_MAX_GROUPS)]
 
@@ -113,6 +113,7 @@ SYMBOLS = {
     'mmnas_last_error': (C.c_char_p, []),
     'mmnas_dropout_mask': (_i, [_fp, _sz, _f, _u64, _u32, _fp]),
     'mmnas_gemm': (_i, [C.POINTER(GemmDesc), _fp]),
+    'mmnas_split_planes': (_i, [_fp, _fp, _sz, _fp]),
     'mmnas_gemm_pair': (_i, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), _fp]),
     'mmnas_gemm_reload_tuning': (_i, []),
     'mmnas_lstm_supported': (_i, [_i, _i]),

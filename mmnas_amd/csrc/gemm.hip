@@ -283,12 +283,22 @@ struct GemmShape {
 // PF: K-tiles of operand loads kept in flight ahead of the MFMA block (1: the tile after the current one; 2: two tiles,
 // a second register stage -- the products of the d = 256 supernet have 8 K-tiles and 1-2 resident workgroups per CU, so
 // with one tile in flight every iteration waits out a full L2 / Infinity-Cache round trip, ~2x its 0.43 us of MFMA).
-template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1>
+// BDMA (NT, 64^2 tiles, NS = 3, PF = 1 only): the B operand -- a weight matrix -- arrives as three PRE-SPLIT bf16 planes
+// (mmnas_split_planes: [3][N][ldb] bf16, plane c = part c of every element) and goes global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR stage, no conversion VALU, no ds_write).  An LDS-DMA instruction writes 1 KiB
+// lane-linearly, so the B image has no row pad: row r = 3 runs of 64 B (192 B), the 16-B chunk j of a run stored at
+// position j ^ ((r >> 2) & 3) -- the swizzle is applied on the per-lane SOURCE address and again on the fragment read.
+// Bank check of the fragment reads (ds_read_b128, 64 banks, lane groups of 16 rows {0-3,12-15,20-27}, ...): the row base
+// 48 r mod 64 takes the four values 0/48/32/16 by r & 3, rows r, r+4, r+8, r+12 of one residue take the four chunk
+// positions by (r >> 2) & 3 -- 16 rows x 4 words cover the 64 banks once: conflict-free.
+template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1, bool BDMA = false>
 __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const int nwg, const int koff,
                                           float* __restrict__ As, float* __restrict__ Bs, float* __restrict__ As1,
                                           float* __restrict__ Bs1, int& s_old) {
   static_assert(PF == 1 || (PF == 2 && FAST && (NS == 0 || NS == 3)), "the two-stage prefetch exists for the buffer-load path (fp32 and bf16x6)");
   static_assert(NS == 0 || (FAST && BK == 32), "the bf16-split path exists for the buffer-load path only");
+  static_assert(!BDMA || (NS == 3 && AKC && BKC && FAST && PF == 1 && BM == 64 && BN == 64 && EPI == 0), "LDS-DMA weight planes: NT 64^2 bf16x6 only");
+  constexpr int RSWB = 48;   // BDMA: words per row of the B image (3 runs of 16 words, no pad)
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   // split rows: NS parts of 32 bf16 (64 B) + 16 B pad -> 144 / 208 B, an odd number of 16-B words (conflict-free b128)
   constexpr int RSW = GemmShape<BM, BN, NS>::RSW;
@@ -427,6 +437,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     // FAST path: per-thread byte offsets of its loads inside the operand (k = 0), ~0u when the row is
     // outside the matrix (the buffer range check then returns zeros)
     unsigned offa[NA], offb[NB];
+    size_t bdma_off[3] = {0, 0, 0};   // BDMA: byte offset of this lane's chunk of piece i inside the plane block (k = 0)
     unsigned stepa = 0, stepb = 0;  // bytes per K-tile
     unsigned bytesa = 0, bytesb = 0;
     if (FAST) {
@@ -449,7 +460,9 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int f = tid + 256 * i;
-        if (BKC) {
+        if (BDMA) {
+          offb[i] = 0;
+        } else if (BKC) {
           const int row = NS ? kc_row(f) : f / KQ, kq = f % KQ, gr = n0 + row;
           offb[i] = gr < h.N ? (unsigned)(gr * h.ldb + 4 * kq) * 4u : ~0u;
         } else if (NS) {
@@ -462,6 +475,14 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
           offb[i] = gr < h.N ? (unsigned)(k * h.ldb + gr) * 4u : ~0u;
         }
       }
+      if (BDMA) {   // piece p = 3 wave + i of the 12 KiB image: this lane's 16 bytes sit at byte p * 1024 + 16 lane
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int o = (wave * 3 + i) * 1024 + lane * 16;
+          const int r = o / 192, w = o - r * 192, c = w >> 6, j = ((w & 63) >> 4) ^ ((r >> 2) & 3);
+          bdma_off[i] = ((size_t)c * (size_t)h.N * (size_t)h.ldb + (size_t)(n0 + r) * (size_t)h.ldb + 8 * j) * 2u;
+        }
+      }
       stepa = AKC ? BK * 4u : (unsigned)h.lda * BK * 4u;
       stepb = BKC ? BK * 4u : (unsigned)h.ldb * BK * 4u;
       bytesa = (unsigned)(AKC ? Mg : h.K) * (unsigned)h.lda * 4u;
@@ -472,7 +493,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     // range, the buffer bounds check answers with zeros and no memory request is made -- a branch-free "no load"
     int seg_c = 0, kt_c = 0;   // segment / K-tile of the next unit gload_to is asked for
     if (q0 != 0) { seg_c = q0 / h.ntk; kt_c = q0 - seg_c * h.ntk; }
-    auto gload_to = [&](int q, bool live, const int st) __attribute__((always_inline)) {
+    auto gload_to = [&](int q, bool live, const int st, const int dbuf = 0) __attribute__((always_inline)) {
       float4* const ra = rA[st];
       float4* const rb = rB[st];
       // (the calls of a tile ask for consecutive units q0, q0 + 1, ...: segment and K-tile are carried along instead of
@@ -487,6 +508,17 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         const unsigned ka = (unsigned)kt * stepa, kb = (unsigned)kt * stepb;
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = buf_load4(ra_src, (offa[i] == ~0u || !live) ? ~0u : offa[i] + ka);
+        if (BDMA) {
+          // the K-tile's 64 bytes of every run: + 64 kt bytes on the source; the LDS destination is wave-uniform
+          const char* bsrc = reinterpret_cast<const char*>(Bp) + (size_t)kt * 64u;
+          float* const bd = dbuf ? Bs1 : Bs;
+          const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + bdma_off[i]),
+                                             (__attribute__((address_space(3))) void*)(bd + (wv * 3 + i) * 256), 16, 0, 0);
+          return;
+        }
 #pragma unroll
         for (int i = 0; i < NB; ++i) rb[i] = buf_load4(rb_src, (offb[i] == ~0u || !live) ? ~0u : offb[i] + kb);
         return;
@@ -559,7 +591,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         rb[i] = v4;
       }
     };
-    auto gload = [&](int q) __attribute__((always_inline)) { gload_to(q, true, 0); };
+    auto gload = [&](int q, int dbuf = 0) __attribute__((always_inline)) { gload_to(q, true, 0, dbuf); };
 
     auto lstore_from = [&](int buf, const int st) __attribute__((always_inline)) {
       const float4* const ra = rA[st];
@@ -576,7 +608,9 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
 #pragma unroll
           for (int j = 0; j < NA / 2; ++j) split_store_t<BM, NS ? NS : 2>(ua, ra[2 * j], ra[2 * j + 1], tid, j);
         }
-        if (BKC) {
+        if (BDMA) {
+          // (the B image was written by the LDS-DMA loads of gload_to)
+        } else if (BKC) {
 #pragma unroll
           for (int i = 0; i < NB; ++i) split_store_kc<BN, true, NS ? NS : 2>(ub, rb[i], tid + 256 * i);
         } else {
@@ -629,7 +663,8 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
           for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int c = 0; c < NS; ++c)
-              bf[j][c] = *reinterpret_cast<const bf16x8*>(b + (wn * WN + j * 32 + l31) * RSW + c * 16 + swz(s * 8 + hh * 4, wn * WN + j * 32 + l31));
+              bf[j][c] = BDMA ? *reinterpret_cast<const bf16x8*>(b + (wn * WN + j * 32 + l31) * RSWB + c * 16 + 4 * ((s * 2 + hh) ^ (((wn * WN + j * 32 + l31) >> 2) & 3)))
+                              : *reinterpret_cast<const bf16x8*>(b + (wn * WN + j * 32 + l31) * RSW + c * 16 + swz(s * 8 + hh * 4, wn * WN + j * 32 + l31));
           // smallest cross terms first; part c of A with part e of B is kept while c + e < NS
 #pragma unroll
           for (int o = NS - 1; o >= 0; --o)
@@ -727,12 +762,12 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
 #endif
       MMNAS_LIFE(3);   // K loop
     } else {
-      gload(q0);
+      gload(q0, 0);
       lstore(0);
       __syncthreads();
       for (int t = 0; t < nq; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nq) gload(q0 + t + 1);  // in flight during the MFMA block
+        if (t + 1 < nq) gload(q0 + t + 1, buf ^ 1);  // in flight during the MFMA block (BDMA: B lands in the other buffer)
         mfma_block(buf);
         if (t + 1 < nq) lstore(buf ^ 1);
         __syncthreads();
@@ -930,12 +965,12 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
   }
 }
 
-template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1>
+template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1, bool BDMA = false>
 __global__ void __launch_bounds__(256, NS ? (BM == 128 ? (BN == 64 ? 2 : 1) : MMNAS_OCC_NS) : (BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64)) gemm_kernel(const GemmK p) {
   __shared__ __attribute__((aligned(16))) float As[GemmShape<BM, BN, NS>::A_SZ], As1[GemmShape<BM, BN, NS>::A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[GemmShape<BM, BN, NS>::B_SZ], Bs1[GemmShape<BM, BN, NS>::B_SZ];
   __shared__ int s_old;
-  gemm_body<BM, BN, AKC, BKC, FAST, NS, EPI, PF>(p, blockIdx.x, gridDim.x, 0, As, Bs, As1, Bs1, s_old);
+  gemm_body<BM, BN, AKC, BKC, FAST, NS, EPI, PF, BDMA>(p, blockIdx.x, gridDim.x, 0, As, Bs, As1, Bs1, s_old);
 }
 
 // Two independent problems in ONE launch: the data gradient (NN) and the weight gradient (TN) of a linear layer.
@@ -1105,6 +1140,7 @@ struct GemmPlan {
   GemmK k;
   int nwg, layout;
   bool big, fast, wide;   // big: 128^2 tiles; wide: 128 x 64 tiles (BM x BN); neither: 64^2
+  bool bdma;              // B = pre-split bf16 planes, loaded by LDS-DMA (NT, 64^2, bf16x6)
   double flops, bytes;
   char tag[96];
 };
@@ -1287,6 +1323,16 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
   out.flops = 2.0 * sumM * d->N * d->K * d->nseg;
   out.bytes = 4.0 * (sumM * d->K * d->nseg + (double)d->N * d->K * d->nseg * d->ngroups + sumM * d->N);
   out.nwg = nwg; out.layout = d->layout; out.big = big; out.fast = fast; out.wide = wide;
+  out.bdma = d->b_planes != 0;
+  if (out.bdma) {
+    // B[i] of every group = mmnas_split_planes output ([3][N][ldb] bf16).  One kernel shape exists for it; anything else
+    // would read the planes as fp32: refuse.
+    MMNAS_REQUIRE(d->layout == MMNAS_GEMM_NT && fast && !big && !wide && !accumulate && g_tune.split == 3 && d->N % 64 == 0 &&
+                  (d->ldb % 8) == 0, MMNAS_E_ARG,
+                  "mmnas_gemm: b_planes needs layout NT, 64^2 tiles on the buffer-load path, N %% 64 == 0, ldb %% 8 == 0, MMNAS_GEMM_SPLIT=6 "
+                  "(N=%d K=%d ldb=%d)", d->N, d->K, d->ldb);
+    if (out.tag[0]) strncat(out.tag, " Bdma", sizeof(out.tag) - strlen(out.tag) - 1);
+  }
   return MMNAS_OK;
 }
 
@@ -1294,6 +1340,10 @@ static int launch_plan(GemmPlan& pl, hipStream_t st) {
   GemmK& k = pl.k;
   ProfScope ps(MMNAS_K_GEMM, pl.flops, pl.bytes, st, pl.tag);
   const int ns = pl.fast ? g_tune.split : 0;   // (odd shapes on the guarded-load path stay on the fp32 MFMA)
+  if (pl.bdma) {
+    MMNAS_LAUNCH((gemm_kernel<64, 64, true, true, true, 3, 0, 1, true>), dim3(pl.nwg), dim3(256), 0, st, k);
+    return check_launch("gemm");
+  }
   if (pl.big) {
     if (ns == 2) return launch<128, 128, true, 2>(k, pl.layout, pl.nwg, st);
     if (ns == 3) return launch<128, 128, true, 3>(k, pl.layout, pl.nwg, st);
@@ -1360,6 +1410,38 @@ int gemm_pair_aux(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, co
 
 extern "C" int mmnas_gemm_pair(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, void* stream) {
   return gemm_pair_aux(dgrad, wgrad, nullptr, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight matrices as three bf16 planes (h, m, l of split_pair: x = h + m + l exactly): what gemm_kernel<..., BDMA> streams
+// into LDS by LDS-DMA.  Weights change once per optimizer step; the split is the same instruction sequence as the
+// in-kernel one, so a product on the planes equals the product on the fp32 matrix bit for bit.
+// ------------------------------------------------------------------------------------------
+namespace mmnas {
+__global__ void __launch_bounds__(256) split_planes_kernel(const float4* __restrict__ w, uint2* __restrict__ p0, uint2* __restrict__ p1,
+                                                           uint2* __restrict__ p2, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = w[i];
+    unsigned a0, a1, a2, b0, b1, b2;
+    split_pair<3>(v.x, v.y, a0, a1, a2);
+    split_pair<3>(v.z, v.w, b0, b1, b2);
+    p0[i] = make_uint2(a0, b0);
+    p1[i] = make_uint2(a1, b1);
+    p2[i] = make_uint2(a2, b2);
+  }
+}
+}  // namespace mmnas
+
+extern "C" int mmnas_split_planes(const float* w, void* planes, size_t n, void* stream) {
+  MMNAS_REQUIRE(w && planes, MMNAS_E_ARG, "split_planes: null pointer");
+  MMNAS_REQUIRE(n > 0 && n % 8 == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)planes & 15) == 0, MMNAS_E_SHAPE,
+                "split_planes: n = %zu must be a multiple of 8 and both buffers 16-byte aligned", n);
+  const size_t n4 = n / 4;
+  unsigned short* pl = (unsigned short*)planes;
+  const int blocks = (int)std::min<size_t>((n4 + 255) / 256, 2048);
+  MMNAS_LAUNCH(split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)w, (uint2*)pl, (uint2*)(pl + n),
+               (uint2*)(pl + 2 * n), n4);
+  return check_launch("split_planes");
 }
 
 // ------------------------------------------------------------------------------------------

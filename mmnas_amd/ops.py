@@ -375,14 +375,25 @@ def mlp_op(x, weights, biases, ln_a, ln_b, *, norm, residual, drop_p, training, 
 # ------------------------------------------------------------------------------------------
 # building blocks for the registry-only operators (GLU, convs, activations) and for LayerNorm
 # ------------------------------------------------------------------------------------------
+def split_planes(w, out=None):
+    """mmnas_split_planes: the three bf16 planes [3, *w.shape] of an fp32 weight matrix (w = p0 + p1 + p2 exactly)."""
+    w = _f32c(w)
+    if out is None:
+        out = torch.empty((3,) + tuple(w.shape), dtype=torch.bfloat16, device=w.device)
+    L.check(L.lib().mmnas_split_planes(L.fptr(w), L.ptr(out), w.numel(), L.stream()))
+    return out
+
+
 def gemm_desc(layout, groups, N, K, lda, ldb, ldc, nseg=1, relu=False, split_k=1, alpha=1.0, drop=None,
-              gate_scale=1.0, ldres=0, ldgate=0, accumulate=False):
-    """mmnas_gemm_desc from Python values.  groups: list of dict(M, A=[..], B=[..], C, bias, residual, gate)."""
+              gate_scale=1.0, ldres=0, ldgate=0, accumulate=False, b_planes=False):
+    """mmnas_gemm_desc from Python values.  groups: list of dict(M, A=[..], B=[..], C, bias, residual, gate).
+    b_planes: every B is the split_planes() tensor of the weight matrix (layout NT)."""
     g = L.GemmDesc()
     g.layout, g.ngroups, g.nseg, g.N, g.K = layout, len(groups), nseg, N, K
     g.lda, g.ldb, g.ldc, g.ldres, g.ldgate = lda, ldb, ldc, ldres, ldgate
     g.relu, g.split_k, g.alpha, g.gate_scale = int(relu), split_k, alpha, gate_scale
     g.accumulate = int(accumulate)
+    g.b_planes = int(b_planes)
     if drop is not None:
         g.drop_p, g.drop_seed, g.drop_site = drop
     for i, grp in enumerate(groups):
@@ -390,7 +401,7 @@ def gemm_desc(layout, groups, N, K, lda, ldb, ldc, nseg=1, relu=False, split_k=1
         gg.M = grp['M']
         for s in range(nseg):
             gg.A[s] = L.fptr(grp['A'][s])
-            gg.B[s] = L.fptr(grp['B'][s])
+            gg.B[s] = L.ptr(grp['B'][s]) if b_planes else L.fptr(grp['B'][s])
         gg.C = L.fptr(grp['C'])
         gg.bias = L.fptr(grp.get('bias'))
         gg.residual = L.fptr(grp.get('residual'))

@@ -1022,3 +1022,36 @@ def test_gemm_streamed_pieces_across_k_segments(layout, wgs, gemm_tuning):
         ops.gemm(L.GEMM_NN, [dict(M=M, A=As, B=Bs, C=C)], N, K, K, N, N, nseg=3)
         ref = sum(a.double() @ b.double() for a, b in zip(As, Bs))
     assert rel_err(C.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('Ms,N,K', [([200], 64, 32), ([6400], 256, 256), ([896, 77, 6400], 128, 512), ([130], 512, 2048)])
+def test_gemm_weight_planes_by_lds_dma_equal_the_in_kernel_split(Ms, N, K):
+    """mmnas_gemm_desc.b_planes: the weight operand as the three bf16 planes of mmnas_split_planes, streamed global -> LDS by
+    LDS-DMA -- the same split, the same MFMA order: the product on the planes equals the product on the fp32 matrix bit
+    for bit (ragged row counts, several groups, bias + ReLU epilogue), and the planes sum back to the matrix exactly."""
+    import ctypes as C
+    from mmnas_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(7)
+    As = [torch.randn(M, K, generator=g).cuda() for M in Ms]
+    Ws = [(torch.randn(N, K, generator=g) * 0.1).cuda() for _ in Ms]
+    Ps = [ops.split_planes(W) for W in Ws]
+    for W, P in zip(Ws, Ps):
+        assert P.dtype == torch.bfloat16 and tuple(P.shape) == (3, N, K)
+        assert torch.equal(P[0].double() + P[1].double() + P[2].double(), W.double())
+    bias = torch.randn(N, generator=g).cuda()
+    outs = []
+    for planes in (False, True):
+        Cs = [torch.full((M, N), float('nan'), device='cuda') for M in Ms]
+        d = ops.gemm_desc(L.GEMM_NT, [dict(M=M, A=[a], B=[(p if planes else w)], C=c, bias=bias)
+                                      for M, a, w, p, c in zip(Ms, As, Ws, Ps, Cs)], N, K, K, K, N, relu=True, b_planes=planes)
+        L.check(L.lib().mmnas_gemm(C.byref(d), L.stream()))
+        torch.cuda.synchronize()
+        outs.append(Cs)
+    for c0, c1, a, w in zip(outs[0], outs[1], As, Ws):
+        assert torch.equal(c0, c1)
+        ref = torch.relu(a.double() @ w.double().t() + bias.double())
+        assert float((c1.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-6
+    # shapes the LDS-DMA kernel does not cover are refused, not misread
+    with pytest.raises(L.MMNasHipError):
+        d = ops.gemm_desc(L.GEMM_NN, [dict(M=Ms[0], A=[As[0]], B=[Ps[0]], C=outs[0][0])], N, K, K, N, N, b_planes=True)
+        L.check(L.lib().mmnas_gemm(C.byref(d), L.stream()))
