@@ -67,6 +67,9 @@ int mmnas_dropout_mask(float* out, size_t n, float p, uint64_t seed, uint32_t si
  * Replaces the mm/addmm/bmm calls behind nn.Linear in modules.py:18,38,172-175 and their
  * autograd backward.  For group g (independent problems launched together):
  *     C_g[M_g,N] = epilogue( alpha * sum_{s<nseg} op(A_{g,s}) * op(B_{g,s}) )
+ *   (Leading dimensions are plain row strides: a row stride SMALLER than the row length -- overlapping rows, lda = d with
+ *   K = k d -- is how a k-tap Conv1d over the sequence (modules.py:472,480) is one product on the zero-padded input with no
+ *   im2col buffer; reads past the M * lda extent of such an operand return zero.)
  *   layout MMNAS_GEMM_NT : A[M,K] (lda), B[N,K] (ldb)        y = x W^T        (forward)
  *   layout MMNAS_GEMM_NN : A[M,K] (lda), B[K,N] (ldb)        dx = dy W        (data gradient)
  *   layout MMNAS_GEMM_TN : A[K,M] (lda), B[K,N] (ldb)        dW = dy^T x      (weight gradient)
@@ -554,6 +557,10 @@ int mmnas_bce_logits_bwd(const float* logits, const float* target, const float* 
  *            bwd overwrites dx and ACCUMULATES dw [d,k], db [d].
  * ------------------------------------------------------------------------------------------ */
 int mmnas_im2col_seq(const float* x, float* col, int B, int S, int d, int k, void* stream);
+/* The zero-padded row grid of the window-buffer-free dense convolution (modules.py:472,480; see mmnas_gemm on overlapping
+ * rows): xp[rows_total, d]; row b * Sp + j holds x[b, j - front, :] for 0 <= j - front < S, zero otherwise (also every row
+ * from B * Sp on: slack the overlapping rows of the last sequence read).  d % 4 == 0. */
+int mmnas_pad_seq(const float* x, float* xp, int B, int S, int d, int front, int Sp, long rows_total, void* stream);
 int mmnas_col2im_seq(const float* dcol, float* dx, int B, int S, int d, int k, void* stream);
 int mmnas_dwconv_seq_fwd(const float* x, const float* w, const float* bias, float* y,
                          int B, int S, int d, int k, void* stream);

@@ -173,6 +173,7 @@ SYMBOLS = {
     'mmnas_bce_logits_sum_fwd': (_i, [_fp, _fp, _fp, _sz, _fp]),
     'mmnas_bce_logits_bwd': (_i, [_fp, _fp, _fp, _fp, _sz, _fp]),
     'mmnas_im2col_seq': (_i, [_fp, _fp, _i, _i, _i, _i, _fp]),
+    'mmnas_pad_seq': (_i, [_fp, _fp, _i, _i, _i, _i, _i, C.c_long, _fp]),
     'mmnas_col2im_seq': (_i, [_fp, _fp, _i, _i, _i, _i, _fp]),
     'mmnas_dwconv_seq_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),
     'mmnas_dwconv_seq_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),

@@ -1,9 +1,13 @@
 // 1-D convolutions over the sequence axis of x[B,S,d] (channels last), zero "same" padding:
 // SepConv = depthwise k-tap stencil + pointwise GEMM (modules.py:431-462), StdConv = dense k-tap
-// Conv1d (modules.py:465-491).  The dense conv runs on the MFMA GEMM through an explicit im2col
-// (row m=(b,s) -> [k*d] window), its gradient through the transposed gather (col2im); the depthwise
-// stencil is a streaming HBM-bound kernel.  k in {3,5,7,11}; these operators are registry-only
-// (in no shipped search space or arch/*.json), so they are built for parity, not for the roofline.
+// Conv1d (modules.py:465-491).  The dense conv runs on the MFMA GEMM with NO window buffer: on the zero-padded
+// input (pad_seq below: every sequence followed / surrounded by its padding rows) the im2col matrix
+// col[m, t d + c] = xp[m + t, c] is just xp read with a row stride of d instead of k d -- overlapping rows -- which
+// mmnas_gemm takes as it is (lda = d, K = k d): forward NT, data gradient NN on the padded output gradient with the
+// taps reversed, weight gradient ONE TN product (ops.ConvSeqFn).  The explicit im2col / col2im kernels stay for
+// shapes outside the buffer-load path and as the A/B baseline (tools/conv_bench.py); the depthwise stencil is a
+// streaming HBM-bound kernel.  k in {3,5,7,11}; these operators are registry-only (in no shipped search space or
+// arch/*.json).
 #include "common.h"
 
 namespace mmnas {
@@ -39,6 +43,22 @@ __global__ void col2im_kernel(const float* __restrict__ dcol, float* __restrict_
       }
     }
     *reinterpret_cast<float4*>(dx + m * d + 4 * c4) = a;
+  }
+}
+
+// xp[r, :] for r < rows_total: sequence b = r / Sp, position j = r % Sp; x[b, j - front] when 0 <= j - front < S and
+// r < B Sp, zero otherwise (the padding rows of every sequence and the slack rows behind the last one)
+__global__ void pad_seq_kernel(const float4* __restrict__ x, float4* __restrict__ xp, int B, int S, int d4, int front, int Sp,
+                               long rows_total) {
+  const size_t n = (size_t)rows_total * d4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const long r = (long)(i / d4);
+    const int c4 = (int)(i - (size_t)r * d4);
+    const long b = r / Sp;
+    const int s = (int)(r - b * Sp) - front;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b < B && s >= 0 && s < S) v = x[((size_t)b * S + s) * d4 + c4];
+    xp[i] = v;
   }
 }
 
@@ -128,6 +148,15 @@ extern "C" int mmnas_im2col_seq(const float* x, float* col, int B, int S, int d,
   MMNAS_LAUNCH(im2col_kernel, dim3(nblocks((size_t)B * S * k * d / 4)), dim3(256), 0, (hipStream_t)stream, x, col,
                      B, S, d, k);
   return check_launch("im2col_seq");
+}
+
+extern "C" int mmnas_pad_seq(const float* x, float* xp, int B, int S, int d, int front, int Sp, long rows_total, void* stream) {
+  MMNAS_REQUIRE(x && xp, MMNAS_E_ARG, "pad_seq: null pointer");
+  MMNAS_REQUIRE(B > 0 && S > 0 && d > 0 && d % 4 == 0 && front >= 0 && Sp >= S + front && rows_total >= (long)B * Sp, MMNAS_E_SHAPE,
+                "pad_seq: B=%d S=%d d=%d front=%d Sp=%d rows=%ld", B, S, d, front, Sp, rows_total);
+  MMNAS_LAUNCH(pad_seq_kernel, dim3(nblocks((size_t)rows_total * d / 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+               (float4*)xp, B, S, d / 4, front, Sp, rows_total);
+  return check_launch("pad_seq");
 }
 
 extern "C" int mmnas_col2im_seq(const float* dcol, float* dx, int B, int S, int d, int k, void* stream) {

@@ -4,6 +4,7 @@ buffer the kernels touch is allocated here through torch's caching allocator and
 raw device pointer together with the current HIP stream.
 """
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -399,7 +400,7 @@ def gemm_desc(layout, groups, N, K, lda, ldb, ldc, nseg=1, relu=False, split_k=1
     for i, grp in enumerate(groups):
         gg = g.g[i]
         gg.M = grp['M']
-        for s in range(nseg):
+        for s in range(min(nseg, len(grp['A']))):   # (strided segments: one pointer pair, the descriptor's strides give the rest)
             gg.A[s] = L.fptr(grp['A'][s])
             gg.B[s] = L.ptr(grp['B'][s]) if b_planes else L.fptr(grp['B'][s])
         gg.C = L.fptr(grp['C'])
@@ -712,12 +713,121 @@ class Im2ColFn(torch.autograd.Function):
         return dx, None
 
 
-def conv_seq(x, weight, bias):
-    """Dense Conv1d over the sequence axis: weight [d_out, d_in, k] (conv.weight, modules.py:472)."""
+def _conv_seq_im2col(x, weight, bias):
+    """The explicit-window form: col[B,S,k*d] (k x the input's bytes) -> one product.  Kept for shapes outside the
+    strided-segment kernels (d % 32 != 0, MMNAS_GEMM_SPLIT=3) and as the A/B baseline of tools/conv_bench.py."""
     co, ci, k = weight.shape
     col = Im2ColFn.apply(x, k)
     wp = weight.permute(0, 2, 1).reshape(co, k * ci)  # [co, t*ci + c] to match the window layout
     return linear(col, wp, bias)
+
+
+_conv_w_cache = {}
+
+
+def _conv_weights(weight):
+    """conv.weight [d_out, d_in, k] in the two arrangements the products read, re-made only when the parameter has been
+    written (its version counter moves with every in-place optimizer update):
+      fwd [d_out, k * d_in]  column t * d_in + c = W[:, c, t]              (B of the forward NT product)
+      rev [k * d_out, d_in]  row j * d_out + o = W[o, :, k - 1 - j]       (B of the data-gradient NN product)"""
+    key = id(weight)
+    hit = _conv_w_cache.get(key)
+    if hit is not None and hit[0] is weight and hit[1] == weight._version and hit[2].device == weight.device:
+        return hit[2], hit[3]
+    co, ci, k = weight.shape
+    w = weight.detach()
+    fwd = w.permute(0, 2, 1).reshape(co, k * ci).contiguous()
+    rev = w.flip(2).permute(2, 0, 1).reshape(k * co, ci).contiguous()
+    if len(_conv_w_cache) > 256:
+        _conv_w_cache.clear()
+    _conv_w_cache[key] = (weight, weight._version, fwd, rev)
+    return fwd, rev
+
+
+def _pad_seq(x, front, Sp, slack):
+    """[B, S, d] -> the zero-padded row grid [B * Sp + slack, d] (mmnas_pad_seq), rows rounded up to a multiple of 32."""
+    B, S, d = x.shape
+    rows = (B * Sp + slack + 31) // 32 * 32
+    xp = torch.empty(rows, d, dtype=torch.float32, device=x.device)
+    L.check(L.lib().mmnas_pad_seq(L.fptr(x), L.fptr(xp), B, S, d, front, Sp, rows, L.stream()))
+    return xp
+
+
+class ConvSeqFn(torch.autograd.Function):
+    """Dense k-tap Conv1d over the sequence axis (StdConv, modules.py:472,480-481) WITHOUT a window buffer.  On the
+    zero-padded row grid xp[b * Sp + j] = x[b, j - pad] (Sp = S + 2 pad) the im2col matrix col[m, t d + c] = xp[m + t, c]
+    is xp itself read with row stride d: overlapping rows, which mmnas_gemm takes as they are (lda = d, K = k d).
+      forward        y''[m]  = col(xp)[m] Wfwd^T            NT, M = B Sp rows; y[b, s] = y''[b Sp + s]
+      data gradient  dx''[m] = col(dyp)[m] Wrev             NN on the padded output gradient, taps reversed
+      weight grad    dW''    = dye^T col(xp)                ONE TN product; dye = dy with 2 pad zero rows behind every sequence
+    Rows of y'' / dx'' in a sequence's padding are never read; a saved tensor is the padded input (1.06x the input at
+    S = 100, k = 7) instead of the k-fold window buffer."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _f32c(x)
+        B, S, d = x.shape
+        co, ci, k = weight.shape
+        pad = k // 2
+        Sp = S + 2 * pad
+        wf, wr = _conv_weights(weight)
+        xp = _pad_seq(x, pad, Sp, k)
+        M = B * Sp
+        yp = torch.empty(M, co, dtype=torch.float32, device=x.device)
+        gemm(L.GEMM_NT, [dict(M=M, A=[xp], B=[wf], C=yp, bias=(_f32c(bias) if bias is not None else None))], co, k * ci, ci, k * ci, co)
+        ctx.save_for_backward(xp, wr)
+        ctx.dims = (B, S, d, co, ci, k, bias is not None)
+        return yp.view(B, Sp, co)[:, :S].contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, wr = ctx.saved_tensors
+        B, S, d, co, ci, k, has_bias = ctx.dims
+        pad = k // 2
+        Sp = S + 2 * pad
+        M = B * Sp
+        dy = _f32c(dy)
+        dev = dy.device
+        dx = dw = None
+        dgrad = wgrad = None
+        if ctx.needs_input_grad[0]:
+            # dx[b,s] = sum_t dy[b, s - t + pad] W_t = sum_j dyp[b Sp + s + j] W_{k-1-j}
+            dyp = _pad_seq(dy, pad, Sp, k)
+            dxp = torch.empty(M, ci, dtype=torch.float32, device=dev)
+            dgrad = gemm_desc(L.GEMM_NN, [dict(M=M, A=[dyp], B=[wr], C=dxp)], ci, k * co, co, ci, ci)
+        if ctx.needs_input_grad[1]:
+            # dW[o, c, t] = sum_{b,s} dy[b,s,o] xp[b Sp + s + t, c]: rows of dy at b Sp + s (padding behind the sequence)
+            dye = _pad_seq(dy, 0, Sp, 0)
+            Kr = dye.shape[0]                                   # (a multiple of 32; xp has at least as many rows)
+            dwf = torch.zeros(co, k * ci, dtype=torch.float32, device=dev)
+            wgrad = gemm_desc(L.GEMM_TN, [dict(M=co, A=[dye], B=[xp], C=dwf)], k * ci, Kr, co, ci, k * ci, accumulate=True)
+        if dgrad is not None and wgrad is not None:
+            gemm_pair(dgrad, wgrad)                             # one launch: the second product starts as the first drains
+        elif dgrad is not None or wgrad is not None:
+            L.check(L.lib().mmnas_gemm(C.byref(dgrad if dgrad is not None else wgrad), L.stream()))
+        if dgrad is not None:
+            dx = dxp.view(B, Sp, ci)[:, :S].contiguous()
+        if wgrad is not None:
+            dw = dwf.view(co, k, ci).permute(0, 2, 1)           # the parameter's own [d_out, d_in, k] layout
+        db = None
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(co, dtype=torch.float32, device=dev)
+            L.check(L.lib().mmnas_colsum(L.fptr(dy), L.fptr(db), B * S, co, co, L.stream()))
+        return dx, dw, db
+
+
+def conv_seq(x, weight, bias):
+    """Dense Conv1d over the sequence axis: weight [d_out, d_in, k] (conv.weight, modules.py:472)."""
+    co, ci, k = weight.shape
+    # (overlapping rows read past an operand's M * lda extent: only the buffer-load path answers that with zeros)
+    # (and the padded grid computes S + 2 pad rows per sequence: for the 14-token stream with wide kernels the window
+    #  buffer is the cheaper form -- profiles/r04_conv_microbench.txt)
+    direct = (x.is_cuda and ci % 32 == 0 and co % 32 == 0 and os.environ.get('MMNAS_CONV_IM2COL', '0') != '1'
+              and (x.shape[1] + 2 * (k // 2) <= 1.25 * x.shape[1] or os.environ.get('MMNAS_CONV_IM2COL') == '0')
+              and os.environ.get('MMNAS_GEMM_GENERIC') is None and 4.0 * x.shape[0] * (x.shape[1] + k) * max(ci, co) * k < 3.9e9)
+    if not direct:
+        return _conv_seq_im2col(x, weight, bias)
+    return ConvSeqFn.apply(x, weight, bias)
 
 
 class DwConvFn(torch.autograd.Function):

@@ -1055,3 +1055,51 @@ def test_gemm_weight_planes_by_lds_dma_equal_the_in_kernel_split(Ms, N, K):
     with pytest.raises(L.MMNasHipError):
         d = ops.gemm_desc(L.GEMM_NN, [dict(M=Ms[0], A=[As[0]], B=[Ps[0]], C=outs[0][0])], N, K, K, N, N, b_planes=True)
         L.check(L.lib().mmnas_gemm(C.byref(d), L.stream()))
+
+
+@pytest.mark.parametrize('B,S,d,k', [(3, 9, 64, 3), (2, 14, 128, 11), (5, 100, 64, 7), (4, 7, 96, 5)])
+def test_conv_seq_overlapping_rows_vs_conv1d_fp64(B, S, d, k, monkeypatch):
+    """StdConv's core (modules.py:472,480-481: nn.Conv1d over the sequence, zero 'same' padding) as ONE product on the
+    zero-padded input read with overlapping rows (lda = d, K = k d) -- no im2col buffer -- against torch's conv1d in fp64,
+    forward and all three gradients; and against the explicit-window form it replaces."""
+    from mmnas_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, S, d, generator=g)
+    w = torch.randn(d, d, k, generator=g) * 0.1
+    b = torch.randn(d, generator=g)
+    dy = torch.randn(B, S, d, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.conv1d(xr.transpose(1, 2), wr, br, padding=k // 2).transpose(1, 2)
+    yr.backward(dy.double())
+    outs = {}
+    for mode in ('direct', 'im2col'):
+        monkeypatch.setenv('MMNAS_CONV_IM2COL', '1' if mode == 'im2col' else '0')
+        xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+        calls = []
+        orig = ops.ConvSeqFn.apply
+        monkeypatch.setattr(ops.ConvSeqFn, 'apply', lambda *a: (calls.append(1), orig(*a))[1])
+        y = ops.conv_seq(xg, wg, bg)
+        monkeypatch.setattr(ops.ConvSeqFn, 'apply', orig)
+        assert len(calls) == (1 if mode == 'direct' else 0)
+        y.backward(dy.cuda())
+        torch.cuda.synchronize()
+        outs[mode] = (y.detach(), xg.grad, wg.grad, bg.grad)
+        for got, ref in zip(outs[mode], (yr, xr.grad, wr.grad, br.grad)):
+            assert got.shape == ref.shape
+            assert float((got.detach().double().cpu() - ref.detach()).abs().max()) <= 3e-6 * float(ref.abs().max()), mode
+    for a, c in zip(outs['direct'], outs['im2col']):
+        assert float((a - c).abs().max()) <= 3e-6 * float(c.abs().max())
+    # the re-arranged copies of the weight are re-made when (and only when) the parameter has been written
+    wg = w.cuda().requires_grad_(True)
+    f0, r0 = ops._conv_weights(wg)
+    assert ops._conv_weights(wg)[0] is f0
+    with torch.no_grad():
+        wg.mul_(2.0)
+    f1, r1 = ops._conv_weights(wg)
+    assert f1 is not f0 and torch.equal(f1.view(d, k, d), wg.detach().permute(0, 2, 1))
+    assert torch.equal(r1.view(k, d, d), wg.detach().flip(2).permute(2, 0, 1))
+    # mmnas_pad_seq: the padded row grid
+    xp = ops._pad_seq(x.cuda(), k // 2, S + 2 * (k // 2), k)
+    ref = torch.nn.functional.pad(x, (0, 0, k // 2, k // 2)).reshape(-1, d)
+    assert xp.shape[0] % 32 == 0 and xp.shape[0] >= ref.shape[0] + k
+    assert torch.equal(xp[:ref.shape[0]].cpu(), ref) and not bool(xp[ref.shape[0]:].any())

@@ -67,6 +67,24 @@ def test_registry_op_vs_reference_golden(name, nr):
     compare_golden(npz, tag, run_hip_op(case))
 
 
+@pytest.mark.parametrize('name', [n for n in O.ALL_OP_NAMES if n.startswith('std_conv')])
+@pytest.mark.parametrize('form', ['direct', 'im2col'])
+def test_std_conv_both_forms_vs_reference_golden(name, form, monkeypatch):
+    """StdConv (modules.py:465-491) against the reference goldens through BOTH forms of its product: the zero-padded
+    input read with overlapping rows (no window buffer; the default where the padding is cheap) and the explicit im2col
+    buffer (the goldens' 5-row sequences would otherwise only see the latter)."""
+    from mmnas_amd import ops
+    monkeypatch.setenv('MMNAS_CONV_IM2COL', '0' if form == 'direct' else '1')
+    calls = []
+    orig = ops.ConvSeqFn.apply
+    monkeypatch.setattr(ops.ConvSeqFn, 'apply', lambda *a: (calls.append(1), orig(*a))[1])
+    npz = load('ops.npz')
+    tag = '%s|11' % name
+    case = cases.op_case(name, True, True, int(npz[tag + '|seed']))
+    compare_golden(npz, tag, run_hip_op(case))
+    assert len(calls) == (1 if form == 'direct' else 0)
+
+
 def _shape_tags():
     npz = load('ops_shapes.npz')
     return sorted({k.rsplit('|', 1)[0] for k in npz.files if k.endswith('|seed')})
