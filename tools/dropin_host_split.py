@@ -1,0 +1,104 @@
+"""Where the host time of the UNCHANGED search loop goes (search_vqa.py:279-301 on the per-operator path, N = 1, no DDP
+wrapper): the script's own statements against what this library adds per step.  Wall clock per step with the queue
+drained between steps (the loop is host-bound: ~6 ms of GPU work under 20+ ms of host issue).
+
+    python tools/dropin_host_split.py > profiles/r04_host_dropin.txt
+
+Variants (each the median of 30 steps after 10 warm-up steps):
+  full        every statement of search_vqa.py:279-301
+  no_zero_sum without the three `loss += 0 * sum(p.sum() for p in ...)` lines (:285-288)
+  fwd_bwd     sample, unused_modules_off, forward, loss, backward, unused_modules_back -- no zero_grad, clip, Adam
+  forward     sample, unused_modules_off, forward, loss, unused_modules_back (no backward)
+  harness     the same arithmetic through mmnas_amd.harness.SearchLoop.weight_step (flat gradients, fused clip + Adam)
+"""
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+
+
+def main():
+    from mmnas.model.hygr_vqa import Net_Search
+    from mmnas.model.mixed import MixedOp
+    from mmnas.utils.optimizer import WarmupOptimizer
+    from mmnas_amd import ops
+    from mmnas_amd.harness import SearchLoop
+    from mmnas_amd.model import mixed
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(888)
+    ops.manual_seed(888)
+    mixed.seed_arch_sampler(888)
+    cfg = bench.make_cfg('search')
+    emb = torch.randn(bench.VOCAB, 300, generator=torch.Generator().manual_seed(1)).numpy()
+    init = {'token_size': bench.VOCAB, 'ans_size': bench.ANS, 'pretrained_emb': emb}
+    cpu_in, cpu_tg = bench.synth_batch(cfg, 64, bench.SX, bench.SY, bench.VOCAB, bench.ANS, 888)
+    inp, tgt = tuple(t.to(dev) for t in cpu_in), cpu_tg.to(dev)
+    net = Net_Search(cfg, init).to(dev).train()
+    opt = WarmupOptimizer(4e-4, torch.optim.Adam(net.net_parameters(), lr=0, betas=(0.9, 0.98), eps=1e-9), epoch_steps=1000, warmup=True)
+    loss_fn = torch.nn.BCEWithLogitsLoss(reduction='sum')
+
+    def step(zero_sum=True, backward=True, optimize=True):
+        MixedOp.MODE = None
+        net.reset_binary_gates()
+        net.unused_modules_off()
+        pred = net(inp)
+        loss = loss_fn(pred, tgt)
+        if zero_sum:
+            loss += 0 * sum(p.sum() for p in net.alpha_prob_parameters())
+            loss += 0 * sum(p.sum() for p in net.alpha_gate_parameters())
+            loss += 0 * sum(p.sum() for p in net.net_parameters())
+        if optimize:
+            net.zero_grad()
+        if backward:
+            loss.backward()
+        if optimize:
+            torch.nn.utils.clip_grad_norm_(net.net_parameters(), 1.0)
+            opt.step()
+        net.unused_modules_back()
+        return loss
+
+    def measure(fn, n=30, warm=10):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            ts.append((1e3 * (t1 - t0), 1e3 * (time.perf_counter() - t0)))
+        return statistics.median(t[0] for t in ts), statistics.median(t[1] for t in ts)
+
+    print('# host issue ms / wall ms per step (queue drained before every step), B = 64, HSIZE 256, %d parameter tensors (%d of them alpha)'
+          % (len(list(net.parameters())), 2 * len(net.redundant_modules)))
+    res = {}
+    for name, kw in (('full', {}), ('no_zero_sum', dict(zero_sum=False)), ('fwd_bwd', dict(zero_sum=False, optimize=False)),
+                     ('forward', dict(zero_sum=False, optimize=False, backward=False))):
+        if name in ('fwd_bwd',):
+            net.zero_grad()
+        res[name] = measure(lambda: step(**kw))
+        print('%-12s host %6.2f ms   wall %6.2f ms' % (name, *res[name]))
+    net2 = Net_Search(cfg, init).to(dev).train()
+    loop = SearchLoop(net2, loss_fn, net_lr=4e-4, clip=1.0, epoch_steps=1000, warmup=True)
+    res['harness'] = measure(lambda: loop.weight_step(inp, tgt))
+    print('%-12s host %6.2f ms   wall %6.2f ms' % ('harness', *res['harness']))
+    f, nz, fb, fw = (res[k][1] for k in ('full', 'no_zero_sum', 'fwd_bwd', 'forward'))
+    print()
+    print('# split of the unchanged loop (wall %.2f ms):' % f)
+    print('#   (i) the script\'s own statements')
+    print('#       three `0 * sum(p.sum())` lines, forward and backward side        %6.2f ms' % (f - nz))
+    print('#       net.zero_grad() + clip_grad_norm_ + WarmupOptimizer/Adam.step()   %6.2f ms' % (nz - fb))
+    print('#   (ii) this library: sample + unused_modules_off/back + forward          %6.2f ms' % fw)
+    print('#        backward of the operators (autograd.Function nodes)              %6.2f ms' % (fb - fw))
+    print('#   the same arithmetic through SearchLoop.weight_step                    %6.2f ms' % res['harness'][1])
+
+
+if __name__ == '__main__':
+    main()
