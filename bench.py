@@ -359,10 +359,12 @@ def main():
     ap.add_argument('--batch', type=int, default=B_DEFAULT)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0, help='seconds of CPU work per cpu_baseline record')
-    ap.add_argument('--gemm-split', type=int, default=6, choices=[0, 3, 6],
+    ap.add_argument('--gemm-split', type=int, default=6, choices=[0, 1, 3, 6],
                     help='matrix products (MMNAS_GEMM_SPLIT): 6 = the library default, 6 bf16-MFMA products of exactly split '
                          'fp32 operands (fp32-grade error); 0 = the fp32 MFMA; 3 = EXPERIMENT (2^-16-class error, not a '
-                         'headline); the JSON line says which in dtype and config')
+                         'headline); 1 = ONE bf16-MFMA product of bf16-rounded operands, fp32 accumulate -- the reduced-precision '
+                         'flavour BASELINE configs[4] names ("fp16 MFMA"; --workload train_itm only, never a headline); the JSON '
+                         'line says which in dtype and config')
     ap.add_argument('--no-prof', action='store_true', help='skip the roofline pass (per-launch HIP events)')
     ap.add_argument('--full-out', default=None, help='where the full record goes (default gpurun_out/bench_full.json)')
     ap.add_argument('--repeats', type=int, default=5, help='timed blocks of --steps steps each; value = the median block')
@@ -372,6 +374,9 @@ def main():
     if env_world is None and args.gpus > 1:
         sys.exit(_self_spawn(args.gpus, sys.argv[1:]))
     world = int(env_world or 1)
+    if args.gemm_split == 1 and args.workload != 'train_itm':
+        sys.stderr.write('bench.py: --gemm-split 1 (single-pass bf16 products) is the BASELINE configs[4] flavour: --workload train_itm only\n')
+        sys.exit(2)
     if world != args.gpus:
         sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a mislabelled number\n' % (args.gpus, world))
         sys.exit(2)
@@ -785,8 +790,12 @@ def main():
                 kname = 'gemm_kernel / gemm_pair_kernel <BM,BN,NS=%d> (each fp32 product as %d v_mfma_f32_32x32x16_bf16 ' \
                         'products of exactly split operands, fp32 accumulate; NT/NN/TN, grouped; dgrad+wgrad pairs in one ' \
                         'launch)' % (args.gemm_split // 3 + 1, args.gemm_split)
-            rec['roofline'] = {'kernel': kname, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_F32_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': ach / PEAK_MFMA_F32_TFLOPS, 'traffic': traffic,
+                if args.gemm_split == 1:
+                    kname = 'gemm_kernel / gemm_pair_kernel <BM,BN,NS=1> (one v_mfma_f32_32x32x16_bf16 product of bf16-rounded operands, fp32 accumulate)'
+            # (single-pass bf16 products are bf16 arithmetic: priced against the bf16 dense peak, nothing else)
+            peak = PEAK_MFMA_BF16_TFLOPS if args.gemm_split == 1 else PEAK_MFMA_F32_TFLOPS
+            rec['roofline'] = {'kernel': kname, 'bound': 'mfma', 'achieved': ach, 'peak': peak,
+                               'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
                                'traffic_pmc': traffic_detail,
                                'traffic_source': (traffic_detail or {}).get('source') and
                                'PMC 2*FETCH+WRITE per launch, replayed from %s' % traffic_detail['source'],
@@ -794,7 +803,7 @@ def main():
                                'avg_launch_us': 1e3 * gm['ms'] / max(gm['launches'], 1),
                                'launches_per_step': gm['launches'] / psteps,
                                'share_of_step_time': gm['ms'] * 1e-3 / prof_elapsed}
-            if args.gemm_split:
+            if args.gemm_split > 1:
                 rec['roofline']['peak_note'] = ('`peak` / `frac`: fp32 MFMA dense peak (the reference arithmetic type; a frac > 1 would be '
                                                 'possible here because the products run on the bf16 pipe); `peak_bf16_div%d` / `frac_bf16_div%d`: '
                                                 'the bf16 dense peak divided by the %d bf16 products per fp32 product') % ((args.gemm_split,) * 3)
@@ -885,7 +894,9 @@ def main():
             'n_gpus': world, 'steps': head['steps'], 'warmup': head['warmup'], 'ms_per_step': head['ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {0: 'f32', 6: 'f32 (bf16x6 split-operand MFMA, fp32 accumulate)',
-                      3: 'f32 results from bf16x3 split-operand MFMA products (EXPERIMENT: 2^-16-class products)'}[args.gemm_split],
+                      3: 'f32 results from bf16x3 split-operand MFMA products (EXPERIMENT: 2^-16-class products)',
+                      1: 'bf16 matrix products (one v_mfma_f32_32x32x16_bf16 pass on bf16-rounded operands, fp32 accumulate; storage, '
+                         'attention cores and everything else f32): REDUCED PRECISION, BASELINE configs[4] flavour'}[args.gemm_split],
             'data': 'synthetic',
             'config': {'workload': head['workload'], 'global_batch': (state[head_wl]['B'] if head_wl in EXTRA else B) * world, 'parallelism': 'dp%d' % world,
                        'grad_allreduce': ('rccl' if backend == 'nccl' else backend) if world > 1 else 'none',

@@ -156,6 +156,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& w0, uns
   f32x2 r = {x0, x1};
   const bf16x2 h = __builtin_convertvector(r, bf16x2);
   w0 = __builtin_bit_cast(unsigned, h);
+  if (NS == 1) return;   // single-pass bf16: the rounded operand is all there is
   float r0, r1;
   asm("v_sub_f32 %0, %1, %2" : "=v"(r0) : "v"(x0), "v"(__uint_as_float(w0 << 16)));
   asm("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(x1), "v"(__uint_as_float(w0 & 0xffff0000u)));
@@ -173,6 +174,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& w0, uns
   f32x2 r = {x0, x1};
   const bf16x2 h = __builtin_convertvector(r, bf16x2);
   w0 = __builtin_bit_cast(unsigned, h);
+  if (NS == 1) return;
   r -= __builtin_convertvector(h, f32x2);
   const bf16x2 m = __builtin_convertvector(r, bf16x2);
   w1 = __builtin_bit_cast(unsigned, m);
@@ -231,22 +233,22 @@ template <int BR, bool KC, int NS>
 __device__ __forceinline__ void split_store_kc(unsigned* dst, const float4 v, int f) {
   constexpr int RSW = NS * 16 + 4;
   const int row = kc_row(f), kq = f & 7;
-  unsigned a0, a1, a2 = 0, b0, b1, b2 = 0;
+  unsigned a0, a1 = 0, a2 = 0, b0, b1 = 0, b2 = 0;
   split_pair<NS>(v.x, v.y, a0, a1, a2);
   split_pair<NS>(v.z, v.w, b0, b1, b2);
   unsigned* d = dst + row * RSW + swz(2 * kq, row);
   *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
-  *reinterpret_cast<uint2*>(d + 16) = make_uint2(a1, b1);
+  if (NS > 1) *reinterpret_cast<uint2*>(d + 16) = make_uint2(a1, b1);
   if (NS > 2) *reinterpret_cast<uint2*>(d + 32) = make_uint2(a2, b2);
 }
 template <int NS>
 __device__ __forceinline__ void split_put(unsigned* dst, float x0, float x1, int row, int kp) {
   constexpr int RSW = NS * 16 + 4;
-  unsigned a0, a1, a2 = 0;
+  unsigned a0, a1 = 0, a2 = 0;
   split_pair<NS>(x0, x1, a0, a1, a2);
   unsigned* d = dst + row * RSW + swz(kp, row);
   d[0] = a0;
-  d[16] = a1;
+  if (NS > 1) d[16] = a1;
   if (NS > 2) d[32] = a2;
 }
 template <int BR, int NS>
@@ -268,6 +270,8 @@ __device__ unsigned long long g_life_acc[8];   // whole-workgroup phases: argume
 
 // NS > 0: the operands are split into NS bf16 parts while they are written to LDS and the products run on
 // v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate per instruction), fp32 accumulation as before:
+//   NS = 1: x ~ h = bf16(x) (8 mantissa bits), ONE product hh                    -- "bf16x1": the single-pass reduced-
+//           precision flavour of BASELINE configs[4] ("fp16 MFMA"); never a default, never behind a parity claim
 //   NS = 2: x = h + l  (16 mantissa bits kept), products hh + hl + lh            -- "bf16x3"
 //   NS = 3: x = h + m + l (all 24 bits),        products hh + hm + mh + mm + hl + lh -- "bf16x6", fp32-grade
 // (the dropped cross terms are below 2^-16 resp. 2^-24 of |a||b|).  NS = 3 is the default path (every shape measured is
@@ -295,7 +299,7 @@ template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, in
 __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const int nwg, const int koff,
                                           float* __restrict__ As, float* __restrict__ Bs, float* __restrict__ As1,
                                           float* __restrict__ Bs1, int& s_old) {
-  static_assert(PF == 1 || (PF == 2 && FAST && (NS == 0 || NS == 3)), "the two-stage prefetch exists for the buffer-load path (fp32 and bf16x6)");
+  static_assert(PF == 1 || (PF == 2 && FAST && (NS == 0 || NS == 1 || NS == 3)), "the two-stage prefetch exists for the buffer-load path (fp32, bf16x1 and bf16x6)");
   static_assert(NS == 0 || (FAST && BK == 32), "the bf16-split path exists for the buffer-load path only");
   static_assert(!BDMA || (NS == 3 && AKC && BKC && FAST && PF == 1 && BM == 64 && BN == 64 && EPI == 0), "LDS-DMA weight planes: NT 64^2 bf16x6 only");
   constexpr int RSWB = 48;   // BDMA: words per row of the B image (3 runs of 16 words, no pad)
@@ -1050,7 +1054,8 @@ static int env_int(const char* name, int dflt) {
 //   MMNAS_GEMM_WGS=n       co-resident workgroup budget (default 1024 for 64^2 tiles, 512 for 128^2)
 //   MMNAS_GEMM_MIN_UNITS=n fewest K-tiles a workgroup is given (default 4)
 //   MMNAS_GEMM_GM=n        row-panels per tile-order block (default 8)     MMNAS_GEMM_XCD=0 identity workgroup mapping
-//   MMNAS_GEMM_SPLIT=0|3|6 products on the fp32 MFMA / as 3 / 6 (default: fp32-grade) bf16 MFMA products of split operands
+//   MMNAS_GEMM_SPLIT=0|1|3|6 products on the fp32 MFMA / as 1 (bf16-rounded operands: reduced precision) / 3 / 6 (default: fp32-grade)
+//                          bf16 MFMA products of split operands
 //   MMNAS_GEMM_PAIR=0      mmnas_gemm_pair launches its two products separately
 //   MMNAS_GEMM_PF=1|2      K-tiles of operand loads in flight ahead of the MFMA block (64^2 fp32 buffer-load path)
 struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split, pair, split_slots, split_p, pf, wide_min, split_minwg, hyb_t; bool loaded; };
@@ -1065,7 +1070,7 @@ static void load_tuning() {
   g_tune.gm = env_int("MMNAS_GEMM_GM", 0);
   g_tune.xcd = env_int("MMNAS_GEMM_XCD", 1);
   const int sp = env_int("MMNAS_GEMM_SPLIT", 6);
-  g_tune.split = sp == 3 ? 2 : (sp == 6 ? 3 : 0);   // number of bf16 parts per operand
+  g_tune.split = sp == 3 ? 2 : (sp == 6 ? 3 : (sp == 1 ? 1 : 0));   // number of bf16 parts per operand
   g_tune.pair = env_int("MMNAS_GEMM_PAIR", 1);
   g_tune.split_slots = env_int("MMNAS_GEMM_SPLIT_SLOTS", 0);
   g_tune.split_p = env_int("MMNAS_GEMM_SPLIT_P", 24);           // K-tiles per split-K piece
@@ -1228,7 +1233,7 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
   if (g_tune.tile == 64 || g_tune.tile == 12864) big = false;
   // 128 x 64 tiles (each wave two 32x32 MFMA tiles down the rows): 1.33x the products per operand byte and per barrier
   // of 64^2 -- for plain products on the buffer-load path whose rows fill the chip anyway (experiment: MMNAS_GEMM_TILE=12864)
-  bool wide = !big && g_tune.tile == 12864 && !accumulate && fast && g_tune.split != 2;
+  bool wide = !big && g_tune.tile == 12864 && !accumulate && fast && g_tune.split != 2 && g_tune.split != 1;
   if (wide) {
     long n = 0;
     for (int g = 0; g < d->ngroups; ++g) n += (long)cdiv(d->g[g].M, 128) * cdiv(d->N, 64);
@@ -1319,7 +1324,7 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
     snprintf(out.tag, sizeof(out.tag), "%s M=%d/%d/%d N=%d K=%d seg=%d t%d wg=%d P=%d/%d %s%s", tn ? "TN" : (bkc ? "NT" : "NN"),
              d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0, d->ngroups > 2 ? d->g[2].M : 0, d->N, d->K, d->nseg, wide ? 12864 : bt, nwg, k.P, k.T,
              k.mode == MODE_TILE ? "tile" : (k.mode == MODE_SPLIT ? "split" : (k.n_full ? "hybrid" : "stream")),
-             fast ? (g_tune.split == 2 ? " bf16x3" : (g_tune.split == 3 ? " bf16x6" : "")) : " generic");
+             fast ? (g_tune.split == 2 ? " bf16x3" : (g_tune.split == 3 ? " bf16x6" : (g_tune.split == 1 ? " bf16x1" : ""))) : " generic");
   out.flops = 2.0 * sumM * d->N * d->K * d->nseg;
   out.bytes = 4.0 * (sumM * d->K * d->nseg + (double)d->N * d->K * d->nseg * d->ngroups + sumM * d->N);
   out.nwg = nwg; out.layout = d->layout; out.big = big; out.fast = fast; out.wide = wide;
@@ -1345,11 +1350,13 @@ static int launch_plan(GemmPlan& pl, hipStream_t st) {
     return check_launch("gemm");
   }
   if (pl.big) {
+    if (ns == 1) return launch<128, 128, true, 1>(k, pl.layout, pl.nwg, st);
     if (ns == 2) return launch<128, 128, true, 2>(k, pl.layout, pl.nwg, st);
     if (ns == 3) return launch<128, 128, true, 3>(k, pl.layout, pl.nwg, st);
     return pl.fast ? launch<128, 128, true, 0>(k, pl.layout, pl.nwg, st) : launch<128, 128, false, 0>(k, pl.layout, pl.nwg, st);
   }
   if (pl.wide) return ns == 3 ? launch<128, 64, true, 3>(k, pl.layout, pl.nwg, st) : launch<128, 64, true, 0, 2>(k, pl.layout, pl.nwg, st);
+  if (ns == 1) return launch<64, 64, true, 1, 2>(k, pl.layout, pl.nwg, st);
   if (ns == 2) return launch<64, 64, true, 2>(k, pl.layout, pl.nwg, st);
   if (ns == 3) return g_tune.pf == 2 ? launch<64, 64, true, 3, 2>(k, pl.layout, pl.nwg, st) : launch<64, 64, true, 3>(k, pl.layout, pl.nwg, st);
   if (pl.fast && g_tune.pf == 2) return launch<64, 64, true, 0, 2>(k, pl.layout, pl.nwg, st);
@@ -1394,6 +1401,7 @@ int gemm_pair_aux(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, co
   const int nwg0p = (p0.nwg + 7) / 8 * 8;
   dim3 grid(naux8 + nwg0p + p1.nwg), block(256);
   switch (g_tune.split) {
+    case 1: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 1, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8); break;
     case 2: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8); break;
     case 3:
       if (g_tune.pf == 2) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);

@@ -319,23 +319,44 @@ def test_itm_triplet_step_vs_reference(products, monkeypatch):
         L.lib().mmnas_gemm_reload_tuning()
 
 
-def _itm_triplet_check(Net_Full, BCE_Loss, itm_triplet_step):
+def test_itm_triplet_step_single_pass_bf16_products(monkeypatch):
+    """BASELINE configs[4] as written ("fp16 MFMA"): MMNAS_GEMM_SPLIT=1, every projection / FFN product as ONE bf16 MFMA pass
+    on bf16-rounded operands with fp32 accumulation (attention cores, LayerNorm, softmax, loss stay fp32).  Reduced
+    precision by construction (8 mantissa bits per operand; the reference's fp16 would keep 11): NOT held to the 1e-3 parity
+    bar -- the stated tolerance against the reference's fp32 step is 3e-2 on loss, scores and gradient norms -- and never
+    the default or a headline."""
+    import mmnas_amd._lib as L
+    from mmnas.model.full_itm import Net_Full
+    from mmnas.utils.itm_loss import BCE_Loss
+    from mmnas_amd.harness import itm_triplet_step
+    monkeypatch.setenv('MMNAS_GEMM_SPLIT', '1')
+    L.lib().mmnas_gemm_reload_tuning()
+    try:
+        _itm_triplet_check(Net_Full, BCE_Loss, itm_triplet_step, tol=3e-2, gtol=3e-2)
+        with pytest.raises(AssertionError):          # ... and it really is the reduced-precision path
+            _itm_triplet_check(Net_Full, BCE_Loss, itm_triplet_step, tol=1e-5, gtol=1e-5)
+    finally:
+        monkeypatch.delenv('MMNAS_GEMM_SPLIT')
+        L.lib().mmnas_gemm_reload_tuning()
+
+
+def _itm_triplet_check(Net_Full, BCE_Loss, itm_triplet_step, tol=TOL, gtol=2e-3):
     npz = load('losses.npz')
     c = cases.net_case('itm', 'mmnas_itm', 9201)
     neg = cases.net_case('itm', 'mmnas_itm', 9202)
     net = _build(Net_Full, c)
     pos = tuple(T(a).to(DEV) for a in c['inputs']); ng = tuple(T(a).to(DEV) for a in neg['inputs'])
     loss = itm_triplet_step(net, BCE_Loss(), pos, ng)
-    assert abs(float(loss) - float(npz['itm|loss'])) < TOL * float(npz['itm|loss'])
+    assert abs(float(loss) - float(npz['itm|loss'])) < tol * float(npz['itm|loss'])
     sp = net(pos)
-    assert rel_err(sp.detach().cpu().numpy(), npz['itm|scores'][0]) < TOL
+    assert rel_err(sp.detach().cpu().numpy(), npz['itm|scores'][0]) < tol
     keys = [str(k) for k in npz['itm|gradnorm_keys']]
     named = dict(net.named_parameters())
     top = float(np.max(npz['itm|gradnorms']))
     for k, n in zip(keys, npz['itm|gradnorms']):
         mine = 0.0 if named[k].grad is None else float(named[k].grad.double().norm())
-        assert abs(mine - n) <= 2e-3 * n + 1e-5 * top, (k, mine, n)
-    assert rel_err(named['proj.weight'].grad.cpu().numpy(), npz['itm|g:proj.weight']) < TOL
+        assert abs(mine - n) <= gtol * n + 1e-5 * top * (gtol / 2e-3), (k, mine, n)
+    assert rel_err(named['proj.weight'].grad.cpu().numpy(), npz['itm|g:proj.weight']) < tol
 
 
 def test_vgd_loss_vs_reference():
