@@ -290,6 +290,20 @@ class RowExchange:
         self.active = False
 
 
+def _inline_collectives(group, is_cuda):
+    """RCCL collectives issued as SYNCHRONOUS ops from inside `with torch.cuda.stream(comm_stream)`: c10d then enqueues
+    the collective on that stream itself, in order behind the pack kernel and in front of the scatter -- no internal
+    communication stream, no event pair per bucket (each cross-stream hop is ~10 us of idle queue at the end of a step,
+    where nothing is left to overlap it).  The host does not block (a wait on a CUDA work object only orders streams).
+    MMNAS_DP_INLINE=0 restores async_op=True + work.wait()."""
+    if not is_cuda or os.environ.get('MMNAS_DP_INLINE', '1') == '0':
+        return False
+    try:
+        return dist.get_backend(group) == 'nccl'
+    except Exception:   # noqa: BLE001
+        return False
+
+
 def _all_reduce_avg(t, group, world):
     if _has_avg(group):
         dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
@@ -336,6 +350,7 @@ class GradReducer:
         self._works = []
         self._launched = [False] * len(self.buckets)
         self.comm_stream = torch.cuda.Stream() if (self.is_cuda and self.comm) else None
+        self.inline = self.comm and _inline_collectives(group, self.is_cuda)
         if self.comm:
             for i, p in enumerate(self.fg.params):
                 # The hook is the ONLY arrival signal.  Autograd runs a parameter's AccumulateGrad node -- and
@@ -389,7 +404,11 @@ class GradReducer:
             ops.side_stream_barrier(self.comm_stream)   # weight gradients the backbone chain put on its side stream
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                self._works.append((dist.all_reduce(chunk, op=op, group=self.group, async_op=True), chunk, not avg))
+                if self.inline:       # on the communication stream itself, in stream order
+                    dist.all_reduce(chunk, op=op, group=self.group)
+                    self._works.append((None, chunk, not avg))
+                else:
+                    self._works.append((dist.all_reduce(chunk, op=op, group=self.group, async_op=True), chunk, not avg))
         else:
             self._works.append((dist.all_reduce(chunk, op=op, group=self.group, async_op=True), chunk, not avg))
 
@@ -421,7 +440,8 @@ class GradReducer:
         if self.is_cuda:
             with torch.cuda.stream(self.comm_stream):   # (the scaling of a summed bucket stays on the comm stream)
                 for w, chunk, need_div in self._works:
-                    w.wait()
+                    if w is not None:
+                        w.wait()
                     if need_div:
                         chunk.mul_(1.0 / self.world)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
@@ -534,6 +554,8 @@ class SupernetReducer:
         self._armed = set()
         self._works = []
         self.comm_stream = torch.cuda.Stream() if (self.is_cuda and self.comm) else None
+        self.inline = self.comm and _inline_collectives(group, self.is_cuda)
+        self._tables = [None] * n_buckets
         if self.comm:
             for i, p in enumerate(fg.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))   # (see GradReducer: the only arrival signal)
@@ -573,7 +595,8 @@ class SupernetReducer:
                     segs.append(self.cand_span[k][a])
                     idxs += self.cand_idx[k][a]
             self._segs[b] = segs
-            self._pending[b] = len(idxs)
+            self._tables[b] = self._segment_table(segs)   # (built here, while the host runs ahead of the GPU: the launch
+            self._pending[b] = len(idxs)                   #  and the scatter at the end of the step are one call each)
             armed.update(idxs)
         self._armed = armed
         self._mark_ev = {}
@@ -629,9 +652,13 @@ class SupernetReducer:
             ops.side_stream_barrier(self.comm_stream)   # weight gradients the backbone chain put on its side stream
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                self._pack(segs, stg, 0)
-                w = dist.all_reduce(stg, op=op, group=self.group, async_op=True)
-                if avg and os.environ.get('MMNAS_DP_EARLY_SCATTER', '0') == '1':
+                self._pack(segs, stg, 0, table=self._tables[b])
+                if self.inline:       # pack -> all-reduce (-> scatter, finish_weight_step) in the order of this one stream
+                    dist.all_reduce(stg, op=op, group=self.group)
+                    w = 'inline'
+                else:
+                    w = dist.all_reduce(stg, op=op, group=self.group, async_op=True)
+                if avg and not self.inline and os.environ.get('MMNAS_DP_EARLY_SCATTER', '0') == '1':
                     # Optional (MMNAS_DP_EARLY_SCATTER=1): scatter the averaged gradients back as soon as THIS bucket's
                     # all-reduce ends (RCCL: wait() only makes the communication stream wait), leaving only the last
                     # bucket's scatter behind the end of backward.  Measured in a one-rank group: +0.06 ms per step --
@@ -663,8 +690,9 @@ class SupernetReducer:
                 for w, b, stg, need_div in self._works:
                     if w is None:
                         continue             # (scattered back right behind its all-reduce: _launch)
-                    w.wait()
-                    self._pack(self._segs[b], stg, 1, 1.0 / self.world if need_div else 1.0)
+                    if w != 'inline':
+                        w.wait()
+                    self._pack(self._segs[b], stg, 1, 1.0 / self.world if need_div else 1.0, table=self._tables[b])
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         else:
             for w, b, stg, need_div in self._works:
@@ -672,15 +700,22 @@ class SupernetReducer:
                 self._pack(self._segs[b], stg, 1, 1.0 / self.world if need_div else 1.0)
         self._works = []
 
-    def _pack(self, segs, stg, direction, scale=1.0):
+    def _segment_table(self, segs):
+        if not self.is_cuda:
+            return None
+        from . import _lib as L
+        arr = (L.Segment * max(len(segs), 1))()
+        base = self.fg.flat.data_ptr()
+        off = 0
+        for k, (o, n) in enumerate(segs):
+            arr[k].ptr, arr[k].offset, arr[k].n = base + 4 * o, off, n
+            off += n
+        return arr
+
+    def _pack(self, segs, stg, direction, scale=1.0, table=None):
         if self.is_cuda:
             from . import _lib as L
-            arr = (L.Segment * len(segs))()
-            base = self.fg.flat.data_ptr()
-            off = 0
-            for k, (o, n) in enumerate(segs):
-                arr[k].ptr, arr[k].offset, arr[k].n = base + 4 * o, off, n
-                off += n
+            arr = table if table is not None else self._segment_table(segs)
             # the table rides in the kernel arguments: no host->device copy, no stream synchronisation per step
             L.check(L.lib().mmnas_pack_segments_host(arr, len(segs), L.fptr(stg), float(scale), direction, L.stream()))
         else:  # CPU tensors (gloo tests): host plumbing only
