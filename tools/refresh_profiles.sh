@@ -1,12 +1,12 @@
 #!/bin/bash
 # Regenerates everything under profiles/ for one round on a GPU box (run from the repo root):
-#   bash tools/refresh_profiles.sh r03
+#   MMNAS_COMMIT=$(git rev-parse --short=12 HEAD) bash tools/refresh_profiles.sh r04      (MMNAS_COMMIT: stamped into the PMC files)
 # rocprofv3 --kernel-trace --stats summaries of the bench command per workload, one-step kernel timelines, the two
 # --pmc passes behind roofline.traffic (FETCH_SIZE / WRITE_SIZE cannot share a pass), the MFMA / LDS counter passes, and
 # the bench lines themselves (the default line with its CPU baselines last: it reads the traffic files written before).
 # Raw traces stay in /tmp; only summaries are written to profiles/.  Counters are collected with --kernel-trace only.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 ROOT=$PWD
 export TMPDIR=/tmp
 W=/tmp/mmnas_prof
@@ -24,6 +24,7 @@ for wl in search_vqa arch_vqa train_vqa; do
     (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d $W/pmc_${wl}_$c -o t -- python3 $ROOT/$small > $W/pmc_${wl}_$c.log 2>&1)
   done
   python3 tools/pmc_traffic.py $W/pmc_${wl}_FETCH_SIZE $W/pmc_${wl}_WRITE_SIZE profiles/${R}_traffic_$wl.json
+  python3 tools/stamp_profiles.py profiles/${R}_traffic_$wl.json > /dev/null   # (before the bench lines below read it)
   [ $wl = arch_vqa ] && continue
   (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace -d $W/pmc_${wl}_mfma -o t -- python3 $ROOT/$small > $W/pmc_${wl}_mfma.log 2>&1)
   (cd /tmp && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $W/pmc_${wl}_lds -o t -- python3 $ROOT/$small > $W/pmc_${wl}_lds.log 2>&1)
@@ -44,26 +45,27 @@ if [ -z "${SKIP_PMC:-}" ]; then
     (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d $W/pmc_bilevel_vqa_$c -o t -- python3 $ROOT/$small > $W/pmc_bilevel_vqa_$c.log 2>&1)
   done
   python3 tools/pmc_traffic.py $W/pmc_bilevel_vqa_FETCH_SIZE $W/pmc_bilevel_vqa_WRITE_SIZE profiles/${R}_traffic_bilevel_vqa.json
+  python3 tools/stamp_profiles.py profiles/${R}_traffic_bilevel_vqa.json > /dev/null
   (cd /tmp && GEMM_PMC_SWEEP=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $W/sweep -o t -- python3 $ROOT/tools/gemm_pmc.py > $W/sweep.log 2>&1)
   python3 tools/traffic_sweep.py $W/sweep > profiles/${R}_gemm_traffic_sweep.txt
 fi
 python3 tools/mha_bench.py > profiles/${R}_mha_microbench.txt 2>/dev/null
 python3 tools/rel_bench.py > profiles/${R}_rel_microbench.txt 2>/dev/null
-python3 tools/gemm_ab.py r2:mmnas_amd/lib/libmmnas_hip_r2.so mmnas_amd/lib/libmmnas_hip.so > profiles/${R}_gemm_vs_round2_build.txt 2>/dev/null
 (cd /tmp && GEMM_PMC_LAYOUTS=1 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $W/pmc_gemm_lds -o t -- python3 $ROOT/tools/gemm_pmc.py > $W/pmc_gemm_lds.log 2>&1)
 (cd /tmp && GEMM_PMC_LAYOUTS=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace -d $W/pmc_gemm_mfma -o t -- python3 $ROOT/tools/gemm_pmc.py > $W/pmc_gemm_mfma.log 2>&1)
 python3 tools/pmc_counters.py profiles/${R}_pmc_gemm_layouts.json $W/pmc_gemm_lds $W/pmc_gemm_mfma
-python3 bench.py > $W/bench_all.log 2> $W/bench_all.err
-grep '^{' $W/bench_all.log | tail -1 > profiles/${R}_bench.json
+# the bench lines: <round>_bench.json = the FULL record (bench.py --full-out), <round>_bench_line.json = the compact stdout line
+python3 bench.py --full-out profiles/${R}_bench.json > $W/bench_all.log 2> $W/bench_all.err
+grep '^{' $W/bench_all.log | tail -1 > profiles/${R}_bench_line.json
 for wl in train_vgd train_itm; do
-  python3 bench.py --workload $wl --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > profiles/${R}_bench_$wl.json
+  python3 bench.py --workload $wl --no-cpu-baseline --full-out profiles/${R}_bench_$wl.json > /dev/null 2>&1
 done
 # the same steps with the matrix products on the fp32 MFMA (MMNAS_GEMM_SPLIT=0) and as 3 bf16 products (experiment)
 for sp in 0 3; do for wl in search_vqa train_vqa; do
-  python3 bench.py --workload $wl --no-cpu-baseline --gemm-split $sp 2>/dev/null | grep '^{' | tail -1 > profiles/${R}_bench_${wl}_gemm_split$sp.json
+  python3 bench.py --workload $wl --no-cpu-baseline --gemm-split $sp --full-out profiles/${R}_bench_${wl}_gemm_split$sp.json > /dev/null 2>&1
 done; done
-# BASELINE configs[4] (the reference runs it in fp16): also as 3 bf16 products per fp32 product (16 mantissa bits kept)
-python3 bench.py --workload train_itm --no-cpu-baseline --gemm-split 3 2>/dev/null | grep '^{' | tail -1 > profiles/${R}_bench_train_itm_gemm_split3.json
+# BASELINE configs[4] ("fp16 MFMA"): the single-pass bf16 flavour (reduced precision, tolerance 3e-2: tests/test_harness_gpu.py)
+python3 bench.py --workload train_itm --no-cpu-baseline --gemm-split 1 --full-out profiles/${R}_bench_train_itm_gemm_split1.json > /dev/null 2>&1
 mkdir -p gpurun_out/profiles_$R && cp profiles/${R}_* gpurun_out/profiles_$R/   # (gpurun merges only gpurun_out/ back)
 ls -la profiles/ | grep $R
 for f in $W/*.log; do echo "== $f"; tail -n 2 $f | cut -c1-300; done

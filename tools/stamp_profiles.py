@@ -17,8 +17,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    head = subprocess.run(['git', 'rev-parse', '--short=12', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-    dirty = subprocess.run(['git', 'status', '--porcelain', '--', 'mmnas_amd', 'bench.py'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    if os.environ.get('MMNAS_COMMIT'):     # on the GPU box (no .git there): the commit the snapshot was taken from, passed in
+        head, dirty = os.environ['MMNAS_COMMIT'], ''
+    else:
+        head = subprocess.run(['git', 'rev-parse', '--short=12', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+        dirty = subprocess.run(['git', 'status', '--porcelain', '--', 'mmnas_amd', 'bench.py'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
     lib = os.path.join(ROOT, 'mmnas_amd', 'lib', 'libmmnas_hip.so')
     md5 = hashlib.md5(open(lib, 'rb').read()).hexdigest() if os.path.exists(lib) else None
     for path in sys.argv[1:]:
