@@ -91,7 +91,10 @@ def test_supernet_weight_step_full_size(monkeypatch):
         gmax = float(g_all.abs().max())
         assert gmax > 0
         # the sample's operators (and the stem / head) have gradients; the candidates left out have none
-        active = {id(p) for p in loop.reducer._active}
+        red = loop.reducer     # (SearchLoop keeps every gradient view attached: the sampled set is the plan's)
+        active = {id(p) for p in red.shared}
+        for k, (a, _) in enumerate(flat):
+            active.update(id(p) for p in red.per_op[k][a[0]])
         n_act = n_off = 0
         for i, p in enumerate(fg.params):
             v = g_all[fg.offsets[i]:fg.offsets[i] + p.numel()]
@@ -117,23 +120,38 @@ def test_supernet_weight_step_full_size(monkeypatch):
             if err > 2e-3 * max(float(g_all[sl].abs().max()), 1e-3 * gmax):
                 bad.append((names[id(p)], err, float(g_all[sl].abs().max())))
         assert not bad, bad[:6]
-        # chain == per-operator path at this size, dropout off and on (same seed -> same masks)
-        for p_drop in (0.0, 0.1):
-            c['cfg'].DROPOUT_R = p_drop
-            for m in net.modules():
-                if isinstance(m, torch.nn.Dropout):
-                    m.p = p_drop
-                if hasattr(m, 'dropout_r'):
-                    m.dropout_r = p_drop
-            o_c, l_c, g_c = run(full, chain=True, seed=11)
-            o_o, l_o, g_o = run(full, chain=False, seed=11)
-            if p_drop:
-                assert abs(l_c - loss) > 1e-4 * abs(loss)          # dropout really on
-            assert float((o_c - o_o).abs().max()) <= 1e-5 * float(o_o.abs().max()), p_drop
-            assert abs(l_c - l_o) <= 1e-5 * abs(l_o)
-            assert float((g_c - g_o).abs().max()) <= 2e-3 * float(g_o.abs().max()), p_drop
+        # chain == per-operator path at this size (dropout off)
+        o_c, l_c, g_c = run(full, chain=True, seed=11)
+        o_o, l_o, g_o = run(full, chain=False, seed=11)
+        assert float((o_c - o_o).abs().max()) <= 1e-5 * float(o_o.abs().max())
+        assert abs(l_c - l_o) <= 1e-5 * abs(l_o)
+        assert float((g_c - g_o).abs().max()) <= 2e-3 * float(g_o.abs().max())
     finally:
         fg.disable_sinks()
+    # ... and with dropout 0.1 (the bench's setting), the masks replayed from the same seed: a second net on the same weights
+    c['cfg'].DROPOUT_R = 0.1
+    net2 = Net_Search(c['cfg'], _init(c))
+    net2.load_state_dict({k: T(v) for k, v in c['P'].items()})
+    net2 = net2.to(DEV).train()
+    lf2 = Loss()
+    loop2 = SearchLoop(net2, lf2)
+    try:
+        res = []
+        for chain in (True, False, True):
+            monkeypatch.setenv('MMNAS_CHAIN', '1' if chain else '0')
+            ops.manual_seed(11)
+            l = loop2.weight_step(tuple(inp), tgt, optimize=False, plan=flat)
+            torch.cuda.synchronize()
+            res.append((lf2.pred.clone(), float(l.detach()), loop2.reducer.fg.flat.clone()))
+        (o_c, l_c, g_c), (o_o, l_o, g_o), (o_r, l_r, g_r) = res
+        assert abs(l_c - loss) > 1e-4 * abs(loss)          # dropout really on
+        assert float((o_c - o_o).abs().max()) <= 1e-5 * float(o_o.abs().max())
+        assert abs(l_c - l_o) <= 1e-5 * abs(l_o)
+        assert float((g_c - g_o).abs().max()) <= 2e-3 * float(g_o.abs().max())
+        # same seed, same path: the same logits bit for bit (the loss is a float-atomic sum over 200k elements: order-dependent)
+        assert torch.equal(o_r, o_c) and abs(l_r - l_c) <= 2e-6 * abs(l_c)
+    finally:
+        loop2.reducer.fg.disable_sinks()
 
 
 def test_supernet_arch_step_full_size():
