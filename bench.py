@@ -51,7 +51,7 @@ if REPO not in sys.path:
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_MFMA_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (v_mfma_f32_32x32x16_bf16 at 32 cycles)
 PEAK_HBM_GBS = 8000.0
-B_DEFAULT, SX, SY, VOCAB, ANS = 64, 14, 100, 20000, 3129
+B_DEFAULT, SX, SY, VOCAB, ANS = 64, 14, int(os.environ.get('MMNAS_BENCH_SY', '100')), 20000, 3129   # (MMNAS_BENCH_SY: tuning experiments only)
 
 WORKLOADS = {
     'search_vqa': 'Net_Search supernet WEIGHT step: sample + fwd + BCE(sum) + bwd (+ gradient all-reduce), HSIZE 256, B=64/GPU, '

@@ -365,6 +365,12 @@ typedef struct mmnas_mha_desc {
   float* dQ; float* dK; float* dV;
   float* dbiasT;           /* [B,H,Sk,Sq] or NULL */
   float* delta;            /* scratch [B,H,Sq] */
+  /* PACKED rows (ragged batches without their padding rows; d_h = 64, Sq, Sk <= 128): q_off / k_off = [B+1] device prefix
+   * offsets -- batch b owns rows q_off[b] .. q_off[b+1] of Q / O / dO / dQ (k_off: of K / V / dK / dV), Sq / Sk are the
+   * maximum lengths (strides of lse / delta / biasT, which keep their padded [B,H,...] layout).  Packed keys carry no
+   * padding, so no mask goes with k_off.  The reference masks padded keys with -1e9 (modules.py:195-196): their
+   * probability is exactly 0 in fp32, so leaving them out changes nothing.  NULL = dense rows b * Sq + q. */
+  const int* q_off; const int* k_off;
 } mmnas_mha_desc;
 
 int mmnas_mha_core_fwd(const mmnas_mha_desc* d, void* stream);

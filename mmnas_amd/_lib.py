@@ -38,7 +38,7 @@ class MhaDesc(C.Structure):
                 ('ldq', C.c_int), ('ldk', C.c_int), ('ldv', C.c_int), ('ldo', C.c_int),
                 ('Q', _fp), ('K', _fp), ('V', _fp), ('mask', _fp), ('biasT', _fp), ('O', _fp), ('lse', _fp),
                 ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64),
-                ('dO', _fp), ('dQ', _fp), ('dK', _fp), ('dV', _fp), ('dbiasT', _fp), ('delta', _fp)]
+                ('dO', _fp), ('dQ', _fp), ('dK', _fp), ('dV', _fp), ('dbiasT', _fp), ('delta', _fp), ('q_off', _fp), ('k_off', _fp)]
 
 
 class AttOp(C.Structure):

@@ -29,6 +29,10 @@ struct MhaK {
   float* O; float* stats;
   DropCfg drop; float scale;
   const float* dO; float* dQ; float* dK; float* dV; float* dbiasT; float* delta;
+  // PACKED rows (sequences of different lengths stored back to back, no padding rows): batch b owns rows
+  // qoff[b] .. qoff[b+1] of Q / O / dO / dQ (koff: of K / V / dK / dV); Sq / Sk are then the MAXIMUM lengths -- the grid and
+  // the strides of stats / delta / bias / the dropout index.  NULL: row b * Sq + q as ever.
+  const int* qoff; const int* koff;
 };
 
 // rows x DHC floats from global (row stride ld) into LDS [rows][DHC+4]; rows >= nvalid are zero
@@ -102,11 +106,16 @@ __global__ void __launch_bounds__(64 * NW, (NKC <= 4 && NW == 4) ? 2 : 1) mha_fw
   __shared__ float sMask[32 * NKC];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32 * NW;
-  const int Sq = p.Sq, Sk = p.Sk;
+  const int SqS = p.Sq, SkS = p.Sk;   // strides of the per-(batch, head) arrays; the lengths of this batch element:
+  int Sq = p.Sq, Sk = p.Sk;
+  size_t qrow0 = (size_t)b * p.Sq, krow0 = (size_t)b * p.Sk;
+  if (p.qoff) { const int o = p.qoff[b]; Sq = p.qoff[b + 1] - o; qrow0 = (size_t)o; }
+  if (p.koff) { const int o = p.koff[b]; Sk = p.koff[b + 1] - o; krow0 = (size_t)o; }
+  if (q0 >= Sq || Sk <= 0) return;   // (packed rows: this query block lies behind the sequence's end; workgroup-uniform)
   const bool active = q0 + 32 * w < Sq;  // wave-uniform
 
   for (int k = tid; k < 32 * NKC; k += NT)
-    sMask[k] = (p.mask && k < Sk && p.mask[(size_t)b * Sk + k]) ? 1.f : 0.f;
+    sMask[k] = (p.mask && k < Sk && p.mask[(size_t)b * SkS + k]) ? 1.f : 0.f;
 
   f32x16 acc[NKC];
 #pragma unroll
@@ -117,8 +126,8 @@ __global__ void __launch_bounds__(64 * NW, (NKC <= 4 && NW == 4) ? 2 : 1) mha_fw
   // ---- S^T = K Q^T over the head-dim chunks ----
   for (int c = 0; c < p.nch; ++c) {
     if (c) __syncthreads();
-    load_tiles2<32 * NW, 32 * NKC, DHC, NT>(Qs, p.Q + (size_t)(b * Sq + q0) * p.ldq + h * p.dh + c * DHC, Sq - q0, p.ldq,
-                                            KVs, p.K + (size_t)(b * Sk) * p.ldk + h * p.dh + c * DHC, Sk, p.ldk, tid);
+    load_tiles2<32 * NW, 32 * NKC, DHC, NT>(Qs, p.Q + (qrow0 + q0) * p.ldq + h * p.dh + c * DHC, Sq - q0, p.ldq,
+                                            KVs, p.K + krow0 * p.ldk + h * p.dh + c * DHC, Sk, p.ldk, tid);
     __syncthreads();
     if (active) {
 #pragma unroll
@@ -147,7 +156,7 @@ __global__ void __launch_bounds__(64 * NW, (NKC <= 4 && NW == 4) ? 2 : 1) mha_fw
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = min(32 * kc + acc_row(r, hh), Sk - 1);
-        bias[r] = p.biasT[(bh * Sk + key) * Sq + qic];
+        bias[r] = p.biasT[(bh * SkS + key) * SqS + qic];
       }
     }
 #pragma unroll
@@ -177,8 +186,8 @@ __global__ void __launch_bounds__(64 * NW, (NKC <= 4 && NW == 4) ? 2 : 1) mha_fw
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
   if (qok && hh == 0) {
-    p.stats[(bh * Sq + qi) * 2] = m;
-    p.stats[(bh * Sq + qi) * 2 + 1] = inv;
+    p.stats[(bh * SqS + qi) * 2] = m;
+    p.stats[(bh * SqS + qi) * 2 + 1] = inv;
   }
 #pragma unroll
   for (int kc = 0; kc < NKC; ++kc)
@@ -187,7 +196,7 @@ __global__ void __launch_bounds__(64 * NW, (NKC <= 4 && NW == 4) ? 2 : 1) mha_fw
       float a = acc[kc][r] * inv;
       if (p.drop.thresh) {
         const int key = 32 * kc + acc_row(r, hh);
-        a *= drop_mult(p.drop, (uint32_t)((bh * Sq + qi) * Sk + key));
+        a *= drop_mult(p.drop, (uint32_t)((bh * SqS + qi) * SkS + key));
       }
       acc[kc][r] = a;
     }
@@ -195,7 +204,7 @@ __global__ void __launch_bounds__(64 * NW, (NKC <= 4 && NW == 4) ? 2 : 1) mha_fw
   // ---- O = A V, head-dim chunk by chunk (A tile = the accumulators, as MFMA A operand) ----
   for (int c = 0; c < p.nch; ++c) {
     __syncthreads();
-    load_tile<32 * NKC, DHC, NT>(KVs, p.V + (size_t)(b * Sk) * p.ldv + h * p.dh + c * DHC, Sk, p.ldv, tid);
+    load_tile<32 * NKC, DHC, NT>(KVs, p.V + krow0 * p.ldv + h * p.dh + c * DHC, Sk, p.ldv, tid);
     __syncthreads();
     if (!active) continue;
     f32x16 o[JC];
@@ -221,7 +230,7 @@ __global__ void __launch_bounds__(64 * NW, (NKC <= 4 && NW == 4) ? 2 : 1) mha_fw
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int q = q0 + 32 * w + acc_row(r, hh);
-          if (q < Sq) p.O[(size_t)(b * Sq + q) * p.ldo + h * p.dh + c * DHC + col] = o[jc][r];
+          if (q < Sq) p.O[(qrow0 + q) * p.ldo + h * p.dh + c * DHC + col] = o[jc][r];
         }
       }
     }
@@ -615,7 +624,12 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
   __shared__ float TrAll[NW][32 * 33];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int b = blockIdx.y, h = blockIdx.x;
-  const int Sq = p.Sq, Sk = p.Sk;
+  const int SqS = p.Sq, SkS = p.Sk;   // strides of the per-(batch, head) arrays; the lengths of this batch element:
+  int Sq = p.Sq, Sk = p.Sk;
+  size_t qrow0 = (size_t)b * p.Sq, krow0 = (size_t)b * p.Sk;
+  if (p.qoff) { const int o = p.qoff[b]; Sq = p.qoff[b + 1] - o; qrow0 = (size_t)o; }
+  if (p.koff) { const int o = p.koff[b]; Sk = p.koff[b + 1] - o; krow0 = (size_t)o; }
+  if (Sq <= 0 || Sk <= 0) return;   // (an empty packed sequence: nothing to read, nothing to write)
   const int q0 = 32 * w;
   const bool active = q0 < Sq;   // wave-uniform
   const int qi = q0 + l31;
@@ -623,8 +637,8 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
   const size_t bh = (size_t)b * p.H + h;
   float* Tr = TrAll[w];
 
-  load_tiles2<KB, KB, DHC, 256>(Ks, p.K + (size_t)(b * Sk) * p.ldk + h * p.dh, Sk, p.ldk,
-                                Vs, p.V + (size_t)(b * Sk) * p.ldv + h * p.dh, Sk, p.ldv, tid);
+  load_tiles2<KB, KB, DHC, 256>(Ks, p.K + krow0 * p.ldk + h * p.dh, Sk, p.ldk,
+                                Vs, p.V + krow0 * p.ldv + h * p.dh, Sk, p.ldv, tid);
   for (int i = tid; i < CP * KB * DHC / 4; i += 256) {
     reinterpret_cast<float4*>(dKs)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     reinterpret_cast<float4*>(dVs)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -634,10 +648,10 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
   float qB[JC][16], gB[JC][16];  // B operands of dK += dZ^T Q, dV += A^T dO: B[k = query acc_row(r, hh)][j = 32 jc + l31]
   if (active) {
     if (qok) {
-      m = p.stats[(bh * Sq + qi) * 2];
-      inv = p.stats[(bh * Sq + qi) * 2 + 1];
+      m = p.stats[(bh * SqS + qi) * 2];
+      inv = p.stats[(bh * SqS + qi) * 2 + 1];
     }
-    const size_t row = (size_t)b * Sq + (qok ? qi : Sq - 1);   // clamped: no branch around the loads
+    const size_t row = qrow0 + (qok ? qi : Sq - 1);   // clamped: no branch around the loads
     const float* qrow = p.Q + row * p.ldq + h * p.dh + 4 * hh;
     const float* grow = p.dO + row * p.ldo + h * p.dh + 4 * hh;
     const float* orow = p.O + row * p.ldo + h * p.dh + 4 * hh;
@@ -659,7 +673,7 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
     for (int r = 0; r < 16; ++r) {
       const int q = q0 + acc_row(r, hh);
       const bool ok = q < Sq;
-      const size_t rr = (size_t)b * Sq + (ok ? q : Sq - 1);
+      const size_t rr = qrow0 + (ok ? q : Sq - 1);
 #pragma unroll
       for (int jc = 0; jc < JC; ++jc) {
 #if MMNAS_DBG_MHA & 32
@@ -684,12 +698,12 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
   // predication: an absent operand is a zero-length buffer (loads return 0), a lane outside the problem an out-of-range
   // offset (loads return 0, stores are dropped).  No branch anywhere in a tile: its whole body is ONE scheduling region,
   // which lets the S^T / dA^T products of the NEXT tile be interleaved with the softmax-backward arithmetic of this one.
-  const size_t bho = bh * (size_t)Sk * Sq;
-  const unsigned plane = (unsigned)Sk * (unsigned)Sq * 4u;
+  const size_t bho = bh * (size_t)SkS * SqS;
+  const unsigned plane = (unsigned)SkS * (unsigned)SqS * 4u;
   const __amdgpu_buffer_rsrc_t bias_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.biasT ? p.biasT + bho : p.Q), 0, p.biasT ? plane : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t mask_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.mask ? p.mask + (size_t)b * Sk : (const uint8_t*)p.Q), 0, p.mask ? (unsigned)Sk : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mask_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.mask ? p.mask + (size_t)b * SkS : (const uint8_t*)p.Q), 0, p.mask ? (unsigned)Sk : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t dbias_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(DB ? p.dbiasT + bho : p.dQ), 0, DB ? plane : 0u, 0x00020000);
-  const uint32_t drop_base = (uint32_t)((bh * Sq + qi) * Sk);
+  const uint32_t drop_base = (uint32_t)((bh * SqS + qi) * SkS);
 
   // phase 1 of a tile: S^T = K Q^T and dA^T = V dO^T (64 MFMAs) + the tile's bias / mask operands
   auto P1 = [&](int k0, f32x16& acc, f32x16& dacc, float (&bias)[16], float (&mk)[16]) __attribute__((always_inline)) {
@@ -697,7 +711,7 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + acc_row(r, hh);
       const bool okk = key < Sk && qok;
-      bias[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bias_rs, okk ? (unsigned)(key * Sq + qi) * 4u : ~0u, 0, 0));
+      bias[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bias_rs, okk ? (unsigned)(key * SqS + qi) * 4u : ~0u, 0, 0));
       mk[r] = (float)__builtin_amdgcn_raw_buffer_load_b8(mask_rs, key < Sk ? (unsigned)key : ~0u, 0, 0);
     }
 #pragma unroll
@@ -729,7 +743,7 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
       const float pr = __expf(v - m) * inv;
       const float dm = drop_mult(p.drop, drop_base + (uint32_t)key);   // (no dropout: thresh 0, scale 1 -> multiplier 1)
       const float dz = (ok && !masked) ? pr * (dacc[r] * dm - del) : 0.f;
-      if (DB) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz), dbias_rs, ok ? (unsigned)(key * Sq + qi) * 4u : ~0u, 0, 0);
+      if (DB) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz), dbias_rs, ok ? (unsigned)(key * SqS + qi) * 4u : ~0u, 0, 0);
       acc[r] = dz * p.scale;
       dacc[r] = ok ? pr * dm : 0.f;
     }
@@ -825,7 +839,7 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int q = q0 + acc_row(r, hh);
-        if (q < Sq) p.dQ[(size_t)(b * Sq + q) * p.ldq + h * p.dh + col] = dq[jc][r];
+        if (q < Sq) p.dQ[(qrow0 + q) * p.ldq + h * p.dh + col] = dq[jc][r];
       }
     }
   }
@@ -840,8 +854,8 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
       a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
       v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
     }
-    *reinterpret_cast<float4*>(p.dK + (size_t)(b * Sk + key) * p.ldk + h * p.dh + 4 * c4) = a;
-    *reinterpret_cast<float4*>(p.dV + (size_t)(b * Sk + key) * p.ldv + h * p.dh + 4 * c4) = v;
+    *reinterpret_cast<float4*>(p.dK + (krow0 + key) * p.ldk + h * p.dh + 4 * c4) = a;
+    *reinterpret_cast<float4*>(p.dV + (krow0 + key) * p.ldv + h * p.dh + 4 * c4) = v;
   }
 }
 
@@ -870,6 +884,11 @@ static int fill(const mmnas_mha_desc* d, MhaK& k, bool bwd) {
   k.drop = make_drop(d->drop_p, d->drop_seed, d->drop_site);
   k.scale = 1.0f / sqrtf((float)d->dh);
   k.dO = d->dO; k.dQ = d->dQ; k.dK = d->dK; k.dV = d->dV; k.dbiasT = d->dbiasT; k.delta = d->delta;
+  k.qoff = d->q_off; k.koff = d->k_off;
+  if (k.qoff || k.koff) {
+    MMNAS_REQUIRE(d->dh == 64 && d->Sq <= 128 && d->Sk <= 128, MMNAS_E_SHAPE, "mha: packed rows (q_off / k_off) need d_h = 64 and at most 128 queries / keys per sequence (Sq=%d Sk=%d dh=%d)", d->Sq, d->Sk, d->dh);
+    MMNAS_REQUIRE(!(k.koff && d->mask), MMNAS_E_ARG, "mha: packed keys carry no padding: no mask with k_off");
+  }
   if (bwd) {
     MMNAS_REQUIRE(d->dO && d->dQ && d->dK && d->dV && d->delta && d->O, MMNAS_E_ARG, "mha_bwd: null gradient buffer");
     MMNAS_REQUIRE((((uintptr_t)d->dO | (uintptr_t)d->O) & 15) == 0, MMNAS_E_ARG, "mha_bwd: dO/O alignment");
@@ -950,7 +969,9 @@ extern "C" int mmnas_mha_core_bwd(const mmnas_mha_desc* d, void* stream) {
   ProfScope ps(MMNAS_K_MHA_BWD, 10.0 * bhqk * k.dh,
                4.0 * ((double)k.B * k.H * k.dh * (4.0 * k.Sq + 4.0 * k.Sk) + (k.biasT ? 2.0 * bhqk : 0.0)), st);
   static const bool fused_on = !(getenv("MMNAS_MHA_BWD_FUSED") && getenv("MMNAS_MHA_BWD_FUSED")[0] == '0');
-  if (fused_on && k.dh == 64 && k.Sq <= 128 && k.Sk <= 128 && (((uintptr_t)k.dK | (uintptr_t)k.dV) & 15) == 0) {
+  const bool packed = k.qoff || k.koff;
+  if (packed) MMNAS_REQUIRE((((uintptr_t)k.dK | (uintptr_t)k.dV) & 15) == 0, MMNAS_E_ARG, "mha_bwd: dK / dV alignment (packed rows run the fused kernel only)");
+  if ((fused_on || packed) && k.dh == 64 && k.Sq <= 128 && k.Sk <= 128 && (((uintptr_t)k.dK | (uintptr_t)k.dV) & 15) == 0) {
     k.nch = 1;
     const dim3 grid(k.H, k.B);
     const int nkb = cdiv(k.Sk, 32);

@@ -748,6 +748,83 @@ def test_mha_core(B, H, Sq, Sk, dh, use_mask, use_bias, p):
         assert rel_err(dbT.cpu().numpy(), bt.grad.numpy()) < 1e-4
 
 
+@pytest.mark.parametrize('B,H,Sqm,Skm,packed_q,packed_k,use_bias,p', [
+    (5, 4, 100, 100, True, True, False, 0.0), (5, 4, 100, 100, True, True, True, 0.1), (4, 8, 100, 14, True, False, False, 0.0),
+    (3, 2, 36, 50, True, True, True, 0.0), (6, 4, 14, 14, True, True, False, 0.0), (4, 4, 128, 128, True, True, False, 0.2)])
+def test_mha_core_packed_rows(B, H, Sqm, Skm, packed_q, packed_k, use_bias, p):
+    """Ragged batches without their padding rows (mmnas_mha_desc.q_off / k_off): sequence b owns the packed rows
+    off[b] .. off[b+1]; lse / biasT / the dropout index keep the padded [B,H,...] layout.  Checked sequence by sequence
+    against the fp64 reference of that sequence alone -- which is what the reference computes for the valid rows of a
+    padded batch, its masked keys having probability exactly 0 (modules.py:195-196)."""
+    import ctypes as C
+    import mmnas_amd._lib as L
+    from oracle import dropout_rng
+    rs = np.random.RandomState(B * 7 + H + Sqm + Skm)
+    dh, di = 64, H * 64
+    lq = [int(rs.randint(1, Sqm + 1)) for _ in range(B)]
+    lq[0], lq[-1] = Sqm, 1                       # the longest and the shortest
+    self_att = packed_q and packed_k and Sqm == Skm
+    lk = list(lq) if self_att else [int(rs.randint(1, Skm + 1)) for _ in range(B)]
+    if not packed_q:
+        lq = [Sqm] * B
+    qoff = np.concatenate([[0], np.cumsum(lq)]).astype(np.int32)
+    koff = np.concatenate([[0], np.cumsum(lk)]).astype(np.int32)
+    Nq, Nk = int(qoff[-1]), (int(koff[-1]) if packed_k else B * Skm)
+    Q, dO = rnd(rs, Nq, di), rnd(rs, Nq, di)
+    K, V = rnd(rs, Nk, di), rnd(rs, Nk, di)
+    mask = None
+    if not packed_k:                             # padded keys with their mask (the guided operators: keys = the language stream)
+        mask = np.zeros((B, Skm), np.bool_)
+        for b in range(B):
+            mask[b, lk[b]:] = True
+    biasT = (rnd(rs, B, H, Skm, Sqm) * 2) if use_bias else None
+    seed = 777
+    Qd, Kd, Vd, dOd = g(Q), g(K), g(V), g(dO)
+    bd = g(biasT) if use_bias else None
+    O_ = torch.full((Nq, di), float('nan'), device=DEV)
+    stats = torch.zeros(B, H, Sqm, 2, device=DEV)
+    qo, ko = g(qoff), g(koff)
+    m8 = g(mask.astype(np.uint8)) if mask is not None else None      # (kept alive: the descriptor holds a raw pointer)
+    d = L.MhaDesc()
+    d.B, d.H, d.Sq, d.Sk, d.dh = B, H, Sqm, Skm, dh
+    d.ldq = d.ldk = d.ldv = d.ldo = di
+    d.Q, d.K, d.V, d.mask, d.biasT, d.O, d.lse = (L.fptr(Qd), L.fptr(Kd), L.fptr(Vd), L.ptr(m8),
+                                                 L.fptr(bd), L.fptr(O_), L.fptr(stats))
+    d.q_off = L.ptr(qo) if packed_q else None
+    d.k_off = L.ptr(ko) if packed_k else None
+    d.drop_p, d.drop_site, d.drop_seed = p, 0, seed
+    L.check(L.lib().mmnas_mha_core_fwd(C.byref(d), L.stream()))
+    dQ, dK, dV = torch.full_like(Qd, float('nan')), torch.full_like(Kd, float('nan')), torch.full_like(Vd, float('nan'))
+    dbT = torch.zeros(B, H, Skm, Sqm, device=DEV) if use_bias else None
+    delta = torch.empty(B, H, Sqm, device=DEV)
+    d.dO, d.dQ, d.dK, d.dV, d.dbiasT, d.delta = L.fptr(dOd), L.fptr(dQ), L.fptr(dK), L.fptr(dV), L.fptr(dbT), L.fptr(delta)
+    L.check(L.lib().mmnas_mha_core_bwd(C.byref(d), L.stream()))
+    torch.cuda.synchronize()
+    dm_all = dropout_rng.scaled_mask(seed, 0, (B, H, Sqm, Skm), p) if p > 0 else None
+    Oc, dQc, dKc, dVc = O_.cpu().numpy(), dQ.cpu().numpy(), dK.cpu().numpy(), dV.cpu().numpy()
+    assert np.isfinite(Oc).all() and np.isfinite(dQc).all()
+    for b in range(B):
+        q0, q1 = int(qoff[b]), int(qoff[b + 1])
+        k0, k1 = (int(koff[b]), int(koff[b + 1])) if packed_k else (b * Skm, b * Skm + lk[b])
+        nq, nk = q1 - q0, k1 - k0
+        Qt, Kt, Vt = (torch.from_numpy(a).double().unsqueeze(0).requires_grad_(True) for a in (Q[q0:q1], K[k0:k1], V[k0:k1]))
+        bt = torch.from_numpy(biasT[b:b + 1, :, :nk, :nq].copy()).double().requires_grad_(True) if use_bias else None
+        dm = torch.from_numpy(dm_all[b:b + 1, :, :nq, :nk].copy()).double() if p > 0 else None
+        ref = _mha_ref(Qt, Kt, Vt, None, bt, H, dh, dm)
+        assert rel_err(Oc[q0:q1], ref[0].detach().numpy()) < 1e-5, b
+        ref.backward(torch.from_numpy(dO[q0:q1]).double().unsqueeze(0))
+        assert rel_err(dQc[q0:q1], Qt.grad[0].numpy()) < 1e-4, b
+        assert rel_err(dKc[k0:k1], Kt.grad[0].numpy()) < 1e-4, b
+        assert rel_err(dVc[k0:k1], Vt.grad[0].numpy()) < 1e-4, b
+        if use_bias:
+            assert rel_err(dbT[b, :, :nk, :nq].cpu().numpy(), bt.grad[0].numpy()) < 1e-4, b
+    if packed_k:       # a mask makes no sense beside packed keys: refused
+        mz = g(np.zeros((B, Skm), np.uint8))
+        d.mask = L.ptr(mz)
+        with pytest.raises(L.MMNasHipError):
+            L.check(L.lib().mmnas_mha_core_fwd(C.byref(d), L.stream()))
+
+
 # ----------------------------------------------------------------------------- convs
 @pytest.mark.parametrize('k', [3, 5, 7, 11])
 def test_conv_building_blocks(k):
