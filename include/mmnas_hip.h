@@ -340,6 +340,16 @@ int mmnas_rel_fused_bwd(const float* raw, const float* Wy, const float* by, cons
                         const float* br, const float* dbiasT, float* dWy, float* dby, float* dWr,
                         float* dbr, float* ws, int B, int Sq, int Sk, int C, int R, int H,
                         void* stream);
+/* The same for RAGGED batches (self-attention over the first n_b = off[b+1] - off[b] of the S rows of sample b; off = [B+1]
+ * device prefix sums of the lengths): the padding rows / columns are masked keys resp. rows nothing downstream reads
+ * (hygr_vqa.py:121-122, modules.py:195-196), their bias gradient is exactly zero.  Forward writes biasT[b,h,k,q] for
+ * k, q < n_b only (padded [B,H,S,S] layout); backward reads dbiasT there only and walks the n_b x n_b valid elements of
+ * every sample: tile_off = [B+1] device prefix sums of ceil(n_b^2 / 32), ntiles = their total (host value). */
+int mmnas_rel_fused_fwd_ragged(const float* raw, const float* Wy, const float* by, const float* Wr, const float* br,
+                               float* biasT, int B, int S, int C, int R, int H, const int* off, void* stream);
+int mmnas_rel_fused_bwd_ragged(const float* raw, const float* Wy, const float* by, const float* Wr, const float* br,
+                               const float* dbiasT, float* dWy, float* dby, float* dWr, float* dbr, float* ws,
+                               int B, int S, int C, int R, int H, const int* off, const int* tile_off, int ntiles, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Attention core: MHAtt.att (modules.py:191-199) for all (batch, head) pairs.

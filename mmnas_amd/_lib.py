@@ -155,6 +155,8 @@ SYMBOLS = {
     'mmnas_rel_fused_fwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     'mmnas_rel_fused_bwd_ws_floats': (_sz, [_i, _i, _i]),
     'mmnas_rel_fused_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
+    'mmnas_rel_fused_fwd_ragged': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp]),
+    'mmnas_rel_fused_bwd_ragged': (_i, [_fp] * 11 + [_i, _i, _i, _i, _i, _fp, _fp, _i, _fp]),
     'mmnas_mha_core_fwd': (_i, [C.POINTER(MhaDesc), _fp]),
     'mmnas_mha_core_bwd': (_i, [C.POINTER(MhaDesc), _fp]),
     'mmnas_att_op_plan': (_i, [C.POINTER(AttOp), C.POINTER(Plan)]),

@@ -29,7 +29,23 @@ struct RelFusedK {
   const float* raw; const float* Wy; const float* by; const float* Wr; const float* br;
   float* biasT; const float* dbiasT; float* part;
   int B, Sq, Sk, C, H, nbq, nbk;
+  // RAGGED batches (self-attention over the first n_b of the S rows of sample b, n_b = off[b+1] - off[b]; the rows behind
+  // are padding whose bias nobody reads and whose bias gradient is exactly zero): forward skips them; backward walks only
+  // the n_b x n_b valid elements of every sample -- tile t of sample b covers valid elements 32 t .. 32 t + 31, element
+  // f' = (key f' / n_b, query f' % n_b); toff[b] = first tile of sample b, toff[B] = the tile count.  NULL: all S x S.
+  const int* off; const int* toff;
 };
+
+// (ragged) tile T of the whole batch -> sample and tile inside it; sample = B when T lies behind the last tile
+__device__ __forceinline__ void rf_locate(const RelFusedK& p, int T, int ntiles, int& b, int& tb) {
+  if (T >= ntiles) { b = p.B; tb = 0; return; }
+  int lo = 0, hi = p.B;          // toff[lo] <= T < toff[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (p.toff[mid] <= T) lo = mid; else hi = mid;
+  }
+  b = lo; tb = T - p.toff[lo];
+}
 
 // element owned by a thread of workgroup-batch `batch`: 64 consecutive q x 4 consecutive k of one b
 __device__ __forceinline__ bool rf_coords(const RelFusedK& p, long batch, int tid, int& b, int& q, int& k) {
@@ -65,7 +81,12 @@ __global__ void __launch_bounds__(256) rel_fused_fwd_kernel(const RelFusedK p, c
                                                             const float* __restrict__ by, const float* __restrict__ Wr,
                                                             const float* __restrict__ br) {
   int b, q, k;
-  const bool ok = rf_coords(p, blockIdx.x, threadIdx.x, b, q, k);
+  bool ok = rf_coords(p, blockIdx.x, threadIdx.x, b, q, k);
+  if (p.off) {   // ragged: elements of padding rows / columns are never read
+    const int n = p.off[b + 1] - p.off[b];
+    ok = ok && q < n && k < n;
+    if (!ok) return;
+  }
   float rawv[C], hid[RF_R];
   rf_hidden<C>(p, Wy, by, ok, b, q, k, rawv, hid);
   if (!ok) return;
@@ -172,10 +193,18 @@ rel_fused_bwd_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const float
   auto tile_load = [&](int b, int tb, float* ex, float (*dbv)[4]) {
     // element of this lane: b, flattened f = k * Sq + q (dbiasT is contiguous in f)
     const unsigned f = (unsigned)tb * 32u + (unsigned)l31;
-    const bool ok = b < p.B && f < SS;
-    const unsigned fc = ok ? f : 0u;
+    bool ok = b < p.B && f < SS;
+    unsigned wq = (unsigned)p.Sq;            // row length of the flattened (key, query) index f
+    if (p.off) {                             // ragged: f runs over the n x n valid elements of the sample
+      const int bb = b < p.B ? b : 0;
+      const unsigned n = (unsigned)max(p.off[bb + 1] - p.off[bb], 1);
+      ok = b < p.B && f < n * n && p.off[bb + 1] > p.off[bb];
+      wq = n;
+    }
+    const unsigned fc0 = ok ? f : 0u;
     const int bc = ok ? b : 0;
-    const unsigned k = fc / (unsigned)p.Sq, q = fc - k * (unsigned)p.Sq;
+    const unsigned k = fc0 / wq, q = fc0 - k * wq;
+    const unsigned fc = k * (unsigned)p.Sq + q;   // position in the padded [Sk, Sq] plane of dbiasT
     const float* src = p.raw + (((size_t)bc * p.Sq + q) * p.Sk + k) * C;
 #pragma unroll
     for (int c = 0; c < RF_CP; ++c) ex[c] = 0.f;
@@ -196,12 +225,14 @@ rel_fused_bwd_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const float
   int cb = tile / tiles_per_b, ct = tile - cb * tiles_per_b;           // this tile
   int nb_ = cb + adv_b, nt_ = ct + adv_t;                              // the next one of this wave
   if (nt_ >= tiles_per_b) { nt_ -= tiles_per_b; ++nb_; }
+  if (p.toff) { rf_locate(p, tile, ntiles, cb, ct); rf_locate(p, tile + nwaves, ntiles, nb_, nt_); }
   tile_load(cb, ct, ext, db);
   for (; tile < ntiles; tile += nwaves) {
     float ext_n[RF_CP], db_n[NG][4];
     tile_load(nb_, nt_, ext_n, db_n);   // in flight during this tile's MFMA chain
     nb_ += adv_b; nt_ += adv_t;
     if (nt_ >= tiles_per_b) { nt_ -= tiles_per_b; ++nb_; }
+    if (p.toff) rf_locate(p, tile + 2 * nwaves, ntiles, nb_, nt_);
     // 1. hidden layer (transposed: rows j, columns e)
     f32x16 hid[2];
 #pragma unroll
@@ -496,10 +527,18 @@ rel_fused_bwd_v_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const flo
   auto tile_load = [&](int b, int tb) __attribute__((always_inline)) {
     TileIn t;
     const unsigned f = (unsigned)tb * 32u + (unsigned)l31;
-    const bool ok = b < p.B && f < SS;
-    const unsigned fc = ok ? f : 0u;
+    bool ok = b < p.B && f < SS;
+    unsigned wq = (unsigned)p.Sq;            // row length of the flattened (key, query) index f
+    if (p.off) {                             // ragged: f runs over the n x n valid elements of the sample
+      const int bb = b < p.B ? b : 0;
+      const unsigned n = (unsigned)max(p.off[bb + 1] - p.off[bb], 1);
+      ok = b < p.B && f < n * n && p.off[bb + 1] > p.off[bb];
+      wq = n;
+    }
+    const unsigned fc0 = ok ? f : 0u;
     const int bc = ok ? b : 0;
-    const unsigned k = fc / (unsigned)p.Sq, q = fc - k * (unsigned)p.Sq;
+    const unsigned k = fc0 / wq, q = fc0 - k * wq;
+    const unsigned fc = k * (unsigned)p.Sq + q;   // position in the padded [Sk, Sq] plane of dbiasT
     const float* src = p.raw + (((size_t)bc * p.Sq + q) * p.Sk + k) * C;
 #pragma unroll
     for (int c = 0; c < RF_CP; ++c) t.ex[c] = 0.f;
@@ -518,11 +557,13 @@ rel_fused_bwd_v_kernel(const RelFusedK p, int ntiles, int tiles_per_b, const flo
   int cb = tile / tiles_per_b, ct = tile - cb * tiles_per_b;
   int nb_ = cb + adv_b, nt_ = ct + adv_t;
   if (nt_ >= tiles_per_b) { nt_ -= tiles_per_b; ++nb_; }
+  if (p.toff) { rf_locate(p, tile, ntiles, cb, ct); rf_locate(p, tile + nwaves, ntiles, nb_, nt_); }
   TileIn cur = tile_load(cb, ct);
   for (; tile < ntiles; tile += nwaves) {
     const TileIn nxt = tile_load(nb_, nt_);   // in flight during this tile's arithmetic
     nb_ += adv_b; nt_ += adv_t;
     if (nt_ >= tiles_per_b) { nt_ -= tiles_per_b; ++nb_; }
+    if (p.toff) rf_locate(p, tile + 2 * nwaves, ntiles, nb_, nt_);
     // 1. hidden layer (transposed: rows j, columns e); relu, and its gate as one bit per accumulator register
     f32x16 hid[2];
     unsigned gm = 0u;
@@ -733,14 +774,16 @@ using namespace mmnas;
 
 extern "C" int mmnas_rel_fused_supported(int C, int R, int H) { return R == RF_R && (C == 3 || C == 4) && H >= 1 && H <= RF_HP; }
 
-extern "C" int mmnas_rel_fused_fwd(const float* raw, const float* Wy, const float* by, const float* Wr, const float* br,
-                                   float* biasT, int B, int Sq, int Sk, int C, int R, int H, void* stream) {
+static int rf_fwd_impl(const float* raw, const float* Wy, const float* by, const float* Wr, const float* br,
+                       float* biasT, int B, int Sq, int Sk, int C, int R, int H, const int* off, void* stream) {
   MMNAS_REQUIRE(raw && Wy && by && Wr && br && biasT, MMNAS_E_ARG, "rel_fused_fwd: null pointer");
   int rc = rf_check("rel_fused_fwd", B, Sq, Sk, C, R, H);
   if (rc) return rc;
   RelFusedK k;
   k.raw = raw; k.Wy = Wy; k.by = by; k.Wr = Wr; k.br = br; k.biasT = biasT; k.dbiasT = nullptr; k.part = nullptr;
   k.B = B; k.Sq = Sq; k.Sk = Sk; k.C = C; k.H = H; k.nbq = cdiv(Sq, 64); k.nbk = cdiv(Sk, 4);
+  k.off = off; k.toff = nullptr;
+  if (off) MMNAS_REQUIRE(Sq == Sk, MMNAS_E_SHAPE, "rel_fused_fwd: ragged batches are self-attention (Sq == Sk)");
   const long nbatch = (long)B * k.nbq * k.nbk;
   hipStream_t st = (hipStream_t)stream;
   const double n = (double)B * Sq * Sk;
@@ -750,13 +793,23 @@ extern "C" int mmnas_rel_fused_fwd(const float* raw, const float* Wy, const floa
   return check_launch("rel_fused_fwd");
 }
 
+extern "C" int mmnas_rel_fused_fwd(const float* raw, const float* Wy, const float* by, const float* Wr, const float* br,
+                                   float* biasT, int B, int Sq, int Sk, int C, int R, int H, void* stream) {
+  return rf_fwd_impl(raw, Wy, by, Wr, br, biasT, B, Sq, Sk, C, R, H, nullptr, stream);
+}
+extern "C" int mmnas_rel_fused_fwd_ragged(const float* raw, const float* Wy, const float* by, const float* Wr, const float* br,
+                                          float* biasT, int B, int S, int C, int R, int H, const int* off, void* stream) {
+  MMNAS_REQUIRE(off, MMNAS_E_ARG, "rel_fused_fwd_ragged: null offsets");
+  return rf_fwd_impl(raw, Wy, by, Wr, br, biasT, B, S, S, C, R, H, off, stream);
+}
+
 extern "C" size_t mmnas_rel_fused_bwd_ws_floats(int B, int Sq, int Sk) {
   return (size_t)rf_grid((long)B * rf_tiles_per_b(Sq, Sk), 2) * RF_ROW;
 }
 
-extern "C" int mmnas_rel_fused_bwd(const float* raw, const float* Wy, const float* by, const float* Wr, const float* br,
-                                   const float* dbiasT, float* dWy, float* dby, float* dWr, float* dbr, float* ws,
-                                   int B, int Sq, int Sk, int C, int R, int H, void* stream) {
+static int rf_bwd_impl(const float* raw, const float* Wy, const float* by, const float* Wr, const float* br,
+                       const float* dbiasT, float* dWy, float* dby, float* dWr, float* dbr, float* ws,
+                       int B, int Sq, int Sk, int C, int R, int H, const int* off, const int* toff, int ntiles_ragged, void* stream) {
   MMNAS_REQUIRE(raw && Wy && by && Wr && br && dbiasT && dWy && dby && dWr && dbr && ws, MMNAS_E_ARG,
                 "rel_fused_bwd: null pointer");
   int rc = rf_check("rel_fused_bwd", B, Sq, Sk, C, R, H);
@@ -766,10 +819,13 @@ extern "C" int mmnas_rel_fused_bwd(const float* raw, const float* Wy, const floa
   k.B = B; k.Sq = Sq; k.Sk = Sk; k.C = C; k.H = H; k.nbq = cdiv(Sq, 64); k.nbk = cdiv(Sk, 4);
   const int tpb = (int)rf_tiles_per_b(Sq, Sk);
   MMNAS_REQUIRE((long)B * tpb < (1l << 30) && (long)Sq * Sk < (1l << 30), MMNAS_E_SHAPE, "rel_fused_bwd: problem too large for 32-bit tile indices");
-  const int ntiles = B * tpb;
+  k.off = off; k.toff = toff;
+  if (off) MMNAS_REQUIRE(toff && Sq == Sk && ntiles_ragged >= 0 && ntiles_ragged <= B * tpb, MMNAS_E_ARG,
+                         "rel_fused_bwd: ragged batches need tile offsets, Sq == Sk and a tile count <= the dense one (%d vs %d)", ntiles_ragged, B * tpb);
+  const int ntiles = off ? ntiles_ragged : B * tpb;
   static const bool vpath = !(getenv("MMNAS_REL_BWD_VALU") && getenv("MMNAS_REL_BWD_VALU")[0] == '0');   // 0: the all-MFMA kernel (A/B runs)
   const bool use_v = H <= 4 && vpath;
-  const int grid = rf_grid(ntiles, 2);
+  const int grid = rf_grid(ntiles > 0 ? ntiles : 1, 2);
   hipStream_t st = (hipStream_t)stream;
   const double n = (double)B * Sq * Sk;
   ProfScope ps(MMNAS_K_REL_BWD, 2.0 * n * (RF_R * (C + 1) + 3.0 * H * RF_R + RF_R * (C + 1)), 4.0 * n * (C + H), st);
@@ -786,4 +842,16 @@ extern "C" int mmnas_rel_fused_bwd(const float* raw, const float* Wy, const floa
 #undef RF_BWDV
   MMNAS_LAUNCH(rel_fused_reduce_kernel, dim3(cdiv(RF_ROW, 64)), dim3(1024), 0, st, ws, grid, C, H, dWr, dbr, dWy, dby);
   return check_launch("rel_fused_bwd");
+}
+
+extern "C" int mmnas_rel_fused_bwd(const float* raw, const float* Wy, const float* by, const float* Wr, const float* br,
+                                   const float* dbiasT, float* dWy, float* dby, float* dWr, float* dbr, float* ws,
+                                   int B, int Sq, int Sk, int C, int R, int H, void* stream) {
+  return rf_bwd_impl(raw, Wy, by, Wr, br, dbiasT, dWy, dby, dWr, dbr, ws, B, Sq, Sk, C, R, H, nullptr, nullptr, 0, stream);
+}
+extern "C" int mmnas_rel_fused_bwd_ragged(const float* raw, const float* Wy, const float* by, const float* Wr, const float* br,
+                                          const float* dbiasT, float* dWy, float* dby, float* dWr, float* dbr, float* ws,
+                                          int B, int S, int C, int R, int H, const int* off, const int* tile_off, int ntiles, void* stream) {
+  MMNAS_REQUIRE(off && tile_off, MMNAS_E_ARG, "rel_fused_bwd_ragged: null offsets");
+  return rf_bwd_impl(raw, Wy, by, Wr, br, dbiasT, dWy, dby, dWr, dbr, ws, B, S, S, C, R, H, off, tile_off, ntiles, stream);
 }

@@ -610,6 +610,55 @@ def test_rel_fused_lazy_handle(B, Sq, Sk, C, H):
     assert rel_err(dby.cpu().numpy(), byt.grad.numpy()) < wtol
 
 
+@pytest.mark.parametrize('B,S,C,H,lens', [(4, 100, 4, 4, [100, 37, 10, 1]), (3, 100, 4, 8, [64, 100, 33]), (5, 14, 3, 4, [14, 3, 7, 1, 9]),
+                                         (2, 36, 4, 16, [36, 20])])
+def test_rel_fused_ragged(B, S, C, H, lens):
+    """mmnas_rel_fused_fwd_ragged / _bwd_ragged: the lazy relation handle over the valid n_b x n_b corner of every sample.
+    Forward equals the dense call there (and touches nothing else); backward equals the dense call on a bias gradient that
+    is zero outside the corners -- what the attention backward of a padded batch produces."""
+    import mmnas_amd._lib as L
+    rs = np.random.RandomState(B * 17 + S + H + C)
+    R = 64
+    raw = rnd(rs, B, S, S, C)
+    Wy, by = rnd(rs, R, C) / 2, 0.1 * rnd(rs, R)
+    Wr, br = rnd(rs, H, R) / 8, 0.1 * rnd(rs, H)
+    gb = rnd(rs, B, H, S, S)
+    valid = np.zeros((B, 1, S, S), np.float32)
+    for b, n in enumerate(lens):
+        valid[b, :, :n, :n] = 1
+    gb_dense = gb * valid
+    rawd, Wyd, byd, Wrd, brd = g(raw), g(Wy), g(by), g(Wr), g(br)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    toff = np.concatenate([[0], np.cumsum([(n * n + 31) // 32 for n in lens])]).astype(np.int32)
+    offd, toffd = g(off), g(toff)
+    dense = torch.empty(B, H, S, S, device=DEV)
+    L.check(L.lib().mmnas_rel_fused_fwd(L.fptr(rawd), L.fptr(Wyd), L.fptr(byd), L.fptr(Wrd), L.fptr(brd), L.fptr(dense), B, S, S, C, R, H, L.stream()))
+    rag = torch.full((B, H, S, S), 12345.0, device=DEV)
+    L.check(L.lib().mmnas_rel_fused_fwd_ragged(L.fptr(rawd), L.fptr(Wyd), L.fptr(byd), L.fptr(Wrd), L.fptr(brd), L.fptr(rag), B, S, C, R, H,
+                                               L.ptr(offd), L.stream()))
+    v = torch.from_numpy(valid).to(DEV).bool().expand(B, H, S, S)
+    assert torch.equal(rag[v], dense[v]) and bool((rag[~v] == 12345.0).all())
+    outs = []
+    for ragged in (False, True):
+        dWy, dby = torch.zeros(R, C, device=DEV), torch.zeros(R, device=DEV)
+        dWr, dbr = torch.zeros(H, R, device=DEV), torch.zeros(H, device=DEV)
+        ws = torch.empty(L.lib().mmnas_rel_fused_bwd_ws_floats(B, S, S), device=DEV)
+        if ragged:
+            gbd = g(np.where(valid > 0, gb, np.nan).astype(np.float32))      # outside the corners: never read
+            L.check(L.lib().mmnas_rel_fused_bwd_ragged(L.fptr(rawd), L.fptr(Wyd), L.fptr(byd), L.fptr(Wrd), L.fptr(brd), L.fptr(gbd),
+                                                       L.fptr(dWy), L.fptr(dby), L.fptr(dWr), L.fptr(dbr), L.fptr(ws), B, S, C, R, H,
+                                                       L.ptr(offd), L.ptr(toffd), int(toff[-1]), L.stream()))
+        else:
+            gbd = g(gb_dense)
+            L.check(L.lib().mmnas_rel_fused_bwd(L.fptr(rawd), L.fptr(Wyd), L.fptr(byd), L.fptr(Wrd), L.fptr(brd), L.fptr(gbd),
+                                                L.fptr(dWy), L.fptr(dby), L.fptr(dWr), L.fptr(dbr), L.fptr(ws), B, S, S, C, R, H, L.stream()))
+        torch.cuda.synchronize()
+        outs.append([t.cpu().numpy() for t in (dWy, dby, dWr, dbr)])
+    for a, c in zip(outs[1], outs[0]):
+        assert np.isfinite(a).all()
+        assert rel_err(a, c) < 2e-4         # (another summation order over the same terms)
+
+
 # ----------------------------------------------------------------------------- stem / head helpers
 @pytest.mark.parametrize('shape', [(64, 100, 2048), (3, 7, 5), (2, 9, 36), (1, 1, 4)])
 def test_row_is_zero_is_make_mask(shape):
