@@ -421,6 +421,16 @@ typedef struct mmnas_att_op {
   int C;
   const float* Wy; const float* by;                    /* [R,C], [R] */
   float* dWy; float* dby;                              /* accumulated (+=) */
+  /* PACKED rows (ragged batches without their padding rows; see mmnas_mha_desc.q_off): q_off != NULL -- xq / y / dy / dxq
+   * hold Mq = q_off[B] rows, sample b owning rows q_off[b] .. q_off[b+1]; Sq is the maximum length.  k_off / Mk likewise
+   * for xkv / dxkv (MMNAS_F_SELF: k_off = q_off; a guided operator keeps padded keys + mask: k_off = NULL).  With packed
+   * keys there is no mask.  MMNAS_F_REL then needs MMNAS_F_RELRAW + MMNAS_F_SELF and the relation tiles of
+   * mmnas_rel_fused_bwd_ragged (rel_tile_off [B+1] device, rel_ntiles host).  Sequences are prefixes: sample b's valid
+   * rows are 0 .. n_b - 1 of its S. */
+  const int* q_off; const int* k_off;
+  int Mq, Mk;
+  const int* rel_tile_off;
+  int rel_ntiles, reserved2;
 } mmnas_att_op;
 
 typedef struct mmnas_plan {
@@ -516,6 +526,16 @@ typedef struct mmnas_chain {
   int mixed, gate_width;
   const float* gate;
   float* dgate;
+  /* RAGGED decoder stream: y_off != NULL -- y_in / y_out / dy_out / dy_in hold Ny = y_off[B] PACKED rows (sample b: rows
+   * y_off[b] .. y_off[b+1], its first n_b regions; the caller packs and unpacks), every decoder operator runs on Ny rows,
+   * self-attention over a sample's own rows without a mask, guided attention from packed queries to the padded language
+   * keys (x_mask).  The padding rows of the reference's decoder stream are masked as keys everywhere and dropped by
+   * AttFlat's mask (hygr_vqa.py:113-122, modules.py:78-84,195-196): no logit and no parameter gradient depends on
+   * them.  y_mask is ignored; y_rel stays the padded raw [B,Sy,Sy,C] tensor; y_tile_off / y_ntiles: see
+   * mmnas_rel_fused_bwd_ragged. */
+  const int* y_off;
+  const int* y_tile_off;
+  int Ny, y_ntiles;
 } mmnas_chain;
 int mmnas_chain_plan(const mmnas_chain* c, size_t* arena_bytes);   /* host only */
 int mmnas_chain_fwd(const mmnas_chain* c, void* stream);
@@ -595,6 +615,11 @@ int mmnas_pack_segments(const mmnas_segment* segs, int nseg, float* staging, flo
                         int direction, void* stream);
 /* Same, with `segs` a HOST array read at call time and carried in the kernel arguments (chunks of 96 records):
  * no host->device copy of the table, hence no stream synchronisation per step. */
+/* Ragged batches: padded [B, S, d] <-> packed [off[B], d] rows; sample b's valid rows are its first off[b+1] - off[b] (the
+ * loaders pad region features behind the detected boxes, load_data_vqa.py:221-246).  unpack writes zeros into the padding
+ * rows.  d % 4 == 0.  Used around mmnas_chain with y_off. */
+int mmnas_pack_rows(const float* x, const int* off, float* packed, int B, int S, int d, void* stream);
+int mmnas_unpack_rows(const float* packed, const int* off, float* x, int B, int S, int d, void* stream);
 int mmnas_pack_segments_host(const mmnas_segment* segs_host, int nseg, float* staging, float scale,
                              int direction, void* stream);
 

@@ -51,7 +51,8 @@ class AttOp(C.Structure):
                 ('dy', _fp), ('dxq', _fp), ('dxkv', _fp), ('drel', _fp),
                 ('dWq', _fp), ('dWk', _fp), ('dWv', _fp), ('dWm', _fp), ('dWr', _fp), ('dbr', _fp),
                 ('dln_a', _fp), ('dln_b', _fp),
-                ('C', C.c_int), ('Wy', _fp), ('by', _fp), ('dWy', _fp), ('dby', _fp)]
+                ('C', C.c_int), ('Wy', _fp), ('by', _fp), ('dWy', _fp), ('dby', _fp),
+                ('q_off', _fp), ('k_off', _fp), ('Mq', C.c_int), ('Mk', C.c_int), ('rel_tile_off', _fp), ('rel_ntiles', C.c_int), ('reserved2', C.c_int)]
 
 
 class Plan(C.Structure):
@@ -76,7 +77,8 @@ class Chain(C.Structure):
                 ('d', C.c_int), ('x_in', _fp), ('y_in', _fp), ('x_mask', _fp), ('y_mask', _fp), ('x_rel', _fp),
                 ('y_rel', _fp), ('arena', _fp), ('x_out', _fp), ('y_out', _fp), ('dx_out', _fp), ('dy_out', _fp),
                 ('dx_in', _fp), ('dy_in', _fp), ('use_side_stream', C.c_int), ('reserved', C.c_int),
-                ('marks', C.c_void_p), ('mixed', C.c_int), ('gate_width', C.c_int), ('gate', _fp), ('dgate', _fp)]
+                ('marks', C.c_void_p), ('mixed', C.c_int), ('gate_width', C.c_int), ('gate', _fp), ('dgate', _fp),
+                ('y_off', _fp), ('y_tile_off', _fp), ('Ny', C.c_int), ('y_ntiles', C.c_int)]
 
 
 CHAIN_MAX_OPS = 128
@@ -175,6 +177,8 @@ SYMBOLS = {
     'mmnas_bce_logits_sum_fwd': (_i, [_fp, _fp, _fp, _sz, _fp]),
     'mmnas_bce_logits_bwd': (_i, [_fp, _fp, _fp, _fp, _sz, _fp]),
     'mmnas_im2col_seq': (_i, [_fp, _fp, _i, _i, _i, _i, _fp]),
+    'mmnas_pack_rows': (_i, [_fp, _fp, _fp, _i, _i, _i, _fp]),
+    'mmnas_unpack_rows': (_i, [_fp, _fp, _fp, _i, _i, _i, _fp]),
     'mmnas_pad_seq': (_i, [_fp, _fp, _i, _i, _i, _i, _i, C.c_long, _fp]),
     'mmnas_col2im_seq': (_i, [_fp, _fp, _i, _i, _i, _i, _fp]),
     'mmnas_dwconv_seq_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),

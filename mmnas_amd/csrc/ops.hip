@@ -39,7 +39,8 @@ struct AttLayout {
 
 static AttLayout att_layout(const mmnas_att_op* op) {
   AttLayout L;
-  L.Mq = (size_t)op->B * op->Sq; L.Mk = (size_t)op->B * op->Sk;
+  L.Mq = op->q_off ? (size_t)op->Mq : (size_t)op->B * op->Sq;     // (packed rows: the sum of the sequences' lengths)
+  L.Mk = op->k_off ? (size_t)op->Mk : (size_t)op->B * op->Sk;
   const bool norm = op->flags & MMNAS_F_NORM, rel = op->flags & MMNAS_F_REL;
   const bool drop = (op->flags & MMNAS_F_TRAIN) && op->drop_p > 0.f;
   Carver s(op->save);
@@ -74,6 +75,15 @@ static int att_check(const mmnas_att_op* op, const char* who) {
   MMNAS_REQUIRE(op->d % 4 == 0 && op->di % 4 == 0, MMNAS_E_SHAPE, "%s: d=%d di=%d must be multiples of 4", who,
                 op->d, op->di);
   if (op->flags & MMNAS_F_SELF) MMNAS_REQUIRE(op->Sq == op->Sk, MMNAS_E_SHAPE, "%s: SELF needs Sq == Sk", who);
+  if (op->q_off || op->k_off) {   // packed rows
+    MMNAS_REQUIRE(op->q_off && op->Mq > 0 && op->Mq <= op->B * op->Sq, MMNAS_E_ARG, "%s: packed rows: q_off / Mq=%d", who, op->Mq);
+    MMNAS_REQUIRE(!op->k_off || (op->Mk > 0 && op->Mk <= op->B * op->Sk), MMNAS_E_ARG, "%s: packed rows: Mk=%d", who, op->Mk);
+    if (op->flags & MMNAS_F_SELF) MMNAS_REQUIRE(op->k_off == op->q_off && op->Mk == op->Mq, MMNAS_E_ARG, "%s: packed SELF needs k_off == q_off", who);
+    MMNAS_REQUIRE(!(op->k_off && (op->flags & MMNAS_F_MASK)), MMNAS_E_ARG, "%s: packed keys carry no mask", who);
+    if (op->flags & MMNAS_F_REL)
+      MMNAS_REQUIRE((op->flags & MMNAS_F_RELRAW) && (op->flags & MMNAS_F_SELF) && op->rel_tile_off && op->rel_ntiles >= 0, MMNAS_E_ARG,
+                    "%s: a relation bias on packed rows needs the lazy handle (RELRAW), SELF and the relation tile offsets", who);
+  }
   return MMNAS_OK;
 }
 
@@ -123,8 +133,10 @@ static int att_core_fwd(const mmnas_att_op* op, const AttLayout& L, void* stream
   if (rel) {
     if (fl & MMNAS_F_RELRAW) {  // lazy handle: bias straight from the raw [B,Sq,Sk,C] relations
       MMNAS_REQUIRE(op->Wy && op->by, MMNAS_E_ARG, "att_op_fwd: RELRAW without Wy/by");
-      rc = mmnas_rel_fused_fwd(op->rel, op->Wy, op->by, op->Wr, op->br, L.biasT, op->B, op->Sq, op->Sk, op->C, op->R,
-                               op->H, stream);
+      rc = op->q_off ? mmnas_rel_fused_fwd_ragged(op->rel, op->Wy, op->by, op->Wr, op->br, L.biasT, op->B, op->Sq, op->C, op->R,
+                                                  op->H, op->q_off, stream)
+                     : mmnas_rel_fused_fwd(op->rel, op->Wy, op->by, op->Wr, op->br, L.biasT, op->B, op->Sq, op->Sk, op->C, op->R,
+                                           op->H, stream);
     } else {
       rc = mmnas_rel_bias_fwd(op->rel, op->Wr, op->br, L.biasT, op->B, op->Sq, op->Sk, op->R, op->H, stream);
     }
@@ -136,6 +148,7 @@ static int att_core_fwd(const mmnas_att_op* op, const AttLayout& L, void* stream
   m.ldq = m.ldk = m.ldv = m.ldo = di;
   m.Q = L.Q; m.K = L.K; m.V = L.V; m.mask = (fl & MMNAS_F_MASK) ? op->mask : nullptr; m.biasT = L.biasT;
   m.O = L.att; m.lse = L.stats;
+  m.q_off = op->q_off; m.k_off = op->k_off;
   m.drop_p = drop ? op->drop_p : 0.f; m.drop_site = 0; m.drop_seed = op->seed;
   return mmnas_mha_core_fwd(&m, stream);
 }
@@ -271,6 +284,7 @@ static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* s
   m.O = L.att; m.lse = L.stats;
   m.drop_p = drop ? op->drop_p : 0.f; m.drop_site = 0; m.drop_seed = op->seed;
   m.dO = L.datt; m.dQ = L.dQ; m.dK = L.dK; m.dV = L.dV; m.dbiasT = L.dbiasT; m.delta = L.delta;
+  m.q_off = op->q_off; m.k_off = op->k_off;
   if ((rc = mmnas_mha_core_bwd(&m, stream))) return rc;
 
   // 5. + 6. projection weight gradients and input gradients (+ the residual branch dz), pairwise in one launch
@@ -332,6 +346,9 @@ static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* s
     float* const dbiasT = L.dbiasT;
     float* const relws = L.relws;
     auto relb = [o, dbiasT, relws](hipStream_t s) {
+      if (o.q_off)
+        return mmnas_rel_fused_bwd_ragged(o.rel, o.Wy, o.by, o.Wr, o.br, dbiasT, o.dWy, o.dby, o.dWr, o.dbr, relws, o.B, o.Sq,
+                                          o.C, o.R, o.H, o.q_off, o.rel_tile_off, o.rel_ntiles, s);
       return mmnas_rel_fused_bwd(o.rel, o.Wy, o.by, o.Wr, o.br, dbiasT, o.dWy, o.dby, o.dWr, o.dbr, relws, o.B, o.Sq, o.Sk,
                                  o.C, o.R, o.H, s);
     };
@@ -560,6 +577,8 @@ static int chain_check(const mmnas_chain* c, const char* who) {
   MMNAS_REQUIRE(c && c->ops, MMNAS_E_ARG, "%s: null chain", who);
   MMNAS_REQUIRE(c->n_ops >= 1 && c->n_ops <= MMNAS_CHAIN_MAX_OPS, MMNAS_E_SHAPE, "%s: %d operators (1..%d)", who, c->n_ops, MMNAS_CHAIN_MAX_OPS);
   MMNAS_REQUIRE(c->B > 0 && c->Sx > 0 && c->Sy > 0 && c->d > 0, MMNAS_E_SHAPE, "%s: B=%d Sx=%d Sy=%d d=%d", who, c->B, c->Sx, c->Sy, c->d);
+  if (c->y_off) MMNAS_REQUIRE(c->Ny > 0 && c->Ny <= c->B * c->Sy && c->Sy <= 128 && !c->use_side_stream, MMNAS_E_ARG,
+                              "%s: ragged decoder stream: Ny=%d of B*Sy=%d rows, Sy=%d <= 128, single stream", who, c->Ny, c->B * c->Sy, c->Sy);
   bool seen_y = false;
   for (int i = 0; i < c->n_ops; ++i) {
     const mmnas_chain_op& o = c->ops[i];
@@ -592,6 +611,9 @@ static int chain_check(const mmnas_chain* c, const char* who) {
   return MMNAS_OK;
 }
 
+// rows of the decoder stream: B * Sy, or the packed row count of a ragged batch
+static inline size_t chain_rows_y(const mmnas_chain* c) { return c->y_off ? (size_t)c->Ny : (size_t)c->B * c->Sy; }
+
 // operator i with its stream-dependent fields filled in (shapes, masks, relation tensors); buffers come later
 static void chain_op_setup(const mmnas_chain* c, int i, mmnas_att_op& a, mmnas_mlp_op& m) {
   const mmnas_chain_op& o = c->ops[i];
@@ -602,12 +624,17 @@ static void chain_op_setup(const mmnas_chain* c, int i, mmnas_att_op& a, mmnas_m
     const bool self = a.flags & MMNAS_F_SELF;
     a.Sk = self ? S : c->Sx;
     const uint8_t* mask = (self && o.on_y) ? c->y_mask : c->x_mask;
+    a.q_off = a.k_off = nullptr; a.Mq = a.Mk = 0; a.rel_tile_off = nullptr; a.rel_ntiles = 0;
+    if (o.on_y && c->y_off) {   // ragged decoder stream: packed queries; self-attention over the sample's own packed rows
+      a.q_off = c->y_off; a.Mq = c->Ny;
+      if (self) { a.k_off = c->y_off; a.Mk = c->Ny; mask = nullptr; a.rel_tile_off = c->y_tile_off; a.rel_ntiles = c->y_ntiles; }
+    }
     a.mask = mask;
     if (mask) a.flags |= MMNAS_F_MASK; else a.flags &= ~MMNAS_F_MASK;
     if (a.flags & MMNAS_F_REL) a.rel = o.on_y ? c->y_rel : c->x_rel;
   } else {
     m = o.mlp;
-    m.M = c->B * S;
+    m.M = (o.on_y && c->y_off) ? c->Ny : c->B * S;
   }
 }
 
@@ -620,7 +647,7 @@ static int chain_layout(const mmnas_chain* c, ChainLayout& L) {
     if (c->ops[i].on_y) { if (L.first_y < 0) L.first_y = i; L.last_y = i; }
     else { if (L.first_x < 0) L.first_x = i; L.last_x = i; }
   }
-  const size_t nx = (size_t)c->B * c->Sx * c->d * sizeof(float), ny = (size_t)c->B * c->Sy * c->d * sizeof(float);
+  const size_t nx = (size_t)c->B * c->Sx * c->d * sizeof(float), ny = chain_rows_y(c) * c->d * sizeof(float);
   for (int i = 0; i < c->n_ops; ++i) {
     const mmnas_chain_op& o = c->ops[i];
     mmnas_att_op a; mmnas_mlp_op m;
@@ -780,7 +807,7 @@ static int chain_fwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
   char* base = (char*)c->arena;
   const float* cur_x = c->x_in;
   const float* cur_y = c->y_in;
-  const size_t nx = (size_t)c->B * c->Sx * c->d * sizeof(float), ny = (size_t)c->B * c->Sy * c->d * sizeof(float);
+  const size_t nx = (size_t)c->B * c->Sx * c->d * sizeof(float), ny = chain_rows_y(c) * c->d * sizeof(float);
   int rc;
   for (int i0 = 0; i0 < c->n_ops;) {
     int i1 = i0;
@@ -870,7 +897,7 @@ static int chain_fwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
     }
     // (candidates of the node that were not evaluated -- mode 'two' -- stay NULL: no term in the sum, no gate gradient)
     float* out = i0 == L.last_x ? c->x_out : (i0 == L.last_y ? c->y_out : (float*)(base + L.nout[i0]));
-    const int M = c->B * (oy ? c->Sy : c->Sx);
+    const int M = oy ? (int)chain_rows_y(c) : c->B * c->Sx;
     if ((rc = mmnas_node_mix_fwd(zs, as, bs, width, c->gate + (size_t)c->ops[i0].node * c->gate_width, out, M, c->d, eps, st))) return rc;
     if (oy) cur_y = out; else cur_x = out;
     i0 = i1;
@@ -883,7 +910,7 @@ static int chain_fwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
 static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayout& L) {
   MMNAS_REQUIRE(c->dgate, MMNAS_E_ARG, "chain_bwd: mixed chain without a gate-gradient block");
   char* base = (char*)c->arena;
-  const size_t ex = (size_t)c->B * c->Sx * c->d, ey = (size_t)c->B * c->Sy * c->d;
+  const size_t ex = (size_t)c->B * c->Sx * c->d, ey = chain_rows_y(c) * c->d;
   float* dpre = (float*)(base + L.dpre);
   int rc;
   if (L.n_guided && hipMemsetAsync(dpre, 0, ex * sizeof(float), st) != hipSuccess) return MMNAS_E_LAUNCH;
@@ -926,7 +953,7 @@ static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
     }
     const float* nin = input_of(k);
     float* dact = (float*)(base + L.ndact[i0]);
-    const int M = c->B * (oy ? c->Sy : c->Sx);
+    const int M = oy ? (int)chain_rows_y(c) : c->B * c->Sx;
     const size_t grow = (size_t)c->ops[i0].node * c->gate_width;
     if ((rc = mmnas_node_mix_bwd(zs, as, bs, width, c->gate + grow, cur_dy, dact, act, c->dgate + grow, (float*)(base + L.mixws), M, c->d, eps, st)))
       return rc;
@@ -979,7 +1006,7 @@ extern "C" int mmnas_chain_fwd(const mmnas_chain* c, void* stream) {
   char* base = (char*)c->arena;
   const float* cur_x = c->x_in;
   const float* cur_y = c->y_in;
-  const size_t nx = (size_t)c->B * c->Sx * c->d * sizeof(float), ny = (size_t)c->B * c->Sy * c->d * sizeof(float);
+  const size_t nx = (size_t)c->B * c->Sx * c->d * sizeof(float), ny = chain_rows_y(c) * c->d * sizeof(float);
   auto run = [&](int i, hipStream_t s) -> int {
     const mmnas_chain_op& o = c->ops[i];
     mmnas_att_op a; mmnas_mlp_op m;
@@ -1044,7 +1071,7 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
   // fills the latency-bound tail of the backward pass (encoder on 896 rows, LSTM, stem) instead.
   static const bool per_op = getenv("MMNAS_SIDE_FLUSH") && !strcmp(getenv("MMNAS_SIDE_FLUSH"), "op");
   char* base = (char*)c->arena;
-  const size_t ex = (size_t)c->B * c->Sx * c->d, ey = (size_t)c->B * c->Sy * c->d;
+  const size_t ex = (size_t)c->B * c->Sx * c->d, ey = chain_rows_y(c) * c->d;
   float* dpre = (float*)(base + L.dpre);
   if (L.n_guided && hipMemsetAsync(dpre, 0, ex * sizeof(float), st) != hipSuccess) return MMNAS_E_LAUNCH;
   // inputs of operator i = outputs of the previous operator on its stream

@@ -301,7 +301,7 @@ static bool small_ops_on() {
 // Does the short-sequence kernel take this operator?  (self-attention without relation bias, <= 16 rows per sample,
 // heads of 64, model width 256 or 512, at most 256 (sample, head) pairs; MMNAS_SMALL_OPS=0 switches the family off)
 bool sa_small_applies(const mmnas_att_op* op) {
-  if (!small_ops_on()) return false;
+  if (!small_ops_on() || op->q_off || op->k_off) return false;   // (packed rows: the general path)
   const int fl = op->flags;
   return (fl & MMNAS_F_SELF) && !(fl & MMNAS_F_REL) && op->Sq == op->Sk && op->Sq <= 16 && op->dh == 64 &&
          op->di == op->d && (op->d == 256 || op->d == 512) && op->xq == op->xkv &&

@@ -5,6 +5,7 @@
 #include <string.h>
 #include <mutex>
 #include <vector>
+#include <algorithm>
 #include "common.h"
 
 namespace mmnas {
@@ -252,6 +253,42 @@ extern "C" int mmnas_pack_segments_host(const mmnas_segment* segs_host, int nseg
     MMNAS_LAUNCH(pack_args_kernel, dim3(pack_grid(npieces)), dim3(256), 0, (hipStream_t)stream, a, n, npieces, staging, scale, direction);
   }
   return check_launch("pack_segments_host");
+}
+
+// ---- ragged batches: padded [B, S, d] <-> packed [sum n_b, d] rows (sample b: its first n_b = off[b+1] - off[b] rows) ----
+namespace mmnas {
+template <bool PACK>
+__global__ void __launch_bounds__(256) ragged_rows_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                          const int* __restrict__ off, int B, int S, int d4) {
+  const size_t n = (size_t)B * S * d4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / d4;
+    const int c = (int)(i - row * d4);
+    const int b = (int)(row / S), s = (int)(row - (size_t)b * S);
+    const int o = off[b], nb = off[b + 1] - o;
+    if (PACK) {
+      if (s < nb) dst[(size_t)(o + s) * d4 + c] = src[i];
+    } else {
+      dst[i] = s < nb ? src[(size_t)(o + s) * d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);   // padding rows: zero
+    }
+  }
+}
+}  // namespace mmnas
+
+extern "C" int mmnas_pack_rows(const float* x, const int* off, float* packed, int B, int S, int d, void* stream) {
+  MMNAS_REQUIRE(x && off && packed && B > 0 && S > 0 && d > 0 && d % 4 == 0, MMNAS_E_ARG, "pack_rows: bad arguments (d %% 4 == 0)");
+  const size_t n = (size_t)B * S * (d / 4);
+  MMNAS_LAUNCH((mmnas::ragged_rows_kernel<true>), dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+               (const float4*)x, (float4*)packed, off, B, S, d / 4);
+  return mmnas::check_launch("pack_rows");
+}
+
+extern "C" int mmnas_unpack_rows(const float* packed, const int* off, float* x, int B, int S, int d, void* stream) {
+  MMNAS_REQUIRE(x && off && packed && B > 0 && S > 0 && d > 0 && d % 4 == 0, MMNAS_E_ARG, "unpack_rows: bad arguments (d %% 4 == 0)");
+  const size_t n = (size_t)B * S * (d / 4);
+  MMNAS_LAUNCH((mmnas::ragged_rows_kernel<false>), dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+               (const float4*)packed, (float4*)x, off, B, S, d / 4);
+  return mmnas::check_launch("unpack_rows");
 }
 
 extern "C" int mmnas_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,

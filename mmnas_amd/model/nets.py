@@ -175,7 +175,13 @@ class _Backbone(nn.Module):
             return None
         xr = x_rel_embed.raw if isinstance(x_rel_embed, RelHandle) else None
         yr = y_rel_embed.raw if isinstance(y_rel_embed, RelHandle) else None
-        return ops.backbone_chain(x, y, x_mask, y_mask, xr, yr, records, params, op_params, mixed)
+        # ragged decoder stream (ops.Ragged; MMNAS_UNPAD / ops.set_unpad): the net's forward attached the description of the
+        # batch to the mask it derived from the region features.  Needs the lazy relation handle (raw boxes) when a relation
+        # operator is sampled.
+        ragged = getattr(y_mask, '_mmnas_ragged', None) if y_mask is not None else None
+        if ragged is not None and y_rel_embed is not None and not isinstance(y_rel_embed, RelHandle):
+            ragged = None
+        return ops.backbone_chain(x, y, x_mask, y_mask, xr, yr, records, params, op_params, mixed, ragged)
 
     def forward(self, x, y, x_mask, y_mask, x_rel_embed, y_rel_embed):
         out = self._chain(x, y, x_mask, y_mask, x_rel_embed, y_rel_embed)
@@ -254,6 +260,10 @@ class _Net(nn.Module):
         C = self._cfg
         x_mask = make_mask(ques_ix.unsqueeze(2))
         y_mask = make_mask(frcn_feat)
+        if self.TASK != 'vgd' and ops.unpad_enabled():
+            # ragged decoder stream: only where the head drops the padding rows (AttFlat's mask; the grounding head scores
+            # EVERY region row, padding included -- full_vgd.py:105-114 -- so it keeps the padded computation)
+            y_mask._mmnas_ragged = ops.ragged_info_for(frcn_feat, y_mask)
         emb = ops.embedding(ques_ix, self.embedding)
         # (one persistent launch per pass: ops.LstmFn; nn.LSTM = MIOpen only for shapes outside its range)
         x_in = ops.lstm(emb, self.lstm) if (ops.lstm_enabled() and ops.lstm_supported(emb, self.lstm)) else self.lstm(emb)[0]

@@ -1072,17 +1072,117 @@ def _release_sinks(ctx, params):
             s.ready()
 
 
+# ------------------------------------------------------------------------------------------
+# Ragged batches ("unpadding").  The loaders pad every image to 100 region rows behind its detected boxes
+# (load_data_vqa.py:221-246); the reference computes on the padding rows and then masks them as keys everywhere and in
+# AttFlat (hygr_vqa.py:113-122, modules.py:78-84,195-196), so no logit and no parameter gradient depends on them.  With
+# MMNAS_UNPAD=1 (or set_unpad(True)) the backbone chain runs the decoder stream on the valid rows only: packed [sum n_b, d]
+# matrices for every projection / FFN / LayerNorm, attention over each sample's own rows, the relation bias over its
+# n_b x n_b corner.  Logits and parameter gradients are those of the padded computation (tests/test_chain_gpu.py); the
+# decoder OUTPUT rows of the padding are zeros instead of the reference's (unread) values, and dropout draws from other
+# element indices.  Off by default.
+# ------------------------------------------------------------------------------------------
+_unpad = [None]
+
+
+def unpad_enabled():
+    if _unpad[0] is None:
+        _unpad[0] = os.environ.get('MMNAS_UNPAD', '0') == '1'
+    return _unpad[0]
+
+
+def set_unpad(on):
+    """Switch the ragged decoder stream on / off (returns the previous setting)."""
+    prev = unpad_enabled()
+    _unpad[0] = bool(on)
+    return prev
+
+
+class Ragged:
+    """Device / host description of a ragged batch: off [B+1] int32 prefix sums of the lengths, tile_off [B+1] prefix sums
+    of ceil(n_b^2 / 32) (the relation-bias backward's tiles), the totals as host ints."""
+
+    def __init__(self, lengths, device):
+        import numpy as np
+        n = np.asarray(lengths, dtype=np.int64)
+        self.lengths = tuple(int(v) for v in n)
+        off = np.concatenate([[0], np.cumsum(n)]).astype(np.int32)
+        toff = np.concatenate([[0], np.cumsum((n * n + 31) // 32)]).astype(np.int32)
+        both = torch.from_numpy(np.stack([off, toff])).to(device, non_blocking=True)
+        self.off, self.tile_off = both[0], both[1]
+        self.N, self.ntiles = int(off[-1]), int(toff[-1])
+
+
+_ragged_cache = {}
+
+
+def ragged_info_for(feat, mask):
+    """Ragged description of the batch whose region features are `feat` [B, S, F] and whose padding mask is `mask` (True =
+    padding), or None when the switch is off / the batch has no padding / the valid rows are not a prefix of every sample /
+    a sample is empty / S > 128.  The lengths come from `feat._mmnas_lengths` when the data pipeline attached them (no
+    synchronisation), else from the mask with ONE device-to-host copy per distinct features tensor (cached on the tensor
+    object and its version counter: a resident batch pays it once)."""
+    if not unpad_enabled() or not feat.is_cuda or feat.dim() != 3:
+        return None
+    B, S = feat.shape[0], feat.shape[1]
+    if S > 128:
+        return None
+    lens = getattr(feat, '_mmnas_lengths', None)
+    if lens is None:
+        key = id(feat)
+        hit = _ragged_cache.get(key)
+        if hit is not None and hit[0]() is feat and hit[1] == feat._version:
+            return hit[2]
+        m = mask.reshape(B, S)
+        n = (~m).sum(1)
+        ok = (m == (torch.arange(S, device=m.device)[None, :] >= n[:, None])).all()
+        host = torch.cat([n, ok.long().view(1)]).cpu()
+        lens = host[:B].tolist() if int(host[B]) else None
+        info = _make_ragged(lens, B, S, feat.device)
+        import weakref
+        if len(_ragged_cache) > 64:
+            _ragged_cache.clear()
+        _ragged_cache[key] = (weakref.ref(feat), feat._version, info)
+        return info
+    return _make_ragged([int(v) for v in lens], B, S, feat.device)
+
+
+def _make_ragged(lens, B, S, device):
+    if lens is None or len(lens) != B or min(lens) < 1 or max(lens) > S or sum(lens) >= B * S:
+        return None
+    return Ragged(lens, device)
+
+
+def pack_rows(x, rg):
+    """[B, S, d] -> packed [rg.N, d]."""
+    B, S, d = x.shape
+    out = torch.empty(rg.N, d, dtype=torch.float32, device=x.device)
+    L.check(L.lib().mmnas_pack_rows(L.fptr(x), L.ptr(rg.off), L.fptr(out), B, S, d, L.stream()))
+    return out
+
+
+def unpack_rows(xp, rg, B, S):
+    """packed [rg.N, d] -> [B, S, d], zeros in the padding rows."""
+    d = xp.shape[-1]
+    out = torch.empty(B, S, d, dtype=torch.float32, device=xp.device)
+    L.check(L.lib().mmnas_unpack_rows(L.fptr(xp), L.ptr(rg.off), L.fptr(out), B, S, d, L.stream()))
+    return out
+
+
 class BackboneFn(torch.autograd.Function):
     """Backbone_*.forward (hygr_vqa.py:45-52) through mmnas_chain_fwd/bwd.  Parameter gradients go straight into the
     flat gradient buffer (every parameter of the chain has an attached sink: checked by the caller), so the parameters
     are not autograd inputs of this node."""
 
     @staticmethod
-    def forward(ctx, x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None, mixed=None):
+    def forward(ctx, x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None, mixed=None, ragged=None):
         lib = L.lib()
         x, y = _f32c(x), _f32c(y)
         B, Sx, d = x.shape
         Sy = y.shape[1]
+        y_pad = y
+        if ragged is not None:     # the decoder stream on its valid rows only (see Ragged)
+            y = pack_rows(y, ragged)
         n = len(records)
         arr = (L.ChainOp * n)(*records)
         ch = L.Chain()
@@ -1095,6 +1195,8 @@ class BackboneFn(torch.autograd.Function):
         ch.x_rel, ch.y_rel = L.fptr(xr), L.fptr(yr)
         if mixed is not None:      # architecture step: (gate block, gate-gradient block, row width) of the supernet's nodes
             ch.mixed, ch.gate, ch.dgate, ch.gate_width = 1, mixed[0], mixed[1], mixed[2]
+        if ragged is not None:
+            ch.y_off, ch.y_tile_off, ch.Ny, ch.y_ntiles = L.ptr(ragged.off), L.ptr(ragged.tile_off), ragged.N, ragged.ntiles
         sz = C.c_size_t()
         L.check(lib.mmnas_chain_plan(C.byref(ch), C.byref(sz)))   # (host arithmetic only: a few microseconds)
         arena = _bytes(sz.value, x.device)
@@ -1103,7 +1205,10 @@ class BackboneFn(torch.autograd.Function):
         L.check(lib.mmnas_chain_fwd(C.byref(ch), L.stream()))
         ctx.keep = (ch, arr, arena, x, y, xm, ym, xr, yr, x_out, y_out, params)
         ctx.op_params = op_params
+        ctx.ragged = (ragged, B, Sy)
         ctx.counted = _acquire_sinks(ctx, params)
+        if ragged is not None:
+            return x_out, unpack_rows(y_out, ragged, B, Sy)
         return x_out, y_out
 
     @staticmethod
@@ -1113,7 +1218,11 @@ class BackboneFn(torch.autograd.Function):
         lib = L.lib()
         ch, arr, arena, x, y, xm, ym, xr, yr, x_out, y_out, params = ctx.keep
         dx_out = _f32c(dx_out) if dx_out is not None else None
-        dy_out = _f32c(dy_out) if dy_out is not None else torch.zeros_like(y_out)
+        ragged, B, Sy = ctx.ragged
+        if ragged is not None:     # (the gradient of the zero-filled padding rows is dropped: nothing was computed there)
+            dy_out = pack_rows(_f32c(dy_out), ragged) if dy_out is not None else torch.zeros_like(y_out)
+        else:
+            dy_out = _f32c(dy_out) if dy_out is not None else torch.zeros_like(y_out)
         dx_in, dy_in = torch.empty_like(x), torch.empty_like(y)
         ch.dx_out, ch.dy_out, ch.dx_in, ch.dy_in = L.fptr(dx_out), L.fptr(dy_out), L.fptr(dx_in), L.fptr(dy_in)
         side = side_stream_enabled()
@@ -1142,11 +1251,13 @@ class BackboneFn(torch.autograd.Function):
                 _side_join_queued[0] = True
                 torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
         _release_sinks(ctx, params)   # data-parallel reducers learn which gradients are now completely enqueued
-        return dx_in, dy_in, None, None, None, None, None, None, None, None
+        if ragged is not None:
+            dy_in = unpack_rows(dy_in, ragged, B, Sy)
+        return dx_in, dy_in, None, None, None, None, None, None, None, None, None
 
 
-def backbone_chain(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None, mixed=None):
-    return BackboneFn.apply(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params, mixed)
+def backbone_chain(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None, mixed=None, ragged=None):
+    return BackboneFn.apply(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params, mixed, ragged)
 
 
 class HeadFn(torch.autograd.Function):

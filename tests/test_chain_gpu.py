@@ -181,3 +181,133 @@ def test_chain_full_size_side_stream_repeatable(monkeypatch):
     for loss, flat in results[1:]:
         assert loss == ref_loss
         assert float((flat - ref).abs().max()) <= 2e-5 * scale
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Ragged decoder stream (MMNAS_UNPAD / ops.set_unpad): the chain on the valid region rows only
+# ----------------------------------------------------------------------------------------------------------------------
+def _run_unpad(task, arch, search, unpad, mode=None, plan=None, B=5, Sy=23, HSIZE=128):
+    """One forward + backward of a whole net through the harness-style flat gradient buffer; returns (outputs, flat
+    gradients by parameter name, whether the chain ran ragged)."""
+    import importlib
+    from mmnas_amd import dp, ops
+    from mmnas.model.mixed import MixedOp
+    c = cases.net_case(task, arch, 4242, search=search, B=B, Sx=6, Sy=Sy, HSIZE=HSIZE)
+    c['cfg'].DROPOUT_R = 0.0
+    mod = importlib.import_module('mmnas.model.%s_%s' % ('hygr' if search else 'full', task))
+    cls = mod.Net_Search if search else mod.Net_Full
+    init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+            'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
+    net = cls(c['cfg'], init)
+    net.load_state_dict({k: T(v) for k, v in c['P'].items()})
+    net = net.to(DEV).train()
+    inp = tuple(T(a).to(DEV) for a in c['inputs'])
+    tgt = T(c['target']).to(DEV)
+    seen = []
+    orig = ops.BackboneFn.apply
+    prev = ops.set_unpad(unpad)
+    ops.BackboneFn.apply = lambda *a: (seen.append(a[10] is not None), orig(*a))[1]
+    red = None
+    try:
+        if search:
+            MixedOp.MODE = mode
+            net.set_sampled(plan)
+            red = dp.SupernetReducer(net)
+            if mode is None:
+                red.begin_weight_step()
+            else:
+                net.begin_arch_step()
+                red.fg.zero()
+                red.fg.attach()
+        else:
+            red = dp.GradReducer(list(net.parameters()))
+            red.begin_step()
+        pred = net(inp)
+        if task == 'itm':
+            loss = torch.nn.functional.binary_cross_entropy(pred, tgt, reduction='sum')
+        else:
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(pred, tgt, reduction='sum')
+        loss.backward()
+        torch.cuda.synchronize()
+        grads = {k: (p.grad.detach().cpu().numpy().copy() if p.grad is not None else None) for k, p in net.named_parameters()}
+        return pred.detach().cpu().numpy(), grads, seen
+    finally:
+        MixedOp.MODE = None
+        ops.BackboneFn.apply = orig
+        ops.set_unpad(prev)
+        if red is not None:
+            red.fg.disable_sinks()
+
+
+def _same(a, b, gtol=2e-5):
+    out_a, g_a, _ = a
+    out_b, g_b, _ = b
+    assert rel_err(out_a, out_b) < 2e-6
+    top = max(float(np.abs(g).max()) for g in g_b.values() if g is not None)
+    for k in g_b:
+        if g_b[k] is None:
+            assert g_a[k] is None or not np.any(g_a[k]), k
+            continue
+        assert g_a[k] is not None, k
+        diff = float(np.abs(g_a[k] - g_b[k]).max())
+        assert diff <= gtol * max(float(np.abs(g_b[k]).max()), 1e-3 * top), (k, diff, float(np.abs(g_b[k]).max()))
+
+
+@pytest.mark.parametrize('task,arch', [('vqa', 'mmnas_vqa'), ('vqa', 'mcan'), ('itm', 'mmnas_itm')])
+def test_ragged_decoder_stream_equals_the_padded_computation_net_full(task, arch):
+    """Net_Full: logits and EVERY parameter gradient of the chain on the valid region rows only (packed rows, attention over
+    each sample's own rows, relation bias over its n_b x n_b corner) equal those of the padded computation -- the padding
+    rows are masked keys and AttFlat-masked outputs in the reference (hygr_vqa.py:113-122, modules.py:195-196)."""
+    padded = _run_unpad(task, arch, False, False)
+    ragged = _run_unpad(task, arch, False, True)
+    assert padded[2] == [False] and ragged[2] == [True]
+    _same(ragged, padded)
+
+
+@pytest.mark.parametrize('mode', [None, 'full'])
+def test_ragged_decoder_stream_equals_the_padded_computation_supernet(mode):
+    """Net_Search weight step (MODE None) and architecture step (MODE 'full': every candidate forward, gate gradients)."""
+    plan = cases.search_plan(np.random.RandomState(5), mode)
+    flat = plan['enc'] + plan['dec']
+    padded = _run_unpad('vqa', None, True, False, mode, flat)
+    ragged = _run_unpad('vqa', None, True, True, mode, flat)
+    assert padded[2] == [False] and ragged[2] == [True]
+    _same(ragged, padded)
+    if mode == 'full':      # the gate gradients live in the alpha_gate parameters' gradients: compared above by name
+        assert any('alpha_gate' in k and g is not None and np.any(g) for k, g in ragged[1].items())
+
+
+def test_grounding_head_keeps_the_padded_computation():
+    """VGD scores every region row, padding included (full_vgd.py:105-114): the ragged stream must not engage."""
+    from mmnas_amd import ops
+    prev = ops.set_unpad(True)
+    try:
+        out = _run_unpad_vgd()
+    finally:
+        ops.set_unpad(prev)
+    assert out == [False]
+
+
+def _run_unpad_vgd():
+    from mmnas_amd import dp, ops
+    from mmnas.model.full_vgd import Net_Full
+    c = cases.net_case('vgd', 'mmnas_vgd', 77, B=3, Sx=6, Sy=11)
+    c['cfg'].DROPOUT_R = 0.0
+    init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+            'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
+    net = Net_Full(c['cfg'], init)
+    net.load_state_dict({k: T(v) for k, v in c['P'].items()})
+    net = net.to(DEV).train()
+    seen = []
+    orig = ops.BackboneFn.apply
+    ops.BackboneFn.apply = lambda *a: (seen.append(a[10] is not None), orig(*a))[1]
+    red = dp.GradReducer(list(net.parameters()))
+    try:
+        red.begin_step()
+        ps, pr = net(tuple(T(a).to(DEV) for a in c['inputs']))
+        (ps.sum() + pr.sum()).backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.BackboneFn.apply = orig
+        red.fg.disable_sinks()
+    return seen
