@@ -23,6 +23,8 @@ and, at N = 1 only (short records: throughput, host issue time, library launches
     search_vqa_dp1 / train_vqa_dp1  the search / training steps with the data-parallel exchange machinery ON in a
                one-rank RCCL group (pack -> all-reduce -> scatter, communication stream, bucket events inside the
                backbone call): the non-network cost of the exchange
+    search_vqa_unpad / train_vqa_unpad  the same steps with the RAGGED decoder stream (ops.set_unpad): the decoder operators
+               on the valid region rows only; logits and gradients equal the padded computation's
 Every timed block is repeated `--repeats` times (default 5, same `--steps` each); `value` / `ms_per_step` are the
 MEDIAN block, `value_min` / `value_max` the slowest / fastest block.
 Every record carries its own `roofline` (the fp32-MFMA GEMM kernel class, the dominant kernel, measured with HIP
@@ -70,13 +72,17 @@ WORKLOADS = {
     'search_vqa_dp1': 'the search_vqa step with the gradient exchange running in a one-rank RCCL group (3 buckets: pack -> all-reduce '
                       '-> scatter on the communication stream, bucket events inside the backbone call)',
     'train_vqa_dp1': 'the train_vqa step with the bucketed in-place all-reduce running in a one-rank RCCL group',
+    'search_vqa_unpad': 'the search_vqa step with the RAGGED decoder stream (ops.set_unpad): same batch, same logits and gradients; the '
+                        'decoder operators run on the valid region rows only (the synthetic batch pads n_b ~ U{10..100} regions to 100, '
+                        'SURVEY 8d; the reference computes on the padding rows and masks them)',
+    'train_vqa_unpad': 'the train_vqa step with the ragged decoder stream',
     'train_vgd': 'arch/mmnas_vgd.json Net_Full fwd + KLDiv/SmoothL1 loss + bwd, HSIZE 512, B=64/GPU, 100x2048 regions + 15 tokens, '
                  'dropout 0.1 (train_vgd.py:309-334; BASELINE configs[3])',
     'train_itm': 'arch/mmnas_itm.json Net_Full hard-negative triplet step: 3 fwd + BCE_Loss + bwd, HSIZE 512, B=160/GPU, 36x2048 regions '
                  '+ 50 tokens, dropout 0.1, fp32 (train_itm.py:380-391; BASELINE configs[4] at the reference precision)',
 }
 EXTRA = ('train_vgd', 'train_itm')   # not part of --workload all (the driver line): run them by name
-N1_SUBS = ('search_vqa_stream', 'search_vqa_dropin', 'search_vqa_dp1', 'train_vqa_dp1')   # part of `all` at N = 1 only
+N1_SUBS = ('search_vqa_stream', 'search_vqa_dropin', 'search_vqa_dp1', 'train_vqa_dp1', 'search_vqa_unpad', 'train_vqa_unpad')   # part of `all` at N = 1 only
 METRICS = {
     'search_vqa': 'supernet fwd+bwd steps/sec (VQA arch, bs=64)',
     'arch_vqa': 'supernet arch-step (all candidates fwd, sampled bwd) steps/sec (VQA, bs=64)',
@@ -86,6 +92,8 @@ METRICS = {
     'search_vqa_dropin': 'reference-loop weight steps/sec, optimizer included (search_vqa.py:279-301 unchanged; VQA arch, bs=64)',
     'search_vqa_dp1': 'supernet fwd+bwd steps/sec with the exchange machinery in a one-rank RCCL group (VQA arch, bs=64)',
     'train_vqa_dp1': 'fixed-architecture fwd+bwd steps/sec with the exchange machinery in a one-rank RCCL group (bs=64)',
+    'search_vqa_unpad': 'supernet fwd+bwd steps/sec, decoder stream on the valid region rows only (VQA arch, bs=64)',
+    'train_vqa_unpad': 'fixed-architecture fwd+bwd steps/sec, decoder stream on the valid region rows only (bs=64)',
     'train_vgd': 'fixed-architecture fwd+bwd steps/sec (arch/mmnas_vgd.json, bs=64)',
     'train_itm': 'triplet (3 fwd + 1 bwd) steps/sec (arch/mmnas_itm.json, bs=160)',
 }
@@ -568,6 +576,16 @@ def main():
 
     def make_step(wl):
         """-> (step() -> loss, flops accumulator [1], steps-per-call)"""
+        if wl.endswith('_unpad'):      # the plain step under ops.set_unpad(True): same net, same batch, same loop object
+            inner, fl, per = make_step(wl[:-len('_unpad')])
+
+            def step():
+                prev = ops.set_unpad(True)
+                try:
+                    return inner()
+                finally:
+                    ops.set_unpad(prev)
+            return step, fl, per
         fl = [0.0]
         if wl in EXTRA:
             from mmnas_amd.harness import itm_triplet_step, vgd_loss
@@ -743,7 +761,7 @@ def main():
         # start/stop HIP event (on the launch stream).  Kept out of the timed region because the events themselves
         # cost ~9 % of the step (a completion signal per dispatch); launches, shapes and data are identical.
         stats = None
-        prof_calls = min(calls, max(1, (4 if wl in N1_SUBS else 10) // per_call))
+        prof_calls = min(calls, max(1, (4 if (wl in N1_SUBS and not wl.endswith('_unpad')) else 10) // per_call))
         prof_elapsed = 0.0
         if not args.no_prof:
             L.check(lib.mmnas_prof_enable(1))
@@ -771,7 +789,7 @@ def main():
             'host_issue_ms_per_step': 1000.0 * t_enqueue / nsteps,
             'host_issue_ms_per_step_empty_queue': host_alone_ms,
         }
-        if stats and wl in N1_SUBS:
+        if stats and wl in N1_SUBS and not wl.endswith('_unpad'):
             psteps = prof_calls * per_call
             rec['library_launches_per_step'] = sum(s_['launches'] for s_ in stats.values()) / psteps
             rec['library_kernel_ms_per_step'] = sum(s_['ms'] for s_ in stats.values()) / psteps
@@ -842,7 +860,8 @@ def main():
                 recs[wl] = {'metric': METRICS[wl], 'value': None, 'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
         else:
             recs[wl] = measure(wl, steps, warm)
-    for wl, ref in (('search_vqa_stream', 'search_vqa'), ('search_vqa_dp1', 'search_vqa'), ('train_vqa_dp1', 'train_vqa')):
+    for wl, ref in (('search_vqa_stream', 'search_vqa'), ('search_vqa_dp1', 'search_vqa'), ('train_vqa_dp1', 'train_vqa'),
+                    ('search_vqa_unpad', 'search_vqa'), ('train_vqa_unpad', 'train_vqa')):
         if recs.get(wl, {}).get('value') and recs.get(ref, {}).get('value'):
             recs[wl]['ms_per_step_vs_plain'] = recs[wl]['ms_per_step'] / recs[ref]['ms_per_step']
             recs[wl]['plain_record'] = ref

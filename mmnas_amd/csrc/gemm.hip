@@ -1205,7 +1205,10 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
   if (bb > maxbytes) maxbytes = bb;
   k.avec = avec; k.bvec = bvec;
   // branch-free buffer-load path: aligned vector loads, K a multiple of the K tile, 32-bit byte offsets
-  bool fast = avec && bvec && (d->K % BK == 0) && maxbytes < 4.0e9;
+  // (TN: both operands are [K][rows]; a K that is no multiple of the K-tile simply ends inside the last tile, whose rows
+  //  behind K lie outside the operands' buffer ranges and read as zero -- the row count of a PACKED ragged batch is
+  //  arbitrary, and it is the reduction length of every weight gradient)
+  bool fast = avec && bvec && (d->K % BK == 0 || tn) && maxbytes < 4.0e9;
   if (g_tune.generic) fast = false;
   k.ntk = cdiv(d->K, BK);
   k.T = k.ntk * d->nseg;

@@ -90,7 +90,11 @@ def test_bench_default_line_is_the_supernet_weight_step_with_sub_records():
     assert d['metric'].startswith('supernet fwd+bwd steps/sec') and 'WEIGHT step' in d['config']['workload']
     main = {'arch_step', 'bilevel', 'train_vqa'}
     n1 = {'search_vqa_stream', 'search_vqa_dropin', 'search_vqa_dp1', 'train_vqa_dp1'}     # N = 1 only: short records
-    assert set(d['sub']) == main | n1
+    unpad = {'search_vqa_unpad', 'train_vqa_unpad'}                                         # N = 1 only: the ragged decoder stream
+    assert set(d['sub']) == main | n1 | unpad
+    for k in unpad:
+        r = d['sub'][k]
+        assert r.get('error') is None and r['value'] > 0 and 0 < r['roofline']['frac'] < 1 and 0.5 < r['ms_per_step_vs_plain'] < 1.02, (k, r.get('ms_per_step_vs_plain'))
     for r in [d] + [d['sub'][k] for k in main]:
         assert r['value'] > 0 and 0 < r['roofline']['frac'] < 1
         assert r['repeats'] == 5 and r['value_min'] <= r['value'] <= r['value_max']   # median of five timed blocks

@@ -154,6 +154,79 @@ def test_supernet_weight_step_full_size(monkeypatch):
         loop2.reducer.fg.disable_sinks()
 
 
+def test_supernet_weight_step_full_size_ragged_stream():
+    """The metric's workload (B=64, 100 regions, HSIZE 256) with the RAGGED decoder stream (ops.set_unpad): lengths from 1 to
+    100 regions, a sampled architecture with relation / guided / self attention and feed-forward operators.  Logits and
+    every parameter gradient equal the padded computation's (dropout off: the two forms draw dropout from different element
+    indices), and the step really ran on the packed rows."""
+    from mmnas.model.hygr_vqa import Net_Search
+    from mmnas_amd import ops
+    from mmnas_amd.harness import SearchLoop, fused_loss
+    B, S = 64, 100
+    c = cases.net_case('vqa', None, 41, search=True, HSIZE=256, B=B, Sx=14, Sy=S, token_size=2000, ans_size=3129)
+    c['cfg'].DROPOUT_R = 0.0
+    rs = np.random.RandomState(12)
+    lens = rs.randint(10, S + 1, size=B)
+    lens[0], lens[1], lens[2] = S, 1, 33
+    frcn, bbox, y_rel, ques, x_rel = (a.copy() for a in c['inputs'])
+    frcn = np.maximum(rs.standard_normal(frcn.shape), 0).astype(np.float32) + 0.01     # (no accidental all-zero valid row)
+    for b in range(B):
+        frcn[b, lens[b]:] = 0
+        y_rel[b, lens[b]:] = 0
+        y_rel[b, :, lens[b]:] = 0
+    inp = tuple(T(a).to(DEV) for a in (frcn, bbox, y_rel, ques, x_rel))
+    tgt = T(c['target']).to(DEV)
+    plan = cases.search_plan(np.random.RandomState(9), None)
+    flat = plan['enc'] + plan['dec']
+
+    class Loss(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.inner = fused_loss(torch.nn.BCEWithLogitsLoss(reduction='sum'))
+
+        def forward(self, pred, target):
+            self.pred = pred.detach()
+            return self.inner(pred, target)
+
+    net = Net_Search(c['cfg'], _init(c))
+    net.load_state_dict({k: T(v) for k, v in c['P'].items()})
+    net = net.to(DEV).train()
+    lf = Loss()
+    loop = SearchLoop(net, lf)
+    fg = loop.reducer.fg
+    seen = []
+    orig = ops.BackboneFn.apply
+    ops.BackboneFn.apply = lambda *a: (seen.append(None if a[10] is None else a[10].N), orig(*a))[1]
+    res = []
+    try:
+        for unpad in (False, True, True):
+            prev = ops.set_unpad(unpad)
+            try:
+                loss = loop.weight_step(inp, tgt, optimize=False, plan=flat)
+                torch.cuda.synchronize()
+            finally:
+                ops.set_unpad(prev)
+            res.append((lf.pred.clone(), float(loss.detach()), fg.flat.clone()))
+    finally:
+        ops.BackboneFn.apply = orig
+        fg.disable_sinks()
+    assert seen == [None, int(lens.sum()), int(lens.sum())] and int(lens.sum()) < B * S * 0.6
+    (o_p, l_p, g_p), (o_r, l_r, g_r), (o_r2, l_r2, g_r2) = res
+    assert torch.isfinite(o_r).all() and torch.isfinite(g_r).all()
+    assert float((o_r - o_p).abs().max()) <= 1e-5 * float(o_p.abs().max())
+    assert abs(l_r - l_p) <= 1e-5 * abs(l_p)
+    gmax = float(g_p.abs().max())
+    bad = []
+    names = {id(p): k for k, p in net.named_parameters()}
+    for i, p in enumerate(fg.params):
+        sl = slice(fg.offsets[i], fg.offsets[i] + p.numel())
+        err = float((g_r[sl] - g_p[sl]).abs().max())
+        if err > 2e-3 * max(float(g_p[sl].abs().max()), 1e-3 * gmax):
+            bad.append((names[id(p)], err, float(g_p[sl].abs().max())))
+    assert not bad, bad[:6]
+    assert torch.equal(o_r2, o_r)                      # the cached description of the batch gives the same step again
+
+
 def test_supernet_arch_step_full_size():
     from mmnas.model.hygr_vqa import Net_Search
     from mmnas.model.mixed import MixedOp

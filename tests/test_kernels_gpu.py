@@ -1235,3 +1235,27 @@ def test_conv_seq_overlapping_rows_vs_conv1d_fp64(B, S, d, k, monkeypatch):
     ref = torch.nn.functional.pad(x, (0, 0, k // 2, k // 2)).reshape(-1, d)
     assert xp.shape[0] % 32 == 0 and xp.shape[0] >= ref.shape[0] + k
     assert torch.equal(xp[:ref.shape[0]].cpu(), ref) and not bool(xp[ref.shape[0]:].any())
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 256, 3517), (1024, 256, 77), (64, 128, 33), (512, 512, 6401)])
+@pytest.mark.parametrize('accumulate', [False, True])
+def test_gemm_tn_ragged_reduction_length(M, N, K, accumulate):
+    """Weight-gradient products (TN) whose reduction length -- the row count of a PACKED ragged batch -- is no multiple of
+    the 32-deep K-tile: they stay on the buffer-load kernels (the rows behind K lie outside the operands' ranges and read
+    as zero) instead of dropping to the guarded-load path, with the same result."""
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    rs = np.random.RandomState(M + N + K)
+    A, B = rnd(rs, K, M), rnd(rs, K, N)
+    C0 = rnd(rs, M, N)
+    ref = torch.from_numpy(A).double().t() @ torch.from_numpy(B).double() + (torch.from_numpy(C0).double() if accumulate else 0)
+    C = g(C0.copy()) if accumulate else torch.full((M, N), float('nan'), device=DEV)
+    L.check(L.lib().mmnas_prof_enable(1))
+    try:
+        ops.gemm(L.GEMM_TN, [dict(M=M, A=[g(A)], B=[g(B)], C=C)], N, K, M, N, N, accumulate=accumulate)
+        torch.cuda.synchronize()
+    finally:
+        arr = (L.ProfStat * len(L.K_NAMES))()
+        L.check(L.lib().mmnas_prof_collect(arr))
+        L.check(L.lib().mmnas_prof_enable(0))
+    assert rel_err(C.cpu().numpy(), ref.numpy()) < 3e-6
