@@ -119,10 +119,16 @@ class DevicePrefetcher:
     structure on `device`.  Each batch is staged in pinned memory and copied on a side stream while the previous
     batch is being consumed; the consumer's stream waits on the copy before the tensors are handed out, and the
     tensors are recorded on it so the caching allocator does not reuse them early.  On a CPU `device` it is a
-    plain pass-through (tests)."""
+    plain pass-through (tests).
 
-    def __init__(self, loader, device):
+    lengths=(features_key, lengths_key): the batch element `lengths_key` (a CPU int tensor / array with the number of
+    detected regions per sample, which the loaders know: load_data_vqa.py:221-246 pads behind them) is attached to the
+    DEVICE copy of element `features_key` as `_mmnas_lengths` -- what ops.ragged_info_for reads when the ragged decoder
+    stream is on (ops.set_unpad), so a fresh batch per step needs no device-to-host copy to learn its lengths."""
+
+    def __init__(self, loader, device, lengths=None):
         self.loader = loader
+        self.lengths = lengths
         self.device = torch.device(device)
         self.cuda = self.device.type == 'cuda'
         self.stream = torch.cuda.Stream(self.device) if self.cuda else None
@@ -141,9 +147,14 @@ class DevicePrefetcher:
 
     def _upload(self, batch):
         if not self.cuda:
-            return self._map(batch, lambda t: t)
-        with torch.cuda.stream(self.stream):
-            return self._map(batch, lambda t: (t if t.is_pinned() else t.pin_memory()).to(self.device, non_blocking=True))
+            out = self._map(batch, lambda t: t)
+        else:
+            with torch.cuda.stream(self.stream):
+                out = self._map(batch, lambda t: (t if t.is_pinned() else t.pin_memory()).to(self.device, non_blocking=True))
+        if self.lengths is not None:
+            fk, lk = self.lengths
+            out[fk]._mmnas_lengths = [int(v) for v in self._to_tensor(batch[lk]).reshape(-1).tolist()]   # host values: no sync
+        return out
 
     def __iter__(self):
         it = iter(self.loader)

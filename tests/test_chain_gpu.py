@@ -311,3 +311,38 @@ def _run_unpad_vgd():
         ops.BackboneFn.apply = orig
         red.fg.disable_sinks()
     return seen
+
+
+def test_ragged_info_sources_and_refusals():
+    """ops.ragged_info_for: lengths from the mask (one device-to-host copy per distinct features tensor, cached on the
+    tensor object + version) or from `_mmnas_lengths` (the data pipeline's region counts); None -- i.e. the padded
+    computation -- when the valid rows are not a prefix, a sample is empty, or nothing is padded."""
+    from mmnas_amd import ops
+    from mmnas_amd.model.nets import make_mask
+    prev = ops.set_unpad(True)
+    try:
+        g = torch.Generator().manual_seed(3)
+        feat = torch.rand(4, 9, 16, generator=g).to(DEV) + 0.1
+        lens = [9, 3, 1, 6]
+        for b, n in enumerate(lens):
+            feat[b, n:] = 0
+        a = ops.ragged_info_for(feat, make_mask(feat))
+        assert a is not None and a.lengths == tuple(lens) and a.N == 19 and a.off.tolist() == [0, 9, 12, 13, 19]
+        assert a.tile_off.tolist() == [0, 3, 4, 5, 7] and a.ntiles == 7
+        assert ops.ragged_info_for(feat, make_mask(feat)) is a                      # cached
+        feat.mul_(2.0)                                                               # written: looked at again
+        assert ops.ragged_info_for(feat, make_mask(feat)) is not a
+        f2 = feat.clone()
+        f2._mmnas_lengths = torch.tensor(lens)
+        b2 = ops.ragged_info_for(f2, None)
+        assert b2.off.tolist() == a.off.tolist()
+        hole = feat.clone(); hole[0, 2] = 0                                          # a zero row in the middle: not a prefix
+        assert ops.ragged_info_for(hole, make_mask(hole)) is None
+        empty = feat.clone(); empty[1] = 0
+        assert ops.ragged_info_for(empty, make_mask(empty)) is None
+        full = torch.rand(2, 5, 8, generator=g).to(DEV) + 0.1
+        assert ops.ragged_info_for(full, make_mask(full)) is None
+        ops.set_unpad(False)
+        assert ops.ragged_info_for(feat, make_mask(feat)) is None
+    finally:
+        ops.set_unpad(prev)

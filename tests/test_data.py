@@ -145,3 +145,14 @@ def test_device_relation_kernels_vs_reference_loader():
         want = np.zeros((14, 14, 3), np.float32)
         want[:n, :n] = npz['sem|%d|out' % i]
         assert np.allclose(out[i], want, rtol=2e-5, atol=2e-5), i
+
+
+def test_prefetcher_attaches_the_region_counts_to_the_features():
+    """DevicePrefetcher(lengths=...): the loaders' region counts ride on the features tensor (CPU pass-through here)."""
+    import torch
+    from mmnas_amd.data import DevicePrefetcher
+    batches = [(torch.zeros(3, 5, 4), torch.tensor([5, 2, 4], dtype=torch.int32)), {'f': torch.zeros(2, 5, 4), 'n': np.array([1, 5])}]
+    out = list(DevicePrefetcher(batches[:1], 'cpu', lengths=(0, 1)))
+    assert out[0][0]._mmnas_lengths == [5, 2, 4]
+    out = list(DevicePrefetcher(batches[1:], 'cpu', lengths=('f', 'n')))
+    assert out[0]['f']._mmnas_lengths == [1, 5]
