@@ -260,3 +260,11 @@ def _w_itm_triplet(rank):
 @pytest.mark.parametrize('fn', ['_w_full', '_w_supernet', '_w_itm_triplet', '_w_arch_then_weight'])
 def test_two_ranks_on_one_gpu(fn):
     mp.spawn(_entry, args=(fn, _free_port()), nprocs=WORLD, join=True)
+
+
+@pytest.mark.parametrize('fn', ['_w_full', '_w_supernet', '_w_arch_then_weight'])
+def test_two_ranks_on_one_gpu_ragged_decoder_stream(fn, monkeypatch):
+    """The same exchanges with the ragged decoder stream on (MMNAS_UNPAD=1 in the ranks): every rank packs its own batch
+    (different row counts per rank), the gradients that travel are the same."""
+    monkeypatch.setenv('MMNAS_UNPAD', '1')
+    mp.spawn(_entry, args=(fn, _free_port()), nprocs=WORLD, join=True)

@@ -501,3 +501,24 @@ def test_search_loop_mode_two_follows_the_per_module_statements():
         assert MixedOp.MODE is None
     finally:
         loop.reducer.fg.disable_sinks()
+
+
+@pytest.mark.parametrize('which', ['bilevel', 'train'])
+def test_reference_loop_trajectories_with_the_ragged_decoder_stream(which):
+    """The reference's OWN loops (traj.npz: search_vqa.py:279-337; train_traj.npz: train_vqa.py:291-311) replayed with the ragged decoder stream on (ops.set_unpad): losses, gradient norms, per-tensor parameter
+    motion and post-step alphas of the padded reference computation are met on the valid rows alone -- and the chain really
+    ran packed."""
+    from mmnas_amd import ops
+    seen = []
+    orig = ops.BackboneFn.apply
+    ops.BackboneFn.apply = lambda *a: (seen.append(a[10] is not None), orig(*a))[1]
+    prev = ops.set_unpad(True)
+    try:
+        if which == 'bilevel':
+            test_bilevel_trajectory_vs_reference_loop()
+        else:
+            test_training_loop_trajectory_vs_reference_loop()
+    finally:
+        ops.set_unpad(prev)
+        ops.BackboneFn.apply = orig
+    assert seen and all(seen), seen
