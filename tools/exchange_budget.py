@@ -39,7 +39,7 @@ def main():
     from mmnas.model.mixed import MixedOp
     emb = np.zeros((bench.VOCAB, 300), np.float32)
     init = {'token_size': bench.VOCAB, 'ans_size': bench.ANS, 'pretrained_emb': emb}
-    # measured on one MI355X (profiles/r03_bench.json): backward of the supernet step ~ 3.6 ms of the 5.4 ms step, of which
+    # measured on one MI355X (profiles/r04_bench.json): backward of the supernet step ~ 3.6 ms of the 5.4 ms step, of which
     # the backbone ~ 3.0 ms; training step: backward ~ 7.7 of 11.5 ms
     out = {}
     for name, bwd_ms, backbone_ms in (('search_vqa', 3.6, 3.0), ('train_vqa', 7.7, 7.0)):
@@ -107,7 +107,7 @@ def main():
             rowb = bench.B_DEFAULT * bench.SX * (300 * 4 + 8)
             print('  N=%d: dense ring all-reduce %.3f ms (exposed: the table completes last) vs row all-gather %.3f ms' % (
                 n, 1e3 * t_ring(out[name]['embedding_dense_bytes'], n), 1e3 * (n - 1) * rowb / LINK))
-    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r03_exchange_budget.json'), 'w'), indent=1, default=str)
+    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r04_exchange_budget.json'), 'w'), indent=1, default=str)
 
 
 if __name__ == '__main__':
