@@ -264,13 +264,14 @@ def test_ragged_decoder_stream_equals_the_padded_computation_net_full(task, arch
     _same(ragged, padded)
 
 
-@pytest.mark.parametrize('mode', [None, 'full'])
-def test_ragged_decoder_stream_equals_the_padded_computation_supernet(mode):
-    """Net_Search weight step (MODE None) and architecture step (MODE 'full': every candidate forward, gate gradients)."""
+@pytest.mark.parametrize('mode,B,Sy', [(None, 5, 23), ('full', 5, 23), (None, 1, 40), ('full', 2, 128), (None, 3, 33)])
+def test_ragged_decoder_stream_equals_the_padded_computation_supernet(mode, B, Sy):
+    """Net_Search weight step (MODE None) and architecture step (MODE 'full': every candidate forward, gate gradients); a
+    single sample, the longest supported sequences (128 rows), odd row counts."""
     plan = cases.search_plan(np.random.RandomState(5), mode)
     flat = plan['enc'] + plan['dec']
-    padded = _run_unpad('vqa', None, True, False, mode, flat)
-    ragged = _run_unpad('vqa', None, True, True, mode, flat)
+    padded = _run_unpad('vqa', None, True, False, mode, flat, B=B, Sy=Sy)
+    ragged = _run_unpad('vqa', None, True, True, mode, flat, B=B, Sy=Sy)
     assert padded[2] == [False] and ragged[2] == [True]
     _same(ragged, padded)
     if mode == 'full':      # the gate gradients live in the alpha_gate parameters' gradients: compared above by name
