@@ -11,14 +11,15 @@ ROOT=$PWD
 export TMPDIR=/tmp
 W=/tmp/mmnas_prof
 rm -rf $W; mkdir -p $W profiles
-for wl in search_vqa arch_vqa train_vqa; do
+for wl in search_vqa arch_vqa train_vqa search_vqa_unpad train_vqa_unpad; do
   cmd="bench.py --workload $wl --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline"
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace_$wl -o t -- python3 $ROOT/$cmd > $W/trace_$wl.log 2>&1)
   python3 tools/summarize_prof.py $W/trace_$wl profiles/${R}_$wl 23 \
     "rocprofv3 --kernel-trace --stats -- python3 $cmd  (3 warm-up + 10 timed + 10 roofline-pass steps)"
-  marker=onehot_rows; [ $wl = train_vqa ] && marker=row_is_zero
+  marker=onehot_rows; [ $wl = train_vqa ] && marker=row_is_zero; [ $wl = train_vqa_unpad ] && marker=row_is_zero
   python3 tools/step_timeline.py $W/trace_$wl $marker > profiles/${R}_timeline_$wl.txt
   [ -n "${SKIP_PMC:-}" ] && continue
+  case $wl in *_unpad) continue;; esac   # (the ragged records: kernel statistics and timeline only)
   small="bench.py --workload $wl --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-prof"
   for c in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d $W/pmc_${wl}_$c -o t -- python3 $ROOT/$small > $W/pmc_${wl}_$c.log 2>&1)
