@@ -306,7 +306,7 @@ struct GemmShape {
 //   * the MFMA operands change roles (B fragment as the A operand): the accumulators come out transposed, lane = row of C,
 //     registers = 4 runs of 4 consecutive columns, so the epilogue is four 16-byte buffer stores (and as many loads of the
 //     residual / gate / old value) with one row address per lane, predicated by the buffer range check.
-template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1, bool BDMA = false, bool LEAN = false>
+template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1, bool BDMA = false, int LEAN = 0>
 __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const int nwg, const int koff,
                                           float* __restrict__ As, float* __restrict__ Bs, float* __restrict__ As1,
                                           float* __restrict__ Bs1, int& s_old) {
@@ -318,6 +318,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
   // on one per-lane offset (range check = predication) instead of 16 guarded 64-bit address computations
   constexpr bool LEAN_TN = LEAN && !AKC;
   constexpr bool LEAN_SW = LEAN && AKC;   // transposed accumulators + 16-byte epilogue rows
+  constexpr bool LEAN_WT = LEAN_SW && LEAN == 1;   // whole tiles only: no stream-K code at all
   constexpr int RSWB = 48;   // BDMA: words per row of the B image (3 runs of 16 words, no pad)
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   // split rows: NS parts of 32 bf16 (64 B) + 16 B pad -> 144 / 208 B, an odd number of 16-B words (conflict-free b128)
@@ -382,7 +383,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
     if (!h.xcd_remap) v = bid;
   }
-  const int mode = LEAN_TN ? (int)MODE_SPLIT : h.mode;
+  const int mode = LEAN_TN ? (int)MODE_SPLIT : (LEAN_WT ? (int)MODE_TILE : h.mode);
   int u = 0, uend = 1;  // MODE_TILE / MODE_SPLIT: a single piece
   int vs = v;           // MODE_STREAM: index among the streaming workgroups
   int whole = -1;       // hybrid: the whole tile of this workgroup
@@ -400,7 +401,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     if (mode == MODE_TILE || whole >= 0) {
       tile = whole >= 0 ? whole : v; q0 = 0; nq = h.T;
       u = uend;
-    } else if (mode == MODE_SPLIT) {  // slice-major: neighbouring workgroups (one XCD) add into different tiles
+    } else if (!LEAN_SW && mode == MODE_SPLIT) {  // slice-major: neighbouring workgroups (one XCD) add into different tiles
       const int sl = LEAN_TN ? (int)__umulhi((unsigned)v, p.nt_magic) : v / h.ntiles;   // and stream the same K-slice of both operands through its L2
       tile = v - sl * h.ntiles;
       q0 = sl * h.P;
@@ -802,7 +803,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
 
     // ---- partial tile: hand the accumulators over; the last contributor to arrive finishes the tile ----
     const bool atomic_out = LEAN_TN || (!LEAN && nq != h.T && p.accumulate);  // "C +=" results: a partial tile simply adds its share
-    if (!LEAN_TN && nq != h.T && !atomic_out) {
+    if (!LEAN_TN && !LEAN_WT && nq != h.T && !atomic_out) {
       const int t0 = (tile - h.n_full) * h.T;  // first unit of the tile in the streamed sequence
       const int v_lo = t0 / h.P, v_hi = (t0 + h.T - 1) / h.P;  // contributors (streaming workgroup indices), inclusive
       // a workgroup has at most two partial tiles: the one it starts inside (slot 2v) and the one it
@@ -881,6 +882,10 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         for (int r = 0; r < 16; ++r)
           __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[0][0][r] * p.alpha, c_rs, base + (unsigned)((r & 3) + 8 * (r >> 2)) * ldc4, 0, 0);
       }
+#ifdef MMNAS_DBG_STAMP
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      MMNAS_LIFE(4);
       continue;
     }
     if constexpr (LEAN_SW) {
@@ -926,6 +931,10 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         w.x = __float_as_uint(o4[0]); w.y = __float_as_uint(o4[1]); w.z = __float_as_uint(o4[2]); w.w = __float_as_uint(o4[3]);
         __builtin_amdgcn_raw_buffer_store_b128(w, c_rs, offc[g], 0, 0);
       }
+#ifdef MMNAS_DBG_STAMP
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      MMNAS_LIFE(4);
       continue;
     }
 #pragma unroll
@@ -1052,7 +1061,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
   }
 }
 
-template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1, bool BDMA = false, bool LEAN = false>
+template <int BM, int BN, bool AKC, bool BKC, bool FAST, int NS, int EPI = 0, int PF = 1, bool BDMA = false, int LEAN = 0>
 __global__ void __launch_bounds__(256, NS ? (BM == 128 ? (BN == 64 ? 2 : 1) : MMNAS_OCC_NS) : (BM == 128 ? MMNAS_OCC128 : MMNAS_OCC64)) gemm_kernel(const GemmK p) {
   __shared__ __attribute__((aligned(16))) float As[GemmShape<BM, BN, NS>::A_SZ], As1[GemmShape<BM, BN, NS>::A_SZ];
   __shared__ __attribute__((aligned(16))) float Bs[GemmShape<BM, BN, NS>::B_SZ], Bs1[GemmShape<BM, BN, NS>::B_SZ];
@@ -1104,7 +1113,7 @@ __device__ __forceinline__ void aux_reduce_body(const AuxReduceK& a, int job, fl
   }
 }
 
-template <int BM, int BN, int NS, int PF = 1, bool LEAN0 = false, bool LEAN1 = false>
+template <int BM, int BN, int NS, int PF = 1, int LEAN0 = 0, int LEAN1 = 0>
 __global__ void __launch_bounds__(256, NS ? MMNAS_OCC_NS : MMNAS_OCC64) gemm_pair_kernel(const GemmK q0, const GemmK q1, const int nwg0,
                                                                                     const int nwg0p, const AuxReduceK aux,
                                                                                     const int naux8) {
@@ -1232,7 +1241,7 @@ struct GemmPlan {
   int nwg, layout;
   bool big, fast, wide;   // big: 128^2 tiles; wide: 128 x 64 tiles (BM x BN); neither: 64^2
   bool bdma;              // B = pre-split bf16 planes, loaded by LDS-DMA (NT, 64^2, bf16x6)
-  bool lean;              // whole tiles of an NT / NN product on the lean kernel (gemm_body<..., LEAN>)
+  int lean;               // the lean kernel (gemm_body<..., LEAN>): 1 whole tiles (NT / NN) or split-K pieces (TN), 2 hybrid / stream-K
   double flops, bytes;
   char tag[96];
 };
@@ -1430,7 +1439,7 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
   }
   // ---- the lean kernel: whole tiles of an NT / NN product on the default split-operand path whose epilogue operands can be
   //      moved as 16-byte rows and whose B matrix an XCD's L2 holds beside the A panels in flight ----
-  out.lean = false;
+  out.lean = 0;
   const bool lean_base = fast && !big && !wide && !out.bdma && g_tune.split == 3 && g_tune.pf == 2 &&
                          (k.tiles_n & (k.tiles_n - 1)) == 0 && d->ldc % 4 == 0;
   if (lean_base && (g_tune.lean & 1) && !tn && k.mode != MODE_SPLIT && d->N % 4 == 0 && 4.0 * d->N * d->K * d->nseg <= (double)g_tune.lean_maxb) {
@@ -1443,7 +1452,7 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
            (!s.residual || (((uintptr_t)s.residual & 15) == 0 && d->ldres % 4 == 0 && rows * d->ldres * 4.0 < 4.0e9)) &&
            (!s.gate || (((uintptr_t)s.gate & 15) == 0 && d->ldgate % 4 == 0 && rows * d->ldgate * 4.0 < 4.0e9));
     }
-    out.lean = ok;
+    out.lean = ok ? (k.mode == MODE_TILE ? 1 : 2) : 0;
   } else if (lean_base && tn && k.mode == MODE_SPLIT && d->nseg == 1 && (g_tune.lean & 2) && k.ntiles >= 2 && k.ntiles < 65536 && nwg < 65536) {
     // weight gradients: split-K pieces added by buffer atomics; nothing else rides on them
     bool ok = true;
@@ -1451,7 +1460,7 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
       const mmnas_gemm_group& s = d->g[g];
       ok = !s.bias && !s.residual && !s.gate && !s.colsum && ((double)s.M + 1.0) * d->ldc * 4.0 < 4.0e9;
     }
-    out.lean = ok;
+    out.lean = ok ? 1 : 0;
     if (ok) k.nt_magic = (unsigned)(((1ull << 32) + (unsigned)k.ntiles - 1) / (unsigned)k.ntiles);
   }
   if (out.lean) {
@@ -1472,9 +1481,14 @@ static int launch_plan(GemmPlan& pl, hipStream_t st) {
     return check_launch("gemm");
   }
   if (pl.lean) {
-    if (pl.layout == MMNAS_GEMM_NT) MMNAS_LAUNCH((gemm_kernel<64, 64, true, true, true, 3, 0, 2, false, true>), dim3(pl.nwg), dim3(256), 0, st, k);
-    else if (pl.layout == MMNAS_GEMM_NN) MMNAS_LAUNCH((gemm_kernel<64, 64, true, false, true, 3, 0, 2, false, true>), dim3(pl.nwg), dim3(256), 0, st, k);
-    else MMNAS_LAUNCH((gemm_kernel<64, 64, false, false, true, 3, 0, 2, false, true>), dim3(pl.nwg), dim3(256), 0, st, k);
+    const dim3 grid(pl.nwg), block(256);
+    if (pl.layout == MMNAS_GEMM_NT) {
+      if (pl.lean == 1) MMNAS_LAUNCH((gemm_kernel<64, 64, true, true, true, 3, 0, 2, false, 1>), grid, block, 0, st, k);
+      else MMNAS_LAUNCH((gemm_kernel<64, 64, true, true, true, 3, 0, 2, false, 2>), grid, block, 0, st, k);
+    } else if (pl.layout == MMNAS_GEMM_NN) {
+      if (pl.lean == 1) MMNAS_LAUNCH((gemm_kernel<64, 64, true, false, true, 3, 0, 2, false, 1>), grid, block, 0, st, k);
+      else MMNAS_LAUNCH((gemm_kernel<64, 64, true, false, true, 3, 0, 2, false, 2>), grid, block, 0, st, k);
+    } else MMNAS_LAUNCH((gemm_kernel<64, 64, false, false, true, 3, 0, 2, false, 1>), grid, block, 0, st, k);
     return check_launch("gemm");
   }
   if (pl.big) {
@@ -1532,9 +1546,10 @@ int gemm_pair_aux(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, co
     case 1: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 1, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8); break;
     case 2: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8); break;
     case 3:
-      if (p0.lean && p1.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, true, true>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
-      else if (p0.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, true, false>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
-      else if (p1.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, false, true>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
+      if (p0.lean == 1 && p1.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, 1, 1>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
+      else if (p0.lean == 2 && p1.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, 2, 1>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
+      else if (p0.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, 2, 0>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
+      else if (p1.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, 0, 1>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
       else if (g_tune.pf == 2) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
       else MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
       break;
