@@ -121,8 +121,8 @@ constexpr int KQ = BK / 4;     // float4 chunks per K-contiguous row
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff = 0) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
   float4 f;
   f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
   return f;
@@ -532,6 +532,18 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, bytesa, 0x00020000);
         const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, bytesb, 0x00020000);
         const unsigned ka = (unsigned)kt * stepa, kb = (unsigned)kt * stepb;
+        if (LEAN_SW) {
+          // (NT / NN; measured neutral to negative on the transposing loads of TN)  the K-tile's byte offset rides in the instruction's scalar offset -- the range check covers voffset + soffset and
+          // a voffset of ~0u stays out of range (tools/probe/soffset_probe.hip) -- and "no load" is a descriptor of zero
+          // records: no per-load compare / select / add, and the loads keep their places between the MFMAs
+          const __amdgpu_buffer_rsrc_t la_src = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, live ? bytesa : 0u, 0x00020000);
+          const __amdgpu_buffer_rsrc_t lb_src = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, live ? bytesb : 0u, 0x00020000);
+#pragma unroll
+          for (int i = 0; i < NA; ++i) ra[i] = buf_load4(la_src, offa[i], ka);
+#pragma unroll
+          for (int i = 0; i < NB; ++i) rb[i] = buf_load4(lb_src, offb[i], kb);
+          return;
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = buf_load4(ra_src, (offa[i] == ~0u || !live) ? ~0u : offa[i] + ka);
         if (BDMA) {
