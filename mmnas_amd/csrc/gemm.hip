@@ -1164,7 +1164,7 @@ static int env_int(const char* name, int dflt) {
 //   MMNAS_GEMM_LEAN=0|1|2|3 bit 0: NT / NN products, bit 1: split-K TN products on the lean kernels (default 3)
 //   MMNAS_GEMM_PF=1|2      K-tiles of operand loads in flight ahead of the MFMA block (64^2 fp32 buffer-load path)
 struct Tuning { int tile, generic, sk, wgs, min_units, gm, xcd, split, pair, split_slots, split_p, pf, wide_min, split_minwg, hyb_t, lean, lean_maxb; bool loaded; };
-static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 3, 1, 0, 24, 2, 200, 256, 16, 3, 2 << 20, false};
+static Tuning g_tune = {0, 0, 1, 0, 4, 0, 1, 3, 1, 0, 24, 2, 200, 256, 16, 3, 8 << 20, false};
 static void load_tuning() {
   g_tune.tile = env_int("MMNAS_GEMM_TILE", 0);
   g_tune.generic = getenv("MMNAS_GEMM_GENERIC") != nullptr;
@@ -1185,7 +1185,7 @@ static void load_tuning() {
   g_tune.hyb_t = env_int("MMNAS_GEMM_HYB_T", 16);                // fewest K-tiles per output tile for the whole-tiles + streamed-tail hybrid
   g_tune.wide_min = env_int("MMNAS_GEMM_WIDE_MIN", 200);         // fewest 128x64 tiles for that shape to be chosen
   g_tune.lean = env_int("MMNAS_GEMM_LEAN", 3);                   // bit 0: lean NT / NN kernels (short set-up, 16-byte epilogue rows); bit 1: lean TN
-  g_tune.lean_maxb = env_int("MMNAS_GEMM_LEAN_MAXB", 2 << 20);   // largest B matrix (bytes) the lean tile order is used for
+  g_tune.lean_maxb = env_int("MMNAS_GEMM_LEAN_MAXB", 8 << 20);   // largest B matrix (bytes) the lean tile order is used for
   g_tune.loaded = true;
 }
 

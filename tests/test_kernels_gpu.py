@@ -1156,6 +1156,84 @@ def test_gemm_streamed_pieces_across_k_segments(layout, wgs, gemm_tuning):
     assert rel_err(C.cpu().numpy(), ref.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('layout,Ms,N,K,nseg,epi', [
+    ('NT', [6400], 256, 256, 1, ''), ('NT', [300, 77, 130], 256, 64, 1, 'bRd'), ('NT', [100], 72, 96, 1, 'bdr'),
+    ('NT', [6397], 256, 256, 1, 'dr'), ('NN', [333], 128, 160, 1, 'g'), ('NN', [6400], 1024, 256, 1, 'gc'),
+    ('NN', [500], 256, 64, 3, 'r'), ('NN', [6400], 256, 256, 1, 'a'), ('NT', [129], 8, 32, 1, 'b')])
+def test_gemm_lean_kernels_equal_the_general_kernel(layout, Ms, N, K, nseg, epi, monkeypatch):
+    """Whole-tile NT / NN products run on the lean kernels (short set-up, transposed accumulators, 16-byte epilogue rows;
+    gemm_body<..., LEAN>): the same K loop and the same arithmetic per element, so results equal the general kernel's bit
+    for bit -- every epilogue term (bias, relu, dropout, gate, residual, accumulate), ragged M and N, grouped problems,
+    K-segments.  A product with column sums stays on the general kernel (checked to round-off: float atomics)."""
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=gen)
+    data = []
+    for M in Ms:
+        d = dict(A=[r(M, K) for _ in range(nseg)], B=[r(N, K) if layout == 'NT' else r(K, N) for _ in range(nseg)],
+                 bias=r(N) if 'b' in epi else None, residual=r(M, N) if 'r' in epi else None,
+                 gate=r(M, N) if 'g' in epi else None, C0=r(M, N))
+        data.append(d)
+    kw = dict(nseg=nseg, relu='R' in epi, accumulate='a' in epi)
+    if 'd' in epi:
+        kw['drop'] = (0.2, 4242, 5)
+    if 'g' in epi:
+        kw.update(gate_scale=1.25, ldgate=N)
+    if 'r' in epi:
+        kw['ldres'] = N
+    outs = {}
+    for lean in ('0', '3'):
+        monkeypatch.setenv('MMNAS_GEMM_LEAN', lean)
+        L.check(L.lib().mmnas_gemm_reload_tuning())
+        groups = [dict(M=M, A=d['A'], B=d['B'], C=d['C0'].clone(), bias=d['bias'], residual=d['residual'], gate=d['gate'],
+                       colsum=torch.zeros(N, device=DEV) if 'c' in epi else None) for M, d in zip(Ms, data)]
+        ops.gemm(L.GEMM_NT if layout == 'NT' else L.GEMM_NN, groups, N, K, K, K if layout == 'NT' else N, N, **kw)
+        torch.cuda.synchronize()
+        outs[lean] = groups
+    monkeypatch.delenv('MMNAS_GEMM_LEAN')
+    L.check(L.lib().mmnas_gemm_reload_tuning())
+    for a, b, d, M in zip(outs['0'], outs['3'], data, Ms):
+        assert torch.equal(a['C'], b['C'])
+        if 'c' in epi:
+            ref = a['C'].double().sum(0)
+            assert float((b['colsum'].double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6
+            assert float((a['colsum'].double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6
+    # and against float64 (no epilogue terms beyond bias / residual: the plain cases)
+    if epi in ('', 'r', 'b'):
+        for b, d in zip(outs['3'], data):
+            ref = sum(x.double() @ (w.double().t() if layout == 'NT' else w.double()) for x, w in zip(d['A'], d['B']))
+            if d['bias'] is not None:
+                ref = ref + d['bias'].double()
+            if d['residual'] is not None:
+                ref = ref + d['residual'].double()
+            assert float((b['C'].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize('Ms,N,K', [([256], 256, 6400), ([256, 256, 256], 256, 1600), ([96], 72, 1888), ([1024], 256, 3517), ([64], 64, 1888)])
+def test_gemm_lean_weight_gradient_pieces(Ms, N, K, monkeypatch):
+    """Split-K weight gradients (TN, "C +=") on the lean kernel: pieces found by multiply-shift, added by buffer atomics with
+    the rows behind M dropped by the range check and the columns behind N masked; one tile (no split) stays on the general
+    kernel."""
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=gen)
+    data = [dict(A=r(K, M), B=r(K, N), C0=r(M, N)) for M in Ms]
+    for lean in ('0', '3'):
+        monkeypatch.setenv('MMNAS_GEMM_LEAN', lean)
+        L.check(L.lib().mmnas_gemm_reload_tuning())
+        groups = [dict(M=M, A=[d['A']], B=[d['B']], C=d['C0'].clone()) for M, d in zip(Ms, data)]
+        if len(set(Ms)) == 1:
+            ops.gemm(L.GEMM_TN, groups, N, K, Ms[0], N, N, accumulate=True)
+        torch.cuda.synchronize()
+        for g, d in zip(groups, data):
+            ref = d['C0'].double() + d['A'].double().t() @ d['B'].double()
+            assert float((g['C'].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    monkeypatch.delenv('MMNAS_GEMM_LEAN')
+    L.check(L.lib().mmnas_gemm_reload_tuning())
+
+
 @pytest.mark.parametrize('Ms,N,K', [([200], 64, 32), ([6400], 256, 256), ([896, 77, 6400], 128, 512), ([130], 512, 2048)])
 def test_gemm_weight_planes_by_lds_dma_equal_the_in_kernel_split(Ms, N, K):
     """mmnas_gemm_desc.b_planes: the weight operand as the three bf16 planes of mmnas_split_planes, streamed global -> LDS by

@@ -37,6 +37,8 @@ def make(layout, Ms, N, K, epi, nseg=1):
             grp['residual'] = r(M, N)
         if 'g' in epi:
             grp['gate'] = r(M, N)
+        if 'c' in epi:
+            grp['colsum'] = torch.zeros(N, device=DEV)
         groups.append(grp)
     kw = dict(nseg=nseg)
     if 'R' in epi:
@@ -84,7 +86,7 @@ def main():
         ('NT', [6400], 1024, 256, 'bRd'), ('NT', [6400], 256, 1024, 'bdr'),
         ('NT', [896], 256, 256, ''), ('NT', [896] * 3, 256, 256, ''), ('NT', [896], 1024, 256, 'bRd'),
         ('NN', [6400], 256, 256, 'r'), ('NN', [6400], 1024, 256, 'g'), ('NN', [6400], 256, 256, '', 3), ('NN', [6400], 256, 1024, 'r'),
-        ('NN', [896], 256, 256, 'r'), ('NN', [6400], 256, 256, 'a'),
+        ('NN', [896], 256, 256, 'r'), ('NN', [6400], 256, 256, 'a'), ('NN', [6400], 1024, 256, 'gc'),
         ('NT', [6400], 512, 512, ''), ('NT', [6400] * 3, 512, 512, ''), ('NT', [6400], 512, 512, 'dr'), ('NT', [6400], 2048, 512, 'bRd'),
         ('NN', [6400], 512, 512, 'r'),
         ('NT', [6397], 256, 256, 'bdr'), ('NT', [100, 6400, 37], 256, 256, 'r'),
@@ -115,7 +117,7 @@ def main():
               % (layout, Ms, N, K, nseg, epi or '-', res[0][1], flops / res[0][1] * 1e-6, res[3][1], flops / res[3][1] * 1e-6,
                  res[3][1] / res[0][1], 'bit-equal' if same else 'max rel diff %.3g' % err), flush=True)
     # gradient pairs (one launch): dX = dY W (NN, + residual) and dW += dY^T X (TN)
-    for (M, N, K, epi) in [(6400, 256, 256, 'r'), (6400, 256, 256, ''), (6400, 1024, 256, 'g'), (6400, 256, 1024, 'r'), (896, 256, 256, 'r'),
+    for (M, N, K, epi) in [(6400, 256, 256, 'r'), (6400, 256, 256, ''), (6400, 1024, 256, 'gc'), (6400, 256, 1024, 'r'), (896, 256, 256, 'r'),
                            (6400, 512, 512, 'r')]:
         res = {}
         for lean in (0, 3):
