@@ -176,9 +176,11 @@ int mmnas_lstm_seq_bwd(const float* dout, const float* Whh, const float* Cs, con
                        int B, int H, void* stream);
 int mmnas_lstm_seq_timed_out(void* stream);
 
-/* Scheduling knobs of mmnas_gemm (MMNAS_GEMM_TILE, _SK, _WGS, _MIN_UNITS, _GENERIC, _GM, _XCD: tuning and tests only)
- * and the opt-in MMNAS_GEMM_SPLIT=3|6 (products as 3 / 6 bf16-MFMA products of exactly split fp32 operands, fp32
- * accumulation; default 0 = fp32 MFMA) are read from the environment on the first call; this re-reads them. */
+/* Scheduling knobs of mmnas_gemm (MMNAS_GEMM_TILE, _SK, _WGS, _MIN_UNITS, _GENERIC, _GM, _XCD, _LEAN: tuning and tests only;
+ * _LEAN=0 keeps every product on the general kernel instead of the lean instantiations, whose whole-tile results are
+ * bit-equal) and MMNAS_GEMM_SPLIT (6, the default: each fp32 product as 6 bf16-MFMA products of exactly split operands,
+ * fp32 accumulation; 0: fp32 MFMA; 3 / 1: reduced-precision experiments) are read from the environment on the first call;
+ * this re-reads them. */
 int mmnas_gemm_reload_tuning(void);
 
 /* ------------------------------------------------------------------------------------------
