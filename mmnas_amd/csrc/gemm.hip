@@ -317,8 +317,12 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
   // LEAN, TN (weight gradients): split-K pieces only ("C +=" by float atomics), one K-segment; the adds are buffer atomics
   // on one per-lane offset (range check = predication) instead of 16 guarded 64-bit address computations
   constexpr bool LEAN_TN = LEAN && !AKC;
-  constexpr bool LEAN_SW = LEAN && AKC;   // transposed accumulators + 16-byte epilogue rows
-  constexpr bool LEAN_WT = LEAN_SW && LEAN == 1;   // whole tiles only: no stream-K code at all
+  // LEAN 3 (NN, whole tiles): the accumulators keep their natural layout (lane = column) and the epilogue works element by
+  // element through buffer loads / stores on one per-lane offset -- for the products whose epilogue takes column sums (the
+  // hidden-layer gradient of an FFN with its bias gradient): a column's rows sit in one lane's registers
+  constexpr bool LEAN_EL = LEAN == 3;
+  constexpr bool LEAN_SW = LEAN && AKC && !LEAN_EL;   // transposed accumulators + 16-byte epilogue rows
+  constexpr bool LEAN_WT = (LEAN_SW && LEAN == 1) || LEAN_EL;   // whole tiles only: no stream-K code at all
   constexpr int RSWB = 48;   // BDMA: words per row of the B image (3 runs of 16 words, no pad)
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   // split rows: NS parts of 32 bf16 (64 B) + 16 B pad -> 144 / 208 B, an odd number of 16-B words (conflict-free b128)
@@ -401,7 +405,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
     if (mode == MODE_TILE || whole >= 0) {
       tile = whole >= 0 ? whole : v; q0 = 0; nq = h.T;
       u = uend;
-    } else if (!LEAN_SW && mode == MODE_SPLIT) {  // slice-major: neighbouring workgroups (one XCD) add into different tiles
+    } else if (!LEAN_SW && !LEAN_EL && mode == MODE_SPLIT) {  // slice-major: neighbouring workgroups (one XCD) add into different tiles
       const int sl = LEAN_TN ? (int)__umulhi((unsigned)v, p.nt_magic) : v / h.ntiles;   // and stream the same K-slice of both operands through its L2
       tile = v - sl * h.ntiles;
       q0 = sl * h.P;
@@ -532,7 +536,7 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
         const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, bytesa, 0x00020000);
         const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, bytesb, 0x00020000);
         const unsigned ka = (unsigned)kt * stepa, kb = (unsigned)kt * stepb;
-        if (LEAN_SW) {
+        if (LEAN_SW || LEAN_EL) {
           // (NT / NN; measured neutral to negative on the transposing loads of TN)  the K-tile's byte offset rides in the instruction's scalar offset -- the range check covers voffset + soffset and
           // a voffset of ~0u stays out of range (tools/probe/soffset_probe.hip) -- and "no load" is a descriptor of zero
           // records: no per-load compare / select / add, and the loads keep their places between the MFMAs
@@ -893,6 +897,51 @@ __device__ __forceinline__ void gemm_body(const GemmK& p, const int bid, const i
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[0][0][r] * p.alpha, c_rs, base + (unsigned)((r & 3) + 8 * (r >> 2)) * ldc4, 0, 0);
+      }
+#ifdef MMNAS_DBG_STAMP
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      MMNAS_LIFE(4);
+      continue;
+    }
+    if constexpr (LEAN_EL) {
+      // lane = column n0 + 32 wn + l31, register r = row m0 + 32 wm + 4 hh + (r & 3) + 8 (r >> 2): one byte offset per lane,
+      // + a scalar multiple of the leading dimension per register; rows behind M lie behind the buffers' ranges
+      const int col = n0 + wn * 32 + l31;
+      const int rbase = m0 + wm * 32 + 4 * hh;
+      const bool cok = col < h.N;
+      const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Cp, 0, (unsigned)Mg * (unsigned)p.ldc * 4u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc((void*)resp, 0, has_res ? (unsigned)Mg * (unsigned)p.ldres * 4u : 0u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)gatep, 0, has_gate ? (unsigned)Mg * (unsigned)p.ldgate * 4u : 0u, 0x00020000);
+      const unsigned cbase = cok ? (unsigned)(rbase * p.ldc + col) * 4u : ~0u;
+      const unsigned rbase_o = cok ? (unsigned)(rbase * p.ldres + col) * 4u : ~0u;
+      const unsigned gbase = cok ? (unsigned)(rbase * p.ldgate + col) * 4u : ~0u;
+      const unsigned ldc4 = (unsigned)p.ldc * 4u, ldr4 = (unsigned)p.ldres * 4u, ldg4 = (unsigned)p.ldgate * 4u;
+      float resv[16], gatev[16], oldv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned k = (unsigned)((r & 3) + 8 * (r >> 2));
+        resv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rs, rbase_o, k * ldr4, 0));
+        gatev[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(g_rs, gbase, k * ldg4, 0));
+        oldv[r] = has_acc ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c_rs, cbase, k * ldc4, 0)) : 0.f;
+      }
+      const float bv = biasp ? biasp[cok ? col : 0] : 0.f;
+      float cs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        float val = acc[0][0][r] * p.alpha + bv;
+        if (has_relu) val = fmaxf(val, 0.f);
+        if (has_drop) val *= drop_mult(gdrop, (uint32_t)row * (uint32_t)h.N + (uint32_t)col);
+        if (has_gate) val = gatev[r] > 0.f ? val * p.gate_scale : 0.f;
+        if (has_res) val += resv[r];
+        if (has_acc) val += oldv[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), c_rs, cbase, (unsigned)((r & 3) + 8 * (r >> 2)) * ldc4, 0);
+        if (row < Mg) cs += val;
+      }
+      if (csp != nullptr) {   // the two lane halves hold the other 16 rows of a column
+        cs += __shfl_xor(cs, 32, 64);
+        if (hh == 0 && cok) atomicAdd(csp + col, cs);
       }
 #ifdef MMNAS_DBG_STAMP
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1455,16 +1504,19 @@ static int plan_gemm(const mmnas_gemm_desc* d, hipStream_t st, GemmPlan& out) {
   const bool lean_base = fast && !big && !wide && !out.bdma && g_tune.split == 3 && g_tune.pf == 2 &&
                          (k.tiles_n & (k.tiles_n - 1)) == 0 && d->ldc % 4 == 0;
   if (lean_base && (g_tune.lean & 1) && !tn && k.mode != MODE_SPLIT && d->N % 4 == 0 && 4.0 * d->N * d->K * d->nseg <= (double)g_tune.lean_maxb) {
-    bool ok = true;
+    bool ok = true, any_colsum = false;
     for (int g = 0; g < d->ngroups && ok; ++g) {
       const mmnas_gemm_group& s = d->g[g];
       const double rows = (double)s.M + 1.0;
-      ok = !s.colsum && ((uintptr_t)s.C & 15) == 0 && rows * d->ldc * 4.0 < 4.0e9 &&
+      if (s.colsum) any_colsum = true;
+      ok = ((uintptr_t)s.C & 15) == 0 && rows * d->ldc * 4.0 < 4.0e9 &&
            (!s.bias || ((uintptr_t)s.bias & 15) == 0) &&
            (!s.residual || (((uintptr_t)s.residual & 15) == 0 && d->ldres % 4 == 0 && rows * d->ldres * 4.0 < 4.0e9)) &&
            (!s.gate || (((uintptr_t)s.gate & 15) == 0 && d->ldgate % 4 == 0 && rows * d->ldgate * 4.0 < 4.0e9));
     }
     out.lean = ok ? (k.mode == MODE_TILE ? 1 : 2) : 0;
+    // column sums: the element-wise lean form (NN, whole tiles) or the general kernel
+    if (any_colsum) out.lean = (ok && k.mode == MODE_TILE && d->layout == MMNAS_GEMM_NN) ? 3 : 0;
   } else if (lean_base && tn && k.mode == MODE_SPLIT && d->nseg == 1 && (g_tune.lean & 2) && k.ntiles >= 2 && k.ntiles < 65536 && nwg < 65536) {
     // weight gradients: split-K pieces added by buffer atomics; nothing else rides on them
     bool ok = true;
@@ -1498,7 +1550,8 @@ static int launch_plan(GemmPlan& pl, hipStream_t st) {
       if (pl.lean == 1) MMNAS_LAUNCH((gemm_kernel<64, 64, true, true, true, 3, 0, 2, false, 1>), grid, block, 0, st, k);
       else MMNAS_LAUNCH((gemm_kernel<64, 64, true, true, true, 3, 0, 2, false, 2>), grid, block, 0, st, k);
     } else if (pl.layout == MMNAS_GEMM_NN) {
-      if (pl.lean == 1) MMNAS_LAUNCH((gemm_kernel<64, 64, true, false, true, 3, 0, 2, false, 1>), grid, block, 0, st, k);
+      if (pl.lean == 3) MMNAS_LAUNCH((gemm_kernel<64, 64, true, false, true, 3, 0, 2, false, 3>), grid, block, 0, st, k);
+      else if (pl.lean == 1) MMNAS_LAUNCH((gemm_kernel<64, 64, true, false, true, 3, 0, 2, false, 1>), grid, block, 0, st, k);
       else MMNAS_LAUNCH((gemm_kernel<64, 64, true, false, true, 3, 0, 2, false, 2>), grid, block, 0, st, k);
     } else MMNAS_LAUNCH((gemm_kernel<64, 64, false, false, true, 3, 0, 2, false, 1>), grid, block, 0, st, k);
     return check_launch("gemm");
@@ -1558,7 +1611,9 @@ int gemm_pair_aux(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, co
     case 1: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 1, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8); break;
     case 2: MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 2>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8); break;
     case 3:
-      if (p0.lean == 1 && p1.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, 1, 1>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
+      if (p0.lean == 3 && p1.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, 3, 1>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
+      else if (p0.lean == 3) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, 3, 0>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
+      else if (p0.lean == 1 && p1.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, 1, 1>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
       else if (p0.lean == 2 && p1.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, 2, 1>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
       else if (p0.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, 2, 0>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);
       else if (p1.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, 0, 1>), grid, block, 0, st, p0.k, p1.k, p0.nwg, nwg0p, ak, naux8);

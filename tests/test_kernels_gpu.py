@@ -1159,12 +1159,13 @@ def test_gemm_streamed_pieces_across_k_segments(layout, wgs, gemm_tuning):
 @pytest.mark.parametrize('layout,Ms,N,K,nseg,epi', [
     ('NT', [6400], 256, 256, 1, ''), ('NT', [300, 77, 130], 256, 64, 1, 'bRd'), ('NT', [100], 72, 96, 1, 'bdr'),
     ('NT', [6397], 256, 256, 1, 'dr'), ('NN', [333], 128, 160, 1, 'g'), ('NN', [6400], 1024, 256, 1, 'gc'),
+    ('NN', [333, 70], 72, 160, 1, 'gcr'),
     ('NN', [500], 256, 64, 3, 'r'), ('NN', [6400], 256, 256, 1, 'a'), ('NT', [129], 8, 32, 1, 'b')])
 def test_gemm_lean_kernels_equal_the_general_kernel(layout, Ms, N, K, nseg, epi, monkeypatch):
     """Whole-tile NT / NN products run on the lean kernels (short set-up, transposed accumulators, 16-byte epilogue rows;
     gemm_body<..., LEAN>): the same K loop and the same arithmetic per element, so results equal the general kernel's bit
     for bit -- every epilogue term (bias, relu, dropout, gate, residual, accumulate), ragged M and N, grouped problems,
-    K-segments.  A product with column sums stays on the general kernel (checked to round-off: float atomics)."""
+    K-segments.  Column sums (the element-wise lean form of NN products) are float atomics: checked to round-off."""
     from mmnas_amd import ops
     import mmnas_amd._lib as L
     gen = torch.Generator(device=DEV).manual_seed(5)
