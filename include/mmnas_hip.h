@@ -234,6 +234,18 @@ int mmnas_glu_bwd(const float* h, const float* dy, float* dh, int M, int C, int 
  *   S <= 1024.
  * ------------------------------------------------------------------------------------------ */
 int mmnas_row_is_zero(const float* f, uint8_t* mask, long rows, int d, void* stream);
+/* nn.Linear with ONE output unit (AttFlat's glimpse logits at ATTFLAT_GLIMPSES = 1: MLP.linear, modules.py:34-41): a
+ * matrix-vector product instead of a GEMM launch with one live column, and its backward as one pass over x:
+ *   fwd: y[r] = x[r,:] . w + b[0]                                  x [rows,K], w [K], b [1] or NULL, y [rows]
+ *   bwd: dx[r,:] = dy[r] w;  dw[:] += sum_r dy[r] x[r,:];  db[0] += sum_r dy[r]   (db may be NULL)
+ *        ws: mmnas_glimpse1_bwd_ws_floats(rows, K) floats of scratch (partial column sums, reduced by a second launch)
+ * K % 4 == 0, K <= 1024 (mmnas_glimpse1_supported); the native head (mmnas_head_*) uses the same kernels, there with the
+ * relu' / dropout replay of the hidden layer folded in. */
+int mmnas_glimpse1_supported(int K);
+size_t mmnas_glimpse1_bwd_ws_floats(long rows, int K);
+int mmnas_glimpse1_fwd(const float* x, const float* w, const float* b, float* y, long rows, int K, void* stream);
+int mmnas_glimpse1_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, float* ws, long rows, int K,
+                       void* stream);
 int mmnas_attflat_pool_fwd(const float* logits, const float* x, const uint8_t* mask, float* probs, float* pooled,
                            int B, int S, int d, int G, void* stream);
 int mmnas_attflat_pool_bwd(const float* probs, const float* x, const uint8_t* mask, const float* dpooled,

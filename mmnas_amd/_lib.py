@@ -139,6 +139,10 @@ SYMBOLS = {
     'mmnas_rel_bias_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp]),
     'mmnas_rel_bias_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     'mmnas_row_is_zero': (_i, [_fp, _fp, C.c_long, _i, _fp]),
+    'mmnas_glimpse1_supported': (_i, [_i]),
+    'mmnas_glimpse1_bwd_ws_floats': (_sz, [C.c_long, _i]),
+    'mmnas_glimpse1_fwd': (_i, [_fp, _fp, _fp, _fp, C.c_long, _i, _fp]),
+    'mmnas_glimpse1_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_long, _i, _fp]),
     'mmnas_attflat_pool_fwd': (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),
     'mmnas_attflat_pool_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),
     'mmnas_relation_embedding': (_i, [_fp, _fp, _fp, _i, _i, _fp]),

@@ -140,6 +140,115 @@ __global__ void __launch_bounds__(AF_THREADS) attflat_pool_bwd_kernel(const floa
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// One glimpse (ATTFLAT_GLIMPSES = 1, every shipped configuration): the glimpse-logit layer of AttFlat's MLP
+// (MLP.linear, modules.py:34-41) is a matrix-VECTOR product and its backward an outer product plus three reductions.
+// On the GEMM kernel they were launches of 64-wide tiles with one live column or one K step (13-27 us each on the guarded
+// path: N = 1 / K = 1 is no shape for vector loads); here they are one pass over h each.
+//   forward : logit[r] = h[r,:] . w2 + b2                                  (both AttFlat sides in one launch)
+//   backward: dh[r,c] = h[r,c] > 0 ? dlog[r] w2[c] gate_scale : 0          (gated: relu' and the dropout replay from h; the
+//                                                                           per-operator path passes gated = 0, scale 1)
+//             db1[c] += sum_r dh[r,c];  dW2[c] += sum_r dlog[r] h[r,c];  db2 += sum_r dlog[r]
+// ------------------------------------------------------------------------------------------
+struct Glimpse1Side { const float* h; const float* w2; const float* b2; float* logit; long rows; };
+
+__global__ void __launch_bounds__(256) glimpse1_fwd_kernel(const Glimpse1Side s0, const Glimpse1Side s1, int MID) {
+  const int lane = threadIdx.x & 63;
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool first = row < s0.rows;
+  const Glimpse1Side& s = first ? s0 : s1;
+  if (!first) row -= s0.rows;
+  if (row >= s.rows) return;
+  const float* hr = s.h + row * MID;
+  float a = 0.f;
+  for (int c = lane * 4; c < MID; c += 256) {
+    const float4 hv = *reinterpret_cast<const float4*>(hr + c);
+    const float4 wv = *reinterpret_cast<const float4*>(s.w2 + c);
+    a += (hv.x * wv.x + hv.y * wv.y) + (hv.z * wv.z + hv.w * wv.w);
+  }
+  a = wave_sum(a);
+  if (lane == 0) s.logit[row] = a + (s.b2 ? s.b2[0] : 0.f);
+}
+
+// Backward: many small workgroups (a thread walks <= 8 rows with its loads issued ahead: the pass is latency-bound, one
+// block per CU with a serial row loop took 50-78 us); a workgroup's column sums go to partial row blockIdx of a
+// [blocks][3][MID] buffer (planes db1 | dW2 | unused) that the NEXT gradient-pair launch reduces with a few extra
+// workgroups (AuxReduce, as for the LayerNorm parameter gradients) -- same-address float atomics from hundreds of
+// workgroups cost ~120 ns each.  db2 (one number) stays a column-sum launch of dlog.
+constexpr int G1_ITER = 4;    // rows per thread
+__global__ void __launch_bounds__(256) glimpse1_bwd_kernel(const float* __restrict__ dlog, const float* __restrict__ h,
+                                                           const float* __restrict__ w2, float gate_scale, int gated,
+                                                           float* __restrict__ dh, float* __restrict__ part, long rows, int MID) {
+  __shared__ float red[2][1024];   // [db1 | dW2][slot * MID + column]: rs * MID <= 1024 (rs = 256 / (MID / 4) row slots)
+  const int nc4 = MID >> 2;               // threads along the columns (<= 256)
+  const int rs = 256 / nc4;               // row slots of the workgroup
+  const int c4 = threadIdx.x % nc4, slot = threadIdx.x / nc4;
+  const long r0 = (long)blockIdx.x * (rs * G1_ITER);
+  float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sw = sb;
+  if (slot < rs) {
+    const float4 wv = *reinterpret_cast<const float4*>(w2 + 4 * c4);
+    float dl[G1_ITER];
+    float4 hv[G1_ITER];
+#pragma unroll
+    for (int i = 0; i < G1_ITER; ++i) {   // all loads first
+      const long r = r0 + slot + (long)i * rs;
+      const long rc = r < rows ? r : rows - 1;
+      dl[i] = r < rows ? dlog[rc] : 0.f;
+      hv[i] = *reinterpret_cast<const float4*>(h + rc * MID + 4 * c4);
+    }
+#pragma unroll
+    for (int i = 0; i < G1_ITER; ++i) {
+      const long r = r0 + slot + (long)i * rs;
+      float4 o;
+      o.x = (!gated || hv[i].x > 0.f) ? dl[i] * wv.x * gate_scale : 0.f; o.y = (!gated || hv[i].y > 0.f) ? dl[i] * wv.y * gate_scale : 0.f;
+      o.z = (!gated || hv[i].z > 0.f) ? dl[i] * wv.z * gate_scale : 0.f; o.w = (!gated || hv[i].w > 0.f) ? dl[i] * wv.w * gate_scale : 0.f;
+      if (r < rows) *reinterpret_cast<float4*>(dh + r * MID + 4 * c4) = o;
+      sb.x += o.x; sb.y += o.y; sb.z += o.z; sb.w += o.w;          // (rows behind the end: dl = 0)
+      sw.x += dl[i] * hv[i].x; sw.y += dl[i] * hv[i].y; sw.z += dl[i] * hv[i].z; sw.w += dl[i] * hv[i].w;
+    }
+    *reinterpret_cast<float4*>(&red[0][slot * MID + 4 * c4]) = sb;
+    *reinterpret_cast<float4*>(&red[1][slot * MID + 4 * c4]) = sw;
+  }
+  __syncthreads();
+  float* mine = part + (size_t)blockIdx.x * 3 * MID;
+  for (int i = threadIdx.x; i < 2 * MID; i += 256) {
+    const int a = i < MID ? 0 : 1, c = i - a * MID;
+    float v = 0.f;
+    for (int q = 0; q < rs; ++q) v += red[a][q * MID + c];
+    mine[a * MID + c] = v;
+  }
+}
+
+bool glimpse1_supported(int MID) { return MID >= 4 && MID % 4 == 0 && MID <= 1024; }
+
+// logits of both AttFlat sides (side 1 may have rows = 0)
+int glimpse1_fwd(const float* h0, const float* w0, const float* b0, float* l0, long rows0, const float* h1, const float* w1,
+                 const float* b1, float* l1, long rows1, int MID, hipStream_t st) {
+  MMNAS_REQUIRE(glimpse1_supported(MID) && h0 && w0 && l0 && rows0 > 0 && (rows1 == 0 || (h1 && w1 && l1)), MMNAS_E_ARG,
+                "glimpse1_fwd: bad arguments");
+  const Glimpse1Side s0{h0, w0, b0, l0, rows0}, s1{h1, w1, b1, l1, rows1};
+  ProfScope ps(MMNAS_K_ROWOPS, 2.0 * (rows0 + rows1) * MID, 4.0 * (rows0 + rows1) * MID, st);
+  MMNAS_LAUNCH(glimpse1_fwd_kernel, dim3((unsigned)((rows0 + rows1 + 3) / 4)), dim3(256), 0, st, s0, s1, MID);
+  return check_launch("glimpse1_fwd");
+}
+
+int glimpse1_bwd_blocks(long rows, int MID) {
+  const int rs = 256 / (MID >> 2);
+  return (int)((rows + rs * G1_ITER - 1) / (rs * G1_ITER));
+}
+
+// dh and the partial column sums part[blocks][3][MID]; *aux names the pending reduction (db1 += plane 0, dW2 += plane 1)
+int glimpse1_bwd(const float* dlog, const float* h, const float* w2, float gate_scale, int gated, float* dh, float* db1, float* dW2,
+                 float* part, long rows, int MID, hipStream_t st, AuxReduce* aux) {
+  MMNAS_REQUIRE(glimpse1_supported(MID) && dlog && h && w2 && dh && dW2 && part && aux && rows > 0, MMNAS_E_ARG, "glimpse1_bwd: bad arguments");
+  const int nb = glimpse1_bwd_blocks(rows, MID);
+  ProfScope ps(MMNAS_K_ROWOPS, 5.0 * rows * MID, 8.0 * rows * MID, st);
+  MMNAS_LAUNCH(glimpse1_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, dlog, h, w2, gate_scale, gated, dh, part, rows, MID);
+  aux->part = part; aux->nrows = nb; aux->d = MID;
+  aux->out[0] = db1; aux->out[1] = dW2; aux->out[2] = nullptr;
+  return check_launch("glimpse1_bwd");
+}
+
 }  // namespace mmnas
 
 using namespace mmnas;
@@ -148,6 +257,23 @@ extern "C" int mmnas_row_is_zero(const float* f, uint8_t* mask, long rows, int d
   MMNAS_REQUIRE(f && mask && rows > 0 && d > 0, MMNAS_E_ARG, "row_is_zero: bad arguments");
   MMNAS_LAUNCH(row_is_zero_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, f, mask, rows, d);
   return check_launch("row_is_zero");
+}
+
+extern "C" int mmnas_glimpse1_supported(int K) { return glimpse1_supported(K) ? 1 : 0; }
+extern "C" size_t mmnas_glimpse1_bwd_ws_floats(long rows, int K) {
+  return glimpse1_supported(K) && rows > 0 ? (size_t)glimpse1_bwd_blocks(rows, K) * 3 * K : 0;
+}
+extern "C" int mmnas_glimpse1_fwd(const float* x, const float* w, const float* b, float* y, long rows, int K, void* stream) {
+  return glimpse1_fwd(x, w, b, y, rows, nullptr, nullptr, nullptr, nullptr, 0, K, (hipStream_t)stream);
+}
+extern "C" int mmnas_glimpse1_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, float* ws, long rows,
+                                  int K, void* stream) {
+  MMNAS_REQUIRE(ws, MMNAS_E_ARG, "glimpse1_bwd: null workspace");
+  AuxReduce aux;
+  int rc = glimpse1_bwd(dy, x, w, 1.0f, 0, dx, nullptr, dw, ws, rows, K, (hipStream_t)stream, &aux);
+  if (rc) return rc;
+  if ((rc = launch_aux_reduce(aux, (hipStream_t)stream))) return rc;
+  return db ? mmnas_colsum(dy, db, (int)rows, 1, 1, stream) : MMNAS_OK;
 }
 
 extern "C" int mmnas_attflat_pool_fwd(const float* logits, const float* x, const uint8_t* mask, float* probs,

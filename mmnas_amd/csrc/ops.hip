@@ -738,6 +738,10 @@ static bool head_overlap_on() {
   static const int on = [] { const char* e = getenv("MMNAS_HEAD_OVERLAP"); return e && e[0] ? atoi(e) : 0; }();
   return on != 0;
 }
+static bool head_glimpse1_on() {   // MMNAS_HEAD_GLIMPSE1=0: the one-glimpse logit layer as GEMM launches (A/B, tests)
+  const char* e = getenv("MMNAS_HEAD_GLIMPSE1");
+  return !(e && e[0] == '0');
+}
 static int first_guided(const mmnas_chain* c) {
   for (int i = 0; i < c->n_ops; ++i)
     if (c->ops[i].kind == MMNAS_CHAIN_ATT && !(c->ops[i].att.flags & MMNAS_F_SELF)) return i;
@@ -1184,10 +1188,10 @@ extern "C" int mmnas_chain_join(void* main_stream, void* waiting_stream) {
 // nodes (the head's kernels take 5-15 us each, so the per-node host cost -- not the GPU -- set its duration).
 namespace mmnas {
 
-struct HeadSideLayout { float *h, *logit, *probs, *pooled, *dpooled, *dlog, *dh, *dxpool; };
+struct HeadSideLayout { float *h, *logit, *probs, *pooled, *dpooled, *dlog, *dh, *dxpool, *g1part; };
 struct HeadLayout {
   HeadSideLayout s[2];
-  float *xo, *sum, *xy, *dxy, *dsum, *lnws;
+  float *xo, *sum, *xy, *dxy, *dsum, *lnws, *g1proj;
   size_t total;
 };
 
@@ -1201,10 +1205,14 @@ static HeadLayout head_layout(const mmnas_head* hd) {
     HeadSideLayout& s = L.s[k];
     s.h = c.take(M * hd->MID); s.logit = c.take(M * hd->G); s.probs = c.take(M * hd->G); s.pooled = c.take(B * hd->G * hd->d);
     s.dpooled = c.take(B * hd->G * hd->d); s.dlog = c.take(M * hd->G); s.dh = c.take(M * hd->MID); s.dxpool = c.take(M * hd->d);
+    // one glimpse: partial column sums of the glimpse-logit backward (head.hip), reduced by the next pair launch
+    s.g1part = (hd->G == 1 && glimpse1_supported(hd->MID)) ? c.take((size_t)glimpse1_bwd_blocks((long)M, hd->MID) * 3 * hd->MID) : nullptr;
   }
   L.xo = c.take(B * hd->OUT); L.sum = c.take(B * hd->OUT); L.xy = c.take(B * hd->OUT);
   L.dxy = c.take(B * hd->OUT); L.dsum = c.take(B * hd->OUT);
   L.lnws = c.take(mmnas_layernorm_bwd_ws_floats(hd->B, hd->OUT));
+  // one answer unit (the ITM matching score): the projection through the one-unit kernels of head.hip
+  L.g1proj = (hd->ANS == 1 && glimpse1_supported(hd->OUT)) ? c.take((size_t)glimpse1_bwd_blocks((long)B, hd->OUT) * 3 * hd->OUT) : nullptr;
   L.total = c.off;
   return L;
 }
@@ -1259,14 +1267,20 @@ extern "C" int mmnas_head_fwd(const mmnas_head* hd, void* stream) {
     if ((rc = mmnas_gemm(&g, side_stream(k)))) return rc;
   }
   // glimpse logits = h W2^T + b2                                   (MLP.linear, modules.py:34-41)
+  const bool g1 = G == 1 && !oc && glimpse1_supported(MID) && head_glimpse1_on();
+  if (g1) {   // one glimpse: a matrix-vector product per side, both in one launch (head.hip)
+    if ((rc = glimpse1_fwd(L.s[0].h, hd->sx.W2, hd->sx.b2, L.s[0].logit, (long)B * hd->sx.S, L.s[1].h, hd->sy.W2, hd->sy.b2,
+                           L.s[1].logit, (long)B * hd->sy.S, MID, st)))
+      return rc;
+  }
   gemm_init(g, MMNAS_GEMM_NT, G, MID, MID, MID, G);
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 2 && !g1; ++k) {
     const mmnas_attflat_side& sd = *sides[k];
     mmnas_gemm_group& gg = g.g[oc ? 0 : k];
     gg.M = B * sd.S; gg.A[0] = L.s[k].h; gg.B[0] = sd.W2; gg.bias = sd.b2; gg.C = L.s[k].logit;
     if (oc && (rc = mmnas_gemm(&g, side_stream(k)))) return rc;
   }
-  if (!oc) { g.ngroups = 2; if ((rc = mmnas_gemm(&g, stream))) return rc; }
+  if (!oc && !g1) { g.ngroups = 2; if ((rc = mmnas_gemm(&g, stream))) return rc; }
   for (int k = 0; k < 2; ++k) {
     const mmnas_attflat_side& sd = *sides[k];
     const HeadSideLayout& s = L.s[k];
@@ -1281,6 +1295,8 @@ extern "C" int mmnas_head_fwd(const mmnas_head* hd, void* stream) {
     if ((rc = mmnas_gemm(&g, ks))) return rc;
   }
   if ((rc = mmnas_layernorm_fwd(L.sum, hd->ln_a, hd->ln_b, L.xy, B, OUT, hd->eps, stream))) return rc;
+  if (L.g1proj && head_glimpse1_on())
+    return glimpse1_fwd(L.xy, hd->Wp, hd->bp, hd->logits, B, nullptr, nullptr, nullptr, nullptr, 0, OUT, st);
   gemm_init(g, MMNAS_GEMM_NT, hd->ANS, OUT, OUT, OUT, hd->ANS);
   g.g[0].M = B; g.g[0].A[0] = L.xy; g.g[0].B[0] = hd->Wp; g.g[0].bias = hd->bp; g.g[0].C = hd->logits;
   return mmnas_gemm(&g, stream);
@@ -1297,11 +1313,17 @@ extern "C" int mmnas_head_bwd(const mmnas_head* hd, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   mmnas_gemm_desc g, w;
   // answer projection
-  gemm_init(w, MMNAS_GEMM_TN, OUT, B, ANS, OUT, OUT);
-  w.g[0].M = ANS; w.g[0].A[0] = hd->dlogits; w.g[0].B[0] = L.xy; w.g[0].C = hd->dWp; w.accumulate = 1;
-  gemm_init(g, MMNAS_GEMM_NN, OUT, ANS, ANS, OUT, OUT);
-  g.g[0].M = B; g.g[0].A[0] = hd->dlogits; g.g[0].B[0] = hd->Wp; g.g[0].C = L.dxy;
-  if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
+  if (L.g1proj && head_glimpse1_on()) {
+    AuxReduce pr;
+    if ((rc = glimpse1_bwd(hd->dlogits, L.xy, hd->Wp, 1.0f, 0, L.dxy, nullptr, hd->dWp, L.g1proj, B, OUT, st, &pr))) return rc;
+    if ((rc = launch_aux_reduce(pr, st))) return rc;
+  } else {
+    gemm_init(w, MMNAS_GEMM_TN, OUT, B, ANS, OUT, OUT);
+    w.g[0].M = ANS; w.g[0].A[0] = hd->dlogits; w.g[0].B[0] = L.xy; w.g[0].C = hd->dWp; w.accumulate = 1;
+    gemm_init(g, MMNAS_GEMM_NN, OUT, ANS, ANS, OUT, OUT);
+    g.g[0].M = B; g.g[0].A[0] = hd->dlogits; g.g[0].B[0] = hd->Wp; g.g[0].C = L.dxy;
+    if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
+  }
   if (hd->dbp && (rc = mmnas_colsum(hd->dlogits, hd->dbp, B, ANS, ANS, stream))) return rc;
   // proj_norm
   AuxReduce lnred;
@@ -1328,6 +1350,12 @@ extern "C" int mmnas_head_bwd(const mmnas_head* hd, void* stream) {
     // pooling
     if ((rc = mmnas_attflat_pool_bwd(s.probs, sd.x, sd.mask, s.dpooled, s.dlog, s.dxpool, B, sd.S, d, G, stream))) return rc;
     // glimpse-logit linear: dh = dlog W2 with relu' and the dropout replay from h; db1 rides as column sums of dh
+    AuxReduce g1red;
+    g1red.part = nullptr;
+    if (G == 1 && glimpse1_supported(MID) && head_glimpse1_on()) {   // one glimpse: an outer product + three reductions, one pass over h
+      if ((rc = glimpse1_bwd(s.dlog, s.h, sd.W2, gate_scale, 1, s.dh, sd.db1, sd.dW2, s.g1part, M, MID, st, &g1red))) return rc;
+      if (sd.db2 && (rc = mmnas_colsum(s.dlog, sd.db2, M, G, G, stream))) return rc;
+    } else {
     gemm_init(w, MMNAS_GEMM_TN, MID, M, G, MID, MID);
     w.g[0].M = G; w.g[0].A[0] = s.dlog; w.g[0].B[0] = s.h; w.g[0].C = sd.dW2; w.accumulate = 1;
     gemm_init(g, MMNAS_GEMM_NN, MID, G, G, MID, MID);
@@ -1336,13 +1364,14 @@ extern "C" int mmnas_head_bwd(const mmnas_head* hd, void* stream) {
     g.g[0].colsum = sd.db1;
     if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
     if (sd.db2 && (rc = mmnas_colsum(s.dlog, sd.db2, M, G, G, stream))) return rc;
+    }
     // FC: dx = dh W1 + the pooling path's share
     gemm_init(w, MMNAS_GEMM_TN, d, M, MID, d, d);
     w.g[0].M = MID; w.g[0].A[0] = s.dh; w.g[0].B[0] = sd.x; w.g[0].C = sd.dW1; w.accumulate = 1;
     gemm_init(g, MMNAS_GEMM_NN, d, MID, MID, d, d);
     g.g[0].M = M; g.g[0].A[0] = s.dh; g.g[0].B[0] = sd.W1; g.g[0].C = sd.dx;
     g.g[0].residual = s.dxpool; g.ldres = d;
-    if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
+    if ((rc = gemm_pair_aux(&g, &w, g1red.part ? &g1red : nullptr, st))) return rc;
   }
   if (oc && (rc = ev_fork(oc->enc, st, oc->ovl[3]))) return rc;
   return MMNAS_OK;

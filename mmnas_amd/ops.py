@@ -422,6 +422,11 @@ def gemm_pair(dgrad, wgrad):
     L.check(L.lib().mmnas_gemm_pair(C.byref(dgrad), C.byref(wgrad), L.stream()))
 
 
+def _glimpse1_on():
+    """MMNAS_HEAD_GLIMPSE1=0: the one-unit linear layers as GEMM launches (A/B, tests) -- read per call, like the native head."""
+    return os.environ.get('MMNAS_HEAD_GLIMPSE1', '1') != '0'
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x W^T + b) on the MFMA GEMM (nn.Linear, modules.py:18,115)."""
 
@@ -433,8 +438,14 @@ class LinearFn(torch.autograd.Function):
         M = x.numel() // K
         N = W.shape[0]
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
-        gemm(L.GEMM_NT, [dict(M=M, A=[x], B=[W], C=y, bias=(_f32c(b) if b is not None else None))],
-             N, K, K, K, N, relu=relu)
+        # one output unit (AttFlat's glimpse logits): a matrix-vector product, the kernels the native head uses
+        ctx.one = N == 1 and not relu and _glimpse1_on() and bool(L.lib().mmnas_glimpse1_supported(K))
+        if ctx.one:
+            L.check(L.lib().mmnas_glimpse1_fwd(L.fptr(x), L.fptr(W), L.fptr(_f32c(b) if b is not None else None), L.fptr(y), M, K,
+                                               L.stream()))
+        else:
+            gemm(L.GEMM_NT, [dict(M=M, A=[x], B=[W], C=y, bias=(_f32c(b) if b is not None else None))],
+                 N, K, K, K, N, relu=relu)
         ctx.save_for_backward(x, W, y if relu else None)
         ctx.has_bias, ctx.relu = b is not None, relu
         return y
@@ -451,6 +462,14 @@ class LinearFn(torch.autograd.Function):
         # Both parameter gradients are ADDED into their buffers: the flat gradient buffer's views when the parameter
         # has a sink (no zero-fill, no autograd accumulate kernel), one fresh zeroed allocation otherwise.
         (dW, db), rets, sinks = _grad_bufs(ctx.params, x.device)
+        if ctx.one:
+            dx = torch.empty_like(x)   # (always formed: the kernel is one pass over x either way)
+            ws = torch.empty(L.lib().mmnas_glimpse1_bwd_ws_floats(M, K), dtype=torch.float32, device=x.device)
+            L.check(L.lib().mmnas_glimpse1_bwd(L.fptr(dy), L.fptr(x), L.fptr(W), L.fptr(dx), L.fptr(dW),
+                                               L.fptr(db if ctx.has_bias else None), L.fptr(ws), M, K, L.stream()))
+            for sk in sinks:
+                sk.done()
+            return (dx if ctx.needs_input_grad[0] else None), rets[0], rets[1], None
         wgrad = gemm_desc(L.GEMM_TN, [dict(M=N, A=[dy], B=[x], C=dW)], K, M, N, K, K, accumulate=True)
         dx = None
         if ctx.needs_input_grad[0]:   # e.g. the relation/region feature inputs of the stem need none

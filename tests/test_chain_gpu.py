@@ -14,12 +14,14 @@ DEV = 'cuda:0'
 T = torch.from_numpy
 
 
-def _run(task, arch, search, chain, side, monkeypatch, dropout=0.1, plan=None, B=3):
+def _run(task, arch, search, chain, side, monkeypatch, dropout=0.1, plan=None, B=3, glimpse1=True):
     import importlib
     from mmnas_amd import dp, ops
     from mmnas.model.mixed import MixedOp
     monkeypatch.setenv('MMNAS_CHAIN', '1' if chain else '0')
     monkeypatch.setenv('MMNAS_SIDE_STREAM', '1' if side else '0')
+    # (0: AttFlat's glimpse-logit layer as GEMM launches instead of the matrix-vector kernels -- in both paths)
+    monkeypatch.setenv('MMNAS_HEAD_GLIMPSE1', '1' if glimpse1 else '0')
     c = cases.net_case(task, arch, 31337, search=search, B=B, Sx=6, Sy=9)
     c['cfg'].DROPOUT_R = dropout
     mod = importlib.import_module('mmnas.model.%s_%s' % ('hygr' if search else 'full', task))
@@ -88,6 +90,31 @@ def test_chain_equals_per_operator_path_net_full(task, arch, monkeypatch):
         got = _run(task, arch, False, True, side, monkeypatch)
         assert got[2] == 1, 'the backbone chain was not taken'
         _compare(got, ref)
+
+
+@pytest.mark.parametrize('task,arch,search', [('vqa', 'mmnas_vqa', False), ('itm', 'mmnas_itm', False), ('vqa', None, True)])
+def test_head_one_glimpse_kernels_equal_the_gemm_form(task, arch, search, monkeypatch):
+    """ATTFLAT_GLIMPSES = 1: the native head computes the glimpse logits as a matrix-vector product and their backward as an
+    outer product + column sums reduced by the next pair launch (head.hip glimpse1_*), instead of GEMM launches with one
+    live column / one K step.  Same logits; every parameter gradient to round-off (the relation projections amplify the
+    head's last bits the most: 6e-5 of their largest entry seen)."""
+    plan = None
+    if search:
+        pl = cases.search_plan(np.random.RandomState(1), None)
+        plan = pl['enc'] + pl['dec']
+    ref = _run(task, arch, search, True, False, monkeypatch, plan=plan, glimpse1=False)
+    got = _run(task, arch, search, True, False, monkeypatch, plan=plan, glimpse1=True)
+    assert ref[2] == 1 and got[2] == 1
+    out_a, g_a, _ = got
+    out_b, g_b, _ = ref
+    assert rel_err(out_a, out_b) < 2e-6
+    top = max(float(np.abs(g).max()) for g in g_b.values() if g is not None)
+    for k in g_b:
+        if g_b[k] is None:
+            assert g_a[k] is None or not np.any(g_a[k]), k
+            continue
+        diff = float(np.abs(g_a[k] - g_b[k]).max())
+        assert diff <= 3e-4 * max(float(np.abs(g_b[k]).max()), 1e-3 * top), (k, diff)
 
 
 @pytest.mark.parametrize('task', ['vqa', 'vgd', 'itm'])

@@ -1156,6 +1156,43 @@ def test_gemm_streamed_pieces_across_k_segments(layout, wgs, gemm_tuning):
     assert rel_err(C.cpu().numpy(), ref.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('rows,K,bias', [(6400, 512, True), (37, 512, False), (896, 1024, True), (160, 300, True), (5, 4, True)])
+def test_one_unit_linear_matrix_vector_kernels(rows, K, bias):
+    """mmnas_glimpse1_fwd / _bwd: nn.Linear with one output unit (AttFlat's glimpse logits, the ITM matching score) as a
+    matrix-vector product and, backward, one pass over x with the column sums reduced by a second launch -- against float64;
+    dw / db are ADDED to their buffers; and through ops.linear, which routes N = 1 here."""
+    import ctypes as C
+    from mmnas_amd import ops
+    import mmnas_amd._lib as L
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=gen)
+    x, w, b, dy = r(rows, K), r(K), r(1) if bias else None, r(rows)
+    lib = L.lib()
+    assert lib.mmnas_glimpse1_supported(K) == 1 and lib.mmnas_glimpse1_supported(2048) == 0 and lib.mmnas_glimpse1_supported(6) == 0
+    y = torch.empty(rows, device=DEV)
+    L.check(lib.mmnas_glimpse1_fwd(L.fptr(x), L.fptr(w), L.fptr(b), L.fptr(y), rows, K, L.stream()))
+    ref = x.double() @ w.double() + (b.double() if bias else 0.0)
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    dx, dw0, db0 = torch.empty_like(x), r(K), r(1)
+    dw, db = dw0.clone(), db0.clone()
+    ws = torch.empty(lib.mmnas_glimpse1_bwd_ws_floats(rows, K), device=DEV)
+    L.check(lib.mmnas_glimpse1_bwd(L.fptr(dy), L.fptr(x), L.fptr(w), L.fptr(dx), L.fptr(dw), L.fptr(db if bias else None), L.fptr(ws),
+                                   rows, K, L.stream()))
+    assert torch.equal(dx, dy[:, None] * w[None, :])
+    rw = dw0.double() + dy.double() @ x.double()
+    assert float((dw.double() - rw).abs().max()) <= 2e-6 * float(rw.abs().max())
+    if bias:
+        assert abs(float(db.double() - db0.double() - dy.double().sum())) <= 2e-6 * float(dy.abs().sum())
+    # through the operator layer (autograd): the same numbers
+    xa, wa = x.clone().requires_grad_(True), w.clone()[None, :].requires_grad_(True)
+    ba = b.clone().requires_grad_(True) if bias else None
+    ya = ops.linear(xa, wa, ba)
+    assert ya.shape == (rows, 1) and torch.equal(ya[:, 0], y)
+    ya.backward(dy[:, None])
+    assert torch.equal(xa.grad, dx)
+    assert float((wa.grad[0].double() - dy.double() @ x.double()).abs().max()) <= 2e-6 * float(rw.abs().max()) + 1e-6
+
+
 @pytest.mark.parametrize('layout,Ms,N,K,nseg,epi', [
     ('NT', [6400], 256, 256, 1, ''), ('NT', [300, 77, 130], 256, 64, 1, 'bRd'), ('NT', [100], 72, 96, 1, 'bdr'),
     ('NT', [6397], 256, 256, 1, 'dr'), ('NN', [333], 128, 160, 1, 'g'), ('NN', [6400], 1024, 256, 1, 'gc'),
