@@ -219,6 +219,24 @@ __global__ void __launch_bounds__(256) glimpse1_bwd_kernel(const float* __restri
   }
 }
 
+// out[c][r] = in[r][c] (in [R][C] row-major): the loss gradient of an answer layer whose width is no multiple of 4 (3129
+// answers) transposed once, so that both of the projection's gradient products get 16-byte-aligned operand rows
+__global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+  __shared__ float t[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < R && c0 + tx < C) t[i][tx] = in[(size_t)(r0 + i) * C + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < C && r0 + tx < R) out[(size_t)(c0 + i) * R + r0 + tx] = t[tx][i];
+}
+int transpose2d(const float* in, float* out, int R, int C, hipStream_t st) {
+  MMNAS_REQUIRE(in && out && R > 0 && C > 0, MMNAS_E_ARG, "transpose2d: bad arguments");
+  ProfScope ps(MMNAS_K_ROWOPS, 0.0, 8.0 * R * C, st);
+  MMNAS_LAUNCH(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, in, out, R, C);
+  return check_launch("transpose2d");
+}
+
 bool glimpse1_supported(int MID) { return MID >= 4 && MID % 4 == 0 && MID <= 1024; }
 
 // logits of both AttFlat sides (side 1 may have rows = 0)
