@@ -1267,7 +1267,18 @@ extern "C" int mmnas_head_fwd(const mmnas_head* hd, void* stream) {
     MMNAS_REQUIRE(sides[k]->x && sides[k]->W1 && sides[k]->W2 && sides[k]->Wm, MMNAS_E_ARG, "head_fwd: side %d null pointer", k);
   auto side_stream = [&](int k) -> void* { return (oc && k == 0) ? (void*)oc->enc : stream; };
   // h = drop(relu(x W1^T + b1))                                   (FC, modules.py:13-31; own dropout seed per side)
-  for (int k = 0; k < 2; ++k) {
+  if (!oc) {   // both sides as the two groups of one launch (own weights, own dropout stream per group)
+    gemm_init(g, MMNAS_GEMM_NT, MID, d, d, d, MID);
+    g.ngroups = 2; g.relu = 1;
+    if (drop) { g.drop_p = hd->drop_p; g.drop_seed = sides[0]->seed; g.drop_site = 0; }
+    for (int k = 0; k < 2; ++k) {
+      const mmnas_attflat_side& sd = *sides[k];
+      g.g[k].M = B * sd.S; g.g[k].A[0] = sd.x; g.g[k].B[0] = sd.W1; g.g[k].bias = sd.b1; g.g[k].C = L.s[k].h;
+      if (drop) g.g[k].drop_seed = sd.seed;
+    }
+    if ((rc = mmnas_gemm(&g, stream))) return rc;
+  }
+  for (int k = 0; k < 2 && oc; ++k) {
     const mmnas_attflat_side& sd = *sides[k];
     gemm_init(g, MMNAS_GEMM_NT, MID, d, d, d, MID);
     g.g[0].M = B * sd.S; g.g[0].A[0] = sd.x; g.g[0].B[0] = sd.W1; g.g[0].bias = sd.b1; g.g[0].C = L.s[k].h; g.relu = 1;
