@@ -297,7 +297,10 @@ struct GemmShape {
 // Bank check of the fragment reads (ds_read_b128, 64 banks, lane groups of 16 rows {0-3,12-15,20-27}, ...): the row base
 // 48 r mod 64 takes the four values 0/48/32/16 by r & 3, rows r, r+4, r+8, r+12 of one residue take the four chunk
 // positions by (r >> 2) & 3 -- 16 rows x 4 words cover the 64 banks once: conflict-free.
-// LEAN (NT / NN, 64^2 tiles, NS > 0, PF = 2; whole tiles, hybrid and stream-K schedules): the same K loop between a short set-up and a short epilogue.
+// LEAN (64^2 tiles, NS > 0, PF = 2): the same K loop between a short set-up and a short epilogue.  Levels: 1 = whole tiles
+// only (NT / NN; no stream-K code at all: 65 SGPRs, no spills) or, for TN, split-K pieces added by buffer atomics; 2 = whole
+// tiles + hybrid / stream-K schedules (NT / NN); 3 = whole-tile NN products with column sums (natural accumulator layout,
+// element-wise buffer epilogue).
 // A workgroup of the supernet's products lives ~22000 cycles of which the general set-up is ~2400 and the general epilogue
 // ~3900 -- both pure instruction issue (~600 and ~900 instructions at one per four cycles for a lone wave of a SIMD):
 //   * tile order without divisions: a group's tiles are numbered row panel by row panel, tiles_n (a power of two, host
