@@ -99,6 +99,11 @@ int layernorm_bwd_deferred(const float* x, const float* a, const float* dy, floa
 bool glimpse1_supported(int MID);
 int glimpse1_fwd(const float* h0, const float* w0, const float* b0, float* l0, long rows0, const float* h1, const float* w1,
                  const float* b1, float* l1, long rows1, int MID, hipStream_t st);
+// mixed.hip: mmnas_node_mix_bwd with the gate-gradient reduction left pending (partials in ws), and the reduction of many nodes
+int node_mix_bwd_impl(const float* const* z, const float* const* ln_a, const float* const* ln_b, int n, const float* gate,
+                      const float* dout, float* d_active, int active, float* dgate, float* ws, int M, int d, float eps,
+                      hipStream_t stream, bool reduce, int* nwg_out);
+int mixed_reduce_many(const float* const* parts, float* const* dgates, const int* nwg, const int* n, int count, hipStream_t st);
 int transpose2d(const float* in, float* out, int R, int C, hipStream_t st);   // head.hip: out[c][r] = in[r][c]
 int glimpse1_bwd_blocks(long rows, int MID);
 int glimpse1_bwd(const float* dlog, const float* h, const float* w2, float gate_scale, int gated, float* dh, float* db1, float* dW2,

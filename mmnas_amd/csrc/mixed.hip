@@ -11,6 +11,7 @@
 namespace mmnas {
 
 constexpr int MAXC = MMNAS_MIXED_MAX;
+#define MMNAS_MIX_REDUCE_MAX 32
 static_assert(MAXC == 8, "mixed_sum_reduce_kernel assumes 8 candidate slots");
 
 struct MixArgs {
@@ -75,6 +76,39 @@ __global__ void __launch_bounds__(256) mixed_sum_bwd_kernel(MixArgs a, const flo
 __global__ void __launch_bounds__(256) mixed_sum_reduce_kernel(const float* __restrict__ part, int nwg, int n, float* __restrict__ dgate) {
   __shared__ float red[32][MAXC + 1];
   const int j = threadIdx.x & (MAXC - 1), g = threadIdx.x / MAXC;   // MAXC = 8: 32 groups
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  int b = g;
+  for (; b + 96 < nwg; b += 128) {
+    t0 += part[(size_t)b * MAXC + j];
+    t1 += part[(size_t)(b + 32) * MAXC + j];
+    t2 += part[(size_t)(b + 64) * MAXC + j];
+    t3 += part[(size_t)(b + 96) * MAXC + j];
+  }
+  for (; b < nwg; b += 32) t0 += part[(size_t)b * MAXC + j];
+  red[g][j] = (t0 + t1) + (t2 + t3);
+  __syncthreads();
+  if (threadIdx.x < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += red[i][threadIdx.x];
+    dgate[threadIdx.x] += t;
+  }
+}
+
+// The same reduction for MANY nodes in one launch (the backbone chain of the architecture step defers its 30 nodes'
+// reductions to the end of its backward: one workgroup per node instead of 30 one-workgroup launches of ~5 us each).
+struct MixReduceJobs {
+  const float* part[MMNAS_MIX_REDUCE_MAX];
+  float* dgate[MMNAS_MIX_REDUCE_MAX];
+  int nwg[MMNAS_MIX_REDUCE_MAX];
+  int n[MMNAS_MIX_REDUCE_MAX];
+};
+__global__ void __launch_bounds__(256) mixed_sum_reduce_many_kernel(const MixReduceJobs jobs) {
+  __shared__ float red[32][MAXC + 1];
+  const float* __restrict__ part = jobs.part[blockIdx.x];
+  float* __restrict__ dgate = jobs.dgate[blockIdx.x];
+  const int nwg = jobs.nwg[blockIdx.x], n = jobs.n[blockIdx.x];
+  const int j = threadIdx.x & (MAXC - 1), g = threadIdx.x / MAXC;
   float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
   int b = g;
   for (; b + 96 < nwg; b += 128) {
@@ -352,23 +386,48 @@ extern "C" int mmnas_node_mix_fwd(const float* const* z, const float* const* ln_
   return check_launch("node_mix_fwd");
 }
 
+namespace mmnas {
+// reduce == false: the partial sums stay in ws[0 .. *nwg_out * MAXC) for mixed_reduce_many()
+int node_mix_bwd_impl(const float* const* z, const float* const* ln_a, const float* const* ln_b, int n, const float* gate,
+                      const float* dout, float* d_active, int active, float* dgate, float* ws, int M, int d, float eps,
+                      hipStream_t stream, bool reduce, int* nwg_out);
+int mixed_reduce_many(const float* const* parts, float* const* dgates, const int* nwg, const int* n, int count, hipStream_t st) {
+  for (int i0 = 0; i0 < count; i0 += MMNAS_MIX_REDUCE_MAX) {
+    MixReduceJobs jobs;
+    const int c = count - i0 < MMNAS_MIX_REDUCE_MAX ? count - i0 : MMNAS_MIX_REDUCE_MAX;
+    for (int i = 0; i < c; ++i) { jobs.part[i] = parts[i0 + i]; jobs.dgate[i] = dgates[i0 + i]; jobs.nwg[i] = nwg[i0 + i]; jobs.n[i] = n[i0 + i]; }
+    ProfScope ps(MMNAS_K_ROWOPS, 0.0, 0.0, st, "mixed_reduce_many");
+    MMNAS_LAUNCH(mixed_sum_reduce_many_kernel, dim3(c), dim3(256), 0, st, jobs);
+  }
+  return check_launch("mixed_reduce_many");
+}
+}  // namespace mmnas
+
 extern "C" int mmnas_node_mix_bwd(const float* const* z, const float* const* ln_a, const float* const* ln_b, int n, const float* gate,
                                   const float* dout, float* d_active, int active, float* dgate, float* ws, int M, int d, float eps,
                                   void* stream) {
+  return mmnas::node_mix_bwd_impl(z, ln_a, ln_b, n, gate, dout, d_active, active, dgate, ws, M, d, eps, (hipStream_t)stream, true, nullptr);
+}
+
+int mmnas::node_mix_bwd_impl(const float* const* z, const float* const* ln_a, const float* const* ln_b, int n, const float* gate,
+                             const float* dout, float* d_active, int active, float* dgate, float* ws, int M, int d, float eps,
+                             hipStream_t stream, bool reduce, int* nwg_out) {
   NodeMixArgs a;
   int rc = node_args(a, z, ln_a, ln_b, n, d, "mmnas_node_mix_bwd");
   if (rc) return rc;
   MMNAS_REQUIRE(gate && dout && dgate && ws && M >= 0, MMNAS_E_ARG, "mmnas_node_mix_bwd: null pointer");
   MMNAS_REQUIRE(!d_active || (active >= 0 && active < n), MMNAS_E_ARG, "mmnas_node_mix_bwd: active index out of range");
+  if (nwg_out) *nwg_out = 0;
   if (M == 0) return MMNAS_OK;
-  hipStream_t st = (hipStream_t)stream;
+  hipStream_t st = stream;
   int g = cdiv(M, 4);
   if (g > 2048) g = 2048;
+  if (nwg_out) *nwg_out = g;
   ProfScope ps(MMNAS_K_ROWOPS, (2.0 * n + 8.0 * n) * M * d, 4.0 * (n + 2) * M * d, st, "node_mix_bwd");
   const dim3 grid(g), block(256);
   if (d <= 256) MMNAS_LAUNCH((node_mix_bwd_kernel<1>), grid, block, 0, st, a, gate, dout, d_active, active, ws, M, d, eps);
   else if (d <= 512) MMNAS_LAUNCH((node_mix_bwd_kernel<2>), grid, block, 0, st, a, gate, dout, d_active, active, ws, M, d, eps);
   else MMNAS_LAUNCH((node_mix_bwd_kernel<4>), grid, block, 0, st, a, gate, dout, d_active, active, ws, M, d, eps);
-  MMNAS_LAUNCH(mixed_sum_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, g, n, dgate);
+  if (reduce) MMNAS_LAUNCH(mixed_sum_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, g, n, dgate);
   return check_launch("node_mix_bwd");
 }

@@ -673,7 +673,11 @@ static int chain_layout(const mmnas_chain* c, ChainLayout& L) {
       L.nout[i] = first ? take(c->ops[i].on_y ? ny : nx) : 0;
       L.ndact[i] = first ? take(c->ops[i].on_y ? ny : nx) : 0;
     }
-    L.mixws = take(mmnas_mixed_sum_ws_floats() * sizeof(float));
+    {   // one partial-sum area per node: the gate-gradient reductions of the backward are issued as ONE launch at its end
+      int nodes = 0;
+      for (int i = 0; i < c->n_ops; ++i) nodes += (i == 0 || c->ops[i].node != c->ops[i - 1].node);
+      L.mixws = take((size_t)(nodes > 0 ? nodes : 1) * mmnas_mixed_sum_ws_floats() * sizeof(float));
+    }
     // (streams' first / last markers refer to NODES here: the first operator of the first / last node of a stream)
     L.last_x = L.last_y = L.first_x = L.first_y = -1;
     for (int i = 0; i < c->n_ops; ++i) {
@@ -936,6 +940,8 @@ static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
   };
   const float* x_final = L.last_x >= 0 ? c->x_out : c->x_in;
   const float* cur_dy = c->dy_out;
+  const float* red_part[MMNAS_CHAIN_MAX_OPS]; float* red_out[MMNAS_CHAIN_MAX_OPS]; int red_nwg[MMNAS_CHAIN_MAX_OPS], red_n[MMNAS_CHAIN_MAX_OPS];
+  int n_red = 0;
   for (int k = nn - 1; k >= 0; --k) {
     const int i0 = starts[k], i1 = starts[k + 1];
     const bool oy = c->ops[i0].on_y;
@@ -963,8 +969,13 @@ static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
     float* dact = (float*)(base + L.ndact[i0]);
     const int M = oy ? (int)chain_rows_y(c) : c->B * c->Sx;
     const size_t grow = (size_t)c->ops[i0].node * c->gate_width;
-    if ((rc = mmnas_node_mix_bwd(zs, as, bs, width, c->gate + grow, cur_dy, dact, act, c->dgate + grow, (float*)(base + L.mixws), M, c->d, eps, st)))
-      return rc;
+    {
+      float* wsk = (float*)(base + L.mixws) + (size_t)k * mmnas_mixed_sum_ws_floats();
+      int nwg = 0;
+      if ((rc = node_mix_bwd_impl(zs, as, bs, width, c->gate + grow, cur_dy, dact, act, c->dgate + grow, wsk, M, c->d, eps, st, false, &nwg)))
+        return rc;
+      if (nwg > 0) { red_part[n_red] = wsk; red_out[n_red] = c->dgate + grow; red_nwg[n_red] = nwg; red_n[n_red] = width; ++n_red; }
+    }
     // the sampled candidate's backward
     const mmnas_chain_op& o = c->ops[act_op];
     mmnas_att_op a; mmnas_mlp_op m;
@@ -990,6 +1001,7 @@ static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
       return MMNAS_E_LAUNCH;
     }
   }
+  if (n_red && (rc = mixed_reduce_many(red_part, red_out, red_nwg, red_n, n_red, st))) return rc;   // every node's gate gradients
   if (L.first_y < 0 && hipMemcpyAsync(c->dy_in, c->dy_out, ey * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return MMNAS_E_LAUNCH;
   if (L.first_x < 0) {
     const float* g0 = c->dx_out;
