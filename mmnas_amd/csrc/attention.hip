@@ -99,13 +99,13 @@ __device__ __forceinline__ void load_tiles2(float* __restrict__ da, const float*
 // forward: grid (ceil(Sq / (32 NW)), H, B), block 64 NW.  NKC = key chunks of 32 (all keys).
 // ------------------------------------------------------------------------------------------
 template <int DHC, int NKC, int NW>
-__global__ void __launch_bounds__(64 * NW, (NKC <= 4 && NW == 4) ? 2 : 1) mha_fwd_kernel(const MhaK p) {
+__device__ __forceinline__ void mha_fwd_body(const MhaK& p, const int qblk) {
   constexpr int LD = DHC + 4, NT = 64 * NW, JC = DHC >= 32 ? DHC / 32 : 1;
   __shared__ __attribute__((aligned(16))) float Qs[32 * NW * LD];
   __shared__ __attribute__((aligned(16))) float KVs[32 * NKC * LD];
   __shared__ float sMask[32 * NKC];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32 * NW;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = qblk * 32 * NW;
   const int SqS = p.Sq, SkS = p.Sk;   // strides of the per-(batch, head) arrays; the lengths of this batch element:
   int Sq = p.Sq, Sk = p.Sk;
   size_t qrow0 = (size_t)b * p.Sq, krow0 = (size_t)b * p.Sk;
@@ -235,6 +235,21 @@ __global__ void __launch_bounds__(64 * NW, (NKC <= 4 && NW == 4) ? 2 : 1) mha_fw
       }
     }
   }
+}
+
+template <int DHC, int NKC, int NW>
+__global__ void __launch_bounds__(64 * NW, (NKC <= 4 && NW == 4) ? 2 : 1) mha_fwd_kernel(const MhaK p) {
+  mha_fwd_body<DHC, NKC, NW>(p, blockIdx.x);
+}
+
+// Two attention cores of one geometry in ONE launch (the self / relation-self candidates of a supernet decoder node in the
+// architecture step): a core of B*H = 256 workgroups is a single latency-bound round at one workgroup per CU although its
+// LDS image admits two -- the second problem's workgroups ride beside the first's.  blockIdx.x = problem * nqb + query block.
+template <int DHC, int NKC, int NW>
+__global__ void __launch_bounds__(64 * NW, (NKC <= 4 && NW == 4) ? 2 : 1) mha_fwd_pair_kernel(const MhaK p0, const MhaK p1, const int nqb) {
+  const int second = (int)blockIdx.x >= nqb;
+  if (second) mha_fwd_body<DHC, NKC, NW>(p1, (int)blockIdx.x - nqb);
+  else mha_fwd_body<DHC, NKC, NW>(p0, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -940,6 +955,30 @@ static void launch_bwd(const MhaK& k, hipStream_t st) {
   if (nkc <= 1) { if (k.Sq > 32) BKV(1, 4); else BKV(1, 1); }
   else if (nkc <= 2 || nwmax == 2) BKV(2, 1); else BKV(4, 1);
 #undef BKV
+}
+
+// Two cores in one launch when their geometry (B, H, Sq, Sk, d_h = 64, 33..128 keys, more than 64 queries) is the same;
+// otherwise -- or with MMNAS_MHA_PAIR=0 -- two launches.  Internal: the mixed chain of ops.hip.
+int mha_core_fwd_pair(const mmnas_mha_desc* d0, const mmnas_mha_desc* d1, hipStream_t st) {
+  MhaK k0, k1;
+  int rc = fill(d0, k0, false);
+  if (rc) return rc;
+  if ((rc = fill(d1, k1, false))) return rc;
+  static const int on = [] { const char* e = getenv("MMNAS_MHA_PAIR"); return !(e && e[0] == '0'); }();
+  const int nkc = cdiv(k0.Sk, 32);
+  const bool same = on && k0.B == k1.B && k0.H == k1.H && k0.Sq == k1.Sq && k0.Sk == k1.Sk && k0.dh == 64 && k1.dh == 64 &&
+                    nkc > 2 && nkc <= 4 && k0.Sq > 64 && mha_nw() == 4 && !k0.qoff == !k1.qoff && !k0.koff == !k1.koff;
+  if (!same) {
+    if ((rc = mmnas_mha_core_fwd(d0, st))) return rc;
+    return mmnas_mha_core_fwd(d1, st);
+  }
+  k0.nch = k1.nch = 1;
+  const double bhqk = (double)k0.B * k0.H * k0.Sq * k0.Sk;
+  ProfScope ps(MMNAS_K_MHA_FWD, 8.0 * bhqk * k0.dh,
+               4.0 * (2.0 * (double)k0.B * k0.H * k0.dh * (2.0 * k0.Sq + 2.0 * k0.Sk) + (k0.biasT ? bhqk : 0.0) + (k1.biasT ? bhqk : 0.0)), st);
+  const int nqb = cdiv(k0.Sq, 128);
+  MMNAS_LAUNCH((mha_fwd_pair_kernel<64, 4, 4>), dim3(2 * nqb, k0.H, k0.B), dim3(256), 0, st, k0, k1, nqb);
+  return check_launch("mha_core_fwd_pair");
 }
 
 }  // namespace mmnas

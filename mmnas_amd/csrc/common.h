@@ -104,6 +104,7 @@ int node_mix_bwd_impl(const float* const* z, const float* const* ln_a, const flo
                       const float* dout, float* d_active, int active, float* dgate, float* ws, int M, int d, float eps,
                       hipStream_t stream, bool reduce, int* nwg_out);
 int mixed_reduce_many(const float* const* parts, float* const* dgates, const int* nwg, const int* n, int count, hipStream_t st);
+int mha_core_fwd_pair(const mmnas_mha_desc* d0, const mmnas_mha_desc* d1, hipStream_t st);   // attention.hip: two cores, one launch
 int transpose2d(const float* in, float* out, int R, int C, hipStream_t st);   // head.hip: out[c][r] = in[r][c]
 int glimpse1_bwd_blocks(long rows, int MID);
 int glimpse1_bwd(const float* dlog, const float* h, const float* w2, float gate_scale, int gated, float* dh, float* db1, float* dW2,

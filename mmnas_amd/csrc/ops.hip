@@ -125,10 +125,22 @@ static void att_qkv_groups(const mmnas_att_op* op, const AttLayout& L, mmnas_gem
   g[2].M = (int)L.Mk; g[2].A[0] = op->xkv; g[2].B[0] = op->Wv; g[2].C = L.V;
 }
 
-static int att_core_fwd(const mmnas_att_op* op, const AttLayout& L, void* stream) {
+static void att_core_desc(const mmnas_att_op* op, const AttLayout& L, mmnas_mha_desc* m) {
   const int fl = op->flags, di = op->di;
-  const bool rel = fl & MMNAS_F_REL;
   const bool drop = (fl & MMNAS_F_TRAIN) && op->drop_p > 0.f;
+  memset(m, 0, sizeof(*m));
+  m->B = op->B; m->H = op->H; m->Sq = op->Sq; m->Sk = op->Sk; m->dh = op->dh;
+  m->ldq = m->ldk = m->ldv = m->ldo = di;
+  m->Q = L.Q; m->K = L.K; m->V = L.V; m->mask = (fl & MMNAS_F_MASK) ? op->mask : nullptr; m->biasT = L.biasT;
+  m->O = L.att; m->lse = L.stats;
+  m->q_off = op->q_off; m->k_off = op->k_off;
+  m->drop_p = drop ? op->drop_p : 0.f; m->drop_site = 0; m->drop_seed = op->seed;
+}
+
+// desc_only != NULL: the relation bias is computed, the core itself is left to the caller (its descriptor in *desc_only)
+static int att_core_fwd(const mmnas_att_op* op, const AttLayout& L, void* stream, mmnas_mha_desc* desc_only = nullptr) {
+  const int fl = op->flags;
+  const bool rel = fl & MMNAS_F_REL;
   int rc;
   if (rel) {
     if (fl & MMNAS_F_RELRAW) {  // lazy handle: bias straight from the raw [B,Sq,Sk,C] relations
@@ -142,14 +154,9 @@ static int att_core_fwd(const mmnas_att_op* op, const AttLayout& L, void* stream
     }
     if (rc) return rc;
   }
+  if (desc_only) { att_core_desc(op, L, desc_only); return MMNAS_OK; }
   mmnas_mha_desc m;
-  memset(&m, 0, sizeof(m));
-  m.B = op->B; m.H = op->H; m.Sq = op->Sq; m.Sk = op->Sk; m.dh = op->dh;
-  m.ldq = m.ldk = m.ldv = m.ldo = di;
-  m.Q = L.Q; m.K = L.K; m.V = L.V; m.mask = (fl & MMNAS_F_MASK) ? op->mask : nullptr; m.biasT = L.biasT;
-  m.O = L.att; m.lse = L.stats;
-  m.q_off = op->q_off; m.k_off = op->k_off;
-  m.drop_p = drop ? op->drop_p : 0.f; m.drop_site = 0; m.drop_seed = op->seed;
+  att_core_desc(op, L, &m);
   return mmnas_mha_core_fwd(&m, stream);
 }
 
@@ -863,8 +870,21 @@ static int chain_fwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
       g.ngroups = 3 * ng;
       for (int j = 0; j < ng; ++j) att_qkv_groups(&ga[j], gl[j], g.g + 3 * j);
       if ((rc = mmnas_gemm(&g, st))) return rc;
-      for (int j = 0; j < ng; ++j)
-        if ((rc = att_core_fwd(&ga[j], gl[j], st))) return rc;
+      {   // the cores: two of one geometry (self / relation-self) share a launch, the rest one by one
+        mmnas_mha_desc md[MMNAS_MIXED_MAX];
+        for (int j = 0; j < ng; ++j)
+          if ((rc = att_core_fwd(&ga[j], gl[j], st, &md[j]))) return rc;   // (relation biases first)
+        bool done[MMNAS_MIXED_MAX] = {false};
+        for (int j = 0; j < ng; ++j) {
+          if (done[j]) continue;
+          int mate = -1;
+          for (int q = j + 1; q < ng && mate < 0; ++q)
+            if (!done[q] && md[q].Sq == md[j].Sq && md[q].Sk == md[j].Sk && md[q].H == md[j].H && md[q].dh == md[j].dh) mate = q;
+          if (mate >= 0) { if ((rc = mha_core_fwd_pair(&md[j], &md[mate], st))) return rc; done[mate] = true; }
+          else if ((rc = mmnas_mha_core_fwd(&md[j], st))) return rc;
+          done[j] = true;
+        }
+      }
       gemm_init(g, MMNAS_GEMM_NT, c->d, f.di, f.di, f.di, c->d);
       g.ngroups = ng;
       for (int j = 0; j < ng; ++j) att_merge_group(&ga[j], gl[j], &g.g[j]);
