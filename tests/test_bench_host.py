@@ -78,3 +78,34 @@ def test_compact_line_of_a_full_default_record_stays_small():
     assert set(d['cpu_baseline']) >= {'value', 'unit', 'cores', 'kind', 'sample'}
     assert set(d['sub']) == set(rec['sub']) and all('ms_per_step' in s for s in d['sub'].values())
     assert abs(d['value'] - rec['value']) < 1e-3
+
+
+def test_fit_line_drops_optional_detail_instead_of_failing():
+    """A record that grew past the limit must still give the driver its line (the old assert lost the run)."""
+    import json
+    b = _bench()
+    rec = json.load(open(os.path.join(ROOT, 'profiles', 'r04_bench.json')))
+    obj = b.compact_line(rec, 'gpurun_out/bench_full.json')
+    obj['kernel_ms_per_step'] = {'class_%d' % i: 0.001 * i for i in range(600)}      # ~10 KB of optional detail
+    line = b.fit_line(obj)
+    assert len(line) < b.LINE_LIMIT
+    d = json.loads(line)
+    assert d['dropped_for_length'][0] == 'kernel_ms_per_step' and 'kernel_ms_per_step' not in d
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'ms_per_step', 'config', 'roofline', 'cpu_baseline', 'full_record'):
+        assert k in d, k
+    small = b.fit_line(b.compact_line(rec, 'x'))
+    assert 'dropped_for_length' not in json.loads(small)
+
+
+def test_summarize_prof_counts_its_steps_in_the_trace():
+    """the r04 summaries divided by a literal 23 for a 26-step command.  The count now comes from the trace."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('summarize_prof', os.path.join(ROOT, 'tools', 'summarize_prof.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    import csv
+    rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r04_search_vqa_kernel_stats.csv'))))
+    steps, how = m.steps_from_trace(rows, 'auto')
+    assert steps == 26 and 'lstm_seq_fwd_kernel' in how
+    assert m.steps_from_trace(rows, '23')[0] == 26          # a literal that disagrees with the trace loses
+    assert m.steps_from_trace(rows, 'auto/2')[0] == 13

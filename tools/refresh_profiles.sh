@@ -1,12 +1,12 @@
 #!/bin/bash
 # Regenerates everything under profiles/ for one round on a GPU box (run from the repo root):
-#   MMNAS_COMMIT=$(git rev-parse --short=12 HEAD) bash tools/refresh_profiles.sh r04      (MMNAS_COMMIT: stamped into the PMC files)
+#   MMNAS_COMMIT=$(git rev-parse --short=12 HEAD) bash tools/refresh_profiles.sh r05      (MMNAS_COMMIT: stamped into the PMC files)
 # rocprofv3 --kernel-trace --stats summaries of the bench command per workload, one-step kernel timelines, the two
 # --pmc passes behind roofline.traffic (FETCH_SIZE / WRITE_SIZE cannot share a pass), the MFMA / LDS counter passes, and
 # the bench lines themselves (the default line with its CPU baselines last: it reads the traffic files written before).
 # Raw traces stay in /tmp; only summaries are written to profiles/.  Counters are collected with --kernel-trace only.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 ROOT=$PWD
 export TMPDIR=/tmp
 W=/tmp/mmnas_prof
@@ -14,8 +14,8 @@ rm -rf $W; mkdir -p $W profiles
 for wl in search_vqa arch_vqa train_vqa search_vqa_unpad train_vqa_unpad; do
   cmd="bench.py --workload $wl --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline"
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace_$wl -o t -- python3 $ROOT/$cmd > $W/trace_$wl.log 2>&1)
-  python3 tools/summarize_prof.py $W/trace_$wl profiles/${R}_$wl 23 \
-    "rocprofv3 --kernel-trace --stats -- python3 $cmd  (3 warm-up + 10 timed + 10 roofline-pass steps)"
+  python3 tools/summarize_prof.py $W/trace_$wl profiles/${R}_$wl auto \
+    "rocprofv3 --kernel-trace --stats -- python3 $cmd  (3 warm-up + 10 timed + 3 empty-queue + 10 roofline-pass steps)"
   marker=onehot_rows; [ $wl = train_vqa ] && marker=row_is_zero; [ $wl = train_vqa_unpad ] && marker=row_is_zero
   python3 tools/step_timeline.py $W/trace_$wl $marker > profiles/${R}_timeline_$wl.txt
   [ -n "${SKIP_PMC:-}" ] && continue
@@ -31,6 +31,7 @@ for wl in search_vqa arch_vqa train_vqa search_vqa_unpad train_vqa_unpad; do
   (cd /tmp && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $W/pmc_${wl}_lds -o t -- python3 $ROOT/$small > $W/pmc_${wl}_lds.log 2>&1)
   (cd /tmp && rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace -d $W/pmc_${wl}_gui -o t -- python3 $ROOT/$small > $W/pmc_${wl}_gui.log 2>&1)
   python3 tools/pmc_counters.py profiles/${R}_pmc_$wl.json $W/pmc_${wl}_mfma $W/pmc_${wl}_lds $W/pmc_${wl}_gui
+  python3 tools/stamp_profiles.py profiles/${R}_pmc_$wl.json > /dev/null
 done
 # the data-parallel exchange in a one-rank RCCL group, and the streamed-input step with the copy engine's rows
 for wl in search_vqa_dp1 train_vqa_dp1; do
@@ -55,6 +56,7 @@ python3 tools/rel_bench.py > profiles/${R}_rel_microbench.txt 2>/dev/null
 (cd /tmp && GEMM_PMC_LAYOUTS=1 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $W/pmc_gemm_lds -o t -- python3 $ROOT/tools/gemm_pmc.py > $W/pmc_gemm_lds.log 2>&1)
 (cd /tmp && GEMM_PMC_LAYOUTS=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace -d $W/pmc_gemm_mfma -o t -- python3 $ROOT/tools/gemm_pmc.py > $W/pmc_gemm_mfma.log 2>&1)
 python3 tools/pmc_counters.py profiles/${R}_pmc_gemm_layouts.json $W/pmc_gemm_lds $W/pmc_gemm_mfma
+python3 tools/stamp_profiles.py profiles/${R}_pmc_gemm_layouts.json > /dev/null
 # the bench lines: <round>_bench.json = the FULL record (bench.py --full-out), <round>_bench_line.json = the compact stdout line
 python3 bench.py --full-out profiles/${R}_bench.json > $W/bench_all.log 2> $W/bench_all.err
 grep '^{' $W/bench_all.log | tail -1 > profiles/${R}_bench_line.json

@@ -1,6 +1,11 @@
 """Turn a rocprofv3 --kernel-trace --stats output directory into the committed summary under profiles/.
 
-    python tools/summarize_prof.py gpurun_out/prof2 profiles/r01_train_vqa 7 "command line that was profiled"
+    python tools/summarize_prof.py gpurun_out/prof2 profiles/r01_train_vqa auto "command line that was profiled"
+
+The step count is taken FROM THE TRACE (`auto`: the calls of lstm_seq_fwd_kernel -- every step of every workload runs the
+question LSTM forward exactly once; `auto/3` for the ITM triplet step's three forwards); a literal count is still accepted
+but is checked against the trace and the trace wins.  (Round 4 passed a literal 23 for a command that ran 26 steps: every
+per-step column of the r04 .md files is 13 % too high.)
 
 Writes <out>_kernel_stats.csv (verbatim copy of rocprofv3's per-kernel stats) and <out>.md (top
 kernels per step, GEMM durations grouped by launch geometry)."""
@@ -12,16 +17,34 @@ import shutil
 import sys
 
 
+def steps_from_trace(rows, arg):
+    """-> (steps, how it was found).  The marker is the persistent question LSTM's forward launch: one per step."""
+    per = 1
+    if arg.startswith('auto/'):
+        per = int(arg.split('/')[1])
+    marker = [int(r['Calls']) for r in rows if 'lstm_seq_fwd_kernel' in r['Name']]
+    counted = sum(marker) // per if marker else None
+    if arg.startswith('auto'):
+        if counted is None:
+            raise SystemExit('summarize_prof: no lstm_seq_fwd_kernel launch in the trace: pass the step count')
+        return counted, 'counted in the trace: %d lstm_seq_fwd_kernel launches / %d per step' % (sum(marker), per)
+    if counted is not None and counted != int(arg):
+        sys.stderr.write('summarize_prof: %s steps given, the trace holds %d: using the trace\n' % (arg, counted))
+        return counted, 'counted in the trace (the command line said %s)' % arg
+    return int(arg), 'as given'
+
+
 def main():
-    src, out, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    src, out, steps_arg = sys.argv[1], sys.argv[2], sys.argv[3]
     cmd = sys.argv[4] if len(sys.argv) > 4 else ''
     stats = glob.glob(os.path.join(src, '**', '*_kernel_stats.csv'), recursive=True)[0]
     trace = glob.glob(os.path.join(src, '**', '*_kernel_trace.csv'), recursive=True)[0]
     shutil.copy(stats, out + '_kernel_stats.csv')
     rows = list(csv.DictReader(open(stats)))
     tot = sum(float(r['TotalDurationNs']) for r in rows)
+    steps, how = steps_from_trace(rows, steps_arg)
     lines = ['# rocprofv3 --kernel-trace --stats summary', '', '`%s`' % cmd, '',
-             'steps profiled (warm-up included): %d; device-busy time %.2f ms/step' % (steps, tot / steps / 1e6), '',
+             'steps profiled (warm-up included): %d (%s); device-busy time %.2f ms/step' % (steps, how, tot / steps / 1e6), '',
              '| ms/step | launches/step | avg us | % | kernel |', '|---|---|---|---|---|']
     for r in rows[:25]:
         name = r['Name'].replace('void ', '').replace('|', '/')[:110]
