@@ -742,16 +742,28 @@ def _conv_seq_im2col(x, weight, bias):
 
 
 _conv_w_cache = {}
+_param_epoch = 0
+
+
+def note_raw_parameter_write():
+    """Called by everything that writes parameters through RAW POINTERS (FlatAdam / ArchAdam: mmnas_adam_step on the flat
+    buffer the parameters are views of).  Such writes do not move a tensor's version counter, so every cache of values
+    DERIVED from parameters (the re-arranged StdConv weights below) also keys on this epoch.  (without it
+    the cached arrangement of a conv weight survived the optimizer step and the operator trained on its initial weights.)"""
+    global _param_epoch
+    _param_epoch += 1
 
 
 def _conv_weights(weight):
     """conv.weight [d_out, d_in, k] in the two arrangements the products read, re-made only when the parameter has been
-    written (its version counter moves with every in-place optimizer update):
+    written: its version counter moves with every in-place torch update, the library's parameter epoch with every
+    raw-pointer optimizer step (note_raw_parameter_write); a `.data` re-homing changes the storage pointer:
       fwd [d_out, k * d_in]  column t * d_in + c = W[:, c, t]              (B of the forward NT product)
       rev [k * d_out, d_in]  row j * d_out + o = W[o, :, k - 1 - j]       (B of the data-gradient NN product)"""
     key = id(weight)
+    stamp = (weight._version, _param_epoch, weight.data_ptr())
     hit = _conv_w_cache.get(key)
-    if hit is not None and hit[0] is weight and hit[1] == weight._version and hit[2].device == weight.device:
+    if hit is not None and hit[0] is weight and hit[1] == stamp and hit[2].device == weight.device:
         return hit[2], hit[3]
     co, ci, k = weight.shape
     w = weight.detach()
@@ -759,7 +771,7 @@ def _conv_weights(weight):
     rev = w.flip(2).permute(2, 0, 1).reshape(k * co, ci).contiguous()
     if len(_conv_w_cache) > 256:
         _conv_w_cache.clear()
-    _conv_w_cache[key] = (weight, weight._version, fwd, rev)
+    _conv_w_cache[key] = (weight, stamp, fwd, rev)
     return fwd, rev
 
 

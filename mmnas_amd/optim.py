@@ -23,6 +23,11 @@ from . import _lib as L
 from .dp import FlatGrads
 
 
+def _note_write():
+    from . import ops          # (ops imports nothing from here; late import keeps the module graph acyclic)
+    ops.note_raw_parameter_write()
+
+
 class FlatAdam:
     def __init__(self, params, lr=0.0, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.0, grads=None, absent_grads='zero'):
         if absent_grads not in ('zero', 'skip'):
@@ -104,6 +109,7 @@ class FlatAdam:
         L.check(lib.mmnas_adam_step(L.fptr(self.flat_p), L.fptr(fg.flat), L.fptr(self.m), L.fptr(self.v), n, lr,
                                     self.betas[0], self.betas[1], self.eps, self.weight_decay, sumsq_ptr,
                                     float(max_norm or 0.0), self.global_step, st))
+        _note_write()
 
     @torch.no_grad()
     def step(self, max_norm=None):
@@ -128,6 +134,7 @@ class FlatAdam:
                                         self.weight_decay, sumsq_ptr, float(max_norm or 0.0), k + 1, st))
             for i in idx:
                 self.steps[i] += 1
+        _note_write()
 
     def grad_norm(self):
         """Total gradient norm of the last clipped step (device -> host; diagnostics only)."""

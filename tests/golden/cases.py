@@ -184,8 +184,8 @@ def net_inputs(rs, cfg, B, Sx, Sy, token_size):
     return frcn, bbox, y_rel, ques, x_rel
 
 
-def net_case(task, arch, seed, search=False, HSIZE=128, B=2, Sx=5, Sy=7, token_size=40, ans_size=13):
-    cfg = small_cfg(HSIZE=HSIZE)
+def net_case(task, arch, seed, search=False, HSIZE=128, B=2, Sx=5, Sy=7, token_size=40, ans_size=13, cfg_over=None):
+    cfg = small_cfg(HSIZE=HSIZE, **(cfg_over or {}))
     genotype = None
     if not search:
         genotype = load_arch(arch)
@@ -201,6 +201,42 @@ def net_case(task, arch, seed, search=False, HSIZE=128, B=2, Sx=5, Sy=7, token_s
         target = rs.standard_normal((B, Sy)).astype(np.float32)
     return dict(task=task, arch=arch, cfg=cfg, genotype=genotype, P=P, inputs=inputs, target=target,
                 token_size=token_size, ans_size=ans_size)
+
+
+# ---- whole networks at the entry scripts' own dimensions (make_golden.gen_nets_full -> nets_full.npz) -----------------
+# search_vqa.py:87-114 (HSIZE 256, ATTFLAT_OUT 512), train_vqa.py:136-154 / train_vgd.py / train_itm.py:143-154 (HSIZE 512,
+# ATTFLAT_OUT 1024); FRCNFEAT 2048, ATTFLAT_MLP 512, GloVe 300, 3129 answers; 100 regions + 14 tokens (VGD 15 tokens; ITM 36
+# regions + 50 tokens); BASELINE configs[0] literally: arch/mcan.json, batch 4, 36 regions, 14 tokens.  Only the batch is
+# small (2-4: the CPU reference and the CPU oracle run these in seconds) and the vocabulary (2000 rows: the embedding table is
+# outside the path).  Dropout 0 (the reference's Philox stream cannot be replayed).
+FULL_CASES = (
+    # tag-kind, task, arch, HSIZE, B, Sx, Sy, mode
+    ('full', 'vqa', 'mcan', 512, 4, 14, 36, None),
+    ('full', 'vqa', 'mmnas_vqa', 512, 2, 14, 100, None),
+    ('full', 'vgd', 'mmnas_vgd', 512, 2, 15, 100, None),
+    ('full', 'itm', 'mmnas_itm', 512, 2, 50, 36, None),
+    ('search', 'vqa', None, 256, 2, 14, 100, None),
+    ('search', 'vqa', None, 256, 2, 14, 100, 'full'),
+)
+FULL_SEED0 = 9500
+
+
+def full_case_tag(spec):
+    kind, task, arch, d, B, Sx, Sy, mode = spec
+    return '%s|%s|%s|%d_%d_%d_%d|' % (kind, task, arch if kind == 'full' else mode, d, B, Sx, Sy)
+
+
+def net_case_full(spec, seed):
+    """One FULL_CASES entry -> the case dict of net_case at production dimensions (+ the injected sample for a supernet)."""
+    kind, task, arch, d, B, Sx, Sy, mode = spec
+    search = kind == 'search'
+    cfg_over = dict(FRCNFEAT_SIZE=2048, ATTFLAT_MLP_SIZE=512, WORD_EMBED_SIZE=300, ATTFLAT_OUT_SIZE=2 * d, BBOXFEAT_EMB_SIZE=1024)
+    ans = 3129 if task == 'vqa' else 13
+    c = net_case(task, arch, seed, search=search, HSIZE=d, B=B, Sx=Sx, Sy=Sy, token_size=2000, ans_size=ans, cfg_over=cfg_over)
+    if search:
+        c['plan'] = search_plan(np.random.RandomState(seed + 50000), mode)
+        c['mode'] = mode
+    return c
 
 
 def search_plan(rs, mode):

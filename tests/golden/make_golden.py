@@ -11,6 +11,11 @@ Files written (npz, float32 unless noted):
     prims.npz        LayerNorm, AttFlat, make_mask, LSTM stand-alone
     mixed.npz        MixedOp algebra: forward modes, alpha-gradient, rescale, genotype
     nets.npz         Net_Full(arch/*.json) for vqa/vgd/itm and Net_Search weight/arch steps
+    nets_full.npz    the same networks at the entry scripts' OWN dimensions (HSIZE 512 / 256, 100 regions, 14 tokens, 3129
+                     answers, B = 2-4; BASELINE configs[0] literally: mcan, B = 4, 36 regions): logits, loss, per-parameter
+                     gradient norms, strided element samples of every gradient -- fp32 as the reference computes them, and
+                     the same samples from the reference run in FLOAT64 (`gs64`: the yardstick for gradients whose fp32
+                     value is cancellation-limited, the relation projections' `linear_r`)
     traj.npz         capture (v): two Adam weight steps + one 'full' arch step of the reference loop (loss trajectory)
     loader.npz       loader functions (relation_embedding, semantic_embedding, proc_img_feat, proc_bbox_feat, proc_ques)
     losses.npz       ITM triplet step with BCE_Loss; VGD KLDiv + SmoothL1 loss
@@ -98,6 +103,27 @@ def grad_samples(out, tag, net):
     out[tag + 'gs_keys'] = np.array(keys)
     out[tag + 'gs'] = np.concatenate(parts) if parts else np.zeros(0, np.float32)
     out[tag + 'gs_off'] = np.array(off, np.int64)
+
+
+GS64_KEYS = ('linear_r.', 'linear_y_rel.', 'linear_x_rel.')
+
+
+def grad_samples64(out, tag, net64, keys):
+    """tag + 'gs64_keys' / 'gs64' / 'gs64_off': the strided samples of the relation-path parameter gradients (GS64_KEYS) from
+    the reference run in float64 -- same stride as 'gs'.  These gradients are sums with heavy cancellation behind
+    log(clamp(relu(.))): two fp32 evaluations differ by up to 4e-3 of the largest entry, so fp32 results (the oracle's, the HIP
+    path's) are judged against the float64 value, at the ordinary tolerance."""
+    g = dict(net64.named_parameters())
+    ks = [k for k in keys if any(s in k for s in GS64_KEYS) and g[k].grad is not None]
+    parts = [esample64(g[k].grad) for k in ks]
+    out[tag + 'gs64_keys'] = np.array(ks)
+    out[tag + 'gs64'] = np.concatenate(parts) if parts else np.zeros(0, np.float64)
+    out[tag + 'gs64_off'] = np.cumsum([0] + [q.size for q in parts]).astype(np.int64)
+
+
+def esample64(t, n=64):
+    flat = np.ascontiguousarray(t.detach().numpy(), dtype=np.float64).reshape(-1)
+    return flat[::max(1, flat.size // n)][:n].copy()
 
 
 def run_ref_op(case):
@@ -327,6 +353,13 @@ def gen_nets():
         grad_samples(out, tag, net)
         if net.linear_y_rel.weight.grad is not None:
             out[tag + 'g:linear_y_rel.weight'] = net.linear_y_rel.weight.grad.numpy()
+        # the float64 twin (round 5): yardstick for the cancellation-limited relation-path gradients
+        net64 = full[task](c['cfg'], init)
+        net64.train()
+        load_state(net64, c['P'])
+        net64 = net64.double()
+        _net_loss(task, net64(tuple(t if t.dtype == torch.int64 else t.double() for t in inp)), c['target'].astype(np.float64)).backward()
+        grad_samples64(out, tag, net64, [str(k) for k in out[tag + 'gs_keys']])
 
     # supernet: weight step (MODE None) and arch steps ('full', 'two') with injected samples
     MixedOp = RMIX.MixedOp
@@ -380,6 +413,20 @@ def gen_nets():
             out[tag + 'gradnorm_keys'] = np.array(keys)
             out[tag + 'gradnorms'] = np.array([gn[k] for k in keys], np.float64)
             grad_samples(out, tag, net)
+            net64 = hygr[task](c['cfg'], init)
+            net64.train()
+            load_state(net64, c['P'])
+            net64 = net64.double()
+            for m, (act, inact) in zip(net64.redundant_modules, flat):
+                m.alpha_gate.data.zero_()
+                m.alpha_gate.data[act[0]] = 1.0
+                m.active_index, m.inactive_index = list(act), list(inact)
+            net64.unused_modules_off()
+            l64 = _net_loss(task, net64(tuple(t if t.dtype == torch.int64 else t.double() for t in inp)), c['target'].astype(np.float64))
+            net64.zero_grad()
+            l64.backward()
+            net64.unused_modules_back()
+            grad_samples64(out, tag, net64, [str(k) for k in out[tag + 'gs_keys']])
             MixedOp.MODE = None
             if task == 'vqa' and mode is None:
                 # genotype / genotype_weights for the loaded alphas (hygr_vqa.py:242-297)
@@ -397,6 +444,72 @@ def gen_nets():
     np.savez_compressed(os.path.join(HERE, 'nets.npz'), **out)
     print('nets.npz', len(out), 'arrays')
 
+
+
+def gen_nets_full():
+    """Whole networks at the dimensions the entry scripts run (cases.FULL_CASES), fp32 and float64 reference runs."""
+    out = {}
+    full = {'vqa': full_vqa.Net_Full, 'vgd': full_vgd.Net_Full, 'itm': full_itm.Net_Full}
+    MixedOp = RMIX.MixedOp
+    for i, spec in enumerate(cases.FULL_CASES):
+        kind, task, arch, d, B, Sx, Sy, mode = spec
+        seed = cases.FULL_SEED0 + i
+        c = cases.net_case_full(spec, seed)
+        tag = cases.full_case_tag(spec)
+        init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+                'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
+        nets = []
+        for dt in (torch.float32, torch.float64):
+            net = (hygr_vqa.Net_Search if kind == 'search' else full[task])(c['cfg'], init)
+            net.train()
+            load_state(net, c['P'])
+            net = net.to(dt)
+            inp = tuple(T(a) if a.dtype == np.int64 else T(a).to(dt) for a in c['inputs'])
+            if kind == 'search':
+                flat = c['plan']['enc'] + c['plan']['dec']
+                _inject(net.redundant_modules, flat, MixedOp, mode)
+                net.unused_modules_off()
+            pred = net(inp)
+            tgt = c['target'].astype(np.float64 if dt == torch.float64 else np.float32)
+            loss = _net_loss(task, pred, tgt)
+            net.zero_grad()
+            loss.backward()
+            if kind == 'search':
+                net.unused_modules_back()
+                MixedOp.MODE = None
+            nets.append((net, pred, loss))
+        net, pred, loss = nets[0]
+        net64, pred64, loss64 = nets[1]
+        out[tag + 'seed'] = np.int64(seed)
+        out[tag + 'insum'] = np.float64(cases.checksum(dict(c['P'], frcn=c['inputs'][0], yrel=c['inputs'][2],
+                                                           q=c['inputs'][3], xrel=c['inputs'][4])))
+        if task == 'vgd':
+            out[tag + 'scores'] = pred[0].detach().numpy(); out[tag + 'reg'] = pred[1].detach().numpy()
+            out[tag + 'scores64'] = pred64[0].detach().numpy(); out[tag + 'reg64'] = pred64[1].detach().numpy()
+        else:
+            out[tag + 'pred'] = pred.detach().numpy()
+            out[tag + 'pred64'] = pred64.detach().numpy()
+        out[tag + 'loss'] = np.float64(loss.item())
+        out[tag + 'loss64'] = np.float64(loss64.item())
+        if kind == 'search':
+            mops = net.redundant_modules
+            out[tag + 'plan_act'] = np.array([a[0] for a, _ in flat], np.int64)
+            if mode is not None:
+                out[tag + 'gate_grads'] = np.stack([np.pad(m.alpha_gate.grad.numpy(), (0, 4 - m.n_choices)) for m in mops])
+                out[tag + 'gate_grads64'] = np.stack([np.pad(m.alpha_gate.grad.numpy(), (0, 4 - m.n_choices)) for m in net64.redundant_modules])
+        gn = {k: (0.0 if p.grad is None else float(p.grad.double().norm())) for k, p in net.named_parameters()}
+        keys = sorted(gn)
+        out[tag + 'gradnorm_keys'] = np.array(keys)
+        out[tag + 'gradnorms'] = np.array([gn[k] for k in keys], np.float64)
+        gn64 = {k: (0.0 if p.grad is None else float(p.grad.norm())) for k, p in net64.named_parameters()}
+        out[tag + 'gradnorms64'] = np.array([gn64[k] for k in keys], np.float64)
+        grad_samples(out, tag, net)
+        grad_samples64(out, tag, net64, [str(k) for k in out[tag + 'gs_keys']])
+        print(tag, 'loss', loss.item(), 'loss64', loss64.item(), 'max |pred - pred64|',
+              float(np.max(np.abs(np.asarray(out.get(tag + 'pred', out.get(tag + 'scores'))) -
+                                  np.asarray(out.get(tag + 'pred64', out.get(tag + 'scores64')))))))
+    np.savez_compressed(os.path.join(HERE, 'nets_full.npz'), **out)
+    print('nets_full.npz', len(out), 'arrays')
 
 
 def _inject(mops, flat_plan, MixedOp, mode):
@@ -661,6 +774,6 @@ def gen_losses():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['ops', 'ops_shapes', 'prims', 'mixed', 'nets', 'traj', 'train_traj', 'loader', 'losses']
+    which = sys.argv[1:] or ['ops', 'ops_shapes', 'prims', 'mixed', 'nets', 'nets_full', 'traj', 'train_traj', 'loader', 'losses']
     for w in which:
         globals()['gen_' + w]()

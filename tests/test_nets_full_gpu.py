@@ -1,0 +1,144 @@
+"""Whole networks at the entry scripts' OWN dimensions against the reference (tests/golden/nets_full.npz).
+
+HSIZE 512 (search: 256), 100 regions + 14 tokens (VGD 15 tokens; ITM 36 regions + 50 tokens), 2048-wide region features,
+3129 answers, B = 2-4 -- BASELINE configs[0] literally (arch/mcan.json, B = 4, 36 regions) -- dropout 0.  Every case runs
+through the three routes the library has:
+    per-operator   one autograd node per operator (plain autograd use, the unchanged scripts)
+    chain          the backbone / head / LSTM sections as native calls behind a flat gradient buffer (the bench's path:
+                   arena planner, stream-K schedules, 8-head attention inside the chain, the 3129-wide answer layer, the
+                   2048 -> d stem)
+    ragged         the chain with the decoder stream on the valid region rows only (ops.set_unpad)
+and each is compared with the REFERENCE's numbers: logits, loss, every parameter's gradient norm, strided element samples
+of every gradient tensor (relation-path gradients against the reference's float64 run), gate gradients of the arch step.
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import cases
+from tests.util import TOL, check_grad_samples, load, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+T = torch.from_numpy
+IDS = [cases.full_case_tag(s).rstrip('|') for s in cases.FULL_CASES]
+
+
+def _loss(task, pred, target):
+    t = T(target).to(DEV)
+    if task == 'vqa':
+        return torch.nn.functional.binary_cross_entropy_with_logits(pred, t, reduction='sum')
+    if task == 'itm':
+        return torch.nn.functional.binary_cross_entropy(pred, t, reduction='sum')
+    scores, reg = pred
+    return (scores * t).sum() + 0.5 * (reg ** 2).sum()
+
+
+def _run(spec, route, monkeypatch):
+    from mmnas_amd import dp, ops
+    from mmnas.model.mixed import MixedOp
+    kind, task, arch, d, B, Sx, Sy, mode = spec
+    npz = load('nets_full.npz')
+    tag = cases.full_case_tag(spec)
+    c = cases.net_case_full(spec, int(npz[tag + 'seed']))
+    search = kind == 'search'
+    mod = importlib.import_module('mmnas.model.%s_%s' % ('hygr' if search else 'full', task))
+    net = (mod.Net_Search if search else mod.Net_Full)(
+        c['cfg'], {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+                   'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)})
+    net.load_state_dict({k: T(v) for k, v in c['P'].items()}, strict=True)
+    net = net.to(DEV).train()
+    inp = tuple(T(a).to(DEV) for a in c['inputs'])
+    chain_calls, ragged_calls = [], []
+    orig = ops.BackboneFn.apply
+    monkeypatch.setattr(ops.BackboneFn, 'apply', lambda *a: (chain_calls.append(1), ragged_calls.append(a[10] is not None), orig(*a))[2])
+    prev_unpad = ops.set_unpad(route == 'ragged')
+    red = None
+    try:
+        if search:
+            MixedOp.MODE = mode
+            flat = c['plan']['enc'] + c['plan']['dec']
+            net.set_sampled(flat)
+        if route != 'per_operator':
+            if search:
+                red = dp.SupernetReducer(net)
+                if mode is None:
+                    red.begin_weight_step()
+                else:
+                    net.begin_arch_step()
+                    red.fg.zero()
+                    red.fg.attach()
+            else:
+                red = dp.GradReducer(list(net.parameters()))
+                red.begin_step()
+        elif search:
+            net.unused_modules_off()
+        pred = net(inp)
+        loss = _loss(task, pred, c['target'])
+        if route == 'per_operator':
+            net.zero_grad()
+        loss.backward()
+        if red is not None and (not search or mode is None):
+            red.finish_weight_step() if search else red.finish()
+        if route == 'per_operator' and search:
+            net.unused_modules_back()
+        torch.cuda.synchronize()
+        gate = None
+        if mode is not None:
+            gate = np.stack([np.pad(m.alpha_gate.grad.detach().cpu().numpy(), (0, 4 - m.n_choices)) for m in net.redundant_modules])
+        grads = {k: (None if p.grad is None else p.grad.detach().cpu().numpy().copy()) for k, p in net.named_parameters()}
+        preds = tuple(p.detach().cpu().numpy() for p in pred) if task == 'vgd' else pred.detach().cpu().numpy()
+        return npz, tag, preds, float(loss.detach()), grads, gate, chain_calls, ragged_calls
+    finally:
+        MixedOp.MODE = None
+        ops.set_unpad(prev_unpad)
+        if red is not None:
+            red.fg.disable_sinks()
+
+
+def _check(spec, route, res):
+    kind, task, arch, d, B, Sx, Sy, mode = spec
+    npz, tag, pred, loss, grads, gate, chain_calls, ragged_calls = res
+    if route == 'per_operator':
+        assert not chain_calls
+    else:
+        assert chain_calls, 'the backbone chain was not taken'
+        if route == 'ragged':
+            # (the grounding head scores every region row, padding included: there the ragged stream must stay off)
+            assert ragged_calls == [task != 'vgd'], ragged_calls
+    if task == 'vgd':
+        assert rel_err(pred[0], npz[tag + 'scores']) <= TOL
+        assert rel_err(pred[1], npz[tag + 'reg']) <= TOL
+    else:
+        assert pred.shape == npz[tag + 'pred'].shape
+        assert rel_err(pred, npz[tag + 'pred']) <= TOL
+    assert abs(loss - float(npz[tag + 'loss'])) <= TOL * abs(float(npz[tag + 'loss']))
+    keys = [str(k) for k in npz[tag + 'gradnorm_keys']]
+    norms = npz[tag + 'gradnorms']
+    assert set(keys) == set(grads.keys())
+    big = float(np.max(norms))
+    for k, n in zip(keys, norms):
+        if 'alpha' in k:
+            continue
+        g = grads[k]
+        v = 0.0 if g is None else float(np.linalg.norm(g.astype(np.float64)))
+        assert abs(v - n) <= 3e-3 * n + 1e-5 * big, (k, v, n)
+    assert check_grad_samples(npz, tag, grads, skip=lambda k: 'alpha' in k) > 100
+    if mode is not None:
+        assert rel_err(gate, npz[tag + 'gate_grads']) <= 3e-3
+
+
+@pytest.mark.parametrize('route', ['per_operator', 'chain', 'ragged'])
+@pytest.mark.parametrize('spec', cases.FULL_CASES, ids=IDS)
+def test_network_at_production_dimensions_vs_reference(spec, route, monkeypatch):
+    _check(spec, route, _run(spec, route, monkeypatch))
+
+
+def test_mcan_batch4_is_baseline_config0():
+    """BASELINE.json configs[0]: 'arch/mcan.json VQA supernet, batch=4, synthetic 36x2048 region feats + 14-token questions'."""
+    spec = cases.FULL_CASES[0]
+    assert spec[:3] == ('full', 'vqa', 'mcan') and spec[4:7] == (4, 14, 36)
+    c = cases.net_case_full(spec, cases.FULL_SEED0)
+    assert c['inputs'][0].shape == (4, 36, 2048) and c['inputs'][3].shape == (4, 14) and c['cfg'].HSIZE == 512

@@ -196,3 +196,44 @@ def test_flat_adam_checkpoint_interchanges_with_torch_adam(mode):
         assert rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 2e-6
         assert rel_err(c.detach().cpu().numpy(), b.detach().cpu().numpy()) < 2e-6
 
+
+
+@pytest.mark.parametrize('mode', ['zero', 'skip'])
+def test_conv_seq_follows_the_weights_across_a_flat_adam_step(mode):
+    """the re-arranged StdConv weights were cached on the tensor's version counter, which a raw-pointer
+    optimizer step (mmnas_adam_step on the flat buffer) never moves: after the first FlatAdam step the operator kept
+    computing with its INITIAL weights.  conv_seq -> FlatAdam.step -> conv_seq must equal torch's conv1d on the parameter
+    as it stands, forward and all gradients, both before and after the step."""
+    import torch.nn.functional as F
+    from mmnas_amd import ops
+    from mmnas_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(3)
+    B, S, d, k = 3, 100, 64, 7
+    x = torch.randn(B, S, d, generator=g).to(DEV)
+    dy = torch.randn(B, S, d, generator=g).to(DEV)
+    w = torch.nn.Parameter((torch.randn(d, d, k, generator=g) * 0.1).to(DEV))
+    b = torch.nn.Parameter(torch.randn(d, generator=g).to(DEV))
+    opt = FlatAdam([w, b], lr=0.05, absent_grads=mode)
+
+    def check():
+        xr = x.double().requires_grad_(True)
+        wr, br = w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+        yr = F.conv1d(xr.transpose(1, 2), wr, br, padding=k // 2).transpose(1, 2)
+        yr.backward(dy.double())
+        opt.zero_grad()
+        if mode == 'skip':
+            opt.fg.attach()
+        xg = x.clone().requires_grad_(True)
+        y = ops.conv_seq(xg, w, b)
+        y.backward(dy)
+        for got, ref in ((y, yr), (xg.grad, xr.grad), (w.grad, wr.grad), (b.grad, br.grad)):
+            assert float((got.detach().double() - ref.detach()).abs().max()) <= 3e-6 * float(ref.abs().max())
+
+    check()
+    w0 = w.detach().clone()
+    opt.step()
+    torch.cuda.synchronize()
+    assert float((w.detach() - w0).abs().max()) > 1e-3       # the step moved the weights (through the raw pointer) ...
+    check()                                                  # ... and the operator sees them
+    opt.step()
+    check()

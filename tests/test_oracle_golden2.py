@@ -295,15 +295,61 @@ def test_golden_recipe_regenerates_bit_exact(tmp_path):
     code = ("import sys; sys.path.insert(0, %r)\n"
             "import tests.golden.make_golden as mg\n"
             "mg.HERE = %r\n"
-            "for w in ('prims', 'mixed', 'traj', 'train_traj', 'loader', 'losses'):\n"
+            "for w in ('prims', 'mixed', 'traj', 'train_traj', 'loader', 'losses', 'nets_full'):\n"
             "    getattr(mg, 'gen_' + w)()\n" % (REPO, str(tmp_path)))
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
     r = subprocess.run([sys.executable, '-c', code], cwd=str(tmp_path), env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    for w in ('prims', 'mixed', 'traj', 'train_traj', 'loader', 'losses'):
+    for w in ('prims', 'mixed', 'traj', 'train_traj', 'loader', 'losses', 'nets_full'):
         new = np.load(os.path.join(str(tmp_path), w + '.npz'))
         old = np.load(os.path.join(GOLDEN, w + '.npz'))
         assert sorted(new.files) == sorted(old.files), w
         for k in new.files:
             assert np.array_equal(new[k], old[k]), (w, k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# whole networks at the entry scripts' own dimensions (nets_full.npz)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('spec', cases.FULL_CASES, ids=[cases.full_case_tag(s).rstrip('|') for s in cases.FULL_CASES])
+def test_oracle_nets_at_production_dimensions(spec):
+    """The CPU restatement against the reference at HSIZE 512 / 256, 100 regions + 14 tokens (ITM 36 + 50), 3129 answers,
+    B = 2-4 (configs[0] literally: arch/mcan.json, B = 4, 36 regions): logits, loss, every parameter's gradient norm, strided
+    element samples of every gradient (the relation-path ones against the reference's float64 run)."""
+    from tests import oracle_runner as R
+    from tests.util import check_grad_samples
+    npz = load('nets_full.npz')
+    kind, task, arch, d, B, Sx, Sy, mode = spec
+    tag = cases.full_case_tag(spec)
+    c = cases.net_case_full(spec, int(npz[tag + 'seed']))
+    assert abs(cases.checksum(dict(c['P'], frcn=c['inputs'][0], yrel=c['inputs'][2], q=c['inputs'][3], xrel=c['inputs'][4]))
+               - float(npz[tag + 'insum'])) <= 1e-9 * abs(float(npz[tag + 'insum']))
+    search = None
+    if kind == 'search':
+        search = c['plan']
+        flat = search['enc'] + search['dec']
+        assert [a[0] for a, _ in flat] == list(npz[tag + 'plan_act'])
+        gates = [k for k in c['P'] if k.endswith('alpha_gate')]
+        for k, (act, _) in zip(gates, flat):
+            c['P'][k][:] = 0
+            c['P'][k][act[0]] = 1.0
+    pred, loss, grads = R.run_oracle_net(c, search=search)
+    if task == 'vgd':
+        assert rel_err(pred[0].detach().numpy(), npz[tag + 'scores']) < 1e-4
+        assert rel_err(pred[1].detach().numpy(), npz[tag + 'reg']) < 1e-4
+    else:
+        assert rel_err(pred.detach().numpy(), npz[tag + 'pred']) < 1e-4
+    assert abs(loss - float(npz[tag + 'loss'])) < 1e-4 * abs(float(npz[tag + 'loss']))
+    keys = [str(k) for k in npz[tag + 'gradnorm_keys']]
+    assert set(keys) == set(c['P'].keys())
+    top = float(np.max(npz[tag + 'gradnorms']))
+    for k, n in zip(keys, npz[tag + 'gradnorms']):
+        if 'alpha' in k:
+            continue
+        mine = 0.0 if grads[k] is None else float(np.linalg.norm(grads[k].astype(np.float64)))
+        assert abs(mine - n) <= 2e-3 * n + 1e-6 * top, (k, mine, n)
+    assert check_grad_samples(npz, tag, grads, skip=lambda k: 'alpha' in k) > 100
+    if mode is not None:
+        gg = np.stack([np.pad(grads[k], (0, 4 - grads[k].size)) for k in gates])
+        assert rel_err(gg, npz[tag + 'gate_grads']) < 1e-3
