@@ -366,6 +366,40 @@ int mmnas_rel_fused_bwd_ragged(const float* raw, const float* Wy, const float* b
                                int B, int S, int C, int R, int H, const int* off, const int* tile_off, int ntiles, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The relation bias of SEVERAL RelSelfAtt operators in one launch per direction (relmulti.hip, round 5).
+ * Every relation operator of a network reads the same embedding rel = relu(linear_y_rel(raw)) -- ONE stem layer
+ * (hygr_vqa.py:111, full_vqa.py:103) -- and its bias log(max(relu(linear_r(rel)), 1e-6)) (modules.py:231-235) depends on
+ * nothing the backbone computes.  One call computes the hidden layer once per (b, q, k) element and
+ *   fwd: writes biasT[n] [B,H,S,S] (key-major, as mmnas_rel_fused_fwd) for each of the n_ops operators from its own Wr[n] / br[n];
+ *   bwd: reads every operator's dbiasT[n], ACCUMULATES dWr[n] / dbr[n] per operator and dWy / dby ONCE for all of them.
+ * Self-attention only (S x S); R = 64, C in {3,4}, H <= 32, n_ops <= MMNAS_REL_MULTI_MAX (the call loops launches of 32
+ * head rows backward / 96 forward); ragged batches as mmnas_rel_fused_*_ragged (off / tile_off / ntiles, else NULL / 0).
+ * ws: mmnas_rel_multi_bwd_ws_floats(B, S) floats (backward only).  Results equal the per-operator calls to round-off.
+ * ------------------------------------------------------------------------------------------ */
+#define MMNAS_REL_MULTI_MAX 32
+typedef struct mmnas_rel_multi {
+  int B, S, C, R, H, n_ops;
+  const float* raw;                 /* [B,S,S,C] */
+  const float* Wy; const float* by; /* linear_{x,y}_rel: [R,C], [R] */
+  float* dWy; float* dby;           /* bwd: accumulated (+=) */
+  const float* Wr[MMNAS_REL_MULTI_MAX];      /* mhatt.linear_r.weight [H,R] per operator */
+  const float* br[MMNAS_REL_MULTI_MAX];      /* mhatt.linear_r.bias [H] */
+  float* biasT[MMNAS_REL_MULTI_MAX];         /* fwd out: [B,H,S,S] per operator */
+  const float* dbiasT[MMNAS_REL_MULTI_MAX];  /* bwd in */
+  float* dWr[MMNAS_REL_MULTI_MAX]; float* dbr[MMNAS_REL_MULTI_MAX];   /* bwd: accumulated (+=) */
+  const int* off; const int* tile_off; int ntiles, reserved;          /* ragged batches (device arrays [B+1]) or NULL */
+  float* ws;
+} mmnas_rel_multi;
+int mmnas_rel_multi_supported(int C, int R, int H);
+size_t mmnas_rel_multi_bwd_ws_floats(int B, int S);   /* host only */
+int mmnas_rel_multi_fwd(const mmnas_rel_multi* m, void* stream);
+int mmnas_rel_multi_bwd(const mmnas_rel_multi* m, void* stream);
+/* Backbone chains (mmnas_chain_*) compute the bias of all their lazy-handle relation operators this way: forward at chain
+ * entry, backward behind the last relation operator of a stream.  mmnas_set_rel_hoist(0) / MMNAS_REL_HOIST=0 restores one
+ * mmnas_rel_fused_* launch per operator (A/B runs); returns the previous setting. */
+int mmnas_set_rel_hoist(int on);
+
+/* ------------------------------------------------------------------------------------------
  * Attention core: MHAtt.att (modules.py:191-199) for all (batch, head) pairs.
  *   Z = Q K^T / sqrt(dh) (+ biasT) ; Z[mask] = -1e9 ; P = softmax(Z) ; A = dropout(P) ; O = A V
  * Q [B*Sq, ldq], K,V [B*Sk, ldk/ldv], head h occupies columns [h*dh, (h+1)*dh).

@@ -97,6 +97,17 @@ class Head(C.Structure):
                 ('Wp', _fp), ('bp', _fp), ('dWp', _fp), ('dbp', _fp), ('logits', _fp), ('dlogits', _fp), ('arena', _fp)]
 
 
+REL_MULTI_MAX = 32
+
+
+class RelMulti(C.Structure):
+    _fields_ = [('B', C.c_int), ('S', C.c_int), ('C', C.c_int), ('R', C.c_int), ('H', C.c_int), ('n_ops', C.c_int),
+                ('raw', _fp), ('Wy', _fp), ('by', _fp), ('dWy', _fp), ('dby', _fp),
+                ('Wr', _fp * REL_MULTI_MAX), ('br', _fp * REL_MULTI_MAX), ('biasT', _fp * REL_MULTI_MAX),
+                ('dbiasT', _fp * REL_MULTI_MAX), ('dWr', _fp * REL_MULTI_MAX), ('dbr', _fp * REL_MULTI_MAX),
+                ('off', _fp), ('tile_off', _fp), ('ntiles', C.c_int), ('reserved', C.c_int), ('ws', _fp)]
+
+
 class ProfStat(C.Structure):
     _fields_ = [('ms', C.c_double), ('flops', C.c_double), ('bytes', C.c_double), ('launches', C.c_long)]
 
@@ -163,6 +174,11 @@ SYMBOLS = {
     'mmnas_rel_fused_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     'mmnas_rel_fused_fwd_ragged': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp]),
     'mmnas_rel_fused_bwd_ragged': (_i, [_fp] * 11 + [_i, _i, _i, _i, _i, _fp, _fp, _i, _fp]),
+    'mmnas_rel_multi_supported': (_i, [_i, _i, _i]),
+    'mmnas_rel_multi_bwd_ws_floats': (_sz, [_i, _i]),
+    'mmnas_rel_multi_fwd': (_i, [C.POINTER(RelMulti), _fp]),
+    'mmnas_rel_multi_bwd': (_i, [C.POINTER(RelMulti), _fp]),
+    'mmnas_set_rel_hoist': (_i, [_i]),
     'mmnas_mha_core_fwd': (_i, [C.POINTER(MhaDesc), _fp]),
     'mmnas_mha_core_bwd': (_i, [C.POINTER(MhaDesc), _fp]),
     'mmnas_att_op_plan': (_i, [C.POINTER(AttOp), C.POINTER(Plan)]),

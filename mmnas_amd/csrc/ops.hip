@@ -108,7 +108,9 @@ namespace mmnas {
 // defer_ln (mixed chains): with NORM the operator stops behind its residual sum z (saved block) and writes no output --
 // the node epilogue (mmnas_node_mix_fwd) normalises every candidate of the node and forms the gated sum in one pass.
 // *ln_done tells the caller whether the output was normalised here after all (the one-launch short-sequence kernel).
-static int att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_ln, bool* ln_done);
+// rel_ready (backbone chains): the relation bias already sits in the saved block (one mmnas_rel_multi_fwd launch at chain entry
+// computed it for every relation operator of the stream): skip the per-operator bias launch.
+static int att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_ln, bool* ln_done, bool rel_ready = false);
 }
 extern "C" int mmnas_att_op_fwd(const mmnas_att_op* op, void* stream) {
   bool done;
@@ -138,9 +140,9 @@ static void att_core_desc(const mmnas_att_op* op, const AttLayout& L, mmnas_mha_
 }
 
 // desc_only != NULL: the relation bias is computed, the core itself is left to the caller (its descriptor in *desc_only)
-static int att_core_fwd(const mmnas_att_op* op, const AttLayout& L, void* stream, mmnas_mha_desc* desc_only = nullptr) {
+static int att_core_fwd(const mmnas_att_op* op, const AttLayout& L, void* stream, mmnas_mha_desc* desc_only = nullptr, bool rel_ready = false) {
   const int fl = op->flags;
-  const bool rel = fl & MMNAS_F_REL;
+  const bool rel = (fl & MMNAS_F_REL) && !rel_ready;
   int rc;
   if (rel) {
     if (fl & MMNAS_F_RELRAW) {  // lazy handle: bias straight from the raw [B,Sq,Sk,C] relations
@@ -182,7 +184,7 @@ static int att_fwd_args(const mmnas_att_op* op) {
 }
 }  // namespace mmnas
 
-static int mmnas::att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_ln, bool* ln_done) {
+static int mmnas::att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_ln, bool* ln_done, bool rel_ready) {
   *ln_done = true;
   int rc = att_fwd_args(op);
   if (rc) return rc;
@@ -198,7 +200,7 @@ static int mmnas::att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_
   g.ngroups = 3;
   att_qkv_groups(op, L, g.g);
   if ((rc = mmnas_gemm(&g, stream))) return rc;
-  if ((rc = att_core_fwd(op, L, stream))) return rc;
+  if ((rc = att_core_fwd(op, L, stream, nullptr, rel_ready))) return rc;
   gemm_init(g, MMNAS_GEMM_NT, d, di, di, di, d);
   att_merge_group(op, L, &g.g[0]);
   if (fl & MMNAS_F_RESIDUAL) g.ldres = d;
@@ -239,7 +241,9 @@ struct SideQueue {
 // gradient exchange) are queued.
 // acc_kv (guided operators inside the backbone chain): the key / value source's gradient is ADDED to *dxkv (the chain's
 // running sum over the guided operators) instead of overwriting it -- saves the chain a buffer and an add launch each.
-static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* sq, bool acc_kv = false) {
+// rel_defer (backbone chains): the bias gradient dbiasT stays in the operator's scratch block; ONE mmnas_rel_multi_bwd launch
+// behind the stream's last relation operator turns every operator's dbiasT into its dWr / dbr and the shared dWy / dby.
+static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* sq, bool acc_kv = false, bool rel_defer = false) {
   const bool side = sq != nullptr && !sq->rel_only;
   const bool side_rel = sq != nullptr;
   int rc = att_check(op, "att_op_bwd");
@@ -347,6 +351,7 @@ static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* s
     if (!self) sq->work.push_back([w2](hipStream_t s) { return mmnas_gemm(&w2, s); });
   }
   // 7. relation bias
+  if (rel && rel_defer) return MMNAS_OK;
   if (rel && (fl & MMNAS_F_RELRAW)) {
     MMNAS_REQUIRE(op->Wy && op->by && op->dWy && op->dby, MMNAS_E_ARG, "att_op_bwd: RELRAW gradients missing");
     const mmnas_att_op o = *op;
@@ -573,7 +578,7 @@ namespace mmnas {
 struct ChainLayout {
   size_t y[MMNAS_CHAIN_MAX_OPS], save[MMNAS_CHAIN_MAX_OPS], ws[MMNAS_CHAIN_MAX_OPS], dx[MMNAS_CHAIN_MAX_OPS],
       tmp[MMNAS_CHAIN_MAX_OPS];
-  size_t dpre, encdy, total;
+  size_t dpre, encdy, relws, total;
   int last_x, last_y, first_x, first_y, n_guided;
   // mixed chains: per node (indexed by the node's first operator) the node output and the sampled candidate's output
   // gradient; one scratch block for the gate-gradient partials
@@ -673,6 +678,7 @@ static int chain_layout(const mmnas_chain* c, ChainLayout& L) {
   }
   L.dpre = take(nx);
   L.encdy = take(nx);
+  L.relws = take(mmnas_rel_multi_bwd_ws_floats(c->B, c->Sx > c->Sy ? c->Sx : c->Sy) * sizeof(float));
   L.mixws = 0;
   if (c->mixed) {
     for (int i = 0; i < c->n_ops; ++i) {
@@ -770,7 +776,74 @@ static int ev_fork(hipStream_t from, hipStream_t to, hipEvent_t e) {
   return MMNAS_OK;
 }
 
+
+// ---- relation bias of all lazy-handle relation operators of a stream in one launch per direction (relmulti.hip) ----
+static int g_rel_hoist = -1;   // -1: not read yet (MMNAS_REL_HOIST, default 1); mmnas_set_rel_hoist() overrides
+static bool rel_hoist_on() {
+  if (g_rel_hoist < 0) { const char* e = getenv("MMNAS_REL_HOIST"); g_rel_hoist = (e && e[0] ? atoi(e) : 1) ? 1 : 0; }
+  return g_rel_hoist != 0;
+}
+struct RelGroups {
+  std::vector<mmnas_rel_multi> groups[2];      // [0]: the language stream's, [1]: the image stream's
+  bool hoisted[MMNAS_CHAIN_MAX_OPS];
+  RelGroups() { memset(hoisted, 0, sizeof(hoisted)); }
+};
+// Which operators take part: attention operators with MMNAS_F_REL | MMNAS_F_RELRAW whose shape relmulti.hip covers; backward
+// (bwd = true) only the differentiated ones.  Operators of one stream that share (raw, Wy, by, H, C) form a group.
+static void chain_rel_groups(const mmnas_chain* c, const ChainLayout& L, bool bwd, RelGroups& G) {
+  if (!rel_hoist_on() || c->use_side_stream) return;
+  char* base = (char*)c->arena;
+  for (int i = 0; i < c->n_ops; ++i) {
+    const mmnas_chain_op& o = c->ops[i];
+    if (o.kind != MMNAS_CHAIN_ATT) continue;
+    if (bwd && c->mixed && o.detached) continue;
+    mmnas_att_op a; mmnas_mlp_op m;
+    chain_op_setup(c, i, a, m);
+    if (!(a.flags & MMNAS_F_REL) || !(a.flags & MMNAS_F_RELRAW) || !(a.flags & MMNAS_F_SELF)) continue;
+    if (!mmnas_rel_multi_supported(a.C, a.R, a.H) || !a.rel || !a.Wy || !a.by) continue;
+    if ((long)a.B * a.H * a.Sq * a.Sq >= (1l << 31)) continue;
+    a.save = base + L.save[i]; a.ws = base + L.ws[i];
+    const AttLayout al_ = att_layout(&a);
+    std::vector<mmnas_rel_multi>& gs = G.groups[o.on_y ? 1 : 0];
+    mmnas_rel_multi* g = nullptr;
+    for (auto& q : gs)
+      if (q.raw == a.rel && q.Wy == a.Wy && q.by == a.by && q.H == a.H && q.C == a.C && q.n_ops < MMNAS_REL_MULTI_MAX) { g = &q; break; }
+    if (!g) {
+      mmnas_rel_multi q;
+      memset(&q, 0, sizeof(q));
+      q.B = a.B; q.S = a.Sq; q.C = a.C; q.R = a.R; q.H = a.H;
+      q.raw = a.rel; q.Wy = a.Wy; q.by = a.by; q.dWy = a.dWy; q.dby = a.dby;
+      q.off = a.q_off; q.tile_off = a.rel_tile_off; q.ntiles = a.rel_ntiles;
+      q.ws = (float*)(base + L.relws);
+      gs.push_back(q);
+      g = &gs.back();
+    }
+    const int j = g->n_ops++;
+    g->Wr[j] = a.Wr; g->br[j] = a.br; g->biasT[j] = al_.biasT; g->dbiasT[j] = al_.dbiasT; g->dWr[j] = a.dWr; g->dbr[j] = a.dbr;
+    G.hoisted[i] = true;
+  }
+}
+static int chain_rel_fwd(const RelGroups& G, hipStream_t st) {
+  for (int s = 0; s < 2; ++s)
+    for (const auto& g : G.groups[s]) { const int rc = mmnas_rel_multi_fwd(&g, st); if (rc) return rc; }
+  return MMNAS_OK;
+}
+static int chain_rel_bwd(const RelGroups& G, int stream_y, hipStream_t st) {
+  for (const auto& g : G.groups[stream_y]) {
+    MMNAS_REQUIRE(g.dWy && g.dby, MMNAS_E_ARG, "chain_bwd: relation operators without the stem layer's gradient sinks");
+    const int rc = mmnas_rel_multi_bwd(&g, st);
+    if (rc) return rc;
+  }
+  return MMNAS_OK;
+}
+
 }  // namespace mmnas
+
+extern "C" int mmnas_set_rel_hoist(int on) {
+  const int prev = mmnas::rel_hoist_on() ? 1 : 0;
+  mmnas::g_rel_hoist = on ? 1 : 0;
+  return prev;
+}
 
 extern "C" int mmnas_set_chain_overlap(int on) {
   const int prev = mmnas::chain_overlap_on() ? 1 : 0;
@@ -828,6 +901,9 @@ static int chain_fwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
   const float* cur_y = c->y_in;
   const size_t nx = (size_t)c->B * c->Sx * c->d * sizeof(float), ny = chain_rows_y(c) * c->d * sizeof(float);
   int rc;
+  RelGroups RG;     // every relation candidate's bias (18 in the VQA search space) before the first node
+  chain_rel_groups(c, L, false, RG);
+  if ((rc = chain_rel_fwd(RG, st))) return rc;
   for (int i0 = 0; i0 < c->n_ops;) {
     int i1 = i0;
     while (i1 < c->n_ops && c->ops[i1].node == c->ops[i0].node) ++i1;
@@ -873,7 +949,7 @@ static int chain_fwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
       {   // the cores: two of one geometry (self / relation-self) share a launch, the rest one by one
         mmnas_mha_desc md[MMNAS_MIXED_MAX];
         for (int j = 0; j < ng; ++j)
-          if ((rc = att_core_fwd(&ga[j], gl[j], st, &md[j]))) return rc;   // (relation biases first)
+          if ((rc = att_core_fwd(&ga[j], gl[j], st, &md[j], RG.hoisted[gidx[j]]))) return rc;   // (relation biases first, unless hoisted)
         bool done[MMNAS_MIXED_MAX] = {false};
         for (int j = 0; j < ng; ++j) {
           if (done[j]) continue;
@@ -909,7 +985,7 @@ static int chain_fwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
         a.xq = cur;
         a.xkv = (a.flags & MMNAS_F_SELF) ? cur : cur_x;
         a.y = (float*)(base + L.y[i]); a.save = base + L.save[i]; a.ws = base + L.ws[i];
-        if ((rc = att_fwd_impl(&a, st, true, &ln_done))) return rc;
+        if ((rc = att_fwd_impl(&a, st, true, &ln_done, RG.hoisted[i]))) return rc;
         if (a.flags & MMNAS_F_NORM) eps = a.eps;
       } else {
         m.x = cur; m.y = (float*)(base + L.y[i]); m.save = base + L.save[i]; m.ws = base + L.ws[i];
@@ -962,6 +1038,8 @@ static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
   const float* cur_dy = c->dy_out;
   const float* red_part[MMNAS_CHAIN_MAX_OPS]; float* red_out[MMNAS_CHAIN_MAX_OPS]; int red_nwg[MMNAS_CHAIN_MAX_OPS], red_n[MMNAS_CHAIN_MAX_OPS];
   int n_red = 0;
+  RelGroups RG;     // the sampled relation candidates: their bias gradients wait for one launch behind the stream's first node
+  chain_rel_groups(c, L, true, RG);
   for (int k = nn - 1; k >= 0; --k) {
     const int i0 = starts[k], i1 = starts[k + 1];
     const bool oy = c->ops[i0].on_y;
@@ -1009,13 +1087,15 @@ static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
       a.dy = dact; a.dxq = dx;
       a.dxkv = self ? nullptr : dpre;
       a.drel = nullptr;
-      if ((rc = att_bwd_impl(&a, st, nullptr, !self))) return rc;
+      if ((rc = att_bwd_impl(&a, st, nullptr, !self, RG.hoisted[act_op]))) return rc;
     } else {
       m.x = nin; m.save = base + L.save[act_op]; m.ws = base + L.ws[act_op];
       m.dy = dact; m.dx = dx;
       if ((rc = mlp_bwd_impl(&m, st, nullptr))) return rc;
     }
     cur_dy = dx;
+    if (i0 == L.first_y && (rc = chain_rel_bwd(RG, 1, st))) return rc;
+    if (i0 == L.first_x && (rc = chain_rel_bwd(RG, 0, st))) return rc;
     if (c->marks && c->marks[act_op] && hipEventRecord((hipEvent_t)c->marks[act_op], st) != hipSuccess) {
       set_error("chain_bwd: cannot record the mark event of operator %d", act_op);
       return MMNAS_E_LAUNCH;
@@ -1047,6 +1127,9 @@ extern "C" int mmnas_chain_fwd(const mmnas_chain* c, void* stream) {
   const float* cur_x = c->x_in;
   const float* cur_y = c->y_in;
   const size_t nx = (size_t)c->B * c->Sx * c->d * sizeof(float), ny = chain_rows_y(c) * c->d * sizeof(float);
+  RelGroups RG;     // the relation bias of every relation operator of the chain: one launch per stream, here
+  chain_rel_groups(c, L, false, RG);
+  if ((rc = chain_rel_fwd(RG, st))) return rc;
   auto run = [&](int i, hipStream_t s) -> int {
     const mmnas_chain_op& o = c->ops[i];
     mmnas_att_op a; mmnas_mlp_op m;
@@ -1058,7 +1141,8 @@ extern "C" int mmnas_chain_fwd(const mmnas_chain* c, void* stream) {
       a.xq = cur;
       a.xkv = (a.flags & MMNAS_F_SELF) ? cur : cur_x;   // guided: keys / values from the FINAL language state
       a.y = out; a.save = base + L.save[i]; a.ws = base + L.ws[i];
-      if ((r = mmnas_att_op_fwd(&a, s))) return r;
+      bool done;
+      if ((r = att_fwd_impl(&a, s, false, &done, RG.hoisted[i]))) return r;
     } else {
       m.x = cur; m.y = out; m.save = base + L.save[i]; m.ws = base + L.ws[i];
       if ((r = mmnas_mlp_op_fwd(&m, s))) return r;
@@ -1124,6 +1208,8 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
   const float* x_final = L.last_x >= 0 ? c->x_out : c->x_in;
   const int G = first_guided(c);
   const bool ovl = chain_overlap_on() && !c->use_side_stream && L.last_x >= 0 && L.first_y >= 0 && G > L.first_y;
+  RelGroups RG;     // relation operators whose bias gradient waits for the one launch behind their stream's first operator
+  if (!ovl) chain_rel_groups(c, L, true, RG);
   // one operator's backward on stream s: gradient of its output in, gradient of its input out (returned through *dxo)
   auto run = [&](int i, hipStream_t s, const float* dyi, const float** dxo) -> int {
     const mmnas_chain_op& o = c->ops[i];
@@ -1139,13 +1225,17 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
       a.dy = dyi; a.dxq = dx;
       a.dxkv = self ? nullptr : dpre;     // guided: added into the running sum (zeroed above)
       a.drel = nullptr;
-      if ((r = att_bwd_impl(&a, s, sq, !self))) return r;
+      if ((r = att_bwd_impl(&a, s, sq, !self, RG.hoisted[i]))) return r;
     } else {
       m.x = input_of(i); m.save = base + L.save[i]; m.ws = base + L.ws[i];
       m.dy = dyi; m.dx = dx;
       if ((r = mlp_bwd_impl(&m, s, sq))) return r;
     }
     *dxo = dx;
+    // (the stream's first operator is its last in backward order: every relation operator's bias gradient exists now --
+    //  before this operator's mark, which covers the relation parameters, see nets._chain)
+    if (i == L.first_y && (r = chain_rel_bwd(RG, 1, s))) return r;
+    if (i == L.first_x && (r = chain_rel_bwd(RG, 0, s))) return r;
     // (encoder / decoder overlap: an event behind operator i on ONE of the two streams says nothing about the operators
     //  with larger indices still running on the other -- the marks are recorded behind the join below instead)
     if (!ovl && c->marks && c->marks[i] && hipEventRecord((hipEvent_t)c->marks[i], s) != hipSuccess) {

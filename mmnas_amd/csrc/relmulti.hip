@@ -96,23 +96,28 @@ __device__ __forceinline__ RmElem rm_elem(const RelMultiK& p, int b, int tb, int
   return e;
 }
 
+// the lane's raw row, extended by a one (-> by / dby) and zero padding.  A VECTOR value, not an array: an array that is
+// re-filled inside the tile loop and read as `hh ? ex[2 s + 1] : ex[2 s]` became a scratch buffer indexed by hh.
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 template <int C>
-__device__ __forceinline__ void rm_raw(const RelMultiK& p, const RmElem& e, float* ex) {
+__device__ __forceinline__ f32x8 rm_raw(const RelMultiK& p, const RmElem& e) {
   const float* src = p.raw + (((size_t)e.b * p.S + e.q) * p.S + e.k) * C;
-#pragma unroll
-  for (int c = 0; c < RM_CP; ++c) ex[c] = 0.f;
+  f32x8 ex = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < C; ++c) { const float v = src[c]; ex[c] = e.ok ? v : 0.f; }   // (address clamped: the load is unconditional)
   ex[C] = e.ok ? 1.f : 0.f;
+  return ex;
 }
 
 // step-2 A operands of all row tiles: sWrA[rt][step = 16 t + r][lane] = Wr_all[32 rt + (lane & 31)][32 t + acc_row(r, lane >> 5)]
 // (zero for rows behind nrows); sBr[row] likewise
+// sIo[row]: the row's plane of biasT (forward, written) / dbiasT (backward, read), NULL behind nrows -- per-lane row
+// pointers come from LDS (the kernel-argument copy would cost 2 SGPRs per row: 64 of ~100)
 template <bool WITH_T>
-__device__ __forceinline__ void rm_stage_weights(const RelMultiK& p, int nt, float* sWrA, float* sWrB, float* sBr) {
+__device__ __forceinline__ void rm_stage_weights(const RelMultiK& p, int nt, float* sWrA, float* sWrB, float* sBr, float** sIo) {
   const int tid = threadIdx.x;
   for (int i = tid; i < nt * RM_ROWS * RM_R; i += 256) { sWrA[i] = 0.f; if (WITH_T) sWrB[i] = 0.f; }
-  for (int i = tid; i < nt * RM_ROWS; i += 256) sBr[i] = 0.f;
+  for (int i = tid; i < nt * RM_ROWS; i += 256) { sBr[i] = 0.f; sIo[i] = i < p.nrows ? p.io[i] : nullptr; }
   __syncthreads();
   const int H = p.H;
   for (int n = 0; n < p.nops; ++n) {
@@ -152,22 +157,18 @@ template <int C, int NT>
 __global__ void __launch_bounds__(256) rel_multi_fwd_kernel(const RelMultiK p, int ntiles, int tpb, const float* __restrict__ Wy,
                                                             const float* __restrict__ by) {
   __shared__ float sWrA[NT * RM_ROWS * RM_R];
-  __shared__ float sBr[NT * RM_ROWS];
+  __shared__ __attribute__((aligned(16))) float sBr[NT * RM_ROWS];
+  __shared__ __attribute__((aligned(16))) float* sIo[NT * RM_ROWS];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-  rm_stage_weights<false>(p, NT, sWrA, nullptr, sBr);
+  rm_stage_weights<false>(p, NT, sWrA, nullptr, sBr, sIo);
   float wyA[2][4];
   rm_wy_operand<C>(Wy, by, l31, hh, wyA);
   const unsigned SS = (unsigned)p.S * (unsigned)p.S;
   RmWalk wk;
   wk.init(p, ntiles, tpb, w);
   RmElem cur = rm_elem(p, wk.cb, wk.ct, l31);
-  float ext[RM_CP];
-  rm_raw<C>(p, cur, ext);
+  f32x8 ext = rm_raw<C>(p, cur);
   while (wk.tile < ntiles) {
-    wk.next(p);
-    const RmElem nxt = rm_elem(p, wk.cb, wk.ct, l31);
-    float ext_n[RM_CP];
-    rm_raw<C>(p, nxt, ext_n);        // in flight during this tile's MFMA chain
     f32x16 hid[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -178,7 +179,11 @@ __global__ void __launch_bounds__(256) rel_multi_fwd_kernel(const RelMultiK p, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) hid[t][r] = fmaxf(hid[t][r], 0.f);
     }
+    const bool ok = cur.ok;
     const unsigned eoff = (unsigned)cur.b * (unsigned)p.H * SS + cur.fc;   // (host: B H S^2 < 2^31)
+    wk.next(p);
+    cur = rm_elem(p, wk.cb, wk.ct, l31);
+    ext = rm_raw<C>(p, cur);         // the next tile's raw row: in flight during this tile's MFMA chain
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
       if (rt * RM_ROWS >= p.nrows) break;
@@ -190,18 +195,17 @@ __global__ void __launch_bounds__(256) rel_multi_fwd_kernel(const RelMultiK p, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) rr = mfma32(sWrA[(rt * 32 + 16 * t + r) * 64 + lane], hid[t][r], rr);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row0 = rt * RM_ROWS + (r & 3) + 8 * (r >> 2);      // acc_row(r, 0); the upper half-wave holds row0 + 4
-        float* const o0 = p.io[row0];
-        float* const o1 = p.io[row0 + 4];
-        float* const o = hh ? o1 : o0;
-        const int row = row0 + 4 * hh;
-        if (cur.ok && row < p.nrows) o[eoff] = __logf(fmaxf(rr[r] + sBr[row], 1e-6f));   // max(relu(r), 1e-6) == max(r, 1e-6)
+      for (int u = 0; u < 4; ++u) {        // registers 4u .. 4u + 3 hold rows 8u + 4 hh + 0..3: contiguous table entries
+        const int row = rt * RM_ROWS + 8 * u + 4 * hh;
+        const float4 bq = *reinterpret_cast<const float4*>(sBr + row);
+        const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float* const o = sIo[row + i];
+          if (ok && o) o[eoff] = __logf(fmaxf(rr[4 * u + i] + bv[i], 1e-6f));   // max(relu(r), 1e-6) == max(r, 1e-6)
+        }
       }
     }
-    cur = nxt;
-#pragma unroll
-    for (int c = 0; c < RM_CP; ++c) ext[c] = ext_n[c];
   }
 }
 
@@ -214,57 +218,48 @@ __global__ void __launch_bounds__(256, 2) rel_multi_bwd_kernel(const RelMultiK p
   __shared__ __attribute__((aligned(16))) float sRawAll[4][32 * RM_CP];
   __shared__ float sWrA[RM_ROWS * RM_R];
   __shared__ float sWrB[RM_ROWS * RM_R];
-  __shared__ float sBr[RM_ROWS];
+  __shared__ __attribute__((aligned(16))) float sBr[RM_ROWS];
+  __shared__ __attribute__((aligned(16))) float* sIo[RM_ROWS];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int l15 = lane & 15, q4 = lane >> 4;
   float* sHid = sHidAll[w];
   float* sDpre = sDpreAll[w];
   float* sRaw = sRawAll[w];
-  rm_stage_weights<true>(p, 1, sWrA, sWrB, sBr);
+  rm_stage_weights<true>(p, 1, sWrA, sWrB, sBr, sIo);
   float wyA[2][4];
   rm_wy_operand<C>(Wy, by, l31, hh, wyA);
-  float brv[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) brv[r] = sBr[acc_row(r, hh)];
 
   f32x16 accWr[2];
   f32x4 accWy16[4];
-  float accbr[16];
+  float accbr = 0.f;      // lane (row = l31, half): sum over the elements e = half (mod 2) of dpre[row, e]
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { accWr[0][r] = 0.f; accWr[1][r] = 0.f; accbr[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) { accWr[0][r] = 0.f; accWr[1][r] = 0.f; }
 #pragma unroll
   for (int n = 0; n < 4; ++n)
 #pragma unroll
     for (int r = 0; r < 4; ++r) accWy16[n][r] = 0.f;
 
   const unsigned SS = (unsigned)p.S * (unsigned)p.S;
-  // dbias of this lane's 16 rows for one tile
+  // dbias of this lane's 16 rows for one tile (row pointers from LDS; rows behind nrows are NULL and read as zero)
   auto load_db = [&](const RmElem& e, float* db) __attribute__((always_inline)) {
     const unsigned eoff = (unsigned)e.b * (unsigned)p.H * SS + e.fc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row0 = (r & 3) + 8 * (r >> 2);
-      const float* const d0 = p.io[row0];
-      const float* const d1 = p.io[row0 + 4];
-      const int row = row0 + 4 * hh;
-      const bool live = e.ok && row < p.nrows;
-      const float* const d = hh ? d1 : d0;
-      const float v = (live ? d : p.raw)[live ? eoff : 0u];     // (rows behind nrows carry NULL: read a valid address instead)
-      db[r] = live ? v : 0.f;
-    }
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* const d = sIo[8 * u + 4 * hh + i];
+        const bool live = e.ok && d != nullptr;
+        const float v = (live ? d : p.raw)[live ? eoff : 0u];     // (the load itself is unconditional: a valid address either way)
+        db[4 * u + i] = live ? v : 0.f;
+      }
   };
   RmWalk wk;
   wk.init(p, ntiles, tpb, w);
   RmElem cur = rm_elem(p, wk.cb, wk.ct, l31);
-  float ext[RM_CP], db[16];
-  rm_raw<C>(p, cur, ext);
+  float db[16];
+  f32x8 ext = rm_raw<C>(p, cur);
   load_db(cur, db);
   while (wk.tile < ntiles) {
-    wk.next(p);
-    const RmElem nxt = rm_elem(p, wk.cb, wk.ct, l31);
-    float ext_n[RM_CP], db_n[16];
-    rm_raw<C>(p, nxt, ext_n);
-    load_db(nxt, db_n);
     // 1. hidden layer (transposed: rows j, columns e); relu and its gate as one bit per accumulator register
     f32x16 hid[2];
     unsigned gm = 0u;
@@ -291,10 +286,14 @@ __global__ void __launch_bounds__(256, 2) rel_multi_bwd_kernel(const RelMultiK p
     // 3. d(log max(r, 1e-6)) / dr
     float dpre[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float rv = rr[r] + brv[r];
-      dpre[r] = rv >= 1e-6f ? db[r] / rv : 0.f;
-      accbr[r] += dpre[r];
+    for (int u = 0; u < 4; ++u) {
+      const float4 bq = *reinterpret_cast<const float4*>(sBr + 8 * u + 4 * hh);
+      const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float rv = rr[4 * u + i] + bv[i];
+        dpre[4 * u + i] = rv >= 1e-6f ? db[4 * u + i] / rv : 0.f;
+      }
     }
     // the wave's LDS image: hid as [e][j], dpre as [e][row], the raw rows (LDS operations of one wave execute in order; the
     // waits only keep the compiler from moving a read above the write it depends on)
@@ -312,6 +311,11 @@ __global__ void __launch_bounds__(256, 2) rel_multi_bwd_kernel(const RelMultiK p
       *reinterpret_cast<float4*>(sRaw + l31 * RM_CP) = make_float4(ext[0], ext[1], ext[2], ext[3]);
       *reinterpret_cast<float4*>(sRaw + l31 * RM_CP + 4) = make_float4(ext[4], ext[5], ext[6], ext[7]);
     }
+    // the next tile's raw row and bias gradients: into the registers this tile is done with, in flight during steps 4-5
+    wk.next(p);
+    cur = rm_elem(p, wk.cb, wk.ct, l31);
+    ext = rm_raw<C>(p, cur);
+    load_db(cur, db);
     // 4. gradient of the hidden layer, summed over every operator's heads, gated by relu'
     f32x16 dh[2];
 #pragma unroll
@@ -337,6 +341,7 @@ __global__ void __launch_bounds__(256, 2) rel_multi_bwd_kernel(const RelMultiK p
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
+        accbr += av[u];                     // dbr_all[row] = sum_e dpre[row, e]
         accWr[0] = mfma32(av[u], b0[u], accWr[0]);
         accWr[1] = mfma32(av[u], b1[u], accWr[1]);
       }
@@ -370,11 +375,6 @@ __global__ void __launch_bounds__(256, 2) rel_multi_bwd_kernel(const RelMultiK p
         }
       }
     }
-    cur = nxt;
-#pragma unroll
-    for (int c = 0; c < RM_CP; ++c) ext[c] = ext_n[c];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) db[r] = db_n[r];
   }
 
   // ---- the workgroup's partial row: the 4 waves add their accumulators in wave order through LDS (fixed order:
@@ -383,14 +383,7 @@ __global__ void __launch_bounds__(256, 2) rel_multi_bwd_kernel(const RelMultiK p
   float* srow = &sHidAll[0][0];
   static_assert(4 * 32 * RM_LDH >= RM_ROW, "partial row does not fit the hid images");
   float* grow = p.part + (size_t)blockIdx.x * RM_ROW;
-  float brsum[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float v = accbr[r];
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);     // over the 32 elements of the half-wave
-    brsum[r] = v;
-  }
+  const float brsum = accbr + __shfl_xor(accbr, 32, 64);   // even + odd elements: lane l31 = row holds dbr_all[row] of this wave
   for (int turn = 0; turn < 4; ++turn) {
     if (w == turn) {
       const bool first = turn == 0, last = turn == 3;
@@ -411,13 +404,10 @@ __global__ void __launch_bounds__(256, 2) rel_multi_bwd_kernel(const RelMultiK p
             const float v2 = accWy16[n][r] + (first ? 0.f : srow[o2]);
             if (last) grow[o2] = v2; else srow[o2] = v2;
           }
-      if (l31 == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o3 = RM_ROWS * RM_R + RM_R * RM_CP + acc_row(r, hh);             // dbr_all[row]
-          const float v3 = brsum[r] + (first ? 0.f : srow[o3]);
-          if (last) grow[o3] = v3; else srow[o3] = v3;
-        }
+      if (hh == 0) {
+        const int o3 = RM_ROWS * RM_R + RM_R * RM_CP + l31;                           // dbr_all[row]
+        const float v3 = brsum + (first ? 0.f : srow[o3]);
+        if (last) grow[o3] = v3; else srow[o3] = v3;
       }
     }
     __syncthreads();
@@ -473,7 +463,7 @@ static int rm_check(const mmnas_rel_multi* m, const char* who) {
   MMNAS_REQUIRE(m->B > 0 && m->S > 0, MMNAS_E_SHAPE, "%s: B=%d S=%d", who, m->B, m->S);
   MMNAS_REQUIRE(m->R == RM_R, MMNAS_E_SHAPE, "%s: REL_SIZE=%d (the fused path handles 64)", who, m->R);
   MMNAS_REQUIRE(m->C == 3 || m->C == 4, MMNAS_E_SHAPE, "%s: %d raw relation channels (3 or 4)", who, m->C);
-  MMNAS_REQUIRE(m->H >= 1 && m->H <= RM_ROWS, MMNAS_E_SHAPE, "%s: H=%d heads (1..32)", who, m->H);
+  MMNAS_REQUIRE(m->H >= 1 && m->H <= RM_ROWS && RM_ROWS % m->H == 0, MMNAS_E_SHAPE, "%s: H=%d heads (a divisor of 32)", who, m->H);
   MMNAS_REQUIRE(m->n_ops >= 1 && m->n_ops <= MMNAS_REL_MULTI_MAX, MMNAS_E_SHAPE, "%s: %d operators (1..%d)", who, m->n_ops, MMNAS_REL_MULTI_MAX);
   MMNAS_REQUIRE(m->raw && m->Wy && m->by, MMNAS_E_ARG, "%s: null pointer", who);
   MMNAS_REQUIRE((long)m->B * m->H * m->S * m->S < (1l << 31), MMNAS_E_SHAPE, "%s: B H S^2 must fit 31 bits", who);
@@ -491,7 +481,7 @@ static int rm_grid(long ntiles, int per_cu) {
 
 using namespace mmnas;
 
-extern "C" int mmnas_rel_multi_supported(int C, int R, int H) { return R == RM_R && (C == 3 || C == 4) && H >= 1 && H <= RM_ROWS; }
+extern "C" int mmnas_rel_multi_supported(int C, int R, int H) { return R == RM_R && (C == 3 || C == 4) && H >= 1 && H <= RM_ROWS && RM_ROWS % H == 0; }
 
 extern "C" size_t mmnas_rel_multi_bwd_ws_floats(int B, int S) {
   return (size_t)rm_grid((long)B * rm_tiles_per_b(S), 2) * RM_ROW;
@@ -512,19 +502,12 @@ extern "C" int mmnas_rel_multi_fwd(const mmnas_rel_multi* m, void* stream) {
     RelMultiK k;
     memset(&k, 0, sizeof(k));
     k.raw = m->raw; k.B = m->B; k.S = m->S; k.C = m->C; k.H = m->H; k.off = m->off; k.toff = m->tile_off;
-    // rows: operator j of this launch sits in row tile j / ops_per_tile at rows (j % ops_per_tile) * H ..; the staging code
-    // places operator n at rows n * H .. -- so operators are renumbered with gaps when H does not divide 32
-    int slots = 0;
+    // rows: operator j of this launch holds rows j H .. j H + H - 1 (H divides 32: no operator straddles two row tiles)
     for (int j = 0; j < n; ++j) {
       MMNAS_REQUIRE(m->Wr[o0 + j] && m->br[o0 + j] && m->biasT[o0 + j], MMNAS_E_ARG, "rel_multi_fwd: operator %d: null pointer", o0 + j);
-      const int rt = j / ops_per_tile, jl = j % ops_per_tile;
-      const int row = rt * RM_ROWS + jl * m->H;
-      // (H divides 32 for every head count of the registry: 2, 4, 8, 16; otherwise a tile's tail rows stay empty and the
-      //  operator index -> row map below still holds because the staging walks rows, not operators)
-      for (int h = 0; h < m->H; ++h) k.io[row + h] = m->biasT[o0 + j] + (size_t)h * SS;
-      slots = row + m->H;
+      for (int h = 0; h < m->H; ++h) k.io[j * m->H + h] = m->biasT[o0 + j] + (size_t)h * SS;
     }
-    MMNAS_REQUIRE(RM_ROWS % m->H == 0 || n <= ops_per_tile, MMNAS_E_SHAPE, "rel_multi_fwd: H=%d does not divide 32: at most %d operators per call", m->H, ops_per_tile);
+    const int slots = n * m->H;
     for (int j = 0; j < n; ++j) { k.Wr[j] = m->Wr[o0 + j]; k.br[j] = m->br[o0 + j]; }
     k.nops = n; k.nrows = slots;
     const int nt = (slots + RM_ROWS - 1) / RM_ROWS;

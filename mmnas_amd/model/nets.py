@@ -171,6 +171,22 @@ class _Backbone(nn.Module):
                     return None
             mixed = (g0.data_ptr(), gr0.data_ptr(), width)
             op_params = None
+        if op_params is not None:
+            # The relation-bias backward of every lazy-handle relation operator of a stream is ONE launch behind the stream's
+            # first operator (its last in backward order; relmulti.hip, ops.hip chain_rel_bwd): that operator completes the
+            # relation parameters' gradients -- linear_r of each relation operator and the shared stem layer -- so a
+            # reducer's bucket mark (dp._chain_marks: "the operator that issues a parameter's last gradient") must see them
+            # there, not at the relation operator itself.  (Holds with MMNAS_REL_HOIST=0 too: a later mark is never wrong.)
+            first = {}
+            for i, rec in enumerate(records):
+                first.setdefault(rec.on_y, i)
+            moved = {}
+            for i, rec in enumerate(records):
+                if rec.kind == 0 and rec.att.flags & ops.L.F_REL and i != first[rec.on_y]:
+                    moved.setdefault(first[rec.on_y], []).extend(op_params[i][-4:])
+                    op_params[i] = op_params[i][:-4]
+            for i, ps in moved.items():
+                op_params[i] = list(op_params[i]) + ps
         if not records or len(records) > 128:
             return None
         xr = x_rel_embed.raw if isinstance(x_rel_embed, RelHandle) else None

@@ -374,3 +374,63 @@ def test_ragged_info_sources_and_refusals():
         assert ops.ragged_info_for(feat, make_mask(feat)) is None
     finally:
         ops.set_unpad(prev)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Relation bias of all relation operators of a stream in one launch per direction (relmulti.hip; mmnas_set_rel_hoist)
+# ----------------------------------------------------------------------------------------------------------------------
+def _rel_heavy_plan(mode, n_rel):
+    """A sampled architecture whose decoder takes the relation operator (candidate 1 of dec_safe) at n_rel nodes."""
+    plan = cases.search_plan(np.random.RandomState(9), mode)
+    dec = []
+    for k, (act, inact) in enumerate(plan['dec']):
+        a = 1 if k < n_rel else (act[0] if act[0] != 1 else 0)
+        dec.append(([a], [i for i in range(4) if i != a]))
+    return plan['enc'] + dec
+
+
+@pytest.mark.parametrize('mode,n_rel,unpad', [(None, 6, False), (None, 18, False), (None, 1, False), ('full', 5, False),
+                                              (None, 7, True), ('full', 4, True)])
+def test_hoisted_relation_bias_equals_the_per_operator_launches(mode, n_rel, unpad):
+    """Supernet weight and architecture steps with the relation bias of every (sampled / evaluated) relation operator
+    computed by ONE mmnas_rel_multi launch per direction against one mmnas_rel_fused launch per operator: same logits,
+    every parameter gradient to round-off -- padded and ragged decoder streams; 18 relation operators = 3 row tiles
+    forward, 3 launches backward at 4 heads ... here HSIZE 128: 2 heads, 36 rows."""
+    from mmnas_amd import _lib as L
+    lib = L.lib()
+    flat = _rel_heavy_plan(mode, n_rel)
+    outs = []
+    for hoist in (0, 1):
+        prev = lib.mmnas_set_rel_hoist(hoist)
+        try:
+            outs.append(_run_unpad('vqa', None, True, unpad, mode, flat, B=4, Sy=19))
+        finally:
+            lib.mmnas_set_rel_hoist(prev)
+    assert outs[0][2] == [unpad] and outs[1][2] == [unpad]
+    _same(outs[1], outs[0], gtol=2e-4)
+    assert any('linear_r.weight' in k and g is not None and np.any(g) for k, g in outs[1][1].items())
+    assert np.any(outs[1][1]['linear_y_rel.weight'])
+
+
+@pytest.mark.parametrize('task,arch', [('vqa', 'mmnas_vqa'), ('vgd', 'mmnas_vgd'), ('itm', 'mmnas_itm')])
+def test_hoisted_relation_bias_net_full(task, arch, monkeypatch):
+    """The fixed architectures of arch/*.json (4-5 relation operators each) through the chain with and without the hoist."""
+    from mmnas_amd import _lib as L
+    lib = L.lib()
+    outs = []
+    for hoist in (0, 1):
+        prev = lib.mmnas_set_rel_hoist(hoist)
+        try:
+            outs.append(_run(task, arch, False, True, False, monkeypatch, dropout=0.1))
+        finally:
+            lib.mmnas_set_rel_hoist(prev)
+    assert outs[0][2] == 1 and outs[1][2] == 1
+    out_a, g_a, _ = outs[1]
+    out_b, g_b, _ = outs[0]
+    assert rel_err(out_a, out_b) < 2e-6
+    top = max(float(np.abs(g).max()) for g in g_b.values() if g is not None)
+    for k in g_b:
+        if g_b[k] is None:
+            continue
+        diff = float(np.abs(g_a[k] - g_b[k]).max())
+        assert diff <= 2e-4 * max(float(np.abs(g_b[k]).max()), 1e-3 * top), (k, diff)

@@ -659,6 +659,121 @@ def test_rel_fused_ragged(B, S, C, H, lens):
         assert rel_err(a, c) < 2e-4         # (another summation order over the same terms)
 
 
+@pytest.mark.parametrize('B,S,C,H,n_ops,lens', [
+    (2, 7, 4, 2, 3, None), (2, 100, 4, 4, 6, None), (2, 100, 4, 8, 5, None), (3, 14, 3, 4, 1, None), (1, 33, 4, 16, 3, None),
+    (2, 40, 4, 4, 18, None), (2, 23, 4, 1, 2, None), (4, 23, 4, 4, 9, (23, 1, 7, 16)), (3, 100, 4, 8, 4, (100, 37, 64)), (2, 9, 4, 32, 2, None)])
+def test_rel_multi_all_relation_operators_in_one_launch(B, S, C, H, n_ops, lens):
+    """mmnas_rel_multi_fwd / _bwd (relmulti.hip): the relation bias of n_ops RelSelfAtt operators that share the stem layer
+    linear_y_rel, each with its own linear_r (modules.py:231-235, hygr_vqa.py:111) -- the hidden layer computed once per
+    element, every operator's bias written / bias gradient read in the same launch, dWy / dby contracted once.  Against the
+    float64 restatement of the reference arithmetic (forward: on max(r, 1e-6) itself, the log's argument -- an r next to
+    zero carries its cancellation error into the log at any precision) and against the per-operator kernels of
+    relfused.hip (dense and ragged)."""
+    import ctypes as C_
+    import mmnas_amd._lib as L
+    lib = L.lib()
+    rs = np.random.RandomState(B * 31 + S + 7 * H + C + n_ops)
+    R = 64
+    assert lib.mmnas_rel_multi_supported(C, R, H) == 1
+    raw = rnd(rs, B, S, S, C)
+    Wy, by = rnd(rs, R, C) / 2, 0.1 * rnd(rs, R)
+    Wrs = [rnd(rs, H, R) / 8 for _ in range(n_ops)]
+    brs = [0.1 * rnd(rs, H) for _ in range(n_ops)]
+    gbs = [rnd(rs, B, H, S, S) for _ in range(n_ops)]
+    valid = np.ones((B, 1, S, S), np.float32)
+    offd = toffd = None
+    ntiles = 0
+    if lens is not None:
+        valid[:] = 0
+        for b, n in enumerate(lens):
+            valid[b, :, :n, :n] = 1
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        toff = np.concatenate([[0], np.cumsum([(n * n + 31) // 32 for n in lens])]).astype(np.int32)
+        offd, toffd, ntiles = g(off), g(toff), int(toff[-1])
+    vmask = torch.from_numpy(valid).bool().expand(B, H, S, S)
+    rawd, Wyd, byd = g(raw), g(Wy), g(by)
+    Wrd, brd = [g(w) for w in Wrs], [g(b) for b in brs]
+    # outside the valid corners the bias gradient is never read: poison it
+    gbd = [g(np.where(valid > 0, gb, np.nan).astype(np.float32)) for gb in gbs]
+    bias = [torch.full((B, H, S, S), 12345.0, device=DEV) for _ in range(n_ops)]
+    dWr, dbr = [torch.zeros(H, R, device=DEV) for _ in range(n_ops)], [torch.zeros(H, device=DEV) for _ in range(n_ops)]
+    dWy, dby = torch.zeros(R, C, device=DEV), torch.zeros(R, device=DEV)
+    ws = torch.empty(lib.mmnas_rel_multi_bwd_ws_floats(B, S), device=DEV)
+    m = L.RelMulti()
+    m.B, m.S, m.C, m.R, m.H, m.n_ops = B, S, C, R, H, n_ops
+    m.raw, m.Wy, m.by, m.dWy, m.dby, m.ws = L.fptr(rawd), L.fptr(Wyd), L.fptr(byd), L.fptr(dWy), L.fptr(dby), L.fptr(ws)
+    for i in range(n_ops):
+        m.Wr[i], m.br[i], m.biasT[i], m.dbiasT[i] = L.fptr(Wrd[i]), L.fptr(brd[i]), L.fptr(bias[i]), L.fptr(gbd[i])
+        m.dWr[i], m.dbr[i] = L.fptr(dWr[i]), L.fptr(dbr[i])
+    if lens is not None:
+        m.off, m.tile_off, m.ntiles = L.ptr(offd), L.ptr(toffd), ntiles
+    L.check(lib.mmnas_rel_multi_fwd(C_.byref(m), L.stream()))
+    L.check(lib.mmnas_rel_multi_bwd(C_.byref(m), L.stream()))
+    torch.cuda.synchronize()
+    # float64 restatement
+    T = lambda a: torch.from_numpy(a).double().requires_grad_(True)
+    Wyt, byt = T(Wy), T(by)
+    rel = torch.relu(torch.from_numpy(raw).double() @ Wyt.t() + byt)
+    vm = torch.from_numpy(valid).double()
+    refs = []
+    for i in range(n_ops):
+        Wrt, brt = T(Wrs[i]), T(brs[i])
+        r = torch.clamp(torch.relu(rel @ Wrt.t() + brt), min=1e-6).permute(0, 3, 2, 1)      # [B, H, S_k, S_q]
+        (torch.log(r) * torch.from_numpy(gbs[i]).double() * vm).sum().backward(retain_graph=True)
+        refs.append((r.detach(), Wrt.grad, brt.grad))
+    n_el = float(valid.sum()) * 1.0
+    wtol = 6e-3 if n_el > 5000 else TOL          # (1/r-amplified random-sign sums: see test_rel_fused_lazy_handle)
+    for i in range(n_ops):
+        got = bias[i].cpu()
+        assert bool((got[~vmask] == 12345.0).all()), 'the forward wrote outside the valid corners'
+        rr = torch.exp(got.double())
+        scale = float(refs[i][0].abs().max())
+        assert float(((rr - refs[i][0]).abs() * vm).max()) <= 2e-5 * scale, i
+        assert rel_err(dWr[i].cpu().numpy(), refs[i][1].numpy()) < wtol, i
+        assert rel_err(dbr[i].cpu().numpy(), refs[i][2].numpy()) < wtol, i
+    assert rel_err(dWy.cpu().numpy(), Wyt.grad.numpy()) < wtol
+    assert rel_err(dby.cpu().numpy(), byt.grad.numpy()) < wtol
+    # ... and the per-operator kernels: same numbers to round-off (another summation order over the same terms)
+    p_dWy, p_dby = torch.zeros(R, C, device=DEV), torch.zeros(R, device=DEV)
+    ws1 = torch.empty(lib.mmnas_rel_fused_bwd_ws_floats(B, S, S), device=DEV)
+    for i in range(n_ops):
+        pb = torch.full((B, H, S, S), 12345.0, device=DEV)
+        p_dWr, p_dbr = torch.zeros(H, R, device=DEV), torch.zeros(H, device=DEV)
+        if lens is None:
+            L.check(lib.mmnas_rel_fused_fwd(L.fptr(rawd), L.fptr(Wyd), L.fptr(byd), L.fptr(Wrd[i]), L.fptr(brd[i]), L.fptr(pb), B, S, S, C, R, H, L.stream()))
+            L.check(lib.mmnas_rel_fused_bwd(L.fptr(rawd), L.fptr(Wyd), L.fptr(byd), L.fptr(Wrd[i]), L.fptr(brd[i]), L.fptr(gbd[i]),
+                                            L.fptr(p_dWy), L.fptr(p_dby), L.fptr(p_dWr), L.fptr(p_dbr), L.fptr(ws1), B, S, S, C, R, H, L.stream()))
+        else:
+            L.check(lib.mmnas_rel_fused_fwd_ragged(L.fptr(rawd), L.fptr(Wyd), L.fptr(byd), L.fptr(Wrd[i]), L.fptr(brd[i]), L.fptr(pb), B, S, C, R, H,
+                                                   L.ptr(offd), L.stream()))
+            L.check(lib.mmnas_rel_fused_bwd_ragged(L.fptr(rawd), L.fptr(Wyd), L.fptr(byd), L.fptr(Wrd[i]), L.fptr(brd[i]), L.fptr(gbd[i]),
+                                                   L.fptr(p_dWy), L.fptr(p_dby), L.fptr(p_dWr), L.fptr(p_dbr), L.fptr(ws1), B, S, C, R, H,
+                                                   L.ptr(offd), L.ptr(toffd), ntiles, L.stream()))
+        torch.cuda.synchronize()
+        a, c = torch.exp(bias[i].double()), torch.exp(pb.double())
+        assert float(((a - c).abs() * vm.to(DEV)).max()) <= 2e-5 * float(c.abs().max())
+        assert rel_err(dWr[i].cpu().numpy(), p_dWr.cpu().numpy()) < 3e-4
+        assert rel_err(dbr[i].cpu().numpy(), p_dbr.cpu().numpy()) < 3e-4
+    assert rel_err(dWy.cpu().numpy(), p_dWy.cpu().numpy()) < 3e-4
+    assert rel_err(dby.cpu().numpy(), p_dby.cpu().numpy()) < 3e-4
+
+
+def test_rel_multi_refuses_what_it_does_not_cover():
+    import ctypes as C_
+    import mmnas_amd._lib as L
+    lib = L.lib()
+    assert lib.mmnas_rel_multi_supported(4, 64, 3) == 0 and lib.mmnas_rel_multi_supported(4, 32, 4) == 0 and lib.mmnas_rel_multi_supported(5, 64, 4) == 0
+    m = L.RelMulti()
+    m.B, m.S, m.C, m.R, m.H, m.n_ops = 2, 5, 4, 64, 3, 1
+    t = torch.zeros(4096, device=DEV)
+    m.raw = m.Wy = m.by = L.fptr(t)
+    with pytest.raises(L.MMNasHipError):
+        L.check(lib.mmnas_rel_multi_fwd(C_.byref(m), L.stream()))
+    m.H, m.n_ops = 4, 0
+    with pytest.raises(L.MMNasHipError):
+        L.check(lib.mmnas_rel_multi_fwd(C_.byref(m), L.stream()))
+
+
 # ----------------------------------------------------------------------------- stem / head helpers
 @pytest.mark.parametrize('shape', [(64, 100, 2048), (3, 7, 5), (2, 9, 36), (1, 1, 4)])
 def test_row_is_zero_is_make_mask(shape):
