@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from tests.golden import cases
-from tests.util import rel_err
+from tests.util import REL_PATH_SELF_TOL, is_rel_path, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -79,7 +79,12 @@ def _compare(a, b):
             continue
         assert g_a[k] is not None, k
         diff = float(np.abs(g_a[k] - g_b[k]).max())
-        assert diff <= 2e-5 * max(float(np.abs(g_b[k]).max()), 1e-3 * top), (k, diff)
+        # (relation path: the chain computes all relation operators' bias on the fp32 MFMA in one launch per direction
+        #  (relmulti.hip), the per-operator path one vector-pipe / MFMA launch each (relfused.hip) -- two summation orders
+        #  over 1/r-weighted terms of random sign.  Both are held to the reference's float64 value elsewhere
+        #  (tests/util.py::check_grad_samples); against each other they get the bound two fp32 orders can meet)
+        tol = REL_PATH_SELF_TOL if is_rel_path(k) else 2e-5
+        assert diff <= tol * max(float(np.abs(g_b[k]).max()), 1e-3 * top), (k, diff)
 
 
 @pytest.mark.parametrize('task,arch', [('vqa', 'mmnas_vqa'), ('vqa', 'mcan'), ('vgd', 'mmnas_vgd'), ('itm', 'mmnas_itm')])
@@ -277,7 +282,8 @@ def _same(a, b, gtol=4e-5):   # (summation order: packed and padded batches cut 
             continue
         assert g_a[k] is not None, k
         diff = float(np.abs(g_a[k] - g_b[k]).max())
-        assert diff <= gtol * max(float(np.abs(g_b[k]).max()), 1e-3 * top), (k, diff, float(np.abs(g_b[k]).max()))
+        t = max(gtol, REL_PATH_SELF_TOL) if is_rel_path(k) else gtol
+        assert diff <= t * max(float(np.abs(g_b[k]).max()), 1e-3 * top), (k, diff, float(np.abs(g_b[k]).max()))
 
 
 @pytest.mark.parametrize('task,arch', [('vqa', 'mmnas_vqa'), ('vqa', 'mcan'), ('itm', 'mmnas_itm')])
@@ -407,7 +413,7 @@ def test_hoisted_relation_bias_equals_the_per_operator_launches(mode, n_rel, unp
         finally:
             lib.mmnas_set_rel_hoist(prev)
     assert outs[0][2] == [unpad] and outs[1][2] == [unpad]
-    _same(outs[1], outs[0], gtol=2e-4)
+    _same(outs[1], outs[0])
     assert any('linear_r.weight' in k and g is not None and np.any(g) for k, g in outs[1][1].items())
     assert np.any(outs[1][1]['linear_y_rel.weight'])
 
@@ -433,4 +439,4 @@ def test_hoisted_relation_bias_net_full(task, arch, monkeypatch):
         if g_b[k] is None:
             continue
         diff = float(np.abs(g_a[k] - g_b[k]).max())
-        assert diff <= 2e-4 * max(float(np.abs(g_b[k]).max()), 1e-3 * top), (k, diff)
+        assert diff <= (REL_PATH_SELF_TOL if is_rel_path(k) else 2e-5) * max(float(np.abs(g_b[k]).max()), 1e-3 * top), (k, diff)

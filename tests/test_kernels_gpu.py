@@ -693,6 +693,14 @@ def test_rel_multi_all_relation_operators_in_one_launch(B, S, C, H, n_ops, lens)
     vmask = torch.from_numpy(valid).bool().expand(B, H, S, S)
     rawd, Wyd, byd = g(raw), g(Wy), g(by)
     Wrd, brd = [g(w) for w in Wrs], [g(b) for b in brs]
+    # d log(max(r, 1e-6)) / dr = 1 / r jumps to 0 at the clamp: an element whose pre-activation sits next to zero is on either
+    # side of it depending on the last bit, and weighs up to 1e6 in the sums.  The test keeps such elements out of the
+    # gradient (zero bias gradient inside the band |pre| < 0.05) so that what is left is well-conditioned and can be held to
+    # a tight bound; elements safely BELOW the clamp keep a non-zero bias gradient (their contribution must be exactly zero).
+    rel64 = torch.relu(torch.from_numpy(raw).double() @ torch.from_numpy(Wy).double().t() + torch.from_numpy(by).double())
+    for i in range(n_ops):
+        pre = (rel64 @ torch.from_numpy(Wrs[i]).double().t() + torch.from_numpy(brs[i]).double()).permute(0, 3, 2, 1).numpy()
+        gbs[i] = np.where(np.abs(pre) < 0.05, 0.0, gbs[i]).astype(np.float32)
     # outside the valid corners the bias gradient is never read: poison it
     gbd = [g(np.where(valid > 0, gb, np.nan).astype(np.float32)) for gb in gbs]
     bias = [torch.full((B, H, S, S), 12345.0, device=DEV) for _ in range(n_ops)]
@@ -721,12 +729,11 @@ def test_rel_multi_all_relation_operators_in_one_launch(B, S, C, H, n_ops, lens)
         r = torch.clamp(torch.relu(rel @ Wrt.t() + brt), min=1e-6).permute(0, 3, 2, 1)      # [B, H, S_k, S_q]
         (torch.log(r) * torch.from_numpy(gbs[i]).double() * vm).sum().backward(retain_graph=True)
         refs.append((r.detach(), Wrt.grad, brt.grad))
-    n_el = float(valid.sum()) * 1.0
-    wtol = 6e-3 if n_el > 5000 else TOL          # (1/r-amplified random-sign sums: see test_rel_fused_lazy_handle)
+    wtol = 1e-4
     for i in range(n_ops):
         got = bias[i].cpu()
         assert bool((got[~vmask] == 12345.0).all()), 'the forward wrote outside the valid corners'
-        rr = torch.exp(got.double())
+        rr = torch.exp(torch.where(vmask, got, torch.zeros(())).double())
         scale = float(refs[i][0].abs().max())
         assert float(((rr - refs[i][0]).abs() * vm).max()) <= 2e-5 * scale, i
         assert rel_err(dWr[i].cpu().numpy(), refs[i][1].numpy()) < wtol, i
@@ -750,8 +757,9 @@ def test_rel_multi_all_relation_operators_in_one_launch(B, S, C, H, n_ops, lens)
                                                    L.fptr(p_dWy), L.fptr(p_dby), L.fptr(p_dWr), L.fptr(p_dbr), L.fptr(ws1), B, S, C, R, H,
                                                    L.ptr(offd), L.ptr(toffd), ntiles, L.stream()))
         torch.cuda.synchronize()
-        a, c = torch.exp(bias[i].double()), torch.exp(pb.double())
-        assert float(((a - c).abs() * vm.to(DEV)).max()) <= 2e-5 * float(c.abs().max())
+        vd = vmask.to(DEV)
+        a, c = torch.exp(torch.where(vd, bias[i], 0.0).double()), torch.exp(torch.where(vd, pb, 0.0).double())
+        assert float((a - c).abs().max()) <= 2e-5 * float(c.abs().max())
         assert rel_err(dWr[i].cpu().numpy(), p_dWr.cpu().numpy()) < 3e-4
         assert rel_err(dbr[i].cpu().numpy(), p_dbr.cpu().numpy()) < 3e-4
     assert rel_err(dWy.cpu().numpy(), p_dWy.cpu().numpy()) < 3e-4

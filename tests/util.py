@@ -56,23 +56,46 @@ def esample(a, n=64):
     return flat[::max(1, flat.size // n)][:n]
 
 
+def is_rel_path(key):
+    """Parameters whose gradient is a relation-bias contraction (linear_r of a RelSelfAtt, the shared stem linear_{x,y}_rel)."""
+    return 'linear_r.' in key or 'linear_y_rel.' in key or 'linear_x_rel.' in key
+
+
+# Two fp32 evaluations of the SAME relation-path gradient through different kernels (per-operator relfused.hip on the
+# vector pipe vs all operators at once on the MFMA, relmulti.hip; or packed vs padded rows) add 1/r-weighted terms of random
+# sign in different orders: measured 2e-4 ... 3e-4 of the tensor's largest entry apart (MI355X, round 5), both within the
+# float64-yardstick bound of check_grad_samples.  Self-consistency tests use this for those keys and their own (tight)
+# bound for every other parameter.
+REL_PATH_SELF_TOL = 1e-3
+
+KAPPA = 3e-4   # relation-path gradients: bound on |error| / (sum of the absolute values of the entry's terms)
+
+
 def check_grad_samples(npz, tag, grads, tol=3e-3, skip=lambda k: False):
     """Element-wise check of EVERY parameter gradient of a network against the reference's strided samples
     (`tag + 'gs_keys' / 'gs' / 'gs_off'`): a sign or permutation error inside a weight gradient keeps its norm, not these.
     grads: name -> array (None / missing = no gradient).  Tolerance: `tol` of the tensor's largest sampled reference
     element, floored at 1e-3 of the largest over all tensors (round-off-sized gradients).
 
-    The relation-path gradients (`linear_r`, `linear_{x,y}_rel`) are sums with heavy cancellation behind
-    log(clamp(relu(.))): the reference's own fp32 value is off by up to 4e-3 of the largest entry, and so is any other fp32
-    evaluation.  For them the yardstick is the reference run in FLOAT64 (`gs64*`, make_golden.grad_samples64) at the SAME
-    tolerance -- not a looser bound against the fp32 value."""
+    The relation-path gradients (`linear_r`, `linear_{x,y}_rel`) are 1/r-weighted sums of random sign behind
+    log(clamp(relu(.))) that cancel to a small fraction of their terms.  For them the yardstick is the reference run in
+    FLOAT64 (`gs64*`, make_golden.grad_samples64), and the bound is the ordinary `tol` on the entry OR KAPPA on the entry's
+    cancellation scale (`gs64_scale`: the sum of the absolute values of its terms, from the same float64 run), whichever is
+    larger -- not a blanket looser tolerance.  Measured on MI355X (tools/tmp-style probe, nets.npz
+    full|vqa|mmnas_vqa, the worst entry: dag.15 linear_r.bias = 1.5e-3 against a scale of 4.9e-2): 7e-6 ... 1.2e-4 of the
+    scale depending on which LSTM / relation kernels ran upstream (the same entry moves by 3.5e-3 of its value when only
+    the LSTM kernel changes: conditioning, not a kernel property); the reference's own fp32 run: <= 1e-5 of the scale."""
     keys = [str(k) for k in npz[tag + 'gs_keys']]
     off = npz[tag + 'gs_off']
     gs = npz[tag + 'gs']
-    ref64 = {}
+    ref64, scale64 = {}, {}
     if tag + 'gs64_keys' in npz.files:
         o64, g64 = npz[tag + 'gs64_off'], npz[tag + 'gs64']
-        ref64 = {str(k): g64[o64[i]:o64[i + 1]] for i, k in enumerate(npz[tag + 'gs64_keys'])}
+        sc = npz[tag + 'gs64_scale'] if tag + 'gs64_scale' in npz.files else None
+        for i, k in enumerate(npz[tag + 'gs64_keys']):
+            ref64[str(k)] = g64[o64[i]:o64[i + 1]]
+            if sc is not None:
+                scale64[str(k)] = sc[o64[i]:o64[i + 1]]
     top = float(np.max(np.abs(gs))) if gs.size else 0.0
     checked = 0
     for i, k in enumerate(keys):
@@ -83,7 +106,12 @@ def check_grad_samples(npz, tag, grads, tol=3e-3, skip=lambda k: False):
         assert g is not None, ('no gradient for', k)
         mine = esample(g)
         assert mine.shape == ref.shape, (k, mine.shape, ref.shape)
-        err = float(np.max(np.abs(mine.astype(np.float64) - ref)))
-        assert err <= tol * max(float(np.max(np.abs(ref))), 1e-3 * top), (k, err, float(np.max(np.abs(ref))), 'fp64 yardstick' if k in ref64 else 'fp32')
+        err = np.abs(mine.astype(np.float64) - ref)
+        bound = tol * max(float(np.max(np.abs(ref))), 1e-3 * top) * np.ones_like(err)
+        if k in scale64:
+            bound = np.maximum(bound, KAPPA * scale64[k])
+        bad = err > bound
+        assert not bad.any(), (k, float(err[bad].max()), float(np.max(np.abs(ref))), 'fp64 yardstick' if k in ref64 else 'fp32',
+                               float(scale64[k][bad].max()) if k in scale64 else None)
         checked += 1
     return checked
