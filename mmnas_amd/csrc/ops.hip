@@ -147,6 +147,22 @@ static int att_core_fwd(const mmnas_att_op* op, const AttLayout& L, void* stream
   if (rel) {
     if (fl & MMNAS_F_RELRAW) {  // lazy handle: bias straight from the raw [B,Sq,Sk,C] relations
       MMNAS_REQUIRE(op->Wy && op->by, MMNAS_E_ARG, "att_op_fwd: RELRAW without Wy/by");
+      // Self-attention (every RelSelfAtt): the one-operator form of the kernel the backbone chains run for ALL relation
+      // operators of a stream (relmulti.hip).  A row's bias does not depend on which other rows share its launch, so the
+      // per-operator path and the chains produce the same bias BIT FOR BIT -- and with it the same logits.
+      if (op->Sq == op->Sk && mmnas_rel_multi_supported(op->C, op->R, op->H) && (long)op->B * op->H * op->Sq * op->Sq < (1l << 31) &&
+          !(getenv("MMNAS_REL_FWD_VALU") && getenv("MMNAS_REL_FWD_VALU")[0] == '1')) {
+        mmnas_rel_multi q;
+        memset(&q, 0, sizeof(q));
+        q.B = op->B; q.S = op->Sq; q.C = op->C; q.R = op->R; q.H = op->H; q.n_ops = 1;
+        q.raw = op->rel; q.Wy = op->Wy; q.by = op->by;
+        q.Wr[0] = op->Wr; q.br[0] = op->br; q.biasT[0] = L.biasT;
+        if (op->q_off) {
+          MMNAS_REQUIRE(op->rel_tile_off, MMNAS_E_ARG, "att_op_fwd: packed rows without the relation tile offsets");
+          q.off = op->q_off; q.tile_off = op->rel_tile_off; q.ntiles = op->rel_ntiles;
+        }
+        rc = mmnas_rel_multi_fwd(&q, stream);
+      } else
       rc = op->q_off ? mmnas_rel_fused_fwd_ragged(op->rel, op->Wy, op->by, op->Wr, op->br, L.biasT, op->B, op->Sq, op->C, op->R,
                                                   op->H, op->q_off, stream)
                      : mmnas_rel_fused_fwd(op->rel, op->Wy, op->by, op->Wr, op->br, L.biasT, op->B, op->Sq, op->Sk, op->C, op->R,

@@ -27,7 +27,7 @@ def _init(c):
             'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
 
 
-def _check_gradnorms(npz, tag, net, skip_alpha=False):
+def _check_gradnorms(npz, tag, net, skip_alpha=False, kappa=None):
     keys = [str(k) for k in npz[tag + 'gradnorm_keys']]
     norms = npz[tag + 'gradnorms']
     mine = dict(net.named_parameters())
@@ -42,7 +42,7 @@ def _check_gradnorms(npz, tag, net, skip_alpha=False):
     # ... and element-wise on the reference's strided samples of every gradient tensor (a permutation or sign error inside
     # a weight gradient keeps the norm)
     grads = {k: (None if p.grad is None else p.grad.detach().cpu().numpy()) for k, p in mine.items()}
-    n_checked = check_grad_samples(npz, tag, grads, skip=(lambda k: 'alpha' in k) if skip_alpha else (lambda k: False))
+    n_checked = check_grad_samples(npz, tag, grads, skip=(lambda k: 'alpha' in k) if skip_alpha else (lambda k: False), kappa=kappa)
     assert n_checked > 100
 
 
@@ -78,7 +78,7 @@ def test_mixed_op(mode, kind):
 
 
 @pytest.mark.parametrize('task,arch', [('vqa', 'mcan'), ('vqa', 'mmnas_vqa'), ('vgd', 'mmnas_vgd'), ('itm', 'mmnas_itm')])
-def test_net_full(task, arch):
+def test_net_full(task, arch, kappa=None):
     import importlib
     Net_Full = importlib.import_module('mmnas.model.full_%s' % task).Net_Full
     npz = load('nets.npz')
@@ -96,7 +96,7 @@ def test_net_full(task, arch):
     loss = _loss(task, pred, c['target'])
     assert abs(float(loss) - float(npz[tag + 'loss'])) <= TOL * abs(float(npz[tag + 'loss']))
     loss.backward()
-    _check_gradnorms(npz, tag, net)
+    _check_gradnorms(npz, tag, net, kappa=kappa)
     assert rel_err(net.imgfeat_linear.bias.grad.cpu().numpy(), npz[tag + 'g:imgfeat_linear.bias']) <= 3e-3
 
 
@@ -111,7 +111,10 @@ def test_net_full_uses_the_persistent_lstm_and_has_a_miopen_fallback(monkeypatch
     assert calls, 'the persistent-kernel LSTM was not used'
     n = len(calls)
     monkeypatch.setenv('MMNAS_LSTM', '0')
-    test_net_full('vqa', 'mmnas_vqa')
+    # (MIOpen's LSTM is the less accurate of the two: upstream of the relation path its output noise moves the worst
+    #  cancellation-limited entry -- dag.15 linear_r.bias, 1.6e-4 against a scale of 1.5e-2 -- by 3.6e-4 of that scale, the
+    #  persistent kernel by 2.3e-5; the fallback gets the wider bound, the product path keeps tests/util.py::KAPPA)
+    test_net_full('vqa', 'mmnas_vqa', kappa=1e-3)
     assert len(calls) == n, 'MMNAS_LSTM=0 must fall back to nn.LSTM'
 
 

@@ -71,7 +71,7 @@ REL_PATH_SELF_TOL = 1e-3
 KAPPA = 3e-4   # relation-path gradients: bound on |error| / (sum of the absolute values of the entry's terms)
 
 
-def check_grad_samples(npz, tag, grads, tol=3e-3, skip=lambda k: False):
+def check_grad_samples(npz, tag, grads, tol=3e-3, skip=lambda k: False, kappa=None):
     """Element-wise check of EVERY parameter gradient of a network against the reference's strided samples
     (`tag + 'gs_keys' / 'gs' / 'gs_off'`): a sign or permutation error inside a weight gradient keeps its norm, not these.
     grads: name -> array (None / missing = no gradient).  Tolerance: `tol` of the tensor's largest sampled reference
@@ -109,7 +109,7 @@ def check_grad_samples(npz, tag, grads, tol=3e-3, skip=lambda k: False):
         err = np.abs(mine.astype(np.float64) - ref)
         bound = tol * max(float(np.max(np.abs(ref))), 1e-3 * top) * np.ones_like(err)
         if k in scale64:
-            bound = np.maximum(bound, KAPPA * scale64[k])
+            bound = np.maximum(bound, (KAPPA if kappa is None else kappa) * scale64[k])
         bad = err > bound
         assert not bad.any(), (k, float(err[bad].max()), float(np.max(np.abs(ref))), 'fp64 yardstick' if k in ref64 else 'fp32',
                                float(scale64[k][bad].max()) if k in scale64 else None)
