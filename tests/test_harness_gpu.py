@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from tests.golden import cases
-from tests.util import TOL, load, rel_err
+from tests.util import TOL, load, rel_err, REL_PATH_SELF_TOL, is_rel_path
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -458,7 +458,7 @@ def test_arch_step_through_the_mixed_chain_equals_the_per_candidate_path(mode, m
     assert rel_err(b['alpha'], a['alpha']) < 1e-5
     top = max(float(np.abs(v).max()) for v in a['grads'].values())
     for k, v in a['grads'].items():
-        assert float(np.abs(b['grads'][k] - v).max()) <= 1e-4 * max(float(np.abs(v).max()), 1e-3 * top), k
+        assert float(np.abs(b['grads'][k] - v).max()) <= (REL_PATH_SELF_TOL if is_rel_path(k) else 1e-4) * max(float(np.abs(v).max()), 1e-3 * top), k
     nz = sum(float(np.abs(v).max()) > 0 for v in a['grads'].values())
     assert nz > 60          # the sampled candidates, stem and head carry gradients on both paths
 
