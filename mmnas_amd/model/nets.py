@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import ops, zeroterm
 from ..utils.ops_adapter import OpsAdapter
 from .mixed import MixedOp, sample_indices, sample_rows
 from .modules import AttFlat, LayerNorm, RelHandle
@@ -327,6 +327,7 @@ class NetFullBase(_Net):
     def __init__(self, __C, init_dict):
         super().__init__()
         self._build(__C, init_dict)
+        zeroterm.adopt(self)      # the scripts' `0 * sum(p.sum() ...)` line (train_vqa.py:299) as ONE autograd node
 
 
 class NetSearchBase(_Net):
@@ -344,6 +345,7 @@ class NetSearchBase(_Net):
         self._flat = None
         self._flat_grads = None
         self._probs_cache = None
+        zeroterm.adopt(self)      # the scripts' three `0 * sum(p.sum() ...)` lines (search_vqa.py:285-288) as three autograd nodes
 
     # -- architecture parameters ------------------------------------------------------------
     def init_arch(self):
