@@ -319,7 +319,8 @@ def compact_line(out, full_ref):
     """The one stdout line: the contract's fields, `roofline`, `cpu_baseline` and one short object per sub record."""
     keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
             'dtype', 'data', 'config', 'repeats', 'value_min', 'value_max', 'final_loss', 'samples_per_s',
-            'algorithmic_tflops_per_gpu', 'step_frac_of_mfma_peak', 'host_issue_ms_per_step_empty_queue', 'gpu_vs_cpu')
+            'algorithmic_tflops_per_gpu', 'step_frac_of_mfma_peak', 'host_issue_ms_per_step_empty_queue', 'gpu_vs_cpu',
+            'rank_ms_per_step')
     line = {k: _r(out[k]) for k in keep if k in out}
 
     def roof(r):
@@ -456,6 +457,21 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # N > 1: what the line reports about the exchange is OBSERVED, not configured -- the rank count from a real all-reduce of
+    # rank ids on the backend the steps use (sum of 0..N-1 and of ones), the sampled architectures compared across ranks
+    # before the timed blocks, the persistent LSTM's hand-off timeout flag read after every block, every rank's own time
+    multi = {'rccl_ranks_observed': 1, 'rank_id_sum_ok': True, 'same_architecture': None, 'lstm_timed_out': 0}
+    if world > 1:
+        t = torch.tensor([float(rank), 1.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        multi['rccl_ranks_observed'] = int(round(float(t[1])))
+        multi['rank_id_sum_ok'] = bool(abs(float(t[0]) - world * (world - 1) / 2.0) < 1e-9)
+        if multi['rccl_ranks_observed'] != world or not multi['rank_id_sum_ok']:
+            sys.stderr.write('bench.py: the all-reduce saw %d ranks (rank-id sum %s), expected %d\n'
+                             % (multi['rccl_ranks_observed'], float(t[0]), world))
+            sys.exit(3)
 
     torch.manual_seed(888)
     ops.manual_seed(888 + rank)
@@ -738,6 +754,13 @@ def main():
         for _ in range(wcalls):
             step()
         barrier()
+        if world > 1 and wl in ('search_vqa', 'arch_vqa', 'bilevel_vqa'):
+            # every rank must have sampled the same operators (seeded CPU sampler): one check before the timed blocks
+            same = dp.check_same_architecture(search_state()['net'])
+            multi['same_architecture'] = same if multi['same_architecture'] is None else (multi['same_architecture'] and same)
+            if not same:
+                sys.stderr.write('bench.py: the ranks sampled DIFFERENT architectures: refusing to time a mislabelled exchange\n')
+                sys.exit(3)
         if os.environ.get('MMNAS_BENCH_HOST_PROFILE'):   # tuning aid: where the HOST spends a step (cProfile, not timed)
             import cProfile, pstats
             pr = cProfile.Profile()
@@ -753,6 +776,7 @@ def main():
         # sides; the reported block is the MEDIAN (a 0.1 s block on a fresh box is at the mercy of clock ramps)
         nsteps = calls * per_call
         blocks = []
+        rank_el = []
         for _ in range(max(1, args.repeats)):
             fl[0] = 0.0
             barrier()
@@ -762,10 +786,15 @@ def main():
             t_enq = time.perf_counter() - t0   # host time to issue the steps (close to `elapsed` = host-bound)
             barrier()
             el = time.perf_counter() - t0
+            # the persistent LSTM's hand-off gives up (and poisons the pass with NaN) when a workgroup of its grid was not
+            # resident -- e.g. a collective's kernel held the slot: read the flag after EVERY block and report it
+            multi['lstm_timed_out'] += int(lib.mmnas_lstm_seq_timed_out(L.stream()))
             if world > 1:
-                t = torch.tensor([el], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el = float(t)
+                mine = torch.zeros(world, device=dev, dtype=torch.float64)
+                mine[rank] = el
+                dist.all_reduce(mine)                      # every rank's own time (the line's time is their maximum)
+                rank_el.append([float(v) for v in mine])
+                el = max(rank_el[-1])
             blocks.append((el, t_enq, fl[0]))
         order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
         elapsed, t_enqueue, timed_flops = blocks[order[len(order) // 2]]
@@ -813,6 +842,10 @@ def main():
             'host_issue_ms_per_step': 1000.0 * t_enqueue / nsteps,
             'host_issue_ms_per_step_empty_queue': host_alone_ms,
         }
+        if world > 1:
+            mid = order[len(order) // 2]
+            rec['rank_ms_per_step'] = [round(1000.0 * v / nsteps, 4) for v in rank_el[mid]]   # of the median block, by rank
+            rec['rank_ms_per_step_blocks'] = [[round(1000.0 * v / nsteps, 4) for v in row] for row in rank_el]
         if stats and wl in N1_SUBS and not wl.endswith('_unpad'):
             psteps = prof_calls * per_call
             rec['library_launches_per_step'] = sum(s_['launches'] for s_ in stats.values()) / psteps
@@ -947,7 +980,11 @@ def main():
             'data': 'synthetic',
             'config': {'workload': head['workload'], 'global_batch': (state[head_wl]['B'] if head_wl in EXTRA else B) * world, 'parallelism': 'dp%d' % world,
                        'grad_allreduce': ('rccl' if backend == 'nccl' else backend) if world > 1 else 'none',
-                       'rccl_ranks': dist.get_world_size() if world > 1 else 1,
+                       'rccl_ranks': multi['rccl_ranks_observed'],     # counted by an all-reduce of ones, not read from the env
+                       'rank_id_sum_ok': multi['rank_id_sum_ok'], 'same_architecture': multi['same_architecture'],
+                       'lstm_timed_out': multi['lstm_timed_out'],
+                       'dp_rows': os.environ.get('MMNAS_DP_ROWS', '1'),      # embedding gradient exchanged as rows (dp.RowExchange)
+                       'dp_buckets': getattr(getattr(state.get('search', {}).get('loop'), 'reducer', None), 'n_buckets', None),
                        'rccl_env': {k: v for k, v in os.environ.items() if k.startswith(('NCCL_', 'RCCL_'))},
                        'rccl_version': '.'.join(str(x) for x in torch.cuda.nccl.version()) if hasattr(torch.cuda, 'nccl') else None,
                        'optimizer_in_step': False, 'gemm_split': args.gemm_split,

@@ -153,3 +153,13 @@ def test_bench_two_ranks_one_gpu(workload, tmp_path):
     else:
         _check(d, 2)
     assert d['config']['parallelism'] == 'dp2' and d['config']['grad_allreduce'] == 'gloo'
+    # what the line says about the exchange is observed in the run: ranks counted by an all-reduce, the ranks' sampled
+    # architectures compared before the timed blocks, the LSTM hand-off flag read after every block, each rank's own time
+    c = d['config']
+    assert c['rccl_ranks'] == 2 and c['rank_id_sum_ok'] is True and c['lstm_timed_out'] == 0
+    assert c['dp_rows'] in ('0', '1')
+    if workload != 'train_vqa':
+        assert c['same_architecture'] is True and c['dp_buckets'] == 3
+    full = json.load(open(str(tmp_path / 'f.json')))
+    assert len(full['rank_ms_per_step']) == 2 and max(full['rank_ms_per_step']) == pytest.approx(full['ms_per_step'], rel=1e-3)
+    assert len(d['rank_ms_per_step']) == 2
