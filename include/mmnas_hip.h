@@ -398,6 +398,11 @@ int mmnas_rel_multi_bwd(const mmnas_rel_multi* m, void* stream);
  * entry, backward behind the last relation operator of a stream.  mmnas_set_rel_hoist(0) / MMNAS_REL_HOIST=0 restores one
  * mmnas_rel_fused_* launch per operator (A/B runs); returns the previous setting. */
 int mmnas_set_rel_hoist(int on);
+/* Likewise the key / value projections of a chain's guided operators (all read the final language state; GuidedAtt,
+ * modules.py:313-325): forward as grouped launches behind the encoder, backward (key / value source gradient, dWk, dWv) as
+ * grouped gradient-pair launches behind the last guided operator.  MMNAS_GUIDED_HOIST=0 / mmnas_set_guided_hoist(0): one
+ * launch set per operator; returns the previous setting. */
+int mmnas_set_guided_hoist(int on);
 
 /* ------------------------------------------------------------------------------------------
  * Attention core: MHAtt.att (modules.py:191-199) for all (batch, head) pairs.

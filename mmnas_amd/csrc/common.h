@@ -110,6 +110,10 @@ int glimpse1_bwd_blocks(long rows, int MID);
 int glimpse1_bwd(const float* dlog, const float* h, const float* w2, float gate_scale, int gated, float* dh, float* db1, float* dW2,
                  float* part, long rows, int MID, hipStream_t st, AuxReduce* aux);
 
+// rowops.hip: y = srcs[0] + ... + srcs[n-1] (count % 4 == 0, 16-byte aligned), n <= ADD_MANY_MAX
+constexpr int ADD_MANY_MAX = 24;
+int add_many(const float* const* srcs, int n, float* y, size_t count, hipStream_t st);
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace mmnas

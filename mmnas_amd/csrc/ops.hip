@@ -110,7 +110,9 @@ namespace mmnas {
 // *ln_done tells the caller whether the output was normalised here after all (the one-launch short-sequence kernel).
 // rel_ready (backbone chains): the relation bias already sits in the saved block (one mmnas_rel_multi_fwd launch at chain entry
 // computed it for every relation operator of the stream): skip the per-operator bias launch.
-static int att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_ln, bool* ln_done, bool rel_ready = false);
+// kv_ready (backbone chains, guided operators): the key / value projections of every guided operator of the chain were
+// issued as one grouped launch behind the encoder (they all read the final language state): only Q is projected here.
+static int att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_ln, bool* ln_done, bool rel_ready = false, bool kv_ready = false);
 }
 extern "C" int mmnas_att_op_fwd(const mmnas_att_op* op, void* stream) {
   bool done;
@@ -200,7 +202,7 @@ static int att_fwd_args(const mmnas_att_op* op) {
 }
 }  // namespace mmnas
 
-static int mmnas::att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_ln, bool* ln_done, bool rel_ready) {
+static int mmnas::att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_ln, bool* ln_done, bool rel_ready, bool kv_ready) {
   *ln_done = true;
   int rc = att_fwd_args(op);
   if (rc) return rc;
@@ -213,7 +215,7 @@ static int mmnas::att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_
 
   mmnas_gemm_desc g;
   gemm_init(g, MMNAS_GEMM_NT, di, d, d, d, di);
-  g.ngroups = 3;
+  g.ngroups = kv_ready ? 1 : 3;
   att_qkv_groups(op, L, g.g);
   if ((rc = mmnas_gemm(&g, stream))) return rc;
   if ((rc = att_core_fwd(op, L, stream, nullptr, rel_ready))) return rc;
@@ -259,7 +261,9 @@ struct SideQueue {
 // running sum over the guided operators) instead of overwriting it -- saves the chain a buffer and an add launch each.
 // rel_defer (backbone chains): the bias gradient dbiasT stays in the operator's scratch block; ONE mmnas_rel_multi_bwd launch
 // behind the stream's last relation operator turns every operator's dbiasT into its dWr / dbr and the shared dWy / dby.
-static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* sq, bool acc_kv = false, bool rel_defer = false) {
+// kv_defer (backbone chains, guided operators): dK / dV stay in the scratch block; the chain turns every guided operator's
+// pair into its key / value source gradient and dWk / dWv by grouped launches behind the last guided operator's backward.
+static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* sq, bool acc_kv = false, bool rel_defer = false, bool kv_defer = false) {
   const bool side = sq != nullptr && !sq->rel_only;
   const bool side_rel = sq != nullptr;
   int rc = att_check(op, "att_op_bwd");
@@ -342,6 +346,7 @@ static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* s
     if (side) {
       if ((rc = mmnas_gemm(&g, stream))) return rc;
     } else if ((rc = mmnas_gemm_pair(&g, &w, stream))) return rc;
+    if (kv_defer) goto params;
     gemm_init(w2, MMNAS_GEMM_TN, d, Mk, di, d, d);
     w2.ngroups = 2;
     w2.g[0].M = di; w2.g[0].A[0] = L.dK; w2.g[0].B[0] = op->xkv; w2.g[0].C = op->dWk;
@@ -358,6 +363,7 @@ static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* s
     } else if ((rc = mmnas_gemm_pair(&g, &w2, stream))) return rc;
   }
 
+params:
   // Parameter-gradient work.  Single stream: the weight gradients went out paired above, the relation-bias backward
   // follows.  Side stream: all of it goes there, behind ONE event recorded at this point of `stream`.
   if (side) {
@@ -689,7 +695,7 @@ static int chain_layout(const mmnas_chain* c, ChainLayout& L) {
     L.ws[i] = take(pl.ws_bwd_bytes);
     L.dx[i] = take(n);
     const bool guided = o.kind == MMNAS_CHAIN_ATT && !(a.flags & MMNAS_F_SELF) && !(c->mixed && o.detached);
-    L.tmp[i] = 0;   // (guided operators add their key / value gradient straight into dpre)
+    L.tmp[i] = guided ? take(nx) : 0;   // (hoisted key / value source gradient of a guided operator: summed once, chain_guided_kv_bwd)
     L.n_guided += guided;
   }
   L.dpre = take(nx);
@@ -853,7 +859,106 @@ static int chain_rel_bwd(const RelGroups& G, int stream_y, hipStream_t st) {
   return MMNAS_OK;
 }
 
+
+// ---- key / value projections of all guided operators of a chain in grouped launches ----
+// Every GuidedAtt of a decoder reads the SAME key / value source -- the final language state (hygr_vqa.py:45-52: pre = x) --
+// through its own Wk / Wv: M = B * Sx = 896 rows, 56 tiles per product, a quarter of a round of workgroups.  Forward: right
+// behind the encoder, K_n = x Wk_n^T and V_n = x Wv_n^T of up to 4 operators per grouped launch (8 groups); each operator
+// then projects only its queries.  Backward: behind the LAST guided operator's backward (the first in chain order), the
+// key / value source gradients dxkv_n = dK_n Wk_n + dV_n Wv_n into per-operator buffers and dWk_n / dWv_n, 4 operators per
+// gradient-pair launch; one add_many launch sums the buffers (and the head's gradient) into the encoder's output gradient.
+static int g_guided_hoist = -1;   // MMNAS_GUIDED_HOIST, default 1
+static bool guided_hoist_on() {
+  if (g_guided_hoist < 0) { const char* e = getenv("MMNAS_GUIDED_HOIST"); g_guided_hoist = (e && e[0] ? atoi(e) : 1) ? 1 : 0; }
+  return g_guided_hoist != 0;
+}
+struct GuidedSet {
+  int idx[MMNAS_CHAIN_MAX_OPS], n;
+  bool hoisted[MMNAS_CHAIN_MAX_OPS];
+  GuidedSet() : n(0) { memset(hoisted, 0, sizeof(hoisted)); }
+};
+constexpr int GUIDED_PER_LAUNCH = 4;   // 2 groups each of <= MMNAS_GEMM_MAX_GROUPS = 9
+static void chain_guided_set(const mmnas_chain* c, bool bwd, bool allow, GuidedSet& G) {
+  if (!allow || !guided_hoist_on() || c->use_side_stream) return;
+  int di = -1;
+  for (int i = 0; i < c->n_ops; ++i) {
+    const mmnas_chain_op& o = c->ops[i];
+    if (o.kind != MMNAS_CHAIN_ATT || (o.att.flags & MMNAS_F_SELF)) continue;
+    if (bwd && c->mixed && o.detached) continue;
+    if (di < 0) di = o.att.di;
+    if (o.att.di != di || G.n >= ADD_MANY_MAX - 2) continue;   // (another head layout: that operator keeps its own launches)
+    G.idx[G.n++] = i; G.hoisted[i] = true;
+  }
+  if (G.n < 2) { for (int j = 0; j < G.n; ++j) G.hoisted[G.idx[j]] = false; G.n = 0; }   // (one operator: nothing to merge)
+}
+static int chain_guided_kv_fwd(const mmnas_chain* c, const ChainLayout& L, const GuidedSet& G, const float* x_final, hipStream_t st) {
+  char* base = (char*)c->arena;
+  for (int j0 = 0; j0 < G.n; j0 += GUIDED_PER_LAUNCH) {
+    const int n = G.n - j0 < GUIDED_PER_LAUNCH ? G.n - j0 : GUIDED_PER_LAUNCH;
+    mmnas_gemm_desc g;
+    for (int j = 0; j < n; ++j) {
+      const int i = G.idx[j0 + j];
+      mmnas_att_op a; mmnas_mlp_op m;
+      chain_op_setup(c, i, a, m);
+      a.save = base + L.save[i]; a.ws = base + L.ws[i];
+      const AttLayout al_ = att_layout(&a);
+      if (j == 0) { gemm_init(g, MMNAS_GEMM_NT, a.di, c->d, c->d, c->d, a.di); g.ngroups = 2 * n; }
+      mmnas_gemm_group* gg = g.g + 2 * j;
+      memset(gg, 0, 2 * sizeof(*gg));
+      gg[0].M = (int)al_.Mk; gg[0].A[0] = x_final; gg[0].B[0] = a.Wk; gg[0].C = al_.K;
+      gg[1].M = (int)al_.Mk; gg[1].A[0] = x_final; gg[1].B[0] = a.Wv; gg[1].C = al_.V;
+    }
+    const int rc = mmnas_gemm(&g, st);
+    if (rc) return rc;
+  }
+  return MMNAS_OK;
+}
+// behind the last guided operator's backward: per-operator key / value source gradients + dWk / dWv, then their sum (+ the
+// head's gradient of the language state, when there is one) into `out`
+static int chain_guided_kv_bwd(const mmnas_chain* c, const ChainLayout& L, const GuidedSet& G, const float* x_final, const float* extra,
+                               const float* extra2, float* out, hipStream_t st) {
+  char* base = (char*)c->arena;
+  const float* srcs[ADD_MANY_MAX + 2];
+  int ns = 0;
+  if (extra) srcs[ns++] = extra;
+  if (extra2) srcs[ns++] = extra2;
+  for (int j0 = 0; j0 < G.n; j0 += GUIDED_PER_LAUNCH) {
+    const int n = G.n - j0 < GUIDED_PER_LAUNCH ? G.n - j0 : GUIDED_PER_LAUNCH;
+    mmnas_gemm_desc g, w;
+    for (int j = 0; j < n; ++j) {
+      const int i = G.idx[j0 + j];
+      mmnas_att_op a; mmnas_mlp_op m;
+      chain_op_setup(c, i, a, m);
+      a.save = base + L.save[i]; a.ws = base + L.ws[i];
+      const AttLayout al_ = att_layout(&a);
+      const int Mk = (int)al_.Mk, di = a.di, d = c->d;
+      if (j == 0) {
+        gemm_init(g, MMNAS_GEMM_NN, d, di, di, d, d); g.ngroups = n; g.nseg = 2;
+        gemm_init(w, MMNAS_GEMM_TN, d, Mk, di, d, d); w.ngroups = 2 * n; w.accumulate = 1;
+      }
+      float* tmp = (float*)(base + L.tmp[i]);
+      memset(&g.g[j], 0, sizeof(g.g[j]));
+      g.g[j].M = Mk; g.g[j].C = tmp;
+      g.g[j].A[0] = al_.dK; g.g[j].B[0] = a.Wk;
+      g.g[j].A[1] = al_.dV; g.g[j].B[1] = a.Wv;
+      memset(&w.g[2 * j], 0, 2 * sizeof(w.g[0]));
+      w.g[2 * j].M = di; w.g[2 * j].A[0] = al_.dK; w.g[2 * j].B[0] = x_final; w.g[2 * j].C = a.dWk;
+      w.g[2 * j + 1].M = di; w.g[2 * j + 1].A[0] = al_.dV; w.g[2 * j + 1].B[0] = x_final; w.g[2 * j + 1].C = a.dWv;
+      srcs[ns++] = tmp;
+    }
+    const int rc = mmnas_gemm_pair(&g, &w, st);
+    if (rc) return rc;
+  }
+  return add_many(srcs, ns, out, (size_t)c->B * c->Sx * c->d, st);
+}
+
 }  // namespace mmnas
+
+extern "C" int mmnas_set_guided_hoist(int on) {
+  const int prev = mmnas::guided_hoist_on() ? 1 : 0;
+  mmnas::g_guided_hoist = on ? 1 : 0;
+  return prev;
+}
 
 extern "C" int mmnas_set_rel_hoist(int on) {
   const int prev = mmnas::rel_hoist_on() ? 1 : 0;
@@ -1037,7 +1142,13 @@ static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
   const size_t ex = (size_t)c->B * c->Sx * c->d, ey = chain_rows_y(c) * c->d;
   float* dpre = (float*)(base + L.dpre);
   int rc;
-  if (L.n_guided && hipMemsetAsync(dpre, 0, ex * sizeof(float), st) != hipSuccess) return MMNAS_E_LAUNCH;
+  GuidedSet GS;     // the sampled guided candidates: dK / dV wait for the grouped launches behind the first of them
+  chain_guided_set(c, true, true, GS);
+  int Gm = -1;      // chain index of the first differentiated guided candidate (the last in backward order)
+  for (int i = 0; i < c->n_ops && Gm < 0; ++i)
+    if (GS.hoisted[i]) Gm = i;
+  const float* enc_grad = nullptr;
+  if (L.n_guided > GS.n && hipMemsetAsync(dpre, 0, ex * sizeof(float), st) != hipSuccess) return MMNAS_E_LAUNCH;
   // node starts in order
   int starts[MMNAS_CHAIN_MAX_OPS + 1], nn = 0;
   for (int i = 0; i < c->n_ops; ++i)
@@ -1061,7 +1172,8 @@ static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
     const bool oy = c->ops[i0].on_y;
     if (!oy && i0 == L.last_x) {   // entering the encoder: its output gradient = the head's + the guided operators'
       MMNAS_REQUIRE(c->dx_out || L.n_guided, MMNAS_E_ARG, "chain_bwd: no gradient reaches the encoder (dx_out NULL, no guided operator)");
-      if (c->dx_out && L.n_guided) {
+      if (enc_grad) cur_dy = enc_grad;
+      else if (c->dx_out && L.n_guided) {
         float* g0 = (float*)(base + L.encdy);
         if ((rc = mmnas_drop_add(c->dx_out, dpre, g0, ex, 0.f, 0, 0, st))) return rc;
         cur_dy = g0;
@@ -1103,7 +1215,12 @@ static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
       a.dy = dact; a.dxq = dx;
       a.dxkv = self ? nullptr : dpre;
       a.drel = nullptr;
-      if ((rc = att_bwd_impl(&a, st, nullptr, !self, RG.hoisted[act_op]))) return rc;
+      if ((rc = att_bwd_impl(&a, st, nullptr, !self, RG.hoisted[act_op], GS.hoisted[act_op]))) return rc;
+      if (GS.n && act_op == Gm) {
+        float* g0 = (float*)(base + L.encdy);
+        if ((rc = chain_guided_kv_bwd(c, L, GS, x_final, c->dx_out, GS.n < L.n_guided ? dpre : nullptr, g0, st))) return rc;
+        enc_grad = g0;
+      }
     } else {
       m.x = nin; m.save = base + L.save[act_op]; m.ws = base + L.ws[act_op];
       m.dy = dact; m.dx = dx;
@@ -1121,7 +1238,8 @@ static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
   if (L.first_y < 0 && hipMemcpyAsync(c->dy_in, c->dy_out, ey * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return MMNAS_E_LAUNCH;
   if (L.first_x < 0) {
     const float* g0 = c->dx_out;
-    if (c->dx_out && L.n_guided) {
+    if (enc_grad) g0 = enc_grad;
+    else if (c->dx_out && L.n_guided) {
       if ((rc = mmnas_drop_add(c->dx_out, dpre, c->dx_in, ex, 0.f, 0, 0, st))) return rc;
       g0 = nullptr;
     } else if (!c->dx_out) g0 = dpre;
@@ -1146,6 +1264,10 @@ extern "C" int mmnas_chain_fwd(const mmnas_chain* c, void* stream) {
   RelGroups RG;     // the relation bias of every relation operator of the chain: one launch per stream, here
   chain_rel_groups(c, L, false, RG);
   if ((rc = chain_rel_fwd(RG, st))) return rc;
+  const int G = first_guided(c);
+  const bool ovl = chain_overlap_on() && !c->use_side_stream && L.last_x >= 0 && L.first_y >= 0 && G > L.first_y;
+  GuidedSet GS;
+  chain_guided_set(c, false, !ovl, GS);
   auto run = [&](int i, hipStream_t s) -> int {
     const mmnas_chain_op& o = c->ops[i];
     mmnas_att_op a; mmnas_mlp_op m;
@@ -1158,7 +1280,7 @@ extern "C" int mmnas_chain_fwd(const mmnas_chain* c, void* stream) {
       a.xkv = (a.flags & MMNAS_F_SELF) ? cur : cur_x;   // guided: keys / values from the FINAL language state
       a.y = out; a.save = base + L.save[i]; a.ws = base + L.ws[i];
       bool done;
-      if ((r = att_fwd_impl(&a, s, false, &done, RG.hoisted[i]))) return r;
+      if ((r = att_fwd_impl(&a, s, false, &done, RG.hoisted[i], GS.hoisted[i]))) return r;
     } else {
       m.x = cur; m.y = out; m.save = base + L.save[i]; m.ws = base + L.ws[i];
       if ((r = mmnas_mlp_op_fwd(&m, s))) return r;
@@ -1166,11 +1288,12 @@ extern "C" int mmnas_chain_fwd(const mmnas_chain* c, void* stream) {
     if (o.on_y) cur_y = out; else cur_x = out;
     return MMNAS_OK;
   };
-  const int G = first_guided(c);
-  const bool ovl = chain_overlap_on() && !c->use_side_stream && L.last_x >= 0 && L.first_y >= 0 && G > L.first_y;
   if (!ovl) {
-    for (int i = 0; i < c->n_ops; ++i)
+    for (int i = 0; i < c->n_ops; ++i) {
+      // the final language state exists: key / value projections of every guided operator (grouped launches)
+      if (GS.n && i == G && (rc = chain_guided_kv_fwd(c, L, GS, cur_x, st))) return rc;
       if ((rc = run(i, st))) return rc;
+    }
   } else {
     SideCtx* sc = side_ctx(st, true);
     MMNAS_REQUIRE(sc, MMNAS_E_LAUNCH, "chain_fwd: cannot create the encoder stream");
@@ -1213,7 +1336,6 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
   char* base = (char*)c->arena;
   const size_t ex = (size_t)c->B * c->Sx * c->d, ey = chain_rows_y(c) * c->d;
   float* dpre = (float*)(base + L.dpre);
-  if (L.n_guided && hipMemsetAsync(dpre, 0, ex * sizeof(float), st) != hipSuccess) return MMNAS_E_LAUNCH;
   // inputs of operator i = outputs of the previous operator on its stream
   auto input_of = [&](int i) -> const float* {
     const bool oy = c->ops[i].on_y;
@@ -1226,6 +1348,10 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
   const bool ovl = chain_overlap_on() && !c->use_side_stream && L.last_x >= 0 && L.first_y >= 0 && G > L.first_y;
   RelGroups RG;     // relation operators whose bias gradient waits for the one launch behind their stream's first operator
   if (!ovl) chain_rel_groups(c, L, true, RG);
+  GuidedSet GS;     // guided operators whose dK / dV wait for the grouped launches behind operator G
+  chain_guided_set(c, true, !ovl, GS);
+  const float* enc_grad = nullptr;   // set by the hoisted launch: the encoder's output gradient, complete
+  if (L.n_guided > GS.n && hipMemsetAsync(dpre, 0, ex * sizeof(float), st) != hipSuccess) return MMNAS_E_LAUNCH;
   // one operator's backward on stream s: gradient of its output in, gradient of its input out (returned through *dxo)
   auto run = [&](int i, hipStream_t s, const float* dyi, const float** dxo) -> int {
     const mmnas_chain_op& o = c->ops[i];
@@ -1241,7 +1367,12 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
       a.dy = dyi; a.dxq = dx;
       a.dxkv = self ? nullptr : dpre;     // guided: added into the running sum (zeroed above)
       a.drel = nullptr;
-      if ((r = att_bwd_impl(&a, s, sq, !self, RG.hoisted[i]))) return r;
+      if ((r = att_bwd_impl(&a, s, sq, !self, RG.hoisted[i], GS.hoisted[i]))) return r;
+      if (GS.n && i == G) {   // the last guided operator in backward order: every hoisted dK / dV exists
+        float* g0 = (float*)(base + L.encdy);
+        if ((r = chain_guided_kv_bwd(c, L, GS, x_final, c->dx_out, GS.n < L.n_guided ? dpre : nullptr, g0, s))) return r;
+        enc_grad = g0;
+      }
     } else {
       m.x = input_of(i); m.save = base + L.save[i]; m.ws = base + L.ws[i];
       m.dy = dyi; m.dx = dx;
@@ -1263,6 +1394,7 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
   // entering the encoder: its output gradient = head's + the guided operators'
   auto encoder_dy = [&](hipStream_t s, const float** out) -> int {
     MMNAS_REQUIRE(c->dx_out || L.n_guided, MMNAS_E_ARG, "chain_bwd: no gradient reaches the encoder (dx_out NULL, no guided operator)");
+    if (enc_grad) { *out = enc_grad; return MMNAS_OK; }
     if (c->dx_out && L.n_guided) {
       float* g0 = (float*)(base + L.encdy);
       const int r = mmnas_drop_add(c->dx_out, dpre, g0, ex, 0.f, 0, 0, s);
@@ -1304,7 +1436,8 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
   if (L.first_y < 0 && hipMemcpyAsync(c->dy_in, c->dy_out, ey * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return MMNAS_E_LAUNCH;
   if (L.first_x < 0) {
     const float* g0 = c->dx_out;
-    if (c->dx_out && L.n_guided) {
+    if (enc_grad) g0 = enc_grad;
+    else if (c->dx_out && L.n_guided) {
       if ((rc = mmnas_drop_add(c->dx_out, dpre, c->dx_in, ex, 0.f, 0, 0, stream))) return rc;
       g0 = nullptr;
     } else if (!c->dx_out) g0 = dpre;

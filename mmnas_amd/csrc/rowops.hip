@@ -275,6 +275,19 @@ __global__ void drop_add_kernel(const float* __restrict__ x, const float* __rest
   }
 }
 
+// y = sum_j src[j] (n <= ADD_MANY_MAX sources, fixed order): the key / value source gradients of a chain's guided operators
+struct AddManyK { const float* src[ADD_MANY_MAX]; int n; };
+__global__ void add_many_kernel(const AddManyK p, float* __restrict__ y, size_t count4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 acc = reinterpret_cast<const float4*>(p.src[0])[i];
+    for (int j = 1; j < p.n; ++j) {
+      const float4 v = reinterpret_cast<const float4*>(p.src[j])[i];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(y)[i] = acc;
+  }
+}
+
 __global__ void glu_fwd_kernel(const float* __restrict__ h, float* __restrict__ y, int M, int C, int relu,
                                DropCfg drop) {
   const size_t n = (size_t)M * C;
@@ -403,6 +416,19 @@ extern "C" int mmnas_drop_add(const float* x, const float* res, float* y, size_t
                      make_drop(drop_p, seed, site));
   return check_launch("drop_add");
 }
+namespace mmnas {
+int add_many(const float* const* srcs, int n, float* y, size_t count, hipStream_t st) {
+  MMNAS_REQUIRE(srcs && y && n >= 1 && n <= ADD_MANY_MAX && count % 4 == 0, MMNAS_E_ARG, "add_many: %d sources, %zu elements", n, count);
+  AddManyK k;
+  k.n = n;
+  for (int j = 0; j < n; ++j) { MMNAS_REQUIRE(srcs[j], MMNAS_E_ARG, "add_many: null source %d", j); k.src[j] = srcs[j]; }
+  if (count == 0) return MMNAS_OK;
+  ProfScope ps(MMNAS_K_ROWOPS, 0.0, 4.0 * (double)count * (n + 1), st);
+  MMNAS_LAUNCH(add_many_kernel, dim3(blocks_for(count / 4)), dim3(256), 0, st, k, y, count / 4);
+  return check_launch("add_many");
+}
+}  // namespace mmnas
+
 extern "C" int mmnas_glu_fwd(const float* h, float* y, int M, int C, int relu, float drop_p, uint64_t seed,
                              uint32_t site, void* stream) {
   MMNAS_REQUIRE(h && y && M > 0 && C > 0, MMNAS_E_ARG, "glu_fwd: bad arguments");

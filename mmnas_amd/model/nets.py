@@ -187,6 +187,17 @@ class _Backbone(nn.Module):
                     op_params[i] = op_params[i][:-4]
             for i, ps in moved.items():
                 op_params[i] = list(op_params[i]) + ps
+            # Likewise the key / value projections of the guided operators: their weight gradients (and the key / value source
+            # gradient) are issued by grouped launches behind the FIRST guided operator of the chain, the last in backward
+            # order (ops.hip chain_guided_kv_bwd).  chain_att_record: params = [Wq, Wk, Wv, Wm, ...].
+            guided = [i for i, rec in enumerate(records) if rec.kind == 0 and not (rec.att.flags & ops.L.F_SELF)]
+            if len(guided) > 1:
+                g0 = guided[0]
+                extra = []
+                for i in guided[1:]:
+                    extra += list(op_params[i][1:3])
+                    op_params[i] = [op_params[i][0]] + list(op_params[i][3:])
+                op_params[g0] = list(op_params[g0]) + extra
         if not records or len(records) > 128:
             return None
         xr = x_rel_embed.raw if isinstance(x_rel_embed, RelHandle) else None

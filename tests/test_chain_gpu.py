@@ -443,3 +443,54 @@ def test_hoisted_relation_bias_net_full(task, arch, monkeypatch):
             continue
         diff = float(np.abs(g_a[k] - g_b[k]).max())
         assert diff <= (REL_PATH_SELF_TOL if is_rel_path(k) else 2e-5) * max(float(np.abs(g_b[k]).max()), 1e-3 * top), (k, diff)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Key / value projections of all guided operators in grouped launches (mmnas_set_guided_hoist)
+# ----------------------------------------------------------------------------------------------------------------------
+def _guided_heavy_plan(mode, n_guided, first=2):
+    """A sampled architecture whose decoder takes the guided operator (candidate 2 of dec_safe) at n_guided nodes, the first
+    of them at node `first`."""
+    plan = cases.search_plan(np.random.RandomState(11), mode)
+    dec = []
+    for k, (act, inact) in enumerate(plan['dec']):
+        a = 2 if first <= k < first + n_guided else (act[0] if act[0] != 2 else 3)
+        dec.append(([a], [i for i in range(4) if i != a]))
+    return plan['enc'] + dec
+
+
+@pytest.mark.parametrize('mode,n_guided,first,unpad', [(None, 5, 2, False), (None, 9, 0, False), (None, 16, 1, False), (None, 1, 3, False),
+                                                       ('full', 4, 2, False), (None, 6, 1, True), ('full', 3, 0, True)])
+def test_hoisted_guided_projections_equal_the_per_operator_launches(mode, n_guided, first, unpad):
+    """The key / value projections of all guided operators of a chain as grouped launches behind the encoder, their gradients
+    as grouped gradient-pair launches behind the last guided operator's backward + ONE sum of the key / value source
+    gradients -- against one launch set per operator.  Forward: the same products in other launches (bit-equal logits);
+    backward: the language state's gradient is summed in another order."""
+    from mmnas_amd import _lib as L
+    lib = L.lib()
+    flat = _guided_heavy_plan(mode, n_guided, first)
+    outs = []
+    for hoist in (0, 1):
+        prev = lib.mmnas_set_guided_hoist(hoist)
+        try:
+            outs.append(_run_unpad('vqa', None, True, unpad, mode, flat, B=4, Sy=19))
+        finally:
+            lib.mmnas_set_guided_hoist(prev)
+    assert outs[0][2] == [unpad] and outs[1][2] == [unpad]
+    assert rel_err(outs[1][0], outs[0][0]) < 1e-6
+    _same(outs[1], outs[0])
+    assert sum(1 for k, g in outs[1][1].items() if 'linear_k.weight' in k and g is not None and np.any(g)) >= n_guided
+
+
+@pytest.mark.parametrize('task,arch', [('vqa', 'mmnas_vqa'), ('vqa', 'mcan'), ('itm', 'mmnas_itm')])
+def test_hoisted_guided_projections_net_full(task, arch, monkeypatch):
+    from mmnas_amd import _lib as L
+    lib = L.lib()
+    outs = []
+    for hoist in (0, 1):
+        prev = lib.mmnas_set_guided_hoist(hoist)
+        try:
+            outs.append(_run(task, arch, False, True, False, monkeypatch, dropout=0.1))
+        finally:
+            lib.mmnas_set_guided_hoist(prev)
+    _compare(outs[1], outs[0])
