@@ -215,9 +215,13 @@ def stem_flops_fwd(cfg, B, Sx, Sy, ans):
     return stem
 
 
-def step_flops(cfg, names_enc, names_dec, B, Sx, Sy, ans, all_enc=None, all_dec=None):
+def step_flops(cfg, names_enc, names_dec, B, Sx, Sy, ans, all_enc=None, all_dec=None, lens=None):
     """fwd + bwd (= 2 x fwd) of the differentiated operators and the stem/head; `all_*`: operators that are evaluated
-    forward only (the detached candidates of the arch step)."""
+    forward only (the detached candidates of the arch step).  lens (the ragged records): the region count of every sample
+    -- the work is then counted on the VALID rows, sample by sample (n_b rows, n_b x n_b attention), which is what the
+    ragged stream computes; without it a `_unpad` record would be credited with the padding rows' flops it never executes."""
+    if lens is not None:       # (every term of the count is per sample)
+        return sum(step_flops(cfg, names_enc, names_dec, 1, Sx, int(n), ans, all_enc, all_dec) for n in lens)
     d = cfg.HSIZE
     f = sum(op_flops_fwd(n, B, Sx, Sy, d, 'enc') for n in names_enc)
     f += sum(op_flops_fwd(n, B, Sx, Sy, d, 'dec') for n in names_dec)
@@ -614,17 +618,25 @@ def main():
         return ([m.Used_OPS[m.active_index[0]] for m in ms[:12]], [m.Used_OPS[m.active_index[0]] for m in ms[12:]],
                 [m.Used_OPS[i] for m in ms[:12] for i in m.inactive_index], [m.Used_OPS[i] for m in ms[12:] for i in m.inactive_index])
 
+    valid_lens = [None]     # set while a `_unpad` record's step runs: step_flops then counts the valid region rows only
+
     def make_step(wl):
         """-> (step() -> loss, flops accumulator [1], steps-per-call)"""
         if wl.endswith('_unpad'):      # the plain step under ops.set_unpad(True): same net, same batch, same loop object
-            inner, fl, per = make_step(wl[:-len('_unpad')])
+            base_wl = wl[:-len('_unpad')]
+            S0 = train_state() if base_wl.startswith('train') else search_state()
+            frcn = S0['cpu'][0][0]
+            lens_of_record = [int(v) for v in (frcn.abs().sum(-1) != 0).sum(-1)]     # flops of these records: valid rows only
+            inner, fl, per = make_step(base_wl)
 
             def step():
                 prev = ops.set_unpad(True)
+                valid_lens[0] = lens_of_record
                 try:
                     return inner()
                 finally:
                     ops.set_unpad(prev)
+                    valid_lens[0] = None
             return step, fl, per
         fl = [0.0]
         if wl in EXTRA:
@@ -655,13 +667,19 @@ def main():
             ne = [n[0] for n in cfg.GENOTYPE['enc']]
             nd = [n[0] for n in cfg.GENOTYPE['dec']]
             per = step_flops(cfg, ne, nd, B, SX, SY, ANS)
+            per_valid = {}
 
             def step():
                 red.begin_step()
                 loss = loss_fn(net(S['gpu'][0]), S['gpu'][1])
                 loss.backward()
                 red.finish()
-                fl[0] += per
+                if valid_lens[0] is None:
+                    fl[0] += per
+                else:
+                    if 'v' not in per_valid:
+                        per_valid['v'] = step_flops(cfg, ne, nd, B, SX, SY, ANS, lens=valid_lens[0])
+                    fl[0] += per_valid['v']
                 return loss
             return step, fl, 1
         if wl == 'train_vqa_dp1':
@@ -727,7 +745,7 @@ def main():
         def weight(optimize):
             loss = loop.weight_step(S['gpu'][0], S['gpu'][1], optimize=optimize)
             ne, nd, _, _ = used_names(net)
-            fl[0] += step_flops(cfg, ne, nd, B, SX, SY, ANS)
+            fl[0] += step_flops(cfg, ne, nd, B, SX, SY, ANS, lens=valid_lens[0])
             return loss
 
         def arch(optimize):

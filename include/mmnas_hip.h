@@ -619,6 +619,11 @@ typedef struct mmnas_attflat_side {
   float* dW1; float* db1; float* dW2; float* db2; float* dWm; float* dbm;
   uint64_t seed;
   float* dx;
+  /* PACKED rows (ragged batches without their padding rows, the image side of a ragged decoder stream): off != NULL -- x / dx
+   * hold M = off[B] rows, sample b owning rows off[b] .. off[b+1]; S is the longest sample; `mask` is ignored (every packed
+   * row is valid -- the reference masks the padding rows out of AttFlat's softmax, modules.py:78-81: same result). */
+  const int* off;
+  int M, reserved2;
 } mmnas_attflat_side;
 typedef struct mmnas_head {
   int B, d, MID, G, OUT, ANS, flags, reserved;

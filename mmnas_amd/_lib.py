@@ -87,7 +87,7 @@ CHAIN_MAX_OPS = 128
 class AttFlatSide(C.Structure):
     _fields_ = [('S', C.c_int), ('reserved', C.c_int), ('x', _fp), ('mask', _fp), ('W1', _fp), ('b1', _fp), ('W2', _fp),
                 ('b2', _fp), ('Wm', _fp), ('bm', _fp), ('dW1', _fp), ('db1', _fp), ('dW2', _fp), ('db2', _fp), ('dWm', _fp),
-                ('dbm', _fp), ('seed', C.c_uint64), ('dx', _fp)]
+                ('dbm', _fp), ('seed', C.c_uint64), ('dx', _fp), ('off', _fp), ('M', C.c_int), ('reserved2', C.c_int)]
 
 
 class Head(C.Structure):

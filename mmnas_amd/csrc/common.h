@@ -110,6 +110,11 @@ int glimpse1_bwd_blocks(long rows, int MID);
 int glimpse1_bwd(const float* dlog, const float* h, const float* w2, float gate_scale, int gated, float* dh, float* db1, float* dW2,
                  float* part, long rows, int MID, hipStream_t st, AuxReduce* aux);
 
+// head.hip: AttFlat pooling over packed rows (ragged batches)
+int attflat_pool_fwd_packed(const float* logits, const float* x, float* probs, float* pooled, int B, int S, int d, int G, const int* off, hipStream_t st);
+int attflat_pool_bwd_packed(const float* probs, const float* x, const float* dpooled, float* dlogits, float* dx, int B, int S, int d, int G,
+                            const int* off, hipStream_t st);
+
 // rowops.hip: y = srcs[0] + ... + srcs[n-1] (count % 4 == 0, 16-byte aligned), n <= ADD_MANY_MAX
 constexpr int ADD_MANY_MAX = 24;
 int add_many(const float* const* srcs, int n, float* y, size_t count, hipStream_t st);

@@ -48,16 +48,20 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
 
 __global__ void __launch_bounds__(AF_THREADS) attflat_pool_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ x,
                                                                       const uint8_t* __restrict__ mask, float* __restrict__ probs,
-                                                                      float* __restrict__ pooled, int S, int d, int G) {
+                                                                      float* __restrict__ pooled, int S, int d, int G,
+                                                                      const int* __restrict__ off) {
   __shared__ float sp[AF_MAXS];
   __shared__ float red[AF_WAVES];
   __shared__ float part[AF_WAVES / 4][1024];   // partial column sums of the row groups (d <= 1024 per pass)
   const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
-  const float* lg = logits + (size_t)b * S * G + g;
+  // PACKED rows (off != NULL): sample b owns rows off[b] .. off[b+1] of logits / x / probs, all of them valid (no mask)
+  const size_t row0 = off ? (size_t)off[b] : (size_t)b * S;
+  if (off) S = off[b + 1] - off[b];
+  const float* lg = logits + row0 * G + g;
   float m = -INFINITY;
   for (int s = tid; s < S; s += AF_THREADS) {
     float v = lg[(size_t)s * G];
-    if (mask && mask[(size_t)b * S + s]) v = -1e9f;
+    if (mask && !off && mask[(size_t)b * S + s]) v = -1e9f;
     sp[s] = v;
     m = fmaxf(m, v);
   }
@@ -73,11 +77,11 @@ __global__ void __launch_bounds__(AF_THREADS) attflat_pool_fwd_kernel(const floa
   for (int s = tid; s < S; s += AF_THREADS) {
     const float pr = sp[s] * inv;
     sp[s] = pr;
-    probs[((size_t)b * S + s) * G + g] = pr;
+    probs[(row0 + s) * G + g] = pr;
   }
   __syncthreads();
   // pooled: 256 column threads x 4 row groups (rows s = rg mod 4), 4 independent accumulators each
-  const float* xb = x + (size_t)b * S * d;
+  const float* xb = x + row0 * d;
   const int col = tid & 255, rg = tid >> 8;
   for (int j0 = 0; j0 < d; j0 += 1024) {
     for (int j = j0 + col; j < min(d, j0 + 1024); j += 256) {
@@ -105,11 +109,14 @@ __global__ void __launch_bounds__(AF_THREADS) attflat_pool_fwd_kernel(const floa
 __global__ void __launch_bounds__(AF_THREADS) attflat_pool_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ x,
                                                                       const uint8_t* __restrict__ mask,
                                                                       const float* __restrict__ dpooled, float* __restrict__ dlogits,
-                                                                      float* __restrict__ dx, int S, int d, int G) {
+                                                                      float* __restrict__ dx, int S, int d, int G,
+                                                                      const int* __restrict__ off) {
   __shared__ float st[AF_MAXS];
   __shared__ float red[AF_WAVES];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const float* xb = x + (size_t)b * S * d;
+  const size_t row0 = off ? (size_t)off[b] : (size_t)b * S;
+  if (off) S = off[b + 1] - off[b];
+  const float* xb = x + row0 * d;
   for (int g = 0; g < G; ++g) {
     const float* dp = dpooled + (size_t)b * G * d + (size_t)g * d;
     // t[s]: one wave per row, lanes over the feature dimension
@@ -121,12 +128,12 @@ __global__ void __launch_bounds__(AF_THREADS) attflat_pool_bwd_kernel(const floa
     }
     __syncthreads();
     float dot = 0.f;
-    for (int s = tid; s < S; s += AF_THREADS) dot += probs[((size_t)b * S + s) * G + g] * st[s];
+    for (int s = tid; s < S; s += AF_THREADS) dot += probs[(row0 + s) * G + g] * st[s];
     dot = block_reduce(dot, red, false);
     for (int s = tid; s < S; s += AF_THREADS) {
-      const float pr = probs[((size_t)b * S + s) * G + g];
-      const bool masked = mask && mask[(size_t)b * S + s];
-      dlogits[((size_t)b * S + s) * G + g] = masked ? 0.f : pr * (st[s] - dot);
+      const float pr = probs[(row0 + s) * G + g];
+      const bool masked = mask && !off && mask[(size_t)b * S + s];
+      dlogits[(row0 + s) * G + g] = masked ? 0.f : pr * (st[s] - dot);
     }
     __syncthreads();
   }
@@ -134,8 +141,8 @@ __global__ void __launch_bounds__(AF_THREADS) attflat_pool_bwd_kernel(const floa
   for (int s = w; s < S; s += AF_WAVES) {
     for (int j = lane; j < d; j += 64) {
       float a = 0.f;
-      for (int g = 0; g < G; ++g) a += probs[((size_t)b * S + s) * G + g] * dpooled[(size_t)b * G * d + (size_t)g * d + j];
-      dx[((size_t)b * S + s) * d + j] = a;
+      for (int g = 0; g < G; ++g) a += probs[(row0 + s) * G + g] * dpooled[(size_t)b * G * d + (size_t)g * d + j];
+      dx[(row0 + s) * d + j] = a;
     }
   }
 }
@@ -299,16 +306,32 @@ extern "C" int mmnas_attflat_pool_fwd(const float* logits, const float* x, const
   MMNAS_REQUIRE(logits && x && probs && pooled, MMNAS_E_ARG, "attflat_pool_fwd: null pointer");
   MMNAS_REQUIRE(B > 0 && S > 0 && S <= AF_MAXS && d > 0 && G > 0, MMNAS_E_SHAPE, "attflat_pool_fwd: B=%d S=%d d=%d G=%d (S <= %d)",
                 B, S, d, G, AF_MAXS);
-  MMNAS_LAUNCH(attflat_pool_fwd_kernel, dim3(B, G), dim3(AF_THREADS), 0, (hipStream_t)stream, logits, x, mask, probs, pooled, S, d, G);
+  MMNAS_LAUNCH(attflat_pool_fwd_kernel, dim3(B, G), dim3(AF_THREADS), 0, (hipStream_t)stream, logits, x, mask, probs, pooled, S, d, G, (const int*)nullptr);
   return check_launch("attflat_pool_fwd");
 }
+namespace mmnas {
+// the same over PACKED rows (sample b = rows off[b] .. off[b+1], S = the longest sample; no mask: every packed row is valid)
+int attflat_pool_fwd_packed(const float* logits, const float* x, float* probs, float* pooled, int B, int S, int d, int G, const int* off, hipStream_t st) {
+  MMNAS_REQUIRE(logits && x && probs && pooled && off, MMNAS_E_ARG, "attflat_pool_fwd: null pointer");
+  MMNAS_REQUIRE(B > 0 && S > 0 && S <= AF_MAXS && d > 0 && G > 0, MMNAS_E_SHAPE, "attflat_pool_fwd: B=%d S=%d d=%d G=%d (S <= %d)", B, S, d, G, AF_MAXS);
+  MMNAS_LAUNCH(attflat_pool_fwd_kernel, dim3(B, G), dim3(AF_THREADS), 0, st, logits, x, (const uint8_t*)nullptr, probs, pooled, S, d, G, off);
+  return check_launch("attflat_pool_fwd");
+}
+int attflat_pool_bwd_packed(const float* probs, const float* x, const float* dpooled, float* dlogits, float* dx, int B, int S, int d, int G,
+                            const int* off, hipStream_t st) {
+  MMNAS_REQUIRE(probs && x && dpooled && dlogits && dx && off, MMNAS_E_ARG, "attflat_pool_bwd: null pointer");
+  MMNAS_REQUIRE(B > 0 && S > 0 && S <= AF_MAXS && d > 0 && G > 0, MMNAS_E_SHAPE, "attflat_pool_bwd: B=%d S=%d d=%d G=%d (S <= %d)", B, S, d, G, AF_MAXS);
+  MMNAS_LAUNCH(attflat_pool_bwd_kernel, dim3(B), dim3(AF_THREADS), 0, st, probs, x, (const uint8_t*)nullptr, dpooled, dlogits, dx, S, d, G, off);
+  return check_launch("attflat_pool_bwd");
+}
+}  // namespace mmnas
 
 extern "C" int mmnas_attflat_pool_bwd(const float* probs, const float* x, const uint8_t* mask, const float* dpooled,
                                       float* dlogits, float* dx, int B, int S, int d, int G, void* stream) {
   MMNAS_REQUIRE(probs && x && dpooled && dlogits && dx, MMNAS_E_ARG, "attflat_pool_bwd: null pointer");
   MMNAS_REQUIRE(B > 0 && S > 0 && S <= AF_MAXS && d > 0 && G > 0, MMNAS_E_SHAPE, "attflat_pool_bwd: B=%d S=%d d=%d G=%d (S <= %d)",
                 B, S, d, G, AF_MAXS);
-  MMNAS_LAUNCH(attflat_pool_bwd_kernel, dim3(B), dim3(AF_THREADS), 0, (hipStream_t)stream, probs, x, mask, dpooled, dlogits, dx, S, d, G);
+  MMNAS_LAUNCH(attflat_pool_bwd_kernel, dim3(B), dim3(AF_THREADS), 0, (hipStream_t)stream, probs, x, mask, dpooled, dlogits, dx, S, d, G, (const int*)nullptr);
   return check_launch("attflat_pool_bwd");
 }
 

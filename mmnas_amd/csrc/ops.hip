@@ -1464,6 +1464,7 @@ extern "C" int mmnas_chain_join(void* main_stream, void* waiting_stream) {
 namespace mmnas {
 
 struct HeadSideLayout { float *h, *logit, *probs, *pooled, *dpooled, *dlog, *dh, *dxpool, *g1part; };
+static inline int head_rows(const mmnas_head* hd, const mmnas_attflat_side& sd) { return sd.off ? sd.M : hd->B * sd.S; }
 struct HeadLayout {
   HeadSideLayout s[2];
   float *xo, *sum, *xy, *dxy, *dsum, *lnws, *g1proj, *dlogT;
@@ -1476,7 +1477,7 @@ static HeadLayout head_layout(const mmnas_head* hd) {
   const size_t B = hd->B;
   for (int k = 0; k < 2; ++k) {
     const mmnas_attflat_side& sd = k ? hd->sy : hd->sx;
-    const size_t M = B * sd.S;
+    const size_t M = sd.off ? (size_t)sd.M : B * sd.S;
     HeadSideLayout& s = L.s[k];
     s.h = c.take(M * hd->MID); s.logit = c.take(M * hd->G); s.probs = c.take(M * hd->G); s.pooled = c.take(B * hd->G * hd->d);
     s.dpooled = c.take(B * hd->G * hd->d); s.dlog = c.take(M * hd->G); s.dh = c.take(M * hd->MID); s.dxpool = c.take(M * hd->d);
@@ -1502,6 +1503,10 @@ static int head_check(const mmnas_head* hd, const char* who) {
                 MMNAS_E_SHAPE, "%s: B=%d d=%d MID=%d G=%d OUT=%d ANS=%d Sx=%d Sy=%d", who, hd->B, hd->d, hd->MID, hd->G, hd->OUT,
                 hd->ANS, hd->sx.S, hd->sy.S);
   MMNAS_REQUIRE(hd->d % 4 == 0 && hd->MID % 4 == 0 && hd->OUT % 4 == 0, MMNAS_E_SHAPE, "%s: d, MID, OUT must be multiples of 4", who);
+  for (int k = 0; k < 2; ++k) {
+    const mmnas_attflat_side& sd = k ? hd->sy : hd->sx;
+    if (sd.off) MMNAS_REQUIRE(sd.M > 0 && sd.M <= hd->B * sd.S, MMNAS_E_ARG, "%s: packed side %d: M=%d of B*S=%d rows", who, k, sd.M, hd->B * sd.S);
+  }
   return MMNAS_OK;
 }
 
@@ -1544,7 +1549,7 @@ extern "C" int mmnas_head_fwd(const mmnas_head* hd, void* stream) {
     if (drop) { g.drop_p = hd->drop_p; g.drop_seed = sides[0]->seed; g.drop_site = 0; }
     for (int k = 0; k < 2; ++k) {
       const mmnas_attflat_side& sd = *sides[k];
-      g.g[k].M = B * sd.S; g.g[k].A[0] = sd.x; g.g[k].B[0] = sd.W1; g.g[k].bias = sd.b1; g.g[k].C = L.s[k].h;
+      g.g[k].M = head_rows(hd, sd); g.g[k].A[0] = sd.x; g.g[k].B[0] = sd.W1; g.g[k].bias = sd.b1; g.g[k].C = L.s[k].h;
       if (drop) g.g[k].drop_seed = sd.seed;
     }
     if ((rc = mmnas_gemm(&g, stream))) return rc;
@@ -1552,22 +1557,22 @@ extern "C" int mmnas_head_fwd(const mmnas_head* hd, void* stream) {
   for (int k = 0; k < 2 && oc; ++k) {
     const mmnas_attflat_side& sd = *sides[k];
     gemm_init(g, MMNAS_GEMM_NT, MID, d, d, d, MID);
-    g.g[0].M = B * sd.S; g.g[0].A[0] = sd.x; g.g[0].B[0] = sd.W1; g.g[0].bias = sd.b1; g.g[0].C = L.s[k].h; g.relu = 1;
+    g.g[0].M = head_rows(hd, sd); g.g[0].A[0] = sd.x; g.g[0].B[0] = sd.W1; g.g[0].bias = sd.b1; g.g[0].C = L.s[k].h; g.relu = 1;
     if (drop) { g.drop_p = hd->drop_p; g.drop_seed = sd.seed; g.drop_site = 0; }
     if ((rc = mmnas_gemm(&g, side_stream(k)))) return rc;
   }
   // glimpse logits = h W2^T + b2                                   (MLP.linear, modules.py:34-41)
   const bool g1 = G == 1 && !oc && glimpse1_supported(MID) && head_glimpse1_on();
   if (g1) {   // one glimpse: a matrix-vector product per side, both in one launch (head.hip)
-    if ((rc = glimpse1_fwd(L.s[0].h, hd->sx.W2, hd->sx.b2, L.s[0].logit, (long)B * hd->sx.S, L.s[1].h, hd->sy.W2, hd->sy.b2,
-                           L.s[1].logit, (long)B * hd->sy.S, MID, st)))
+    if ((rc = glimpse1_fwd(L.s[0].h, hd->sx.W2, hd->sx.b2, L.s[0].logit, (long)head_rows(hd, hd->sx), L.s[1].h, hd->sy.W2, hd->sy.b2,
+                           L.s[1].logit, (long)head_rows(hd, hd->sy), MID, st)))
       return rc;
   }
   gemm_init(g, MMNAS_GEMM_NT, G, MID, MID, MID, G);
   for (int k = 0; k < 2 && !g1; ++k) {
     const mmnas_attflat_side& sd = *sides[k];
     mmnas_gemm_group& gg = g.g[oc ? 0 : k];
-    gg.M = B * sd.S; gg.A[0] = L.s[k].h; gg.B[0] = sd.W2; gg.bias = sd.b2; gg.C = L.s[k].logit;
+    gg.M = head_rows(hd, sd); gg.A[0] = L.s[k].h; gg.B[0] = sd.W2; gg.bias = sd.b2; gg.C = L.s[k].logit;
     if (oc && (rc = mmnas_gemm(&g, side_stream(k)))) return rc;
   }
   if (!oc && !g1) { g.ngroups = 2; if ((rc = mmnas_gemm(&g, stream))) return rc; }
@@ -1576,7 +1581,8 @@ extern "C" int mmnas_head_fwd(const mmnas_head* hd, void* stream) {
     const HeadSideLayout& s = L.s[k];
     void* const ks = side_stream(k);
     // masked softmax over the sequence + weighted sum                (modules.py:78-84)
-    if ((rc = mmnas_attflat_pool_fwd(s.logit, sd.x, sd.mask, s.probs, s.pooled, B, sd.S, d, G, ks))) return rc;
+    if ((rc = sd.off ? attflat_pool_fwd_packed(s.logit, sd.x, s.probs, s.pooled, B, sd.S, d, G, sd.off, (hipStream_t)ks)
+                     : mmnas_attflat_pool_fwd(s.logit, sd.x, sd.mask, s.probs, s.pooled, B, sd.S, d, G, ks))) return rc;
     // merge; the image side adds the language side's result (x_out + y_out, hygr_vqa.py:116)
     gemm_init(g, MMNAS_GEMM_NT, OUT, G * d, G * d, G * d, OUT);
     g.g[0].M = B; g.g[0].A[0] = s.pooled; g.g[0].B[0] = sd.Wm; g.g[0].bias = sd.bm; g.g[0].C = k ? L.sum : L.xo;
@@ -1637,7 +1643,7 @@ extern "C" int mmnas_head_bwd(const mmnas_head* hd, void* stream) {
     MMNAS_REQUIRE(sd.x && sd.dx && sd.dW1 && sd.dW2 && sd.dWm, MMNAS_E_ARG, "head_bwd: side %d null pointer", k);
     hipStream_t st = (oc && k == 0) ? oc->enc : (hipStream_t)stream;   // (shadows: the language side on the second stream)
     void* const stream = (void*)st;
-    const int M = B * sd.S;
+    const int M = head_rows(hd, sd);
     // merge: the sum's gradient reaches both sides unchanged
     gemm_init(w, MMNAS_GEMM_TN, G * d, B, OUT, G * d, G * d);
     w.g[0].M = OUT; w.g[0].A[0] = L.dsum; w.g[0].B[0] = s.pooled; w.g[0].C = sd.dWm; w.accumulate = 1;
@@ -1646,7 +1652,8 @@ extern "C" int mmnas_head_bwd(const mmnas_head* hd, void* stream) {
     if ((rc = gemm_pair_aux(&g, &w, k ? &lnred : nullptr, st))) return rc;
     if (sd.dbm && (rc = mmnas_colsum(L.dsum, sd.dbm, B, OUT, OUT, stream))) return rc;
     // pooling
-    if ((rc = mmnas_attflat_pool_bwd(s.probs, sd.x, sd.mask, s.dpooled, s.dlog, s.dxpool, B, sd.S, d, G, stream))) return rc;
+    if ((rc = sd.off ? attflat_pool_bwd_packed(s.probs, sd.x, s.dpooled, s.dlog, s.dxpool, B, sd.S, d, G, sd.off, st)
+                     : mmnas_attflat_pool_bwd(s.probs, sd.x, sd.mask, s.dpooled, s.dlog, s.dxpool, B, sd.S, d, G, stream))) return rc;
     // glimpse-logit linear: dh = dlog W2 with relu' and the dropout replay from h; db1 rides as column sums of dh
     AuxReduce g1red;
     g1red.part = nullptr;

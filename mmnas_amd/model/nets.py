@@ -76,7 +76,7 @@ class _Backbone(nn.Module):
         self.cells_enc = nn.ModuleList([self.CELL(__C, type='enc') for _ in range(__C.LAYERS)])
         self.cells_dec = nn.ModuleList([self.CELL(__C, type='dec') for _ in range(__C.LAYERS)])
 
-    def _chain(self, x, y, x_mask, y_mask, x_rel_embed, y_rel_embed):
+    def _chain(self, x, y, x_mask, y_mask, x_rel_embed, y_rel_embed, packed=False):
         """The whole backbone as ONE native call per direction (ops.BackboneFn) -- possible when every node holds a
         single attention- or MLP-family operator, relation operators can take the lazy handle, and every parameter's
         gradient lives in a flat buffer the kernels may add into (a reducer / FlatAdam is attached).  Returns None
@@ -208,7 +208,15 @@ class _Backbone(nn.Module):
         ragged = getattr(y_mask, '_mmnas_ragged', None) if y_mask is not None else None
         if ragged is not None and y_rel_embed is not None and not isinstance(y_rel_embed, RelHandle):
             ragged = None
-        return ops.backbone_chain(x, y, x_mask, y_mask, xr, yr, records, params, op_params, mixed, ragged)
+        if packed and ragged is None:
+            return None           # (packed image rows only make sense on the ragged stream: the caller falls back to padded rows)
+        return ops.backbone_chain(x, y, x_mask, y_mask, xr, yr, records, params, op_params, mixed, ragged, packed)
+
+    def chain_packed(self, x, y_packed, x_mask, y_mask, x_rel_embed, y_rel_embed):
+        """The ragged decoder stream end to end: `y_packed` [sum n_b, d] are the projected VALID region rows (the stem ran
+        on them only), the decoder output comes back packed (for the head's AttFlat over packed rows).  None when the chain
+        or the ragged stream cannot take this call -- the caller then projects the padded rows and calls forward()."""
+        return self._chain(x, y_packed, x_mask, y_mask, x_rel_embed, y_rel_embed, packed=True)
 
     def forward(self, x, y, x_mask, y_mask, x_rel_embed, y_rel_embed):
         out = self._chain(x, y, x_mask, y_mask, x_rel_embed, y_rel_embed)
@@ -297,7 +305,6 @@ class _Net(nn.Module):
         if C.BBOX_FEATURE:
             bb = ops.linear(bbox_feat, self.bboxfeat_linear.weight, self.bboxfeat_linear.bias)
             frcn_feat = torch.cat((frcn_feat, bb), dim=-1)
-        y_in = ops.linear(frcn_feat, self.imgfeat_linear.weight, self.imgfeat_linear.bias)
         # relation embeddings relu(linear_*_rel(raw)) (hygr_vqa.py:110-111): passed down as lazy handles
         # -- the [B,S,S,64] tensors are only materialised if an operator asks for a plain tensor
         if LAZY_REL:
@@ -308,13 +315,27 @@ class _Net(nn.Module):
             if hasattr(self, 'linear_x_rel'):
                 x_rel_embed = ops.linear(x_rel_embed, self.linear_x_rel.weight, self.linear_x_rel.bias, relu=True)
             y_rel_embed = ops.linear(y_rel_embed, self.linear_y_rel.weight, self.linear_y_rel.bias, relu=True)
-        x_out, y_out = self.backnone(x_in, y_in, x_mask, y_mask, x_rel_embed, y_rel_embed)
-        if self.TASK != 'vgd' and ops.chain_enabled() and x_out.is_cuda:
-            # AttFlat x 2 + proj_norm + proj as one native call per direction (needs the flat-gradient sinks)
+        # Ragged decoder stream end to end (round 5): the stem projects the VALID region rows only (packed), the backbone
+        # chain runs on them, the head's AttFlat pools over each sample's own rows -- no padded row is computed anywhere
+        # (hygr_vqa.py:97-122 computes them and masks them out).  Engages when the native head and the chain both do.
+        rg = getattr(y_mask, '_mmnas_ragged', None)
+        packed = None
+        hd = hp = None
+        if self.TASK != 'vgd' and ops.chain_enabled() and frcn_feat.is_cuda:
             hd, hp = ops.head_record(self.attflat_x, self.attflat_y, self.proj_norm, self.proj, self.training)
-            if hd is not None:
-                out = ops.HeadFn.apply(x_out, y_out, x_mask, y_mask, hd, hp)
-                return torch.sigmoid(out.squeeze(-1)) if self.TASK == 'itm' else out
+        if rg is not None and hd is not None:
+            y_pk = ops.linear(ops.pack_rows(frcn_feat, rg), self.imgfeat_linear.weight, self.imgfeat_linear.bias)
+            packed = self.backnone.chain_packed(x_in, y_pk, x_mask, y_mask, x_rel_embed, y_rel_embed)
+        if packed is not None:
+            x_out, y_out = packed
+            out = ops.HeadFn.apply(x_out, y_out, x_mask, y_mask, hd, hp, rg)
+            return torch.sigmoid(out.squeeze(-1)) if self.TASK == 'itm' else out
+        y_in = ops.linear(frcn_feat, self.imgfeat_linear.weight, self.imgfeat_linear.bias)
+        x_out, y_out = self.backnone(x_in, y_in, x_mask, y_mask, x_rel_embed, y_rel_embed)
+        if hd is not None and x_out.is_cuda:
+            # AttFlat x 2 + proj_norm + proj as one native call per direction (needs the flat-gradient sinks)
+            out = ops.HeadFn.apply(x_out, y_out, x_mask, y_mask, hd, hp)
+            return torch.sigmoid(out.squeeze(-1)) if self.TASK == 'itm' else out
         x_out = self.attflat_x(x_out, x_mask)
         if self.TASK == 'vgd':  # per-object scores + box regression (full_vgd.py:105-114)
             y_out = ops.linear(y_out, self.attfc_y.weight, self.attfc_y.bias)

@@ -1206,13 +1206,15 @@ class BackboneFn(torch.autograd.Function):
     are not autograd inputs of this node."""
 
     @staticmethod
-    def forward(ctx, x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None, mixed=None, ragged=None):
+    def forward(ctx, x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None, mixed=None, ragged=None, packed_io=False):
+        """packed_io (with ragged): `y` arrives PACKED [ragged.N, d] (the stem projected the valid region rows only) and the
+        decoder output is returned packed too (the head's AttFlat takes packed rows): no pack / unpack launches at all."""
         lib = L.lib()
         x, y = _f32c(x), _f32c(y)
         B, Sx, d = x.shape
-        Sy = y.shape[1]
-        y_pad = y
-        if ragged is not None:     # the decoder stream on its valid rows only (see Ragged)
+        packed_io = bool(packed_io and ragged is not None)
+        Sy = int(y_mask.shape[-1]) if packed_io else y.shape[1]
+        if ragged is not None and not packed_io:     # the decoder stream on its valid rows only (see Ragged)
             y = pack_rows(y, ragged)
         n = len(records)
         arr = (L.ChainOp * n)(*records)
@@ -1236,9 +1238,9 @@ class BackboneFn(torch.autograd.Function):
         L.check(lib.mmnas_chain_fwd(C.byref(ch), L.stream()))
         ctx.keep = (ch, arr, arena, x, y, xm, ym, xr, yr, x_out, y_out, params)
         ctx.op_params = op_params
-        ctx.ragged = (ragged, B, Sy)
+        ctx.ragged = (ragged, B, Sy, packed_io)
         ctx.counted = _acquire_sinks(ctx, params)
-        if ragged is not None:
+        if ragged is not None and not packed_io:
             return x_out, unpack_rows(y_out, ragged, B, Sy)
         return x_out, y_out
 
@@ -1249,8 +1251,10 @@ class BackboneFn(torch.autograd.Function):
         lib = L.lib()
         ch, arr, arena, x, y, xm, ym, xr, yr, x_out, y_out, params = ctx.keep
         dx_out = _f32c(dx_out) if dx_out is not None else None
-        ragged, B, Sy = ctx.ragged
-        if ragged is not None:     # (the gradient of the zero-filled padding rows is dropped: nothing was computed there)
+        ragged, B, Sy, packed_io = ctx.ragged
+        if packed_io:
+            dy_out = _f32c(dy_out) if dy_out is not None else torch.zeros_like(y_out)
+        elif ragged is not None:     # (the gradient of the zero-filled padding rows is dropped: nothing was computed there)
             dy_out = pack_rows(_f32c(dy_out), ragged) if dy_out is not None else torch.zeros_like(y_out)
         else:
             dy_out = _f32c(dy_out) if dy_out is not None else torch.zeros_like(y_out)
@@ -1282,13 +1286,13 @@ class BackboneFn(torch.autograd.Function):
                 _side_join_queued[0] = True
                 torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
         _release_sinks(ctx, params)   # data-parallel reducers learn which gradients are now completely enqueued
-        if ragged is not None:
+        if ragged is not None and not packed_io:
             dy_in = unpack_rows(dy_in, ragged, B, Sy)
-        return dx_in, dy_in, None, None, None, None, None, None, None, None, None
+        return dx_in, dy_in, None, None, None, None, None, None, None, None, None, None
 
 
-def backbone_chain(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None, mixed=None, ragged=None):
-    return BackboneFn.apply(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params, mixed, ragged)
+def backbone_chain(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None, mixed=None, ragged=None, packed_io=False):
+    return BackboneFn.apply(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params, mixed, ragged, packed_io)
 
 
 class HeadFn(torch.autograd.Function):
@@ -1296,26 +1300,36 @@ class HeadFn(torch.autograd.Function):
     per direction.  As for BackboneFn the parameters' gradients go straight into the flat gradient buffer."""
 
     @staticmethod
-    def forward(ctx, x, y, x_mask, y_mask, hd, params):
+    def forward(ctx, x, y, x_mask, y_mask, hd, params, ragged=None):
+        """ragged (ops.Ragged): `y` holds the PACKED image rows [ragged.N, d] of a ragged decoder stream; AttFlat's masked
+        softmax runs over each sample's own rows (the mask hides exactly the padding rows: modules.py:78-81)."""
         lib = L.lib()
         x, y = _f32c(x), _f32c(y)
         B, Sx, d = x.shape
-        Sy = y.shape[1]
+        if ragged is not None:
+            Sy = int(y_mask.shape[-1])
+            hd.sy.off, hd.sy.M = L.ptr(ragged.off), ragged.N
+        else:
+            Sy = y.shape[1]
+            hd.sy.off, hd.sy.M = None, 0
         xm, ym = _mask_u8(x_mask, B, Sx), _mask_u8(y_mask, B, Sy)
         hd.B, hd.d = B, d
         hd.sx.S, hd.sy.S = Sx, Sy
         hd.sx.x, hd.sy.x, hd.sx.mask, hd.sy.mask = L.fptr(x), L.fptr(y), L.ptr(xm), L.ptr(ym)
-        key = ('head', B, Sx, Sy, d, hd.MID, hd.G, hd.OUT, hd.ANS)
+        key = ('head', B, Sx, Sy, d, hd.MID, hd.G, hd.OUT, hd.ANS)    # (a packed side plans its padded upper bound)
         nbytes = _plan_cache.get(key)
         if nbytes is None:
             sz = C.c_size_t()
+            off, M = hd.sy.off, hd.sy.M
+            hd.sy.off, hd.sy.M = None, 0
             L.check(lib.mmnas_head_plan(C.byref(hd), C.byref(sz)))
+            hd.sy.off, hd.sy.M = off, M
             nbytes = _plan_cache[key] = sz.value
         arena = _bytes(nbytes, x.device)
         logits = torch.empty(B, hd.ANS, dtype=torch.float32, device=x.device)
         hd.arena, hd.logits = L.ptr(arena), L.fptr(logits)
         L.check(lib.mmnas_head_fwd(C.byref(hd), L.stream()))
-        ctx.keep = (hd, arena, x, y, xm, ym, params)
+        ctx.keep = (hd, arena, x, y, xm, ym, params, ragged)
         ctx.counted = _acquire_sinks(ctx, params)
         return logits
 
@@ -1323,14 +1337,14 @@ class HeadFn(torch.autograd.Function):
     def backward(ctx, dlogits):
         if ctx.keep is None:
             raise RuntimeError('HeadFn: backward ran a second time (its arena is released after the first)')
-        hd, arena, x, y, xm, ym, params = ctx.keep
+        hd, arena, x, y, xm, ym, params, ragged = ctx.keep
         dlogits = _f32c(dlogits)
         dx, dy = torch.empty_like(x), torch.empty_like(y)
         hd.dlogits, hd.sx.dx, hd.sy.dx = L.fptr(dlogits), L.fptr(dx), L.fptr(dy)
         L.check(L.lib().mmnas_head_bwd(C.byref(hd), L.stream()))
         ctx.keep = None
         _release_sinks(ctx, params)
-        return dx, dy, None, None, None, None
+        return dx, dy, None, None, None, None, None
 
 
 def head_record(att_x, att_y, ln, proj, training):

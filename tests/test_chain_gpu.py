@@ -494,3 +494,31 @@ def test_hoisted_guided_projections_net_full(task, arch, monkeypatch):
         finally:
             lib.mmnas_set_guided_hoist(prev)
     _compare(outs[1], outs[0])
+
+
+@pytest.mark.parametrize('task,arch,search,mode', [('vqa', 'mmnas_vqa', False, None), ('itm', 'mmnas_itm', False, None),
+                                                   ('vqa', None, True, None), ('vqa', None, True, 'full')])
+def test_ragged_stream_runs_stem_and_head_on_packed_rows(task, arch, search, mode, monkeypatch):
+    """Round 5: with the ragged decoder stream on, the stem projects the valid region rows only (packed), the chain takes and
+    returns packed rows, and AttFlat pools over each sample's own rows (mmnas_attflat_side.off) -- no pack / unpack launch,
+    no padded row computed anywhere; logits and every parameter gradient equal the padded computation's (the imgfeat_linear
+    and AttFlat parameters among them)."""
+    from mmnas_amd import ops
+    packs, heads, chains = [], [], []
+    o_pack, o_unpack, o_head, o_chain = ops.pack_rows, ops.unpack_rows, ops.HeadFn.apply, ops.BackboneFn.apply
+    monkeypatch.setattr(ops, 'pack_rows', lambda x, rg: (packs.append(tuple(x.shape)), o_pack(x, rg))[1])
+    monkeypatch.setattr(ops, 'unpack_rows', lambda *a: (packs.append('unpack'), o_unpack(*a))[1])
+    monkeypatch.setattr(ops.HeadFn, 'apply', lambda *a: (heads.append(len(a) > 6 and a[6] is not None), o_head(*a))[1])
+    plan = None
+    if search:
+        pl = cases.search_plan(np.random.RandomState(5), mode)
+        plan = pl['enc'] + pl['dec']
+    padded = _run_unpad(task, arch, search, False, mode, plan)
+    assert heads == [False] and not packs
+    ragged = _run_unpad(task, arch, search, True, mode, plan)
+    assert heads == [False, True], heads                       # the head took packed image rows
+    assert len(packs) == 1 and packs[0][-1] == 32, packs       # ONE pack: the raw region features (FRCNFEAT_SIZE 32 here)
+    assert ragged[2] == [True]
+    _same(ragged, padded)
+    for k in ('imgfeat_linear.weight', 'imgfeat_linear.bias', 'attflat_y.mlp.fc.linear.weight', 'attflat_y.linear_merge.weight'):
+        assert ragged[1][k] is not None and np.any(ragged[1][k]), k
