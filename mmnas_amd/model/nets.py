@@ -320,22 +320,28 @@ class _Net(nn.Module):
         # (hygr_vqa.py:97-122 computes them and masks them out).  Engages when the native head and the chain both do.
         rg = getattr(y_mask, '_mmnas_ragged', None)
         packed = None
-        hd = hp = None
-        if self.TASK != 'vgd' and ops.chain_enabled() and frcn_feat.is_cuda:
-            hd, hp = ops.head_record(self.attflat_x, self.attflat_y, self.proj_norm, self.proj, self.training)
-        if rg is not None and hd is not None:
+        native_head = self.TASK != 'vgd' and ops.chain_enabled() and frcn_feat.is_cuda
+        # (head_record() draws the head's dropout seeds: it stays BEHIND the backbone call, where the per-operator path draws
+        #  them too -- the seed order is what lets dropout be replayed across the paths)
+        if rg is not None and native_head and ops._sinked((self.attflat_x.mlp.fc.linear.weight,)):
             y_pk = ops.linear(ops.pack_rows(frcn_feat, rg), self.imgfeat_linear.weight, self.imgfeat_linear.bias)
             packed = self.backnone.chain_packed(x_in, y_pk, x_mask, y_mask, x_rel_embed, y_rel_embed)
         if packed is not None:
             x_out, y_out = packed
-            out = ops.HeadFn.apply(x_out, y_out, x_mask, y_mask, hd, hp, rg)
-            return torch.sigmoid(out.squeeze(-1)) if self.TASK == 'itm' else out
-        y_in = ops.linear(frcn_feat, self.imgfeat_linear.weight, self.imgfeat_linear.bias)
-        x_out, y_out = self.backnone(x_in, y_in, x_mask, y_mask, x_rel_embed, y_rel_embed)
-        if hd is not None and x_out.is_cuda:
-            # AttFlat x 2 + proj_norm + proj as one native call per direction (needs the flat-gradient sinks)
-            out = ops.HeadFn.apply(x_out, y_out, x_mask, y_mask, hd, hp)
-            return torch.sigmoid(out.squeeze(-1)) if self.TASK == 'itm' else out
+            hd, hp = ops.head_record(self.attflat_x, self.attflat_y, self.proj_norm, self.proj, self.training)
+            if hd is not None:
+                out = ops.HeadFn.apply(x_out, y_out, x_mask, y_mask, hd, hp, rg)
+                return torch.sigmoid(out.squeeze(-1)) if self.TASK == 'itm' else out
+            y_out = ops.unpack_rows_fn(y_out, rg, frcn_feat.shape[0], frcn_feat.shape[1])   # (no native head after all)
+        else:
+            y_in = ops.linear(frcn_feat, self.imgfeat_linear.weight, self.imgfeat_linear.bias)
+            x_out, y_out = self.backnone(x_in, y_in, x_mask, y_mask, x_rel_embed, y_rel_embed)
+            if native_head and x_out.is_cuda:
+                # AttFlat x 2 + proj_norm + proj as one native call per direction (needs the flat-gradient sinks)
+                hd, hp = ops.head_record(self.attflat_x, self.attflat_y, self.proj_norm, self.proj, self.training)
+                if hd is not None:
+                    out = ops.HeadFn.apply(x_out, y_out, x_mask, y_mask, hd, hp)
+                    return torch.sigmoid(out.squeeze(-1)) if self.TASK == 'itm' else out
         x_out = self.attflat_x(x_out, x_mask)
         if self.TASK == 'vgd':  # per-object scores + box regression (full_vgd.py:105-114)
             y_out = ops.linear(y_out, self.attfc_y.weight, self.attfc_y.bias)

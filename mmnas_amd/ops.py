@@ -1200,6 +1200,23 @@ def unpack_rows(xp, rg, B, S):
     return out
 
 
+class _UnpackRowsFn(torch.autograd.Function):
+    """unpack_rows with a gradient (the rare route: packed decoder output, but no native head to take it)."""
+
+    @staticmethod
+    def forward(ctx, xp, rg, B, S):
+        ctx.rg = rg
+        return unpack_rows(_f32c(xp), rg, B, S)
+
+    @staticmethod
+    def backward(ctx, g):
+        return pack_rows(_f32c(g), ctx.rg), None, None, None
+
+
+def unpack_rows_fn(xp, rg, B, S):
+    return _UnpackRowsFn.apply(xp, rg, B, S)
+
+
 class BackboneFn(torch.autograd.Function):
     """Backbone_*.forward (hygr_vqa.py:45-52) through mmnas_chain_fwd/bwd.  Parameter gradients go straight into the
     flat gradient buffer (every parameter of the chain has an attached sink: checked by the caller), so the parameters
