@@ -283,7 +283,10 @@ def _same(a, b, gtol=4e-5):   # (summation order: packed and padded batches cut 
         assert g_a[k] is not None, k
         diff = float(np.abs(g_a[k] - g_b[k]).max())
         t = max(gtol, REL_PATH_SELF_TOL) if is_rel_path(k) else gtol
-        assert diff <= t * max(float(np.abs(g_b[k]).max()), 1e-3 * top), (k, diff, float(np.abs(g_b[k]).max()))
+        # (floor: gradients that are small against the largest one in the net are compared on that scale -- 1e-3 of it, 3e-3
+        #  for the cancellation-limited relation path)
+        floor = (3e-3 if is_rel_path(k) else 1e-3) * top
+        assert diff <= t * max(float(np.abs(g_b[k]).max()), floor), (k, diff, float(np.abs(g_b[k]).max()))
 
 
 @pytest.mark.parametrize('task,arch', [('vqa', 'mmnas_vqa'), ('vqa', 'mcan'), ('itm', 'mmnas_itm')])
@@ -294,7 +297,9 @@ def test_ragged_decoder_stream_equals_the_padded_computation_net_full(task, arch
     padded = _run_unpad(task, arch, False, False)
     ragged = _run_unpad(task, arch, False, True)
     assert padded[2] == [False] and ragged[2] == [True]
-    _same(ragged, padded)
+    # (round 5: the head pools over packed rows too -- AttFlat's glimpse-logit weight gradient, a cancelling sum over the
+    #  region rows, is reduced in another order: 9e-8 of the net's largest gradient entry apart)
+    _same(ragged, padded, gtol=1e-4)
 
 
 @pytest.mark.parametrize('mode,B,Sy', [(None, 5, 23), ('full', 5, 23), (None, 1, 40), ('full', 2, 128), (None, 3, 33)])
@@ -519,6 +524,6 @@ def test_ragged_stream_runs_stem_and_head_on_packed_rows(task, arch, search, mod
     assert heads == [False, True], heads                       # the head took packed image rows
     assert len(packs) == 1 and packs[0][-1] == 32, packs       # ONE pack: the raw region features (FRCNFEAT_SIZE 32 here)
     assert ragged[2] == [True]
-    _same(ragged, padded)
+    _same(ragged, padded, gtol=1e-4)
     for k in ('imgfeat_linear.weight', 'imgfeat_linear.bias', 'attflat_y.mlp.fc.linear.weight', 'attflat_y.linear_merge.weight'):
         assert ragged[1][k] is not None and np.any(ragged[1][k]), k
