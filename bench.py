@@ -729,7 +729,9 @@ def main():
                 while True:
                     yield batches[i % len(batches)]
                     i += 1
-            it = iter(DevicePrefetcher(endless(), dev))   # batch i + 1 uploads on the copy stream while step i computes
+            # batch i + 1 uploads on the copy stream while step i computes; the region counts ride on the features (checked
+            # against the zero-row padding on the host copy): the ragged stream then needs no device-to-host copy per batch
+            it = iter(DevicePrefetcher(endless(), dev, lengths=(0, 3)))
 
             def step():
                 frcn, bbox, boxes, nobj, ques, x_rel, tgt = next(it)

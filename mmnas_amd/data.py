@@ -124,11 +124,17 @@ class DevicePrefetcher:
     lengths=(features_key, lengths_key): the batch element `lengths_key` (a CPU int tensor / array with the number of
     detected regions per sample, which the loaders know: load_data_vqa.py:221-246 pads behind them) is attached to the
     DEVICE copy of element `features_key` as `_mmnas_lengths` -- what ops.ragged_info_for reads when the ragged decoder
-    stream is on (ops.set_unpad), so a fresh batch per step needs no device-to-host copy to learn its lengths."""
+    stream is on (ops.set_unpad), so a fresh batch per step needs no device-to-host copy to learn its lengths.
+    CONTRACT (the loaders', load_data_vqa.py:221-246: `proc_img_feat` zero-pads behind the detected boxes): sample b's rows
+    0 .. n_b - 1 are its regions (non-zero rows) and rows n_b .. S - 1 are all-zero -- the same rows the networks' masks
+    (make_mask: all-zero feature rows) call padding.  The counts are checked against the HOST copy of the features before
+    the upload, because the ragged stream trusts them: `validate` = 'boundary' (default: row n_b - 1 non-zero, row n_b
+    all-zero -- two rows per sample), 'full' (every row: one pass over the batch on the host) or None."""
 
-    def __init__(self, loader, device, lengths=None):
+    def __init__(self, loader, device, lengths=None, validate='boundary'):
         self.loader = loader
         self.lengths = lengths
+        self.validate = validate
         self.device = torch.device(device)
         self.cuda = self.device.type == 'cuda'
         self.stream = torch.cuda.Stream(self.device) if self.cuda else None
@@ -153,8 +159,30 @@ class DevicePrefetcher:
                 out = self._map(batch, lambda t: (t if t.is_pinned() else t.pin_memory()).to(self.device, non_blocking=True))
         if self.lengths is not None:
             fk, lk = self.lengths
-            out[fk]._mmnas_lengths = [int(v) for v in self._to_tensor(batch[lk]).reshape(-1).tolist()]   # host values: no sync
+            lens = [int(v) for v in self._to_tensor(batch[lk]).reshape(-1).tolist()]   # host values: no sync
+            if self.validate:
+                self._check_lengths(self._to_tensor(batch[fk]), lens)
+            out[fk]._mmnas_lengths = lens
         return out
+
+    def _check_lengths(self, feat, lens):
+        """The region counts against the all-zero-row mask the networks derive from the same features (see CONTRACT)."""
+        if feat.is_cuda or feat.dim() != 3 or len(lens) != feat.shape[0]:
+            raise ValueError('DevicePrefetcher(lengths=...): %d counts for features of shape %s' % (len(lens), tuple(feat.shape)))
+        S = feat.shape[1]
+        if self.validate == 'full':
+            nz = (feat != 0).any(-1)
+            want = torch.arange(S)[None, :] < torch.tensor(lens)[:, None]
+            bad = (nz != want).any(-1).nonzero().reshape(-1).tolist()
+        else:
+            bad = []
+            for b, n in enumerate(lens):
+                ok = 0 <= n <= S and (n == 0 or bool((feat[b, n - 1] != 0).any())) and (n == S or not bool((feat[b, n] != 0).any()))
+                if not ok:
+                    bad.append(b)
+        if bad:
+            raise ValueError('DevicePrefetcher: region counts disagree with the zero-row padding of the features for samples %s '
+                             '(count n_b: rows < n_b non-zero, rows >= n_b all-zero)' % bad[:8])
 
     def __iter__(self):
         it = iter(self.loader)

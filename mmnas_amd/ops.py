@@ -1155,6 +1155,8 @@ def ragged_info_for(feat, mask):
     object and its version counter: a resident batch pays it once)."""
     if not unpad_enabled() or not feat.is_cuda or feat.dim() != 3:
         return None
+    if side_stream_enabled():      # the chain's side-stream backward runs on padded rows only (mmnas_chain_bwd refuses the
+        return None                # combination -- in the middle of autograd): decide here, before anything is packed
     B, S = feat.shape[0], feat.shape[1]
     if S > 128:
         return None

@@ -147,12 +147,41 @@ def test_device_relation_kernels_vs_reference_loader():
         assert np.allclose(out[i], want, rtol=2e-5, atol=2e-5), i
 
 
+def _feat(lens, S=5, F=4):
+    import torch
+    f = torch.zeros(len(lens), S, F)
+    for b, n in enumerate(lens):
+        f[b, :n] = 1.0 + b
+    return f
+
+
 def test_prefetcher_attaches_the_region_counts_to_the_features():
     """DevicePrefetcher(lengths=...): the loaders' region counts ride on the features tensor (CPU pass-through here)."""
     import torch
     from mmnas_amd.data import DevicePrefetcher
-    batches = [(torch.zeros(3, 5, 4), torch.tensor([5, 2, 4], dtype=torch.int32)), {'f': torch.zeros(2, 5, 4), 'n': np.array([1, 5])}]
+    batches = [(_feat([5, 2, 4]), torch.tensor([5, 2, 4], dtype=torch.int32)), {'f': _feat([1, 5]), 'n': np.array([1, 5])}]
     out = list(DevicePrefetcher(batches[:1], 'cpu', lengths=(0, 1)))
     assert out[0][0]._mmnas_lengths == [5, 2, 4]
     out = list(DevicePrefetcher(batches[1:], 'cpu', lengths=('f', 'n')))
     assert out[0]['f']._mmnas_lengths == [1, 5]
+
+
+def test_prefetcher_checks_the_counts_against_the_zero_row_padding():
+    """the ragged stream trusts the counts the pipeline attaches, while the masks come from the all-zero feature
+    rows -- the two must agree.  Checked on the host copy before the upload: boundary rows by default, every row with
+    validate='full'; a disagreement raises instead of silently changing logits."""
+    import pytest
+    import torch
+    from mmnas_amd.data import DevicePrefetcher
+    good = _feat([5, 2, 4])
+    for lens in ([5, 3, 4], [5, 1, 4], [4, 2, 4]):            # count too large / too small for the zero-row mask
+        with pytest.raises(ValueError, match='region counts disagree'):
+            list(DevicePrefetcher([(good, torch.tensor(lens))], 'cpu', lengths=(0, 1)))
+    hole = _feat([5, 4, 4])
+    hole[1, 1] = 0                                              # an all-zero row INSIDE the prefix: only the full check sees it
+    assert list(DevicePrefetcher([(hole, torch.tensor([5, 4, 4]))], 'cpu', lengths=(0, 1)))
+    with pytest.raises(ValueError, match='region counts disagree'):
+        list(DevicePrefetcher([(hole, torch.tensor([5, 4, 4]))], 'cpu', lengths=(0, 1), validate='full'))
+    assert list(DevicePrefetcher([(hole, torch.tensor([5, 3, 4]))], 'cpu', lengths=(0, 1), validate=None))   # unchecked on request
+    with pytest.raises(ValueError, match='counts for features'):
+        list(DevicePrefetcher([(good, torch.tensor([5, 2]))], 'cpu', lengths=(0, 1)))
