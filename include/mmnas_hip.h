@@ -403,6 +403,10 @@ int mmnas_set_rel_hoist(int on);
  * grouped gradient-pair launches behind the last guided operator.  MMNAS_GUIDED_HOIST=0 / mmnas_set_guided_hoist(0): one
  * launch set per operator; returns the previous setting. */
 int mmnas_set_guided_hoist(int on);
+/* The image stream's relation launches of a chain on a second stream beside the language stream's operators (forward: joined in
+ * front of the decoder's first relation operator; backward: joined at the end of mmnas_chain_bwd).  MMNAS_REL_OVERLAP=0 /
+ * mmnas_set_rel_overlap(0): everything on the caller's stream; returns the previous setting. */
+int mmnas_set_rel_overlap(int on);
 
 /* ------------------------------------------------------------------------------------------
  * Attention core: MHAtt.att (modules.py:191-199) for all (batch, head) pairs.

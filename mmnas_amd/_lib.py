@@ -180,6 +180,7 @@ SYMBOLS = {
     'mmnas_rel_multi_bwd': (_i, [C.POINTER(RelMulti), _fp]),
     'mmnas_set_rel_hoist': (_i, [_i]),
     'mmnas_set_guided_hoist': (_i, [_i]),
+    'mmnas_set_rel_overlap': (_i, [_i]),
     'mmnas_mha_core_fwd': (_i, [C.POINTER(MhaDesc), _fp]),
     'mmnas_mha_core_bwd': (_i, [C.POINTER(MhaDesc), _fp]),
     'mmnas_att_op_plan': (_i, [C.POINTER(AttOp), C.POINTER(Plan)]),

@@ -845,10 +845,23 @@ static void chain_rel_groups(const mmnas_chain* c, const ChainLayout& L, bool bw
     G.hoisted[i] = true;
   }
 }
-static int chain_rel_fwd(const RelGroups& G, hipStream_t st) {
+static int chain_rel_fwd(const RelGroups& G, hipStream_t st, int only = -1) {
   for (int s = 0; s < 2; ++s)
-    for (const auto& g : G.groups[s]) { const int rc = mmnas_rel_multi_fwd(&g, st); if (rc) return rc; }
+    if (only < 0 || only == s)
+      for (const auto& g : G.groups[s]) { const int rc = mmnas_rel_multi_fwd(&g, st); if (rc) return rc; }
   return MMNAS_OK;
+}
+// The image stream's relation launches BESIDE the language stream's operators (round 5, MMNAS_REL_OVERLAP, default on).  The
+// encoder is a dependent chain of ~40 launches of 56-224 workgroups on 896 rows -- 0.25 ms forward, 0.35 ms backward during
+// which most of the chip idles -- and the image stream's relation bias depends on nothing it computes: forward it is issued
+// on the side stream at chain entry and joined in front of the first relation operator of the decoder; backward it is issued
+// on the side stream behind the decoder's first operator (every bias gradient exists) and joined at the end of the call,
+// while the encoder's backward runs on the caller's stream.  A bucket mark that covers the relation parameters is recorded
+// on the side stream behind the launch (the side stream waited for the caller's stream first: the event covers both).
+static int g_rel_overlap = -1;
+static bool rel_overlap_on() {
+  if (g_rel_overlap < 0) { const char* e = getenv("MMNAS_REL_OVERLAP"); g_rel_overlap = (e && e[0] ? atoi(e) : 1) ? 1 : 0; }
+  return g_rel_overlap != 0;
 }
 static int chain_rel_bwd(const RelGroups& G, int stream_y, hipStream_t st) {
   for (const auto& g : G.groups[stream_y]) {
@@ -954,6 +967,12 @@ static int chain_guided_kv_bwd(const mmnas_chain* c, const ChainLayout& L, const
 
 }  // namespace mmnas
 
+extern "C" int mmnas_set_rel_overlap(int on) {
+  const int prev = mmnas::rel_overlap_on() ? 1 : 0;
+  mmnas::g_rel_overlap = on ? 1 : 0;
+  return prev;
+}
+
 extern "C" int mmnas_set_guided_hoist(int on) {
   const int prev = mmnas::guided_hoist_on() ? 1 : 0;
   mmnas::g_guided_hoist = on ? 1 : 0;
@@ -1024,11 +1043,17 @@ static int chain_fwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
   int rc;
   RelGroups RG;     // every relation candidate's bias (18 in the VQA search space) before the first node
   chain_rel_groups(c, L, false, RG);
-  if ((rc = chain_rel_fwd(RG, st))) return rc;
+  SideCtx* rsc = (rel_overlap_on() && !RG.groups[1].empty() && L.last_x >= 0 && L.first_y >= 0) ? side_ctx(st, true) : nullptr;
+  if (rsc) {   // the image stream's candidates beside the encoder nodes (see rel_overlap_on); joined in front of the first decoder node
+    if ((rc = ev_fork(st, rsc->side, rsc->ovl[0]))) return rc;
+    if ((rc = chain_rel_fwd(RG, rsc->side, 1))) return rc;
+    if ((rc = chain_rel_fwd(RG, st, 0))) return rc;
+  } else if ((rc = chain_rel_fwd(RG, st))) return rc;
   for (int i0 = 0; i0 < c->n_ops;) {
     int i1 = i0;
     while (i1 < c->n_ops && c->ops[i1].node == c->ops[i0].node) ++i1;
     const bool oy = c->ops[i0].on_y;
+    if (rsc && i0 == L.first_y && (rc = ev_fork(rsc->side, st, rsc->ovl[1]))) return rc;   // every relation bias exists from here on
     const float* cur = oy ? cur_y : cur_x;
     const float* z[MMNAS_MIXED_MAX]; const float* la[MMNAS_MIXED_MAX]; const float* lb[MMNAS_MIXED_MAX];
     float gate_order[MMNAS_MIXED_MAX];
@@ -1167,6 +1192,7 @@ static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
   int n_red = 0;
   RelGroups RG;     // the sampled relation candidates: their bias gradients wait for one launch behind the stream's first node
   chain_rel_groups(c, L, true, RG);
+  SideCtx* rel_bwd_side = nullptr;
   for (int k = nn - 1; k >= 0; --k) {
     const int i0 = starts[k], i1 = starts[k + 1];
     const bool oy = c->ops[i0].on_y;
@@ -1227,13 +1253,23 @@ static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
       if ((rc = mlp_bwd_impl(&m, st, nullptr))) return rc;
     }
     cur_dy = dx;
-    if (i0 == L.first_y && (rc = chain_rel_bwd(RG, 1, st))) return rc;
+    hipStream_t mark_stream = st;
+    if (i0 == L.first_y && !RG.groups[1].empty()) {
+      SideCtx* rsc = (rel_overlap_on() && L.last_x >= 0) ? side_ctx(st, true) : nullptr;
+      if (rsc) {   // beside the encoder nodes' backward; joined at the end of the call
+        if ((rc = ev_fork(st, rsc->side, rsc->ovl[2]))) return rc;
+        if ((rc = chain_rel_bwd(RG, 1, rsc->side))) return rc;
+        rel_bwd_side = rsc;
+        mark_stream = rsc->side;
+      } else if ((rc = chain_rel_bwd(RG, 1, st))) return rc;
+    }
     if (i0 == L.first_x && (rc = chain_rel_bwd(RG, 0, st))) return rc;
-    if (c->marks && c->marks[act_op] && hipEventRecord((hipEvent_t)c->marks[act_op], st) != hipSuccess) {
+    if (c->marks && c->marks[act_op] && hipEventRecord((hipEvent_t)c->marks[act_op], mark_stream) != hipSuccess) {
       set_error("chain_bwd: cannot record the mark event of operator %d", act_op);
       return MMNAS_E_LAUNCH;
     }
   }
+  if (rel_bwd_side && (rc = ev_fork(rel_bwd_side->side, st, rel_bwd_side->ovl[3]))) return rc;   // the relation gradients are in
   if (n_red && (rc = mixed_reduce_many(red_part, red_out, red_nwg, red_n, n_red, st))) return rc;   // every node's gate gradients
   if (L.first_y < 0 && hipMemcpyAsync(c->dy_in, c->dy_out, ey * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return MMNAS_E_LAUNCH;
   if (L.first_x < 0) {
@@ -1263,9 +1299,20 @@ extern "C" int mmnas_chain_fwd(const mmnas_chain* c, void* stream) {
   const size_t nx = (size_t)c->B * c->Sx * c->d * sizeof(float), ny = chain_rows_y(c) * c->d * sizeof(float);
   RelGroups RG;     // the relation bias of every relation operator of the chain: one launch per stream, here
   chain_rel_groups(c, L, false, RG);
-  if ((rc = chain_rel_fwd(RG, st))) return rc;
   const int G = first_guided(c);
   const bool ovl = chain_overlap_on() && !c->use_side_stream && L.last_x >= 0 && L.first_y >= 0 && G > L.first_y;
+  // the image stream's bias beside the encoder (see rel_overlap_on): joined in front of the decoder's first relation operator
+  int rel_join_at = -1;
+  SideCtx* rsc = nullptr;
+  if (!ovl && rel_overlap_on() && !RG.groups[1].empty() && L.last_x >= 0 && (rsc = side_ctx(st, true)) != nullptr) {
+    for (int i = L.first_y; i < c->n_ops && rel_join_at < 0; ++i)
+      if (RG.hoisted[i] && c->ops[i].on_y) rel_join_at = i;
+  }
+  if (rel_join_at >= 0) {
+    if ((rc = ev_fork(st, rsc->side, rsc->ovl[0]))) return rc;
+    if ((rc = chain_rel_fwd(RG, rsc->side, 1))) return rc;
+    if ((rc = chain_rel_fwd(RG, st, 0))) return rc;
+  } else if ((rc = chain_rel_fwd(RG, st))) return rc;
   GuidedSet GS;
   chain_guided_set(c, false, !ovl, GS);
   auto run = [&](int i, hipStream_t s) -> int {
@@ -1292,6 +1339,7 @@ extern "C" int mmnas_chain_fwd(const mmnas_chain* c, void* stream) {
     for (int i = 0; i < c->n_ops; ++i) {
       // the final language state exists: key / value projections of every guided operator (grouped launches)
       if (GS.n && i == G && (rc = chain_guided_kv_fwd(c, L, GS, cur_x, st))) return rc;
+      if (i == rel_join_at && (rc = ev_fork(rsc->side, st, rsc->ovl[1]))) return rc;   // the image stream's bias exists from here on
       if ((rc = run(i, st))) return rc;
     }
   } else {
@@ -1351,6 +1399,7 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
   GuidedSet GS;     // guided operators whose dK / dV wait for the grouped launches behind operator G
   chain_guided_set(c, true, !ovl, GS);
   const float* enc_grad = nullptr;   // set by the hoisted launch: the encoder's output gradient, complete
+  SideCtx* rel_bwd_side = nullptr;   // set when the image stream's relation backward went to the side stream: joined below
   if (L.n_guided > GS.n && hipMemsetAsync(dpre, 0, ex * sizeof(float), st) != hipSuccess) return MMNAS_E_LAUNCH;
   // one operator's backward on stream s: gradient of its output in, gradient of its input out (returned through *dxo)
   auto run = [&](int i, hipStream_t s, const float* dyi, const float** dxo) -> int {
@@ -1381,11 +1430,20 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
     *dxo = dx;
     // (the stream's first operator is its last in backward order: every relation operator's bias gradient exists now --
     //  before this operator's mark, which covers the relation parameters, see nets._chain)
-    if (i == L.first_y && (r = chain_rel_bwd(RG, 1, s))) return r;
+    hipStream_t mark_stream = s;
+    if (i == L.first_y && !RG.groups[1].empty()) {
+      SideCtx* rsc = (rel_overlap_on() && L.last_x >= 0 && !sq) ? side_ctx(st, true) : nullptr;
+      if (rsc) {   // beside the encoder's backward (see rel_overlap_on); joined at the end of the call
+        if ((r = ev_fork(s, rsc->side, rsc->ovl[2]))) return r;
+        if ((r = chain_rel_bwd(RG, 1, rsc->side))) return r;
+        rel_bwd_side = rsc;
+        mark_stream = rsc->side;
+      } else if ((r = chain_rel_bwd(RG, 1, s))) return r;
+    }
     if (i == L.first_x && (r = chain_rel_bwd(RG, 0, s))) return r;
     // (encoder / decoder overlap: an event behind operator i on ONE of the two streams says nothing about the operators
     //  with larger indices still running on the other -- the marks are recorded behind the join below instead)
-    if (!ovl && c->marks && c->marks[i] && hipEventRecord((hipEvent_t)c->marks[i], s) != hipSuccess) {
+    if (!ovl && c->marks && c->marks[i] && hipEventRecord((hipEvent_t)c->marks[i], mark_stream) != hipSuccess) {
       set_error("chain_bwd: cannot record the mark event of operator %d", i);
       return MMNAS_E_LAUNCH;
     }
@@ -1433,6 +1491,7 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
           return MMNAS_E_LAUNCH;
         }
   }
+  if (rel_bwd_side && (rc = ev_fork(rel_bwd_side->side, st, rel_bwd_side->ovl[3]))) return rc;   // the relation gradients are in
   if (L.first_y < 0 && hipMemcpyAsync(c->dy_in, c->dy_out, ey * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return MMNAS_E_LAUNCH;
   if (L.first_x < 0) {
     const float* g0 = c->dx_out;

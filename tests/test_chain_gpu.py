@@ -527,3 +527,29 @@ def test_ragged_stream_runs_stem_and_head_on_packed_rows(task, arch, search, mod
     _same(ragged, padded, gtol=1e-4)
     for k in ('imgfeat_linear.weight', 'imgfeat_linear.bias', 'attflat_y.mlp.fc.linear.weight', 'attflat_y.linear_merge.weight'):
         assert ragged[1][k] is not None and np.any(ragged[1][k]), k
+
+
+@pytest.mark.parametrize('mode,unpad', [(None, False), ('full', False), (None, True)])
+def test_relation_launches_beside_the_encoder_give_the_same_result(mode, unpad):
+    """mmnas_set_rel_overlap: the image stream's relation-bias launches on the chain's side stream beside the language
+    stream's operators (fork / join by events) against everything on one stream -- the same kernels on the same data, so
+    every number is bit-equal; three repetitions (a missing dependency between the streams shows as a changing result)."""
+    from mmnas_amd import _lib as L
+    lib = L.lib()
+    flat = _rel_heavy_plan(mode, 6)
+    outs = []
+    for on in (0, 1, 1, 1):
+        prev = lib.mmnas_set_rel_overlap(on)
+        try:
+            outs.append(_run_unpad('vqa', None, True, unpad, mode, flat, B=4, Sy=19))
+        finally:
+            lib.mmnas_set_rel_overlap(prev)
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0])
+        for k, g in outs[0][1].items():
+            if g is None:
+                continue
+            # (bit-equal except where split-K weight-gradient pieces add with float atomics in hardware order)
+            assert np.allclose(o[1][k], g, rtol=0, atol=2e-5 * max(float(np.abs(g).max()), 1e-12)), k
+            if 'linear_r' in k or '_rel.' in k:
+                assert np.array_equal(o[1][k], g), k

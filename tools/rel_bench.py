@@ -38,6 +38,33 @@ def main():
             torch.cuda.synchronize()
             out.append('%s %6.1f us' % (name, e0.elapsed_time(e1) * 1e3 / 30))
         print('B=%d S=%3d C=%d H=%d | %s  (bwd includes the 5 us partial-row reduction launch)' % (B, S, C, H, ' | '.join(out)))
+        # all relation operators of a stream in one launch per direction (relmulti.hip)
+        import ctypes as C_
+        for n_ops in (1, 6, 8, 18):
+            Wrs = [torch.randn(H, 64, device=dev) * 0.2 for _ in range(n_ops)]
+            brs = [torch.rand(H, device=dev) for _ in range(n_ops)]
+            biases = [torch.empty(B, H, S, S, device=dev) for _ in range(n_ops)]
+            dbs = [torch.randn(B, H, S, S, device=dev) for _ in range(n_ops)]
+            dWrs, dbrs = [torch.zeros(H, 64, device=dev) for _ in range(n_ops)], [torch.zeros(H, device=dev) for _ in range(n_ops)]
+            wsm = torch.empty(lib.mmnas_rel_multi_bwd_ws_floats(B, S), device=dev)
+            m = L.RelMulti()
+            m.B, m.S, m.C, m.R, m.H, m.n_ops = B, S, C, 64, H, n_ops
+            m.raw, m.Wy, m.by, m.dWy, m.dby, m.ws = L.fptr(raw), L.fptr(Wy), L.fptr(by), L.fptr(dWy), L.fptr(dby), L.fptr(wsm)
+            for i in range(n_ops):
+                m.Wr[i], m.br[i], m.biasT[i], m.dbiasT[i], m.dWr[i], m.dbr[i] = (L.fptr(t) for t in (Wrs[i], brs[i], biases[i], dbs[i], dWrs[i], dbrs[i]))
+            out = []
+            for name, fn in (('fwd', lambda: lib.mmnas_rel_multi_fwd(C_.byref(m), L.stream())), ('bwd', lambda: lib.mmnas_rel_multi_bwd(C_.byref(m), L.stream()))):
+                for _ in range(5):
+                    L.check(fn())
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(30):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                out.append('%s %6.1f us' % (name, e0.elapsed_time(e1) * 1e3 / 30))
+            print('    rel_multi, %2d operators in one call | %s' % (n_ops, ' | '.join(out)))
 
 
 if __name__ == '__main__':
