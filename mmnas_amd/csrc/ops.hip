@@ -851,7 +851,10 @@ static int chain_rel_fwd(const RelGroups& G, hipStream_t st, int only = -1) {
       for (const auto& g : G.groups[s]) { const int rc = mmnas_rel_multi_fwd(&g, st); if (rc) return rc; }
   return MMNAS_OK;
 }
-// The image stream's relation launches BESIDE the language stream's operators (round 5, MMNAS_REL_OVERLAP, default on).  The
+// The image stream's relation launches BESIDE the language stream's operators (round 5, MMNAS_REL_OVERLAP=1; OFF by default:
+// MEASURED SLOWER -- supernet step 4.70 -> 4.81-4.88 ms, arch step 8.02 -> 8.21-8.25 ms, three alternations on one box: the
+// fourth form of stream overlap tried on this path and the fourth that lost to the cross-stream event waits and to the
+// co-running kernels slowing each other; kept because the fork / join structure is tested and documents the negative).  The
 // encoder is a dependent chain of ~40 launches of 56-224 workgroups on 896 rows -- 0.25 ms forward, 0.35 ms backward during
 // which most of the chip idles -- and the image stream's relation bias depends on nothing it computes: forward it is issued
 // on the side stream at chain entry and joined in front of the first relation operator of the decoder; backward it is issued
@@ -860,7 +863,7 @@ static int chain_rel_fwd(const RelGroups& G, hipStream_t st, int only = -1) {
 // on the side stream behind the launch (the side stream waited for the caller's stream first: the event covers both).
 static int g_rel_overlap = -1;
 static bool rel_overlap_on() {
-  if (g_rel_overlap < 0) { const char* e = getenv("MMNAS_REL_OVERLAP"); g_rel_overlap = (e && e[0] ? atoi(e) : 1) ? 1 : 0; }
+  if (g_rel_overlap < 0) { const char* e = getenv("MMNAS_REL_OVERLAP"); g_rel_overlap = (e && e[0] ? atoi(e) : 0) ? 1 : 0; }
   return g_rel_overlap != 0;
 }
 static int chain_rel_bwd(const RelGroups& G, int stream_y, hipStream_t st) {
