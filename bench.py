@@ -970,7 +970,8 @@ def main():
                 t_a, txt_a = cpu_step_seconds(S['cfg'], net, S['cpu'][0], S['cpu'][1], None,
                                               {'mode': 'full', 'enc': plan[:12], 'dec': plan[12:]}, args.cpu_budget)
             if 'search_vqa' in recs:
-                recs['search_vqa']['cpu_baseline'] = {'value': 1.0 / t_w, 'unit': 'steps/s', 'cores': threads, 'kind': 'port', 'sample': txt_w}
+                recs['search_vqa']['cpu_baseline'] = {'value': 1.0 / t_w, 'unit': 'steps/s', 'cores': threads, 'kind': 'port', 'sample': txt_w,
+                                                      'host_cpus': os.cpu_count()}   # (`cores` = threads used: capped at 32, see cpu_threads)
             if 'arch_vqa' in recs:
                 recs['arch_vqa']['cpu_baseline'] = {'value': 1.0 / t_a, 'unit': 'steps/s', 'cores': threads, 'kind': 'port', 'sample': txt_a}
             if 'bilevel_vqa' in recs:
