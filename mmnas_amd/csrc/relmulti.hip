@@ -37,6 +37,7 @@ constexpr int RM_ROW = RM_ROWS * RM_R + RM_R * RM_CP + RM_ROWS;   // partial row
 struct RelMultiK {
   const float* raw;
   int B, S, C, H, nrows, nops;
+  int dbg;                               // timing experiments only (MMNAS_REL_MULTI_DBG): 1 no stores, 2 no raw reloads, 4 no head-projection MFMAs
   const int* off; const int* toff;       // ragged batches (see relfused.hip); NULL = all S x S elements
   float* part;                           // backward: partial rows [grid][RM_ROW]
   const float* Wr[MMNAS_REL_MULTI_MAX];  // per operator of this launch: linear_r.weight [H, 64], .bias [H]
@@ -153,7 +154,15 @@ __device__ __forceinline__ void rm_wy_operand(const float* __restrict__ Wy, cons
 }
 
 // ------------------------------------------------------------------------------------------------------------ forward
-template <int C, int NT>
+// Y (tuning): s_nop behind every MFMA of the long dependent chains.  A wave whose next instruction is another MFMA holds the
+// SIMD's issue port until the matrix pipe takes it (docs/LAB_NOTES.md, the round-3 overlap probe), so the other waves' vector
+// work -- here a third of a tile: relu, log, addresses, stores -- cannot run beside the chain; the nop lets them in.
+template <int Y> __device__ __forceinline__ void rm_yield() {
+  if constexpr (Y == 1) asm volatile("s_nop 1");
+  if constexpr (Y == 3) asm volatile("s_nop 3");
+}
+
+template <int C, int NT, int Y>
 __global__ void __launch_bounds__(256) rel_multi_fwd_kernel(const RelMultiK p, int ntiles, int tpb, const float* __restrict__ Wy,
                                                             const float* __restrict__ by) {
   __shared__ float sWrA[NT * RM_ROWS * RM_R];
@@ -183,7 +192,7 @@ __global__ void __launch_bounds__(256) rel_multi_fwd_kernel(const RelMultiK p, i
     const unsigned eoff = (unsigned)cur.b * (unsigned)p.H * SS + cur.fc;   // (host: B H S^2 < 2^31)
     wk.next(p);
     cur = rm_elem(p, wk.cb, wk.ct, l31);
-    ext = rm_raw<C>(p, cur);         // the next tile's raw row: in flight during this tile's MFMA chain
+    if (!(p.dbg & 2)) ext = rm_raw<C>(p, cur);         // the next tile's raw row: in flight during this tile's MFMA chain
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
       if (rt * RM_ROWS >= p.nrows) break;
@@ -193,7 +202,7 @@ __global__ void __launch_bounds__(256) rel_multi_fwd_kernel(const RelMultiK p, i
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rr = mfma32(sWrA[(rt * 32 + 16 * t + r) * 64 + lane], hid[t][r], rr);
+        for (int r = 0; r < 16; ++r) { if (!(p.dbg & 4) || r == 0) { rr = mfma32(sWrA[(rt * 32 + 16 * t + r) * 64 + lane], hid[t][r], rr); rm_yield<Y>(); } }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {        // registers 4u .. 4u + 3 hold rows 8u + 4 hh + 0..3: contiguous table entries
         const int row = rt * RM_ROWS + 8 * u + 4 * hh;
@@ -202,7 +211,7 @@ __global__ void __launch_bounds__(256) rel_multi_fwd_kernel(const RelMultiK p, i
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float* const o = sIo[row + i];
-          if (ok && o) o[eoff] = __logf(fmaxf(rr[4 * u + i] + bv[i], 1e-6f));   // max(relu(r), 1e-6) == max(r, 1e-6)
+          if (ok && o && !((p.dbg & 1) && rr[4 * u + i] != 12345.f)) o[eoff] = __logf(fmaxf(rr[4 * u + i] + bv[i], 1e-6f));   // max(relu(r), 1e-6) == max(r, 1e-6)
         }
       }
     }
@@ -210,7 +219,7 @@ __global__ void __launch_bounds__(256) rel_multi_fwd_kernel(const RelMultiK p, i
 }
 
 // ----------------------------------------------------------------------------------------------------------- backward
-template <int C>
+template <int C, int Y>
 __global__ void __launch_bounds__(256, 2) rel_multi_bwd_kernel(const RelMultiK p, int ntiles, int tpb, const float* __restrict__ Wy,
                                                                const float* __restrict__ by) {
   __shared__ __attribute__((aligned(16))) float sHidAll[4][32 * RM_LDH];
@@ -282,7 +291,7 @@ __global__ void __launch_bounds__(256, 2) rel_multi_bwd_kernel(const RelMultiK p
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) rr = mfma32(sWrA[(16 * t + r) * 64 + lane], hid[t][r], rr);
+      for (int r = 0; r < 16; ++r) { rr = mfma32(sWrA[(16 * t + r) * 64 + lane], hid[t][r], rr); rm_yield<Y>(); }
     // 3. d(log max(r, 1e-6)) / dr
     float dpre[16];
 #pragma unroll
@@ -323,7 +332,7 @@ __global__ void __launch_bounds__(256, 2) rel_multi_bwd_kernel(const RelMultiK p
 #pragma unroll
       for (int r = 0; r < 16; ++r) dh[t][r] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dh[t] = mfma32(sWrB[(16 * t + r) * 64 + lane], dpre[r], dh[t]);
+      for (int r = 0; r < 16; ++r) { dh[t] = mfma32(sWrB[(16 * t + r) * 64 + lane], dpre[r], dh[t]); rm_yield<Y>(); }
 #pragma unroll
       for (int r = 0; r < 16; ++r) dh[t][r] = (gm >> (16 * t + r)) & 1u ? dh[t][r] : 0.f;
     }
@@ -343,7 +352,9 @@ __global__ void __launch_bounds__(256, 2) rel_multi_bwd_kernel(const RelMultiK p
       for (int u = 0; u < 4; ++u) {
         accbr += av[u];                     // dbr_all[row] = sum_e dpre[row, e]
         accWr[0] = mfma32(av[u], b0[u], accWr[0]);
+        rm_yield<Y>();
         accWr[1] = mfma32(av[u], b1[u], accWr[1]);
+        rm_yield<Y>();
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -502,6 +513,7 @@ extern "C" int mmnas_rel_multi_fwd(const mmnas_rel_multi* m, void* stream) {
     RelMultiK k;
     memset(&k, 0, sizeof(k));
     k.raw = m->raw; k.B = m->B; k.S = m->S; k.C = m->C; k.H = m->H; k.off = m->off; k.toff = m->tile_off;
+    { static const int dbg = [] { const char* e = getenv("MMNAS_REL_MULTI_DBG"); return e && e[0] ? atoi(e) : 0; }(); k.dbg = dbg; }
     // rows: operator j of this launch holds rows j H .. j H + H - 1 (H divides 32: no operator straddles two row tiles)
     for (int j = 0; j < n; ++j) {
       MMNAS_REQUIRE(m->Wr[o0 + j] && m->br[o0 + j] && m->biasT[o0 + j], MMNAS_E_ARG, "rel_multi_fwd: operator %d: null pointer", o0 + j);
@@ -511,10 +523,14 @@ extern "C" int mmnas_rel_multi_fwd(const mmnas_rel_multi* m, void* stream) {
     for (int j = 0; j < n; ++j) { k.Wr[j] = m->Wr[o0 + j]; k.br[j] = m->br[o0 + j]; }
     k.nops = n; k.nrows = slots;
     const int nt = (slots + RM_ROWS - 1) / RM_ROWS;
-    const int grid = rm_grid(ntiles, 3);
+    static const int fwd_per_cu = [] { const char* e = getenv("MMNAS_REL_MULTI_WGS"); return e && e[0] ? atoi(e) : 3; }();   // (tuning: workgroups per CU)
+    const int grid = rm_grid(ntiles, fwd_per_cu);
     const double ne = m->off ? 32.0 * ntiles : (double)m->B * SS;
     ProfScope ps(MMNAS_K_REL_FWD, 2.0 * ne * (RM_R * (m->C + 1) + (double)n * m->H * RM_R), 4.0 * ne * (m->C + n * m->H), st);
-#define RM_FWD(CC, NTT) MMNAS_LAUNCH((rel_multi_fwd_kernel<CC, NTT>), dim3(grid), dim3(256), 0, st, k, ntiles, tpb, m->Wy, m->by)
+    static const int yield = [] { const char* e = getenv("MMNAS_REL_MULTI_YIELD"); return e && e[0] ? atoi(e) : 0; }();
+#define RM_FWD(CC, NTT) do { if (yield == 1) MMNAS_LAUNCH((rel_multi_fwd_kernel<CC, NTT, 1>), dim3(grid), dim3(256), 0, st, k, ntiles, tpb, m->Wy, m->by); \
+      else if (yield == 3) MMNAS_LAUNCH((rel_multi_fwd_kernel<CC, NTT, 3>), dim3(grid), dim3(256), 0, st, k, ntiles, tpb, m->Wy, m->by); \
+      else MMNAS_LAUNCH((rel_multi_fwd_kernel<CC, NTT, 0>), dim3(grid), dim3(256), 0, st, k, ntiles, tpb, m->Wy, m->by); } while (0)
     if (m->C == 4) { if (nt == 1) RM_FWD(4, 1); else if (nt == 2) RM_FWD(4, 2); else RM_FWD(4, 3); }
     else { if (nt == 1) RM_FWD(3, 1); else if (nt == 2) RM_FWD(3, 2); else RM_FWD(3, 3); }
 #undef RM_FWD
@@ -553,8 +569,12 @@ extern "C" int mmnas_rel_multi_bwd(const mmnas_rel_multi* m, void* stream) {
     const double ne = m->off ? 32.0 * ntiles : (double)m->B * SS;
     const double rows = (double)n * m->H;
     ProfScope ps(MMNAS_K_REL_BWD, 2.0 * ne * (2.0 * RM_R * (m->C + 1) + 3.0 * rows * RM_R), 4.0 * ne * (m->C + rows), st);
-    if (m->C == 4) MMNAS_LAUNCH((rel_multi_bwd_kernel<4>), dim3(grid), dim3(256), 0, st, k, ntiles, tpb, m->Wy, m->by);
-    else MMNAS_LAUNCH((rel_multi_bwd_kernel<3>), dim3(grid), dim3(256), 0, st, k, ntiles, tpb, m->Wy, m->by);
+    static const int yield = [] { const char* e = getenv("MMNAS_REL_MULTI_YIELD"); return e && e[0] ? atoi(e) : 0; }();
+#define RM_BWD(CC) do { if (yield == 1) MMNAS_LAUNCH((rel_multi_bwd_kernel<CC, 1>), dim3(grid), dim3(256), 0, st, k, ntiles, tpb, m->Wy, m->by); \
+      else if (yield == 3) MMNAS_LAUNCH((rel_multi_bwd_kernel<CC, 3>), dim3(grid), dim3(256), 0, st, k, ntiles, tpb, m->Wy, m->by); \
+      else MMNAS_LAUNCH((rel_multi_bwd_kernel<CC, 0>), dim3(grid), dim3(256), 0, st, k, ntiles, tpb, m->Wy, m->by); } while (0)
+    if (m->C == 4) RM_BWD(4); else RM_BWD(3);
+#undef RM_BWD
     MMNAS_LAUNCH(rel_multi_reduce_kernel, dim3(cdiv(RM_ROW, 64)), dim3(1024), 0, st, red);
     if ((rc = check_launch("rel_multi_bwd"))) return rc;
   }
