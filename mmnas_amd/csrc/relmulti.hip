@@ -24,6 +24,11 @@
 #include <string.h>
 #include "common.h"
 
+#ifndef MMNAS_DBG_REL
+#define MMNAS_DBG_REL 0     // 1: the timing switches of docs/LAB_NOTES.md "Round 5 notebook" (wrong results by design)
+#endif
+#define RM_DBG(bit) (MMNAS_DBG_REL && (p.dbg & (bit)))
+
 namespace mmnas {
 
 constexpr int RM_R = 64;        // REL_SIZE
@@ -37,7 +42,7 @@ constexpr int RM_ROW = RM_ROWS * RM_R + RM_R * RM_CP + RM_ROWS;   // partial row
 struct RelMultiK {
   const float* raw;
   int B, S, C, H, nrows, nops;
-  int dbg;                               // timing experiments only (MMNAS_REL_MULTI_DBG): 1 no stores, 2 no raw reloads, 4 no head-projection MFMAs
+  int dbg;                               // timing experiments only, in a -DMMNAS_DBG_REL=1 build (MMNAS_REL_MULTI_DBG): 1 no stores, 2 no raw reloads, 4 no head-projection MFMAs
   const int* off; const int* toff;       // ragged batches (see relfused.hip); NULL = all S x S elements
   float* part;                           // backward: partial rows [grid][RM_ROW]
   const float* Wr[MMNAS_REL_MULTI_MAX];  // per operator of this launch: linear_r.weight [H, 64], .bias [H]
@@ -192,7 +197,7 @@ __global__ void __launch_bounds__(256) rel_multi_fwd_kernel(const RelMultiK p, i
     const unsigned eoff = (unsigned)cur.b * (unsigned)p.H * SS + cur.fc;   // (host: B H S^2 < 2^31)
     wk.next(p);
     cur = rm_elem(p, wk.cb, wk.ct, l31);
-    if (!(p.dbg & 2)) ext = rm_raw<C>(p, cur);         // the next tile's raw row: in flight during this tile's MFMA chain
+    if (!RM_DBG(2)) ext = rm_raw<C>(p, cur);         // the next tile's raw row: in flight during this tile's MFMA chain
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
       if (rt * RM_ROWS >= p.nrows) break;
@@ -202,7 +207,7 @@ __global__ void __launch_bounds__(256) rel_multi_fwd_kernel(const RelMultiK p, i
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { if (!(p.dbg & 4) || r == 0) { rr = mfma32(sWrA[(rt * 32 + 16 * t + r) * 64 + lane], hid[t][r], rr); rm_yield<Y>(); } }
+        for (int r = 0; r < 16; ++r) { if (!RM_DBG(4) || r == 0) { rr = mfma32(sWrA[(rt * 32 + 16 * t + r) * 64 + lane], hid[t][r], rr); rm_yield<Y>(); } }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {        // registers 4u .. 4u + 3 hold rows 8u + 4 hh + 0..3: contiguous table entries
         const int row = rt * RM_ROWS + 8 * u + 4 * hh;
@@ -211,7 +216,7 @@ __global__ void __launch_bounds__(256) rel_multi_fwd_kernel(const RelMultiK p, i
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float* const o = sIo[row + i];
-          if (ok && o && !((p.dbg & 1) && rr[4 * u + i] != 12345.f)) o[eoff] = __logf(fmaxf(rr[4 * u + i] + bv[i], 1e-6f));   // max(relu(r), 1e-6) == max(r, 1e-6)
+          if (ok && o && !(RM_DBG(1) && rr[4 * u + i] != 12345.f)) o[eoff] = __logf(fmaxf(rr[4 * u + i] + bv[i], 1e-6f));   // max(relu(r), 1e-6) == max(r, 1e-6)
         }
       }
     }
