@@ -170,6 +170,44 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, size_t
   }
 }
 
+// the same arithmetic on four consecutive elements per thread and pass: 16-byte loads / stores (the scalar form moved
+// 4 bytes per lane and instruction: 0.45 ms for the supernet's 37 M parameters where 1.04 GB of traffic is 0.21 ms at 5 TB/s)
+__device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& vi, float gscale, float lr, float b1, float b2,
+                                         float eps, float wd, float c1, float c2) {
+  gi *= gscale;
+  if (wd != 0.f) gi += wd * pi;
+  mi = b1 * mi + (1.f - b1) * gi;
+  vi = b2 * vi + (1.f - b2) * gi * gi;
+  pi = pi - (lr / c1) * mi / (sqrtf(vi) / c2 + eps);
+}
+__global__ void __launch_bounds__(256) adam4_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                                                    float4* __restrict__ v, size_t n4, float lr, float b1, float b2, float eps,
+                                                    float wd, const float* sumsq, float max_norm, float c1, float c2) {
+  float gscale = 1.f;
+  if (sumsq) gscale = fminf(1.f, max_norm / (sqrtf(*sumsq) + 1e-6f));
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 pi = p[i], mi = m[i], vi = v[i];
+    const float4 gi = g[i];
+    adam_one(pi.x, gi.x, mi.x, vi.x, gscale, lr, b1, b2, eps, wd, c1, c2);
+    adam_one(pi.y, gi.y, mi.y, vi.y, gscale, lr, b1, b2, eps, wd, c1, c2);
+    adam_one(pi.z, gi.z, mi.z, vi.z, gscale, lr, b1, b2, eps, wd, c1, c2);
+    adam_one(pi.w, gi.w, mi.w, vi.w, gscale, lr, b1, b2, eps, wd, c1, c2);
+    m[i] = mi; v[i] = vi; p[i] = pi;
+  }
+}
+__global__ void __launch_bounds__(256) sumsq4_kernel(const float4* __restrict__ g, size_t n4, float* out) {
+  float s0 = 0.f, s1 = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 x = g[i];
+    s0 += x.x * x.x + x.y * x.y; s1 += x.z * x.z + x.w * x.w;
+  }
+  float s = wave_sum(s0 + s1);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
 __global__ void sumsq_kernel(const float* g, size_t n, float* out) {
   float s = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -298,16 +336,35 @@ extern "C" int mmnas_adam_step(float* p, const float* g, float* m, float* v, siz
   MMNAS_REQUIRE(p && g && m && v && step >= 1, MMNAS_E_ARG, "mmnas_adam_step: bad arguments");
   const float c1 = 1.f - powf(beta1, (float)step);
   const float c2 = sqrtf(1.f - powf(beta2, (float)step));
-  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  MMNAS_LAUNCH(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
-                     beta2, eps, weight_decay, sumsq, max_norm, c1, c2);
+  // 16-byte path for the aligned body, the scalar kernel for a misaligned call or the tail (< 4 elements)
+  const bool al16 = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+  const size_t n4 = al16 ? n / 4 : 0, done = 4 * n4;
+  if (n4) {
+    const int blocks4 = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    MMNAS_LAUNCH(adam4_kernel, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g, (float4*)m, (float4*)v, n4,
+                 lr, beta1, beta2, eps, weight_decay, sumsq, max_norm, c1, c2);
+  }
+  if (done < n) {
+    const size_t r = n - done;
+    const int blocks = (int)((r + 255) / 256 < 4096 ? (r + 255) / 256 : 4096);
+    MMNAS_LAUNCH(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p + done, g + done, m + done, v + done, r, lr, beta1,
+                 beta2, eps, weight_decay, sumsq, max_norm, c1, c2);
+  }
   return check_launch("adam_step");
 }
 
 extern "C" int mmnas_sumsq(const float* g, size_t n, float* out, void* stream) {
   if (n == 0) return MMNAS_OK;
   MMNAS_REQUIRE(g && out, MMNAS_E_ARG, "mmnas_sumsq: null pointer");
-  const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-  MMNAS_LAUNCH(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  const size_t n4 = (((uintptr_t)g & 15) == 0) ? n / 4 : 0, done = 4 * n4;
+  if (n4) {
+    const int blocks4 = (int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+    MMNAS_LAUNCH(sumsq4_kernel, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, (const float4*)g, n4, out);
+  }
+  if (done < n) {
+    const size_t r = n - done;
+    const int blocks = (int)((r + 255) / 256 < 1024 ? (r + 255) / 256 : 1024);
+    MMNAS_LAUNCH(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g + done, r, out);
+  }
   return check_launch("sumsq");
 }
