@@ -465,7 +465,7 @@ def main():
     # N > 1: what the line reports about the exchange is OBSERVED, not configured -- the rank count from a real all-reduce of
     # rank ids on the backend the steps use (sum of 0..N-1 and of ones), the sampled architectures compared across ranks
     # before the timed blocks, the persistent LSTM's hand-off timeout flag read after every block, every rank's own time
-    multi = {'rccl_ranks_observed': 1, 'rank_id_sum_ok': True, 'same_architecture': None, 'lstm_timed_out': 0}
+    multi = {'rccl_ranks_observed': 1, 'rank_id_sum_ok': True, 'same_architecture': None, 'lstm_timed_out': 0, 'lstm_fallback': False}
     if world > 1:
         t = torch.tensor([float(rank), 1.0], device=dev, dtype=torch.float64)
         dist.all_reduce(t)
@@ -774,6 +774,14 @@ def main():
         for _ in range(wcalls):
             step()
         barrier()
+        if int(lib.mmnas_lstm_seq_timed_out(L.stream())) and os.environ.get('MMNAS_LSTM', '1') != '0':
+            # the persistent LSTM's hand-off gave up during warm-up (its grid was not co-resident -- e.g. beside a collective's
+            # kernels on a box this was never run on): the step falls back to nn.LSTM (MIOpen) instead of timing NaNs, and says so
+            os.environ['MMNAS_LSTM'] = '0'
+            multi['lstm_fallback'] = True
+            for _ in range(wcalls):
+                step()
+            barrier()
         if world > 1 and wl in ('search_vqa', 'arch_vqa', 'bilevel_vqa'):
             # every rank must have sampled the same operators (seeded CPU sampler): one check before the timed blocks
             same = dp.check_same_architecture(search_state()['net'])
@@ -1003,7 +1011,7 @@ def main():
                        'grad_allreduce': ('rccl' if backend == 'nccl' else backend) if world > 1 else 'none',
                        'rccl_ranks': multi['rccl_ranks_observed'],     # counted by an all-reduce of ones, not read from the env
                        'rank_id_sum_ok': multi['rank_id_sum_ok'], 'same_architecture': multi['same_architecture'],
-                       'lstm_timed_out': multi['lstm_timed_out'],
+                       'lstm_timed_out': multi['lstm_timed_out'], 'lstm_fallback': multi['lstm_fallback'],
                        'dp_rows': os.environ.get('MMNAS_DP_ROWS', '1'),      # embedding gradient exchanged as rows (dp.RowExchange)
                        'dp_buckets': getattr(getattr(state.get('search', {}).get('loop'), 'reducer', None), 'n_buckets', None),
                        'rccl_env': {k: v for k, v in os.environ.items() if k.startswith(('NCCL_', 'RCCL_'))},
