@@ -174,12 +174,14 @@ class DevicePrefetcher:
             nz = (feat != 0).any(-1)
             want = torch.arange(S)[None, :] < torch.tensor(lens)[:, None]
             bad = (nz != want).any(-1).nonzero().reshape(-1).tolist()
-        else:
-            bad = []
-            for b, n in enumerate(lens):
-                ok = 0 <= n <= S and (n == 0 or bool((feat[b, n - 1] != 0).any())) and (n == S or not bool((feat[b, n] != 0).any()))
-                if not ok:
-                    bad.append(b)
+        else:      # two gathered rows per sample: row n_b - 1 must be non-zero, row n_b all-zero (two indexing ops per batch)
+            n = torch.tensor(lens, dtype=torch.long)
+            rng = (n >= 0) & (n <= S)
+            nc = n.clamp(0, S)
+            b = torch.arange(len(lens))
+            last_ok = (nc == 0) | (feat[b, (nc - 1).clamp(min=0)] != 0).any(-1)
+            next_ok = (nc == S) | ~(feat[b, nc.clamp(max=S - 1)] != 0).any(-1)
+            bad = (~(rng & last_ok & next_ok)).nonzero().reshape(-1).tolist()
         if bad:
             raise ValueError('DevicePrefetcher: region counts disagree with the zero-row padding of the features for samples %s '
                              '(count n_b: rows < n_b non-zero, rows >= n_b all-zero)' % bad[:8])
