@@ -89,9 +89,18 @@ class _Backbone(nn.Module):
             return None
         records, params, op_params = [], [], []
         mops = []
+        # Two ways for the parameter gradients to leave the chain: into a flat gradient buffer the parameters' .grad are views
+        # of (a reducer / FlatAdam owns them: "sinks"), or -- plain autograd use: the unchanged scripts under stock DDP -- as
+        # autograd outputs of the node (ops.autograd_chain_enabled: the kernels accumulate into a per-call buffer whose views
+        # backward returns).  Decided by the first operator's first parameter; the arch step's mixed chain needs the sinks.
+        probe = next(self.parameters())
+        ag = not ops._sinked((probe,))
+        if ag and (mixed_mode or not ops.autograd_chain_enabled() or not torch.is_grad_enabled()):
+            return None
 
         def record(op, on_y, rel):
-            """(ChainOp, parameters) of one operator, or None when the chain cannot take it."""
+            """(ChainOp, parameters) of one operator, or None when the chain cannot take it.  Autograd mode: the ChainOp is a
+            cached template without gradient pointers (patched below, once the per-call buffer exists)."""
             t = type(op)
             if t is SelfAtt or t is GuidedAtt or t is RelSelfAtt:
                 if t is GuidedAtt and not on_y:
@@ -101,20 +110,24 @@ class _Backbone(nn.Module):
                     if not (isinstance(rel, RelHandle) and rel.fusable(op.mhatt.linear_r.weight.shape[0])):
                         return None
                     rh = rel
+                if ag:
+                    return ops.chain_att_template(op, on_y, t is not GuidedAtt, rh)
                 ps = _op_params(op)
                 if not ops._sinked(ps) or (rh is not None and not ops._sinked((rh.weight, rh.bias))):
                     return None
                 return ops.chain_att_record_cached(op, on_y, t is not GuidedAtt, rh)
             if t is FeedForward or t is FeedForward_deep:
-                ps = _op_params(op)
-                if not ops._sinked(ps):
-                    return None
                 m = op.mlp
                 if t is FeedForward:
                     ws, bs = [m.fc.linear.weight, m.linear.weight], [m.fc.linear.bias, m.linear.bias]
                 else:
                     ws = [op.fc.linear.weight, m.fc.linear.weight, m.linear.weight]
                     bs = [op.fc.linear.bias, m.fc.linear.bias, m.linear.bias]
+                if ag:
+                    return ops.chain_mlp_template(op, on_y, ws, bs)
+                ps = _op_params(op)
+                if not ops._sinked(ps):
+                    return None
                 return ops.chain_mlp_record_cached(op, on_y, ws, bs)
             return None
 
@@ -155,6 +168,28 @@ class _Backbone(nn.Module):
                     records.append(rec)
                     params += used
                     op_params.append(used)
+        gviews, ptensors = None, ()
+        if ag:
+            # the per-call gradient buffer: one zero fill, one view per distinct parameter (the shared relation stem is listed
+            # by every relation operator), the descriptors patched to point there; seeds drawn in operator order as always
+            if not records or any(not p.requires_grad for p in params):
+                return None
+            uniq = list({id(p): p for p in params}.values())
+            sizes = [(p.numel() + 63) // 64 * 64 for p in uniq]
+            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=x.device)
+            views, off = {}, 0
+            for p, n in zip(uniq, sizes):
+                views[id(p)] = flat[off:off + p.numel()].view(p.shape)
+                off += n
+            gp = lambda p: views[id(p)].data_ptr()
+            patched = []
+            for tmpl, used in zip(records, op_params):
+                rec = ops.patched_record(tmpl, used, gp)
+                rec.node, rec.cand, rec.detached = len(patched), 0, 0
+                patched.append(rec)
+            records = patched
+            gviews, ptensors = [views[id(p)] for p in uniq], tuple(uniq)
+            op_params = None          # (bucket marks are a reducer's: none here)
         mixed = None
         if mixed_mode:
             # the nodes' binary gates / gate gradients must be rows of two [n_nodes, width] blocks (Net_Search._flat_alphas,
@@ -210,7 +245,7 @@ class _Backbone(nn.Module):
             ragged = None
         if packed and ragged is None:
             return None           # (packed image rows only make sense on the ragged stream: the caller falls back to padded rows)
-        return ops.backbone_chain(x, y, x_mask, y_mask, xr, yr, records, params, op_params, mixed, ragged, packed)
+        return ops.backbone_chain(x, y, x_mask, y_mask, xr, yr, records, params, op_params, mixed, ragged, packed, gviews, ptensors)
 
     def chain_packed(self, x, y_packed, x_mask, y_mask, x_rel_embed, y_rel_embed):
         """The ragged decoder stream end to end: `y_packed` [sum n_b, d] are the projected VALID region rows (the stem ran

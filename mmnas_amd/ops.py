@@ -1017,9 +1017,83 @@ def chain_mlp_record_cached(op, on_y, weights, biases):
     return rec, params
 
 
-def chain_att_record(on_y, mh, ln, norm, residual, self_att, rel_handle, training):
+def _grad_ptr(p):
+    return p.grad.data_ptr()
+
+
+# ---- the backbone chain in PLAIN AUTOGRAD use (round 5) ----------------------------------------------------------------
+# Without a flat gradient buffer (no reducer / FlatAdam: the unchanged scripts under stock DDP, any other autograd use) the
+# chain used to step aside for one autograd node per operator.  Now the parameters of the chain's operators are autograd
+# INPUTS of ops.BackboneFn: the kernels accumulate their gradients into the views of one zero-filled buffer made per call,
+# and backward returns those views -- autograd, AccumulateGrad hooks and stock DDP get every gradient the ordinary way,
+# from ONE node per direction instead of ~60 (and with the chain's grouped launches).  MMNAS_AUTOGRAD_CHAIN=0 keeps the
+# per-operator nodes.  Weight steps / fixed architectures only (the arch step's mixed chain needs the gate blocks).
+def autograd_chain_enabled():
+    return os.environ.get('MMNAS_AUTOGRAD_CHAIN', '1') != '0'
+
+
+def _null_ptr(_p):
+    return None
+
+
+def _template(owner, key, first, build):
+    """Per-module cache of a descriptor WITHOUT gradient pointers (autograd-mode chain): rebuilt when the key or the storage
+    of the module's first parameter changes."""
+    c = owner.__dict__.get('_mmnas_tmpl')
+    if c is not None and c[0] == key and c[1] == first.data_ptr():
+        return c[2], c[3]
+    rec, params = build()
+    owner.__dict__['_mmnas_tmpl'] = (key, first.data_ptr(), rec, params)
+    return rec, params
+
+
+def chain_att_template(op, on_y, self_att, rel_handle):
+    mh = op.mhatt
+    key = (on_y, op.training, id(rel_handle.weight) if rel_handle is not None else 0)
+    return _template(op, key, mh.linear_q.weight, lambda: chain_att_record(
+        on_y, mh, op.ln if op.norm else None, op.norm, op.residual, self_att, rel_handle, op.training, gptr=_null_ptr))
+
+
+def chain_mlp_template(op, on_y, weights, biases):
+    return _template(op, (on_y, op.training, 0), weights[0], lambda: chain_mlp_record(
+        on_y, weights, biases, op.ln if op.norm else None, op.norm, op.residual, op.drop_p, op.training, gptr=_null_ptr))
+
+
+def patched_record(tmpl, params, gp):
+    """A private copy of a template descriptor with the gradient pointers gp(p) of its parameters (the order the builders
+    list them in) and a fresh dropout seed."""
+    rec = L.ChainOp.from_buffer_copy(tmpl)
+    if rec.kind == 0:
+        a = rec.att
+        a.dWq, a.dWk, a.dWv, a.dWm = gp(params[0]), gp(params[1]), gp(params[2]), gp(params[3])
+        k = 4
+        if a.flags & L.F_NORM:
+            a.dln_a, a.dln_b = gp(params[k]), gp(params[k + 1])
+            k += 2
+        if a.flags & L.F_REL:
+            a.dWr, a.dbr, a.dWy, a.dby = gp(params[k]), gp(params[k + 1]), gp(params[k + 2]), gp(params[k + 3])
+        if a.drop_p > 0:
+            a.seed = next_seed()
+    else:
+        m = rec.mlp
+        k = 0
+        for i in range(m.nl):
+            m.dW[i] = gp(params[k])
+            k += 1
+            if m.b[i]:
+                m.db[i] = gp(params[k])
+                k += 1
+        if m.flags & L.F_NORM:
+            m.dln_a, m.dln_b = gp(params[k]), gp(params[k + 1])
+        if m.drop_p > 0:
+            m.seed = next_seed()
+    return rec
+
+
+def chain_att_record(on_y, mh, ln, norm, residual, self_att, rel_handle, training, gptr=_grad_ptr):
     """(ChainOp, params) for an attention-family operator: mh = its MHAtt / RelMHAtt, rel_handle = a fusable RelHandle
-    or None."""
+    or None.  gptr(p): where p's gradient is accumulated (default: its flat-buffer view p.grad; the autograd-mode chain
+    builds a template with null pointers and patches a per-call buffer's views in: patch_grad_ptrs)."""
     rec = L.ChainOp()
     rec.kind, rec.on_y = 0, int(on_y)
     a = rec.att
@@ -1034,24 +1108,24 @@ def chain_att_record(on_y, mh, ln, norm, residual, self_att, rel_handle, trainin
     a.drop_p, a.eps = float(drop), float(ln.eps if norm else 1e-6)
     a.seed = 0   # (drawn per call by the cached wrapper)
     a.Wq, a.Wk, a.Wv, a.Wm = Wq.data_ptr(), Wk.data_ptr(), Wv.data_ptr(), Wm.data_ptr()
-    a.dWq, a.dWk, a.dWv, a.dWm = Wq.grad.data_ptr(), Wk.grad.data_ptr(), Wv.grad.data_ptr(), Wm.grad.data_ptr()
+    a.dWq, a.dWk, a.dWv, a.dWm = gptr(Wq), gptr(Wk), gptr(Wv), gptr(Wm)
     if norm:
         a.ln_a, a.ln_b = ln.a_2.data_ptr(), ln.b_2.data_ptr()
-        a.dln_a, a.dln_b = ln.a_2.grad.data_ptr(), ln.b_2.grad.data_ptr()
+        a.dln_a, a.dln_b = gptr(ln.a_2), gptr(ln.b_2)
         params += [ln.a_2, ln.b_2]
     if rel_handle is not None:
         lr = mh.linear_r
         flags |= L.F_REL | L.F_RELRAW
         a.R, a.C = lr.weight.shape[1], rel_handle.weight.shape[1]
-        a.Wr, a.br, a.dWr, a.dbr = lr.weight.data_ptr(), lr.bias.data_ptr(), lr.weight.grad.data_ptr(), lr.bias.grad.data_ptr()
+        a.Wr, a.br, a.dWr, a.dbr = lr.weight.data_ptr(), lr.bias.data_ptr(), gptr(lr.weight), gptr(lr.bias)
         a.Wy, a.by = rel_handle.weight.data_ptr(), rel_handle.bias.data_ptr()
-        a.dWy, a.dby = rel_handle.weight.grad.data_ptr(), rel_handle.bias.grad.data_ptr()
+        a.dWy, a.dby = gptr(rel_handle.weight), gptr(rel_handle.bias)
         params += [lr.weight, lr.bias, rel_handle.weight, rel_handle.bias]
     a.flags = flags
     return rec, params
 
 
-def chain_mlp_record(on_y, weights, biases, ln, norm, residual, drop_p, training):
+def chain_mlp_record(on_y, weights, biases, ln, norm, residual, drop_p, training, gptr=_grad_ptr):
     rec = L.ChainOp()
     rec.kind, rec.on_y = 1, int(on_y)
     m = rec.mlp
@@ -1061,10 +1135,10 @@ def chain_mlp_record(on_y, weights, biases, ln, norm, residual, drop_p, training
     params = []
     for i, (w, b) in enumerate(zip(weights, biases)):
         m.dims[i + 1] = w.shape[0]
-        m.W[i], m.dW[i] = w.data_ptr(), w.grad.data_ptr()
+        m.W[i], m.dW[i] = w.data_ptr(), gptr(w)
         params.append(w)
         if b is not None:
-            m.b[i], m.db[i] = b.data_ptr(), b.grad.data_ptr()
+            m.b[i], m.db[i] = b.data_ptr(), gptr(b)
             params.append(b)
     drop = drop_p if training else 0.0
     flags = (L.F_NORM if norm else 0) | (L.F_RESIDUAL if residual else 0)
@@ -1073,7 +1147,7 @@ def chain_mlp_record(on_y, weights, biases, ln, norm, residual, drop_p, training
     m.flags, m.drop_p, m.eps = flags, float(drop), float(ln.eps if norm else 1e-6)
     m.seed = 0   # (drawn per call by the cached wrapper)
     if norm:
-        m.ln_a, m.ln_b, m.dln_a, m.dln_b = ln.a_2.data_ptr(), ln.b_2.data_ptr(), ln.a_2.grad.data_ptr(), ln.b_2.grad.data_ptr()
+        m.ln_a, m.ln_b, m.dln_a, m.dln_b = ln.a_2.data_ptr(), ln.b_2.data_ptr(), gptr(ln.a_2), gptr(ln.b_2)
         params += [ln.a_2, ln.b_2]
     return rec, params
 
@@ -1225,8 +1299,12 @@ class BackboneFn(torch.autograd.Function):
     are not autograd inputs of this node."""
 
     @staticmethod
-    def forward(ctx, x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None, mixed=None, ragged=None, packed_io=False):
-        """packed_io (with ragged): `y` arrives PACKED [ragged.N, d] (the stem projected the valid region rows only) and the
+    def forward(ctx, x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None, mixed=None, ragged=None, packed_io=False,
+                gviews=None, *ptensors):
+        """gviews + ptensors (plain autograd use, see autograd_chain_enabled): the chain's parameters as autograd inputs and,
+        aligned with them, the views of a per-call zero-filled buffer the kernels accumulate their gradients into (the
+        descriptors in `records` point there); backward returns the views.
+        packed_io (with ragged): `y` arrives PACKED [ragged.N, d] (the stem projected the valid region rows only) and the
         decoder output is returned packed too (the head's AttFlat takes packed rows): no pack / unpack launches at all."""
         lib = L.lib()
         x, y = _f32c(x), _f32c(y)
@@ -1258,7 +1336,11 @@ class BackboneFn(torch.autograd.Function):
         ctx.keep = (ch, arr, arena, x, y, xm, ym, xr, yr, x_out, y_out, params)
         ctx.op_params = op_params
         ctx.ragged = (ragged, B, Sy, packed_io)
-        ctx.counted = _acquire_sinks(ctx, params)
+        ctx.gviews = gviews
+        if gviews is not None:
+            ctx.counted, ctx.uniq = False, []
+        else:
+            ctx.counted = _acquire_sinks(ctx, params)
         if ragged is not None and not packed_io:
             return x_out, unpack_rows(y_out, ragged, B, Sy)
         return x_out, y_out
@@ -1279,12 +1361,12 @@ class BackboneFn(torch.autograd.Function):
             dy_out = _f32c(dy_out) if dy_out is not None else torch.zeros_like(y_out)
         dx_in, dy_in = torch.empty_like(x), torch.empty_like(y)
         ch.dx_out, ch.dy_out, ch.dx_in, ch.dy_in = L.fptr(dx_out), L.fptr(dy_out), L.fptr(dx_in), L.fptr(dy_in)
-        side = side_stream_enabled()
+        side = side_stream_enabled() if ctx.gviews is None else 0   # (autograd mode: the returned gradients are read right away)
         ch.use_side_stream = int(side)
         # a data-parallel reducer gets events recorded INSIDE the call, behind the operator that completes each of its
         # buckets, so that the bucket's all-reduce overlaps the backward of the operators issued after it
         marks = marr = None
-        owner = getattr(params[0]._mmnas_sink, 'owner', None) if params else None
+        owner = getattr(getattr(params[0], '_mmnas_sink', None), 'owner', None) if (params and ctx.gviews is None) else None
         # (marks only from the LAST live node over these parameters: with several forwards before one backward -- the ITM
         #  triplet step -- an earlier node's gradients are a third of the bucket's, not all of it)
         if owner is not None and ctx.op_params is not None and not side and _last_live(ctx, params):
@@ -1304,14 +1386,20 @@ class BackboneFn(torch.autograd.Function):
             if not _side_join_queued[0]:
                 _side_join_queued[0] = True
                 torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
-        _release_sinks(ctx, params)   # data-parallel reducers learn which gradients are now completely enqueued
+        if ctx.gviews is None:
+            _release_sinks(ctx, params)   # data-parallel reducers learn which gradients are now completely enqueued
         if ragged is not None and not packed_io:
             dy_in = unpack_rows(dy_in, ragged, B, Sy)
-        return dx_in, dy_in, None, None, None, None, None, None, None, None, None, None
+        head = (dx_in, dy_in, None, None, None, None, None, None, None, None, None, None, None)
+        if ctx.gviews is not None:
+            gv, ctx.gviews = ctx.gviews, None
+            return head + tuple(gv)
+        return head
 
 
-def backbone_chain(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None, mixed=None, ragged=None, packed_io=False):
-    return BackboneFn.apply(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params, mixed, ragged, packed_io)
+def backbone_chain(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None, mixed=None, ragged=None, packed_io=False,
+                   gviews=None, ptensors=()):
+    return BackboneFn.apply(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params, mixed, ragged, packed_io, gviews, *ptensors)
 
 
 class HeadFn(torch.autograd.Function):

@@ -157,19 +157,94 @@ def test_chain_encoder_decoder_overlap_gives_the_same_result(task, search, monke
             break
 
 
-def test_chain_is_skipped_without_gradient_sinks_and_in_arch_mode(monkeypatch):
-    """No flat gradient buffer attached (plain autograd use) or MODE 'full': the per-operator path serves the call."""
+def _plain_autograd(task, arch, search, monkeypatch, autograd_chain, plan=None, dropout=0.1, mode=None):
+    """One forward + backward of a whole net in PLAIN autograd use (no reducer, no flat buffer): -> (outputs, gradients,
+    number of backbone-chain calls)."""
+    import importlib
+    from mmnas_amd import ops
+    from mmnas.model.mixed import MixedOp
+    monkeypatch.setenv('MMNAS_AUTOGRAD_CHAIN', '1' if autograd_chain else '0')
+    c = cases.net_case(task, arch, 31337, search=search, B=3, Sx=6, Sy=9)
+    c['cfg'].DROPOUT_R = dropout
+    mod = importlib.import_module('mmnas.model.%s_%s' % ('hygr' if search else 'full', task))
+    net = (mod.Net_Search if search else mod.Net_Full)(c['cfg'], {'token_size': c['token_size'], 'ans_size': c['ans_size'],
+           'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)})
+    net.load_state_dict({k: T(v) for k, v in c['P'].items()})
+    net = net.to(DEV).train()
+    calls = []
+    orig = ops.BackboneFn.apply
+    monkeypatch.setattr(ops.BackboneFn, 'apply', lambda *a: (calls.append(1), orig(*a))[1])
+    ops.manual_seed(99)
+    try:
+        if search:
+            MixedOp.MODE = mode
+            net.set_sampled(plan)
+            net.unused_modules_off()
+        pred = net(tuple(T(a).to(DEV) for a in c['inputs']))
+        tgt = T(c['target']).to(DEV)
+        if task == 'vgd':
+            loss = (pred[0] * tgt).sum() + 0.5 * (pred[1] ** 2).sum()
+            out = torch.cat([pred[0].reshape(-1), pred[1].reshape(-1)])
+        elif task == 'itm':
+            loss, out = torch.nn.functional.binary_cross_entropy(pred, tgt, reduction='sum'), pred
+        else:
+            loss, out = torch.nn.functional.binary_cross_entropy_with_logits(pred, tgt, reduction='sum'), pred
+        loss += 0 * sum(p.sum() for p in net.parameters())           # (the scripts' line: every parameter gets a gradient)
+        net.zero_grad()
+        loss.backward()
+        if search:
+            net.unused_modules_back()
+        torch.cuda.synchronize()
+        grads = {k: (p.grad.detach().cpu().numpy().copy() if p.grad is not None else None) for k, p in net.named_parameters()}
+        return out.detach().cpu().numpy(), grads, len(calls)
+    finally:
+        MixedOp.MODE = None
+        monkeypatch.setattr(ops.BackboneFn, 'apply', orig)
+
+
+@pytest.mark.parametrize('task,arch', [('vqa', 'mmnas_vqa'), ('vqa', 'mcan'), ('vgd', 'mmnas_vgd'), ('itm', 'mmnas_itm')])
+def test_plain_autograd_takes_the_chain_and_equals_the_per_operator_nodes(task, arch, monkeypatch):
+    """Round 5: without a flat gradient buffer the backbone is still ONE autograd node per direction -- its parameters are
+    autograd inputs, the kernels accumulate into a per-call buffer whose views backward returns (ops.autograd_chain_enabled).
+    Same dropout masks (the seeds are drawn in operator order on both routes), same logits, every parameter gradient equal to
+    the per-operator nodes' (the `0 * sum(p.sum())` line of the scripts included: every parameter ends with a gradient)."""
+    ref = _plain_autograd(task, arch, False, monkeypatch, False)
+    got = _plain_autograd(task, arch, False, monkeypatch, True)
+    assert ref[2] == 0 and got[2] == 1
+    assert all(g is not None for g in got[1].values())
+    _compare(got, ref)
+
+
+@pytest.mark.parametrize('task', ['vqa', 'itm'])
+def test_plain_autograd_chain_supernet_weight_step_and_arch_mode(task, monkeypatch):
+    pl = cases.search_plan(np.random.RandomState(2), None)
+    flat = pl['enc'] + pl['dec']
+    ref = _plain_autograd(task, None, True, monkeypatch, False, plan=flat)
+    got = _plain_autograd(task, None, True, monkeypatch, True, plan=flat)
+    assert ref[2] == 0 and got[2] == 1
+    _compare(got, ref)
+    # MODE 'full' (the arch step) needs the gate blocks of a flat buffer: plain autograd keeps one node per candidate
+    pf = cases.search_plan(np.random.RandomState(3), 'full')
+    arch = _plain_autograd(task, None, True, monkeypatch, True, plan=pf['enc'] + pf['dec'], mode='full', dropout=0.0)
+    assert arch[2] == 0
+
+
+def test_plain_autograd_chain_is_skipped_without_grad(monkeypatch):
     from mmnas_amd import ops
     from mmnas.model.full_vqa import Net_Full
     calls = []
     orig = ops.BackboneFn.apply
-    monkeypatch.setattr(ops, 'backbone_chain', lambda *a: (calls.append(1), orig(*a))[1])
+    monkeypatch.setattr(ops.BackboneFn, 'apply', lambda *a: (calls.append(1), orig(*a))[1])
     c = cases.net_case('vqa', 'mmnas_vqa', 5)
     init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
             'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
-    net = Net_Full(c['cfg'], init).to(DEV).train()
+    net = Net_Full(c['cfg'], init).to(DEV).eval()
+    with torch.no_grad():
+        out = net(tuple(T(a).to(DEV) for a in c['inputs']))
+    assert not calls and bool(torch.isfinite(out).all())
+    net.train()
     net(tuple(T(a).to(DEV) for a in c['inputs'])).sum().backward()
-    assert not calls and net.proj.weight.grad is not None
+    assert len(calls) == 1 and net.proj.weight.grad is not None
 
 
 def test_chain_full_size_side_stream_repeatable(monkeypatch):

@@ -3,7 +3,9 @@
 HSIZE 512 (search: 256), 100 regions + 14 tokens (VGD 15 tokens; ITM 36 regions + 50 tokens), 2048-wide region features,
 3129 answers, B = 2-4 -- BASELINE configs[0] literally (arch/mcan.json, B = 4, 36 regions) -- dropout 0.  Every case runs
 through the three routes the library has:
-    per-operator   one autograd node per operator (plain autograd use, the unchanged scripts)
+    per-operator   one autograd node per operator (MMNAS_AUTOGRAD_CHAIN=0: the round-4 route of plain autograd use)
+    autograd-chain plain autograd use as it runs by default since round 5 (the unchanged scripts): the backbone as ONE node
+                   whose parameters are autograd inputs (weight steps / fixed architectures; the arch step keeps its nodes)
     chain          the backbone / head / LSTM sections as native calls behind a flat gradient buffer (the bench's path:
                    arena planner, stream-K schedules, 8-head attention inside the chain, the 3129-wide answer layer, the
                    2048 -> d stem)
@@ -55,13 +57,14 @@ def _run(spec, route, monkeypatch):
     orig = ops.BackboneFn.apply
     monkeypatch.setattr(ops.BackboneFn, 'apply', lambda *a: (chain_calls.append(1), ragged_calls.append(a[10] is not None), orig(*a))[2])
     prev_unpad = ops.set_unpad(route == 'ragged')
+    monkeypatch.setenv('MMNAS_AUTOGRAD_CHAIN', '0' if route == 'per_operator' else '1')
     red = None
     try:
         if search:
             MixedOp.MODE = mode
             flat = c['plan']['enc'] + c['plan']['dec']
             net.set_sampled(flat)
-        if route != 'per_operator':
+        if route not in ('per_operator', 'autograd_chain'):
             if search:
                 red = dp.SupernetReducer(net)
                 if mode is None:
@@ -77,12 +80,12 @@ def _run(spec, route, monkeypatch):
             net.unused_modules_off()
         pred = net(inp)
         loss = _loss(task, pred, c['target'])
-        if route == 'per_operator':
+        if route in ('per_operator', 'autograd_chain'):
             net.zero_grad()
         loss.backward()
         if red is not None and (not search or mode is None):
             red.finish_weight_step() if search else red.finish()
-        if route == 'per_operator' and search:
+        if route in ('per_operator', 'autograd_chain') and search:
             net.unused_modules_back()
         torch.cuda.synchronize()
         gate = None
@@ -101,7 +104,7 @@ def _run(spec, route, monkeypatch):
 def _check(spec, route, res):
     kind, task, arch, d, B, Sx, Sy, mode = spec
     npz, tag, pred, loss, grads, gate, chain_calls, ragged_calls = res
-    if route == 'per_operator':
+    if route == 'per_operator' or (route == 'autograd_chain' and mode is not None):
         assert not chain_calls
     else:
         assert chain_calls, 'the backbone chain was not taken'
@@ -130,7 +133,7 @@ def _check(spec, route, res):
         assert rel_err(gate, npz[tag + 'gate_grads']) <= 3e-3
 
 
-@pytest.mark.parametrize('route', ['per_operator', 'chain', 'ragged'])
+@pytest.mark.parametrize('route', ['per_operator', 'autograd_chain', 'chain', 'ragged'])
 @pytest.mark.parametrize('spec', cases.FULL_CASES, ids=IDS)
 def test_network_at_production_dimensions_vs_reference(spec, route, monkeypatch):
     _check(spec, route, _run(spec, route, monkeypatch))
