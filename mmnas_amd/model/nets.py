@@ -93,10 +93,12 @@ class _Backbone(nn.Module):
         # of (a reducer / FlatAdam owns them: "sinks"), or -- plain autograd use: the unchanged scripts under stock DDP -- as
         # autograd outputs of the node (ops.autograd_chain_enabled: the kernels accumulate into a per-call buffer whose views
         # backward returns).  Decided by the first operator's first parameter; the arch step's mixed chain needs the sinks.
-        probe = next(self.parameters())
-        ag = not ops._sinked((probe,))
-        if ag and (mixed_mode or not ops.autograd_chain_enabled() or not torch.is_grad_enabled()):
-            return None
+        mode_ag = [None]      # decided by the FIRST operator the chain takes (an unsampled candidate's parameters tell nothing)
+
+        def autograd_mode(first_param):
+            if mode_ag[0] is None:
+                mode_ag[0] = not ops._sinked((first_param,))
+            return mode_ag[0]
 
         def record(op, on_y, rel):
             """(ChainOp, parameters) of one operator, or None when the chain cannot take it.  Autograd mode: the ChainOp is a
@@ -110,7 +112,9 @@ class _Backbone(nn.Module):
                     if not (isinstance(rel, RelHandle) and rel.fusable(op.mhatt.linear_r.weight.shape[0])):
                         return None
                     rh = rel
-                if ag:
+                if autograd_mode(op.mhatt.linear_q.weight):
+                    if mixed_mode or not ops.autograd_chain_enabled() or not torch.is_grad_enabled():
+                        return None
                     return ops.chain_att_template(op, on_y, t is not GuidedAtt, rh)
                 ps = _op_params(op)
                 if not ops._sinked(ps) or (rh is not None and not ops._sinked((rh.weight, rh.bias))):
@@ -123,7 +127,9 @@ class _Backbone(nn.Module):
                 else:
                     ws = [op.fc.linear.weight, m.fc.linear.weight, m.linear.weight]
                     bs = [op.fc.linear.bias, m.fc.linear.bias, m.linear.bias]
-                if ag:
+                if autograd_mode(ws[0]):
+                    if mixed_mode or not ops.autograd_chain_enabled() or not torch.is_grad_enabled():
+                        return None
                     return ops.chain_mlp_template(op, on_y, ws, bs)
                 ps = _op_params(op)
                 if not ops._sinked(ps):
@@ -169,7 +175,7 @@ class _Backbone(nn.Module):
                     params += used
                     op_params.append(used)
         gviews, ptensors = None, ()
-        if ag:
+        if mode_ag[0]:
             # the per-call gradient buffer: one zero fill, one view per distinct parameter (the shared relation stem is listed
             # by every relation operator), the descriptors patched to point there; seeds drawn in operator order as always
             if not records or any(not p.requires_grad for p in params):
