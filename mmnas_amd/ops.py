@@ -1026,10 +1026,15 @@ def _grad_ptr(p):
 # chain used to step aside for one autograd node per operator.  Now the parameters of the chain's operators are autograd
 # INPUTS of ops.BackboneFn: the kernels accumulate their gradients into the views of one zero-filled buffer made per call,
 # and backward returns those views -- autograd, AccumulateGrad hooks and stock DDP get every gradient the ordinary way,
-# from ONE node per direction instead of ~60 (and with the chain's grouped launches).  MMNAS_AUTOGRAD_CHAIN=0 keeps the
-# per-operator nodes.  Weight steps / fixed architectures only (the arch step's mixed chain needs the gate blocks).
+# from ONE node per direction instead of ~60 (and with the chain's grouped launches).  Weight steps / fixed architectures
+# only (the arch step's mixed chain needs the gate blocks).
+# OFF by default (MMNAS_AUTOGRAD_CHAIN=1 enables it): MEASURED NEUTRAL where it was meant to help -- the unchanged search loop
+# is host-bound on what surrounds the operators (bench `search_vqa_dropin`, one box: 14.0 ms per step with the per-operator
+# nodes, 14.5 ms with this; cProfile: 190 instead of 480 Function.apply calls, but run_backward stays at 5.9 ms -- 900
+# AccumulateGrad nodes, 230 zero + gradient adds -- and stock clip_grad_norm_ + Adam over 900 tensors are 6.3 ms).  Kept,
+# tested against the per-operator nodes and the reference, for callers whose loop is not host-bound.
 def autograd_chain_enabled():
-    return os.environ.get('MMNAS_AUTOGRAD_CHAIN', '1') != '0'
+    return os.environ.get('MMNAS_AUTOGRAD_CHAIN', '0') == '1'
 
 
 def _null_ptr(_p):
@@ -1337,6 +1342,7 @@ class BackboneFn(torch.autograd.Function):
         ctx.op_params = op_params
         ctx.ragged = (ragged, B, Sy, packed_io)
         ctx.gviews = gviews
+        ctx.n_extra = len(ptensors)
         if gviews is not None:
             ctx.counted, ctx.uniq = False, []
         else:
@@ -1394,7 +1400,7 @@ class BackboneFn(torch.autograd.Function):
         if ctx.gviews is not None:
             gv, ctx.gviews = ctx.gviews, None
             return head + tuple(gv)
-        return head
+        return head + (None,) * ctx.n_extra
 
 
 def backbone_chain(x, y, x_mask, y_mask, x_rel, y_rel, records, params, op_params=None, mixed=None, ragged=None, packed_io=False,

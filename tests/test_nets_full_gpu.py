@@ -3,9 +3,9 @@
 HSIZE 512 (search: 256), 100 regions + 14 tokens (VGD 15 tokens; ITM 36 regions + 50 tokens), 2048-wide region features,
 3129 answers, B = 2-4 -- BASELINE configs[0] literally (arch/mcan.json, B = 4, 36 regions) -- dropout 0.  Every case runs
 through the three routes the library has:
-    per-operator   one autograd node per operator (MMNAS_AUTOGRAD_CHAIN=0: the round-4 route of plain autograd use)
-    autograd-chain plain autograd use as it runs by default since round 5 (the unchanged scripts): the backbone as ONE node
-                   whose parameters are autograd inputs (weight steps / fixed architectures; the arch step keeps its nodes)
+    per-operator   one autograd node per operator (plain autograd use, the unchanged scripts: the default)
+    autograd-chain plain autograd use with MMNAS_AUTOGRAD_CHAIN=1 (opt-in, round 5): the backbone as ONE node whose parameters
+                   are autograd inputs (weight steps / fixed architectures; the arch step keeps its nodes)
     chain          the backbone / head / LSTM sections as native calls behind a flat gradient buffer (the bench's path:
                    arena planner, stream-K schedules, 8-head attention inside the chain, the 3129-wide answer layer, the
                    2048 -> d stem)
