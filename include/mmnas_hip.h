@@ -498,6 +498,11 @@ typedef struct mmnas_plan {
  * forward (small.hip) instead of projection / core / merge / LayerNorm launches; the saved block is the same.
  * mmnas_set_small_ops(0) forces the general path (returns the previous setting; default on, env MMNAS_SMALL_OPS). */
 int mmnas_set_small_ops(int on);
+/* The same operators' BACKWARD (single-stream order): LayerNorm backward, d(att), the attention core's backward and the input
+ * gradient as ONE launch, then dWm / dWq / dWk / dWv as one grouped launch carrying the LayerNorm parameter reduction -- 2 launches
+ * instead of 4 dependent ones.  mmnas_set_small_bwd(0): the general backward (returns the previous setting; default on, env
+ * MMNAS_SMALL_BWD).  Either backward follows either forward. */
+int mmnas_set_small_bwd(int on);
 int mmnas_att_op_plan(const mmnas_att_op* op, mmnas_plan* plan);   /* host only */
 int mmnas_att_op_fwd(const mmnas_att_op* op, void* stream);
 int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream);

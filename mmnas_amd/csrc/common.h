@@ -89,6 +89,7 @@ struct AuxReduce {
 };
 int launch_aux_reduce(const AuxReduce& a, hipStream_t st);
 int gemm_pair_aux(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, const AuxReduce* aux, hipStream_t st);
+int gemm_wgrad_aux(const mmnas_gemm_desc* wgrad, const AuxReduce* aux, hipStream_t st);   // the same without a data-gradient half
 // mmnas_layernorm_bwd without the final reduction: fills *aux (part == NULL when nothing is pending)
 int layernorm_bwd_deferred(const float* x, const float* a, const float* dy, float* dx, float* da, float* db, float* ddrop,
                            float* dcol, float* ws, float drop_p, uint64_t seed, uint32_t site, int M, int d, float eps,

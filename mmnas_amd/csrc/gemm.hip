@@ -1632,6 +1632,37 @@ int gemm_pair_aux(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, co
 }
 }  // namespace mmnas
 
+namespace mmnas {
+// A weight-gradient product (TN, split-K) with a pending column reduction riding on its launch as a few extra workgroups:
+// gemm_pair_aux without the data-gradient half (the short-sequence backward of small.hip leaves no NN product to pair with).
+int gemm_wgrad_aux(const mmnas_gemm_desc* wgrad, const AuxReduce* aux, hipStream_t st) {
+  GemmPlan p1;
+  int rc;
+  if ((rc = plan_gemm(wgrad, st, p1))) return rc;
+  const bool ride = aux && aux->part && g_tune.pair && g_tune.pair != 3 && g_tune.split == 3 && g_tune.pf == 2 && p1.fast && !p1.big && !p1.wide &&
+                    p1.layout == MMNAS_GEMM_TN && p1.k.mode != MODE_STREAM;
+  if (!ride) {
+    if (aux && (rc = launch_aux_reduce(*aux, st))) return rc;
+    return launch_plan(p1, st);
+  }
+  AuxReduceK ak;
+  memset(&ak, 0, sizeof(ak));
+  ak.part = aux->part; ak.nrows = aux->nrows; ak.d = aux->d;
+  for (int i = 0; i < 3; ++i) ak.out[i] = aux->out[i];
+  ak.ncb = cdiv(aux->d, 16);
+  ak.njobs = 3 * ak.ncb;
+  const int naux8 = (ak.njobs + 7) / 8 * 8;
+  char tag[96] = "";
+  if (prof_enabled()) snprintf(tag, sizeof(tag), "WGRAD+AUX %.60s", p1.tag);
+  ProfScope ps(MMNAS_K_GEMM, p1.flops, p1.bytes, st, tag);
+  dim3 grid(naux8 + p1.nwg), block(256);
+  // (the first descriptor is not run -- 0 workgroups -- but keeps the second one at its kernel-argument offset)
+  if (p1.lean) MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2, 0, 1>), grid, block, 0, st, p1.k, p1.k, 0, 0, ak, naux8);
+  else MMNAS_LAUNCH((gemm_pair_kernel<64, 64, 3, 2>), grid, block, 0, st, p1.k, p1.k, 0, 0, ak, naux8);
+  return check_launch("gemm_wgrad_aux");
+}
+}  // namespace mmnas
+
 extern "C" int mmnas_gemm_pair(const mmnas_gemm_desc* dgrad, const mmnas_gemm_desc* wgrad, void* stream) {
   return gemm_pair_aux(dgrad, wgrad, nullptr, (hipStream_t)stream);
 }

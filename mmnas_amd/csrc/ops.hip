@@ -66,6 +66,9 @@ static AttLayout att_layout(const mmnas_att_op* op) {
 // small.hip: one-launch forms for short sequences
 bool sa_small_applies(const mmnas_att_op* op);
 int sa_small_fwd(const mmnas_att_op* op, float* Q, float* K, float* V, float* att, float* stats, float* z, hipStream_t st);
+bool sa_small_bwd_applies(const mmnas_att_op* op);
+int sa_small_bwd(const mmnas_att_op* op, const float* Q, const float* K, const float* V, const float* stats, const float* z,
+                 float* dt_out, float* dQ, float* dK, float* dV, float* lnpart, hipStream_t st);
 
 static int att_check(const mmnas_att_op* op, const char* who) {
   MMNAS_REQUIRE(op, MMNAS_E_ARG, "%s: null descriptor", who);
@@ -279,6 +282,25 @@ static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* s
   if (rel) MMNAS_REQUIRE(op->rel && op->Wr && op->br && op->dWr && op->dbr, MMNAS_E_ARG, "att_op_bwd: REL gradients missing");
   AttLayout L = att_layout(op);
   const int d = op->d, di = op->di, Mq = (int)L.Mq, Mk = (int)L.Mk;
+
+  // Short sequences (the language stream): steps 1, 2, 4 and the data-gradient half of 5 + 6 as ONE launch (small.hip), then
+  // the four weight gradients as one grouped launch that carries the LayerNorm parameter reduction.
+  if (!sq && self && !rel && sa_small_bwd_applies(op)) {
+    float* const dt_out = drop ? L.dt : (norm ? L.dz : nullptr);
+    if ((rc = sa_small_bwd(op, L.Q, L.K, L.V, L.stats, L.z, dt_out, L.dQ, L.dK, L.dV, norm ? L.lnws : nullptr, stream))) return rc;
+    mmnas_gemm_desc w4;
+    gemm_init(w4, MMNAS_GEMM_TN, d, Mq, d, d, d);
+    w4.ngroups = 4;
+    w4.g[0].M = d; w4.g[0].A[0] = dt_out ? dt_out : op->dy; w4.g[0].B[0] = L.att; w4.g[0].C = op->dWm;
+    w4.g[1].M = d; w4.g[1].A[0] = L.dQ; w4.g[1].B[0] = op->xq; w4.g[1].C = op->dWq;
+    w4.g[2].M = d; w4.g[2].A[0] = L.dK; w4.g[2].B[0] = op->xq; w4.g[2].C = op->dWk;
+    w4.g[3].M = d; w4.g[3].A[0] = L.dV; w4.g[3].B[0] = op->xq; w4.g[3].C = op->dWv;
+    w4.accumulate = 1;
+    AuxReduce red;
+    red.part = norm ? L.lnws : nullptr; red.nrows = op->B; red.d = d;
+    red.out[0] = op->dln_a; red.out[1] = op->dln_b; red.out[2] = nullptr;
+    return gemm_wgrad_aux(&w4, &red, stream);
+  }
 
   // 1. through LayerNorm and the output dropout
   const float* dz = op->dy;   // gradient wrt z = x + drop(core)

@@ -28,8 +28,10 @@ def small_ops():
     from mmnas_amd import _lib as L
     lib = L.lib()
     prev = lib.mmnas_set_small_ops(1)
+    prev_b = lib.mmnas_set_small_bwd(1)
     yield lib
     lib.mmnas_set_small_ops(prev)
+    lib.mmnas_set_small_bwd(prev_b)
 
 
 @pytest.mark.parametrize('name', ['self_att_64'])
@@ -41,12 +43,20 @@ def test_short_sequence_op_vs_oracle(name, dims, nr, small_ops):
     got = run_hip_op(case)
     ref = R.run_oracle_op(case, dtype=torch.float64)
     _check(got, ref, floor=1e-2 if dims['Sx'] == 1 else 1e-4)
+    # the one-launch forward followed by the GENERAL backward (either backward follows either forward)
+    prev_b = small_ops.mmnas_set_small_bwd(0)
+    try:
+        mixed = run_hip_op(case)
+    finally:
+        small_ops.mmnas_set_small_bwd(prev_b)
+    _check(mixed, ref, floor=1e-2 if dims['Sx'] == 1 else 1e-4)
     small_ops.mmnas_set_small_ops(0)
     gen = run_hip_op(case)
     gscale = max(np.abs(gen[k]).max() for k in gen if k != 'out')
-    for k in got:          # same arithmetic up to summation order
-        den = max(np.abs(gen[k]).max(), 1e-2 * (gscale if k != 'out' else 1.0))
-        assert np.abs(got[k] - gen[k]).max() / den <= (1e-4 if dims['Sx'] == 1 else 2e-5), k
+    for other in (gen, mixed):
+        for k in got:          # same arithmetic up to summation order
+            den = max(np.abs(other[k]).max(), 1e-2 * (gscale if k != 'out' else 1.0))
+            assert np.abs(got[k] - other[k]).max() / den <= (1e-4 if dims['Sx'] == 1 else 2e-5), k
 
 
 @pytest.mark.parametrize('name', ['self_att_64'])
@@ -62,6 +72,14 @@ def test_short_sequence_op_dropout_replay(name, dims, small_ops, monkeypatch):
     _check(got, ref)
     ref0 = R.run_oracle_op(case, dtype=torch.float64)
     assert rel_err(got['out'], ref0['out']) > 1e-2
+    prev_b = small_ops.mmnas_set_small_bwd(0)      # the general backward replays the same masks
+    try:
+        mixed = run_hip_op(case, train=True, drop_p=p)
+    finally:
+        small_ops.mmnas_set_small_bwd(prev_b)
+    _check(mixed, ref)
+    for k in got:
+        assert np.abs(got[k] - mixed[k]).max() <= 2e-5 * max(np.abs(mixed[k]).max(), 1e-3), k
 
 
 def test_fully_padded_sample_is_uniform_attention(small_ops):
