@@ -63,6 +63,30 @@ def main():
         net.unused_modules_back()
         return loss
 
+    def step_statements(acc):
+        """the full step with a host timer behind every statement (no synchronisation in between: issue time only)"""
+        t = [time.perf_counter()]
+        tick = lambda: t.append(time.perf_counter())
+        MixedOp.MODE = None
+        net.reset_binary_gates()
+        net.unused_modules_off(); tick()
+        pred = net(inp); tick()
+        loss = loss_fn(pred, tgt); tick()
+        e0 = 0 * sum(p.sum() for p in net.alpha_prob_parameters())
+        e1 = 0 * sum(p.sum() for p in net.alpha_gate_parameters())
+        e2 = 0 * sum(p.sum() for p in net.net_parameters()); tick()
+        loss += e0
+        loss += e1
+        loss += e2; tick()
+        net.zero_grad(); tick()
+        loss.backward(); tick()
+        torch.nn.utils.clip_grad_norm_(net.net_parameters(), 1.0); tick()
+        opt.step(); tick()
+        net.unused_modules_back(); tick()
+        for i, k in enumerate(('sample + unused_modules_off', 'forward', 'loss', 'build 3 x `0 * sum(p.sum())`', '3 x `loss +=`', 'zero_grad',
+                               'backward', 'clip_grad_norm_', 'opt.step', 'unused_modules_back')):
+            acc.setdefault(k, []).append(1e3 * (t[i + 1] - t[i]))
+
     def measure(fn, n=30, warm=10):
         for _ in range(warm):
             fn()
@@ -85,6 +109,31 @@ def main():
             net.zero_grad()
         res[name] = measure(lambda: step(**kw))
         print('%-12s host %6.2f ms   wall %6.2f ms' % (name, *res[name]))
+    if '--statements' in sys.argv:
+        print()
+        print('# the full step statement by statement (host issue ms, median of 30 steps, queue drained before every step)')
+        for zs in (True, False):
+            acc = {}
+            for i in range(40):
+                torch.cuda.synchronize()
+                if zs:
+                    step_statements(acc)
+                else:      # the same statements without the three lines: what clip / Adam / zero_grad cost on the sampled parameters only
+                    t0 = time.perf_counter()
+                    MixedOp.MODE = None
+                    net.reset_binary_gates()
+                    net.unused_modules_off()
+                    loss = loss_fn(net(inp), tgt)
+                    t1 = time.perf_counter(); net.zero_grad()
+                    t2 = time.perf_counter(); loss.backward()
+                    t3 = time.perf_counter(); torch.nn.utils.clip_grad_norm_(net.net_parameters(), 1.0)
+                    t4 = time.perf_counter(); opt.step()
+                    t5 = time.perf_counter(); net.unused_modules_back()
+                    for k, v in (('forward + loss', t1 - t0), ('zero_grad', t2 - t1), ('backward', t3 - t2), ('clip_grad_norm_', t4 - t3), ('opt.step', t5 - t4)):
+                        acc.setdefault(k, []).append(1e3 * v)
+            print('#   %s' % ('with the three lines' if zs else 'without them'))
+            for k, v in acc.items():
+                print('#     %-34s %6.2f ms' % (k, statistics.median(v[10:])))
     net2 = Net_Search(cfg, init).to(dev).train()
     loop = SearchLoop(net2, loss_fn, net_lr=4e-4, clip=1.0, epoch_steps=1000, warmup=True)
     res['harness'] = measure(lambda: loop.weight_step(inp, tgt))

@@ -6,7 +6,7 @@ one() {  # workload small_bwd
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = d.get('kernel_ms_per_step', {})
-print('%-16s small_bwd=%s  %.4f ms/step  (small %.3f gemm %.3f attention %.3f rowops %.3f ms; GEMM launches/step %.1f)' % ('$1', '$2', d['ms_per_step'], k.get('small', 0), k.get('gemm', 0), k.get('attention', 0), k.get('rowops', 0), d['roofline']['launches_per_step']))"
+print('%-16s small_bwd=%s  %.4f ms/step  (short-sequence ops %.3f gemm %.3f attention cores %.3f rowops %.3f ms; GEMM launches/step %.1f)' % ('$1', '$2', d['ms_per_step'], k.get('small_ops', 0), k.get('gemm', 0), k.get('mha_fwd', 0) + k.get('mha_bwd', 0), k.get('rowops', 0), d['roofline']['launches_per_step']))"
 }
 echo "# round 5: short-sequence backward A/B on one MI355X box, alternating runs of python3 bench.py --workload W (median of 5 blocks of 20 steps)"
 for rep in 1 2 3; do
