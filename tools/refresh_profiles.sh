@@ -56,6 +56,7 @@ python3 tools/rel_bench.py > profiles/${R}_rel_microbench.txt 2>/dev/null
 # the unchanged search loop's host cost, with the library's one-node zero terms (default) and with the literal lines
 { echo "# MMNAS_ZERO_TERMS=1 (default: SumParameter / LazySum, mmnas_amd/zeroterm.py)"; python3 tools/dropin_host_split.py 2>/dev/null
   echo; echo "# MMNAS_ZERO_TERMS=0 (plain parameters: the three 0 * sum(p.sum()) lines run as written)"; MMNAS_ZERO_TERMS=0 python3 tools/dropin_host_split.py 2>/dev/null; } > profiles/${R}_host_dropin.txt
+python3 tools/dropin_host_split.py --statements > profiles/${R}_host_dropin_statements.txt 2>/dev/null
 [ -z "${SKIP_AB:-}" ] && bash tools/hoist_ab.sh > profiles/${R}_hoist_ab.txt 2>&1
 [ -z "${SKIP_AB:-}" ] && bash tools/small_bwd_ab.sh > profiles/${R}_small_bwd_ab.txt 2>&1
 (cd /tmp && GEMM_PMC_LAYOUTS=1 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $W/pmc_gemm_lds -o t -- python3 $ROOT/tools/gemm_pmc.py > $W/pmc_gemm_lds.log 2>&1)
