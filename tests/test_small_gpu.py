@@ -60,7 +60,7 @@ def test_short_sequence_op_vs_oracle(name, dims, nr, small_ops):
 
 
 @pytest.mark.parametrize('name', ['self_att_64'])
-@pytest.mark.parametrize('dims', [dict(B=9, Sx=14, Sy=3, HSIZE=256), dict(B=3, Sx=16, Sy=3, HSIZE=512)])
+@pytest.mark.parametrize('dims', [dict(B=9, Sx=14, Sy=3, HSIZE=256), dict(B=3, Sx=16, Sy=3, HSIZE=512), dict(B=64, Sx=14, Sy=3, HSIZE=256)])
 def test_short_sequence_op_dropout_replay(name, dims, small_ops, monkeypatch):
     from mmnas_amd import ops
     seed, p = 0x1234ABCD0F0F0F0F, 0.1
