@@ -109,6 +109,21 @@ def main():
             net.zero_grad()
         res[name] = measure(lambda: step(**kw))
         print('%-12s host %6.2f ms   wall %6.2f ms' % (name, *res[name]))
+    if '--cprofile' in sys.argv:      # where the per-operator path's own host time goes (forward + backward, no optimizer)
+        import cProfile
+        import pstats
+        net.zero_grad()
+        for _ in range(10):
+            step(zero_sum=False, optimize=False)
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(20):
+            step(zero_sum=False, optimize=False)
+        torch.cuda.synchronize()
+        pr.disable()
+        st = pstats.Stats(pr, stream=sys.stdout)
+        st.sort_stats('tottime').print_stats(45)
+        return
     if '--statements' in sys.argv:
         print()
         print('# the full step statement by statement (host issue ms, median of 30 steps, queue drained before every step)')
