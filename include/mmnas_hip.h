@@ -503,6 +503,9 @@ int mmnas_set_small_ops(int on);
  * instead of 4 dependent ones.  mmnas_set_small_bwd(0): the general backward (returns the previous setting; default on, env
  * MMNAS_SMALL_BWD).  Either backward follows either forward. */
 int mmnas_set_small_bwd(int on);
+/* FeedForward (d = 256, hidden 1024, <= 1024 rows) forward as ONE launch (small.hip: ffn_small_fwd_kernel).  Opt-in: measured
+ * neutral against the two products + LayerNorm it replaces (default off, env MMNAS_SMALL_FFN; returns the previous setting). */
+int mmnas_set_small_ffn(int on);
 int mmnas_att_op_plan(const mmnas_att_op* op, mmnas_plan* plan);   /* host only */
 int mmnas_att_op_fwd(const mmnas_att_op* op, void* stream);
 int mmnas_att_op_bwd(const mmnas_att_op* op, void* stream);

@@ -135,6 +135,7 @@ SYMBOLS = {
     'mmnas_lstm_seq_supported': (_i, [_i, _i]),
     'mmnas_set_small_ops': (_i, [_i]),
     'mmnas_set_small_bwd': (_i, [_i]),
+    'mmnas_set_small_ffn': (_i, [_i]),
     'mmnas_set_chain_overlap': (_i, [_i]),
     'mmnas_lstm_seq_fwd': (_i, [_fp] * 7 + [_i, _i, _i, _fp]),
     'mmnas_lstm_seq_bwd': (_i, [_fp] * 5 + [_i, _i, _i, _fp]),

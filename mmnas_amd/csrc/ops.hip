@@ -66,6 +66,8 @@ static AttLayout att_layout(const mmnas_att_op* op) {
 // small.hip: one-launch forms for short sequences
 bool sa_small_applies(const mmnas_att_op* op);
 int sa_small_fwd(const mmnas_att_op* op, float* Q, float* K, float* V, float* att, float* stats, float* z, hipStream_t st);
+bool ffn_small_applies(const mmnas_mlp_op* op);
+int ffn_small_fwd(const mmnas_mlp_op* op, float* h, float* z, hipStream_t st);
 bool sa_small_bwd_applies(const mmnas_att_op* op);
 int sa_small_bwd(const mmnas_att_op* op, const float* Q, const float* K, const float* V, const float* stats, const float* z,
                  float* dt_out, float* dQ, float* dK, float* dV, float* lnpart, hipStream_t st);
@@ -498,6 +500,9 @@ static int mmnas::mlp_fwd_impl(const mmnas_mlp_op* op, void* stream, bool defer_
   if (norm) MMNAS_REQUIRE(op->ln_a && op->ln_b, MMNAS_E_ARG, "mlp_op_fwd: NORM without ln parameters");
   MlpLayout L = mlp_layout(op);
   const int d = op->dims[0];
+  // short row counts (the language stream): both layers, the residual and the LayerNorm as ONE launch (small.hip); a deferred
+  // LayerNorm (architecture-step nodes) keeps the general path
+  if (!(norm && defer_ln) && ffn_small_applies(op)) return ffn_small_fwd(op, L.h[1], L.z, (hipStream_t)stream);
   const float* in = op->x;
   mmnas_gemm_desc g;
   for (int i = 0; i < op->nl; ++i) {

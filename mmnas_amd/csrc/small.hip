@@ -665,6 +665,223 @@ __global__ void __launch_bounds__(256, 1) sa_small_bwd_kernel(const SaSmallBwdK 
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// FeedForward forward (modules.py:328-347: LayerNorm(x + drop(W2 drop(relu(W1 x + b1)) + b2))) of a short sequence in ONE
+// launch, the same recipe: grid (4, B) -- a workgroup owns one 256-wide slice of the 4d hidden units of one sample.
+//   1. x_b -> LDS; h_j = drop(relu(x_b W1[256j.., :]^T + b1)) [S, 256] (16 x 16 x 4 MFMAs, weight rows streamed as B
+//      fragments, 16 bytes a lane feeding 4 MFMAs); h_j goes to the saved block and to LDS.
+//   2. the slice's share of the second layer, h_j W2[:, 256j..]^T [S, d], to the workspace; the last workgroup of the sample
+//      adds the four shares in slice order, b2, the output dropout, the residual and the LayerNorm.
+// Replaces 3 dependent launches (two ~225-workgroup products and the LayerNorm: 13 + 10.5 + 4 us at M = 896).  The saved
+// block (h, z) is the general path's, whose backward follows.
+// MEASURED NEUTRAL, hence opt-in (MMNAS_SMALL_FFN=1 / mmnas_set_small_ffn(1)): 26.5 us per operator against the 27.5 us of the
+// three launches; supernet step 4.666 vs 4.666 ms (profiles/r05_small_ffn_ab.txt).  A workgroup streams 512 KB of weights (twice
+// the SelfAtt kernel's) through its CU's 64 B/clk L1 path and runs 2 x 3.4 us of fp32 MFMAs at one wave per SIMD; the general
+// path's products run on the split-bf16 pipe at 5x the rate and pay their three launch boundaries instead.
+struct FfnSmallK {
+  int B, M, flags;      // B = groups of 16 consecutive rows (the operator is row-wise: sample boundaries do not matter)
+  const float* x; const float* W1; const float* b1; const float* W2; const float* b2;
+  const float* ln_a; const float* ln_b;
+  float* h; float* z; float* y;
+  float* part; int* cnt;
+  DropCfg drop_h, drop_out;
+  float eps;
+};
+
+template <int D>
+__global__ void __launch_bounds__(256, 1) ffn_small_fwd_kernel(const FfnSmallK p) {
+  constexpr int LDX = D + 4, FF = 4 * D, HS = 256, LDHS = HS + 4, NSL = FF / HS;
+  constexpr int KC = 64, SPC = KC / 16, NCH1 = D / KC, NCH2 = HS / KC;
+  constexpr int NT1 = HS / 64;    // hidden-column tiles per wave (layer 1)
+  constexpr int NT2 = D / 64;     // output-column tiles per wave (layer 2)
+  __shared__ __attribute__((aligned(16))) float xs[16 * LDX];
+  __shared__ __attribute__((aligned(16))) float hs[16 * LDHS];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+  const int j = blockIdx.x, b = blockIdx.y;
+  const size_t row0 = (size_t)b * 16;
+  const int S = min(16, p.M - 16 * b);      // rows of this group
+
+  const float* w1row[NT1];
+#pragma unroll
+  for (int m = 0; m < NT1; ++m) w1row[m] = p.W1 + (size_t)(HS * j + 64 * m + 16 * w + l15) * D + 4 * kq;
+  float4 wb[2][NT1][SPC];
+#pragma unroll
+  for (int m = 0; m < NT1; ++m)
+#pragma unroll
+    for (int s = 0; s < SPC; ++s) wb[0][m][s] = *reinterpret_cast<const float4*>(w1row[m] + 16 * s);
+  {
+    constexpr int F4 = D / 4, N = 16 * F4 / 256;
+    float4 xv[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int f = tid + 256 * i, r = f / F4, c4 = f - r * F4;
+      const float4 t = *reinterpret_cast<const float4*>(p.x + (row0 + (r < S ? r : 0)) * D + 4 * c4);
+      xv[i] = r < S ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int f = tid + 256 * i, r = f / F4, c4 = f - r * F4;
+      *reinterpret_cast<float4*>(xs + r * LDX + 4 * c4) = xv[i];
+    }
+  }
+  __syncthreads();
+
+  // ---- layer 1: hidden columns 256 j + 64 m + 16 w + l15 ----
+  f32x4 acc[NT1];
+#pragma unroll
+  for (int m = 0; m < NT1; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NCH1; ++c) {
+    if (c + 1 < NCH1) {
+#pragma unroll
+      for (int m = 0; m < NT1; ++m)
+#pragma unroll
+        for (int s = 0; s < SPC; ++s) wb[(c + 1) & 1][m][s] = *reinterpret_cast<const float4*>(w1row[m] + KC * (c + 1) + 16 * s);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < SPC; ++s) {
+      const float4 a = *reinterpret_cast<const float4*>(xs + l15 * LDX + KC * c + 16 * s + 4 * kq);
+#pragma unroll
+      for (int m = 0; m < NT1; ++m) { MFMA16x4(acc[m], a, wb[c & 1][m][s]) }
+    }
+  }
+  // layer-2 fragments of the first chunk: rows n = 64 t + 16 w + l15 of W2, columns 256 j + 16 s + 4 kq .. +3
+  const float* w2row[NT2];
+#pragma unroll
+  for (int t = 0; t < NT2; ++t) w2row[t] = p.W2 + (size_t)(64 * t + 16 * w + l15) * FF + HS * j + 4 * kq;
+  float4 wm[2][NT2][SPC];
+#pragma unroll
+  for (int t = 0; t < NT2; ++t)
+#pragma unroll
+    for (int s = 0; s < SPC; ++s) wm[0][t][s] = *reinterpret_cast<const float4*>(w2row[t] + 16 * s);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int m = 0; m < NT1; ++m) {
+    const int col = 64 * m + 16 * w + l15, gcol = HS * j + col;
+    const float bv = p.b1 ? p.b1[gcol] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int s = 4 * kq + r;
+      float v = fmaxf(acc[m][r] + bv, 0.f);
+      if (p.drop_h.thresh) v *= drop_mult(p.drop_h, (uint32_t)(row0 + s) * (uint32_t)FF + (uint32_t)gcol);
+      hs[s * LDHS + col] = v;
+      if (s < S) p.h[(row0 + s) * FF + gcol] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- layer 2: this slice's share of the output, columns 64 t + 16 w + l15 ----
+  f32x4 pm[NT2];
+#pragma unroll
+  for (int t = 0; t < NT2; ++t) pm[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NCH2; ++c) {
+    if (c + 1 < NCH2) {
+#pragma unroll
+      for (int t = 0; t < NT2; ++t)
+#pragma unroll
+        for (int s = 0; s < SPC; ++s) wm[(c + 1) & 1][t][s] = *reinterpret_cast<const float4*>(w2row[t] + KC * (c + 1) + 16 * s);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < SPC; ++s) {
+      const float4 a = *reinterpret_cast<const float4*>(hs + l15 * LDHS + KC * c + 16 * s + 4 * kq);
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) { MFMA16x4(pm[t], a, wm[c & 1][t][s]) }
+    }
+  }
+  const size_t bj = (size_t)b * NSL + j;
+  float* const slot = p.part + (bj * 16) * D;
+#pragma unroll
+  for (int t = 0; t < NT2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st_agent_f(slot + (4 * kq + r) * D + 64 * t + 16 * w + l15, pm[t][r]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) s_last = __hip_atomic_fetch_add(p.cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NSL - 1;
+  __syncthreads();
+  if (!s_last) return;
+  if (tid == 0) __hip_atomic_store(p.cnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  // ---- finisher: z = x + drop(sum_j share_j + b2); y = LN(z) (sa_small_fwd_kernel's, plus the bias) ----
+  constexpr int NV = D / 256;
+  constexpr int RG = D == 256 ? 4 : 2;
+  const bool norm = p.flags & MMNAS_F_NORM, resid = p.flags & MMNAS_F_RESIDUAL;
+  const __amdgpu_buffer_rsrc_t prsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.part + (size_t)b * NSL * 16 * D), 0, (unsigned)(NSL * 16 * D * 4), 0x00020000);
+#pragma unroll 1
+  for (int g = 0; g < 4 / RG; ++g) {
+    u32x4s t[RG][NSL][NV];
+#pragma unroll
+    for (int rr = 0; rr < RG; ++rr) {
+      const int s = min(w + 4 * (g * RG + rr), 15);
+#pragma unroll
+      for (int hh = 0; hh < NSL; ++hh)
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          t[rr][hh][i] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, (unsigned)(((hh * 16 + s) * D + 4 * (lane + 64 * i)) * 4), 0, 16 /* sc1 */);
+    }
+#pragma unroll
+    for (int rr = 0; rr < RG; ++rr) {
+      const int s = w + 4 * (g * RG + rr);
+      if (s >= S) continue;     // wave-uniform
+      float v[4 * NV];
+#pragma unroll
+      for (int i = 0; i < 4 * NV; ++i) v[i] = 0.f;
+#pragma unroll
+      for (int hh = 0; hh < NSL; ++hh)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          v[4 * i] += __uint_as_float(t[rr][hh][i].x); v[4 * i + 1] += __uint_as_float(t[rr][hh][i].y);
+          v[4 * i + 2] += __uint_as_float(t[rr][hh][i].z); v[4 * i + 3] += __uint_as_float(t[rr][hh][i].w);
+        }
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const float4 b2v = p.b2 ? *reinterpret_cast<const float4*>(p.b2 + 4 * (lane + 64 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float bb[4] = {b2v.x, b2v.y, b2v.z, b2v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int col = 4 * (lane + 64 * i) + e;
+          float x = v[4 * i + e] + bb[e];
+          if (p.drop_out.thresh) x *= drop_mult(p.drop_out, (uint32_t)(row0 + s) * (uint32_t)D + (uint32_t)col);
+          if (resid) x += xs[s * LDX + col];
+          v[4 * i + e] = x;
+          sm += x;
+        }
+      }
+      float* const yr = p.y + (row0 + s) * D;
+      if (!norm) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          *reinterpret_cast<float4*>(yr + 4 * (lane + 64 * i)) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+        continue;
+      }
+      float* const zr = p.z + (row0 + s) * D;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        *reinterpret_cast<float4*>(zr + 4 * (lane + 64 * i)) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+      const float mean = wave_sum(sm) / (float)D;
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4 * NV; ++i) { v[i] -= mean; ss += v[i] * v[i]; }
+      const float sd = sqrtf(wave_sum(ss) / (float)(D - 1));
+      const float invs = 1.0f / (sd + p.eps);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int col = 4 * (lane + 64 * i);
+        const float4 av = *reinterpret_cast<const float4*>(p.ln_a + col);
+        const float4 bv = *reinterpret_cast<const float4*>(p.ln_b + col);
+        *reinterpret_cast<float4*>(yr + col) = make_float4(av.x * v[4 * i] * invs + bv.x, av.y * v[4 * i + 1] * invs + bv.y,
+                                                           av.z * v[4 * i + 2] * invs + bv.z, av.w * v[4 * i + 3] * invs + bv.w);
+      }
+    }
+  }
+}
+
+
 static int env_on(const char* name, int dflt) {
   const char* e = getenv(name);
   return e && e[0] ? atoi(e) : dflt;
@@ -754,7 +971,46 @@ int sa_small_bwd(const mmnas_att_op* op, const float* Q, const float* K, const f
   return check_launch("sa_small_bwd");
 }
 
+// Does the one-launch FeedForward forward take this operator?  (two layers d -> 4d -> d with d = 256 and at most 1024 rows:
+// 4 workgroups per group of 16 rows, one round of <= 256)
+static int g_small_ffn = -1;
+static bool small_ffn_on() {     // default OFF: measured neutral against the three launches it replaces (see the header comment)
+  if (g_small_ffn < 0) g_small_ffn = env_on("MMNAS_SMALL_FFN", 0) ? 1 : 0;
+  return g_small_ffn != 0;
+}
+bool ffn_small_applies(const mmnas_mlp_op* op) {
+  if (!small_ops_on() || !small_ffn_on()) return false;
+  return op->nl == 2 && op->dims[0] == 256 && op->dims[1] == 1024 && op->dims[2] == 256 && op->M <= 1024 && op->W[0] && op->W[1];
+}
+
+int ffn_small_fwd(const mmnas_mlp_op* op, float* h, float* z, hipStream_t st) {
+  const int fl = op->flags;
+  const bool drop = (fl & MMNAS_F_TRAIN) && op->drop_p > 0.f;
+  FfnSmallK k;
+  memset(&k, 0, sizeof(k));
+  k.B = (op->M + 15) / 16; k.M = op->M; k.flags = fl;
+  k.x = op->x; k.W1 = op->W[0]; k.b1 = op->b[0]; k.W2 = op->W[1]; k.b2 = op->b[1];
+  k.ln_a = op->ln_a; k.ln_b = op->ln_b; k.h = h; k.z = z; k.y = op->y;
+  k.drop_h = make_drop(drop ? op->drop_p : 0.f, op->seed, 0);
+  k.drop_out = make_drop(drop ? op->drop_p : 0.f, op->seed, 1);
+  k.eps = op->eps;
+  size_t wsf = 0; int ncnt = 0;
+  int rc = sk_workspace(st, &k.part, &wsf, &k.cnt, &ncnt);
+  if (rc) return rc;
+  MMNAS_REQUIRE((size_t)k.B * 4 * 16 * 256 <= wsf && k.B <= ncnt, MMNAS_E_SHAPE, "ffn_small_fwd: M=%d exceeds the hand-off workspace", op->M);
+  const double M = op->M;
+  ProfScope ps(MMNAS_K_SMALL, 2.0 * M * 256.0 * 1024.0 * 2.0, 4.0 * (2.0 * 256.0 * 1024.0 + M * (3.0 * 256.0 + 1024.0)), st, "ffn_small_fwd");
+  MMNAS_LAUNCH(ffn_small_fwd_kernel<256>, dim3(4, k.B), dim3(256), 0, st, k);
+  return check_launch("ffn_small_fwd");
+}
+
 }  // namespace mmnas
+
+extern "C" int mmnas_set_small_ffn(int on) {
+  const int prev = mmnas::small_ffn_on() ? 1 : 0;
+  mmnas::g_small_ffn = on ? 1 : 0;
+  return prev;
+}
 
 extern "C" int mmnas_set_small_bwd(int on) {
   const int prev = mmnas::small_bwd_on() ? 1 : 0;
