@@ -688,9 +688,9 @@ struct FfnSmallK {
   float eps;
 };
 
-template <int D>
-__global__ void __launch_bounds__(256, 1) ffn_small_fwd_kernel(const FfnSmallK p) {
-  constexpr int LDX = D + 4, FF = 4 * D, HS = 256, LDHS = HS + 4, NSL = FF / HS;
+template <int D, int HS>     // HS: hidden units per workgroup (256: 4 workgroups per row group; 128: 8, two per CU)
+__global__ void __launch_bounds__(256, HS == 256 ? 1 : 2) ffn_small_fwd_kernel(const FfnSmallK p) {
+  constexpr int LDX = D + 4, FF = 4 * D, LDHS = HS + 4, NSL = FF / HS;
   constexpr int KC = 64, SPC = KC / 16, NCH1 = D / KC, NCH2 = HS / KC;
   constexpr int NT1 = HS / 64;    // hidden-column tiles per wave (layer 1)
   constexpr int NT2 = D / 64;     // output-column tiles per wave (layer 2)
@@ -975,7 +975,7 @@ int sa_small_bwd(const mmnas_att_op* op, const float* Q, const float* K, const f
 // 4 workgroups per group of 16 rows, one round of <= 256)
 static int g_small_ffn = -1;
 static bool small_ffn_on() {     // default OFF: measured neutral against the three launches it replaces (see the header comment)
-  if (g_small_ffn < 0) g_small_ffn = env_on("MMNAS_SMALL_FFN", 0) ? 1 : 0;
+  if (g_small_ffn < 0) g_small_ffn = env_on("MMNAS_SMALL_FFN", 0);      // 1: four slices of 256 hidden units; 2: eight of 128
   return g_small_ffn != 0;
 }
 bool ffn_small_applies(const mmnas_mlp_op* op) {
@@ -997,10 +997,12 @@ int ffn_small_fwd(const mmnas_mlp_op* op, float* h, float* z, hipStream_t st) {
   size_t wsf = 0; int ncnt = 0;
   int rc = sk_workspace(st, &k.part, &wsf, &k.cnt, &ncnt);
   if (rc) return rc;
-  MMNAS_REQUIRE((size_t)k.B * 4 * 16 * 256 <= wsf && k.B <= ncnt, MMNAS_E_SHAPE, "ffn_small_fwd: M=%d exceeds the hand-off workspace", op->M);
+  const int nsl = g_small_ffn == 2 ? 8 : 4;
+  MMNAS_REQUIRE((size_t)k.B * nsl * 16 * 256 <= wsf && k.B <= ncnt, MMNAS_E_SHAPE, "ffn_small_fwd: M=%d exceeds the hand-off workspace", op->M);
   const double M = op->M;
   ProfScope ps(MMNAS_K_SMALL, 2.0 * M * 256.0 * 1024.0 * 2.0, 4.0 * (2.0 * 256.0 * 1024.0 + M * (3.0 * 256.0 + 1024.0)), st, "ffn_small_fwd");
-  MMNAS_LAUNCH(ffn_small_fwd_kernel<256>, dim3(4, k.B), dim3(256), 0, st, k);
+  if (nsl == 8) MMNAS_LAUNCH((ffn_small_fwd_kernel<256, 128>), dim3(8, k.B), dim3(256), 0, st, k);
+  else MMNAS_LAUNCH((ffn_small_fwd_kernel<256, 256>), dim3(4, k.B), dim3(256), 0, st, k);
   return check_launch("ffn_small_fwd");
 }
 
@@ -1008,7 +1010,7 @@ int ffn_small_fwd(const mmnas_mlp_op* op, float* h, float* z, hipStream_t st) {
 
 extern "C" int mmnas_set_small_ffn(int on) {
   const int prev = mmnas::small_ffn_on() ? 1 : 0;
-  mmnas::g_small_ffn = on ? 1 : 0;
+  mmnas::g_small_ffn = on < 0 ? 0 : (on > 2 ? 2 : on);
   return prev;
 }
 

@@ -97,7 +97,9 @@ def test_fully_padded_sample_is_uniform_attention(small_ops):
 @pytest.mark.parametrize('dims', [dict(B=64, Sx=14, Sy=3, HSIZE=256), dict(B=7, Sx=5, Sy=3, HSIZE=256), dict(B=3, Sx=16, Sy=3, HSIZE=256),
                                   dict(B=1, Sx=1, Sy=3, HSIZE=256)])
 @pytest.mark.parametrize('nr', [(True, True), (False, False), (True, False)])
-def test_short_feed_forward_vs_oracle_and_general_path(dims, nr, small_ops):
+@pytest.mark.parametrize('mode', [1, 2])       # 4 hidden slices of 256 / 8 of 128 (two workgroups per CU)
+def test_short_feed_forward_vs_oracle_and_general_path(dims, nr, mode, small_ops):
+    small_ops.mmnas_set_small_ffn(mode)
     case = cases.op_case('feed_forward', nr[0], nr[1], 77 + dims['Sx'], dims)
     got = run_hip_op(case)
     ref = R.run_oracle_op(case, dtype=torch.float64)
@@ -111,8 +113,10 @@ def test_short_feed_forward_vs_oracle_and_general_path(dims, nr, small_ops):
 
 
 @pytest.mark.parametrize('dims', [dict(B=9, Sx=14, Sy=3, HSIZE=256), dict(B=64, Sx=14, Sy=3, HSIZE=256)])
-def test_short_feed_forward_dropout_replay(dims, small_ops, monkeypatch):
+@pytest.mark.parametrize('mode', [1, 2])
+def test_short_feed_forward_dropout_replay(dims, mode, small_ops, monkeypatch):
     from mmnas_amd import ops
+    small_ops.mmnas_set_small_ffn(mode)
     seed, p = 0x0BADC0DE12345678, 0.1
     monkeypatch.setattr(ops, 'next_seed', lambda: seed)
     case = cases.op_case('feed_forward', True, True, 4343, dims)

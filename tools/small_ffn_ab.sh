@@ -9,7 +9,8 @@ k = d.get('kernel_ms_per_step', {})
 print('%-16s small_ffn=%s  %.4f ms/step  (short-sequence ops %.3f gemm %.3f rowops %.3f ms; GEMM launches/step %.1f)' % ('$1', '$2', d['ms_per_step'], k.get('small_ops', 0), k.get('gemm', 0), k.get('rowops', 0), d['roofline']['launches_per_step']))"
 }
 echo "# round 5: one-launch FeedForward forward (M = 896 rows) A/B on one MI355X box, alternating runs of python3 bench.py --workload W (median of 5 blocks of 20 steps)"
+# small_ffn: 0 = the general path (two products + LayerNorm), 1 = four hidden slices of 256 per row group, 2 = eight of 128
 for rep in 1 2 3; do
-  for wl in search_vqa search_vqa_unpad; do one $wl 1; one $wl 0; done
+  for wl in search_vqa search_vqa_unpad; do one $wl 1; one $wl 2; one $wl 0; done
 done
-for wl in arch_vqa bilevel_vqa; do one $wl 1; one $wl 0; done
+for wl in bilevel_vqa; do one $wl 1; one $wl 2; one $wl 0; done
