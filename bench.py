@@ -420,8 +420,8 @@ def main():
     # Kernel arguments written straight into device memory: 5.1 ms instead of 6.1-7.3 ms per supernet step on this pool
     # (README).  The image exports it; a box that does not must not silently lose 20-40 %: set it before HIP initialises
     # and say in `config` what the run had.
-    kernarg_inherited = 'HIP_FORCE_DEV_KERNARG' in os.environ
-    os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
+    # Round 6: the LIBRARY does that when it is imported (mmnas_amd/_lib.py::_launch_configuration, before the first HIP call
+    # of this process, below); bench.py only records what `ops.runtime_config()` reports.
     # The contract is ONE JSON line on stdout.  Libraries of the process write there too (RCCL prints its version banner to
     # stdout under NCCL_DEBUG=VERSION, which this pool exports -- through C stdio, i.e. behind the JSON line when stdout is a
     # pipe): drop that setting (the version goes into the JSON line instead), and keep file descriptor 1 pointed at stderr
@@ -435,6 +435,8 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+    from mmnas_amd import ops as _ops_early   # BEFORE the first HIP call: the library establishes its launch configuration at import
+    runtime_cfg = _ops_early.runtime_config()
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     # (tests only: MMNAS_BENCH_DEVICE / MMNAS_BENCH_BACKEND=gloo run several ranks on ONE GPU -- RCCL refuses that --
@@ -767,6 +769,20 @@ def main():
             return arch(True)
         return round_, fl, loop.alpha_every + 1
 
+    def lstm_timed_out_any():
+        """1 when the persistent LSTM's hand-off timed out on ANY rank since the last call (MAX over the ranks: all of them
+        take the same branch afterwards); a negative return of the query is an error of the library, not a time-out."""
+        t = int(lib.mmnas_lstm_seq_timed_out(L.stream()))
+        if t < 0:
+            sys.stderr.write('bench.py: mmnas_lstm_seq_timed_out failed: %s\n' % lib.mmnas_last_error().decode())
+            sys.exit(4)
+        t = 1 if t else 0
+        if world > 1:
+            f = torch.tensor([float(t)], device=dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MAX)
+            t = int(f.item() > 0)
+        return t
+
     def measure(wl, steps, warmup):
         step, fl, per_call = make_step(wl)
         calls = max(1, steps // per_call) if per_call > 1 else steps
@@ -774,9 +790,11 @@ def main():
         for _ in range(wcalls):
             step()
         barrier()
-        if int(lib.mmnas_lstm_seq_timed_out(L.stream())) and os.environ.get('MMNAS_LSTM', '1') != '0':
-            # the persistent LSTM's hand-off gave up during warm-up (its grid was not co-resident -- e.g. beside a collective's
-            # kernels on a box this was never run on): the step falls back to nn.LSTM (MIOpen) instead of timing NaNs, and says so
+        if lstm_timed_out_any() and os.environ.get('MMNAS_LSTM', '1') != '0':
+            # the persistent LSTM's hand-off gave up during warm-up ON SOME RANK (its grid was not co-resident -- e.g. beside a
+            # collective's kernels on a box this was never run on): EVERY rank falls back to nn.LSTM (MIOpen) and re-warms
+            # together -- the re-warm-up steps contain collectives, so the decision must not be one rank's own -- instead of
+            # timing NaNs, and the line says so
             os.environ['MMNAS_LSTM'] = '0'
             multi['lstm_fallback'] = True
             for _ in range(wcalls):
@@ -816,7 +834,7 @@ def main():
             el = time.perf_counter() - t0
             # the persistent LSTM's hand-off gives up (and poisons the pass with NaN) when a workgroup of its grid was not
             # resident -- e.g. a collective's kernel held the slot: read the flag after EVERY block and report it
-            multi['lstm_timed_out'] += int(lib.mmnas_lstm_seq_timed_out(L.stream()))
+            multi['lstm_timed_out'] += lstm_timed_out_any()
             if world > 1:
                 mine = torch.zeros(world, device=dev, dtype=torch.float64)
                 mine[rank] = el
@@ -1017,10 +1035,10 @@ def main():
                        'rccl_env': {k: v for k, v in os.environ.items() if k.startswith(('NCCL_', 'RCCL_'))},
                        'rccl_version': '.'.join(str(x) for x in torch.cuda.nccl.version()) if hasattr(torch.cuda, 'nccl') else None,
                        'optimizer_in_step': False, 'gemm_split': args.gemm_split,
-                       'hip_force_dev_kernarg': os.environ.get('HIP_FORCE_DEV_KERNARG'),
-                       # 'set_by_bench' takes effect only if nothing initialised HIP before this script (under rocprofv3 the
-                       # tool's preloaded library does: the variable must then come from the environment)
-                       'hip_force_dev_kernarg_source': 'inherited' if kernarg_inherited else 'set_by_bench'},
+                       'hip_force_dev_kernarg': runtime_cfg['hip_force_dev_kernarg'],
+                       # 'set_by_library' takes effect only if nothing initialised HIP before the library was imported (under
+                       # rocprofv3 the tool's preloaded library does: the variable must then come from the environment)
+                       'hip_force_dev_kernarg_source': runtime_cfg['hip_force_dev_kernarg_source']},
         }
         for k, v in head.items():
             if k not in out and k not in ('workload',):

@@ -119,6 +119,16 @@ typedef struct mmnas_gemm_desc {
 
 int mmnas_gemm(const mmnas_gemm_desc* d, void* stream);
 
+/* y = LayerNorm(z), z = dropout(A W^T + bias) + residual: the merge projection of an attention operator / the last layer of
+ * a feed-forward operator (modules.py:186-187, 261-271, 351-362: `x = self.norm(x + self.dropout(self.linear_merge(att)))`)
+ * with the hand-written LayerNorm behind it (modules.py:44-56) as ONE launch.  *d describes the product exactly as for
+ * mmnas_gemm (layout NT, one group; z = d->g[0].C with leading dimension ldc, may be NULL when nobody needs z); y has
+ * d->N columns.  N = 256, K % 32 == 0 and 16-byte aligned operands run the row-panel kernel (32 x 256 panels, statistics
+ * in-kernel); every other shape -- or MMNAS_GEMM_LN=0 / mmnas_set_gemm_ln(0) -- runs mmnas_gemm + mmnas_layernorm_fwd
+ * (z must then be given, ldc = N).  mmnas_set_gemm_ln returns the previous setting. */
+int mmnas_gemm_ln(const mmnas_gemm_desc* d, const float* ln_a, const float* ln_b, float* y, float eps, void* stream);
+int mmnas_set_gemm_ln(int on);
+
 /* A weight matrix (nn.Linear.weight, modules.py:18,172-175) as three bf16 planes, planes[c * n + i] = part c of w[i]
  * with w[i] = part0 + part1 + part2 exactly -- the split mmnas_gemm otherwise performs on every K-tile it stages; done
  * once per optimizer step instead.  n % 8 == 0; `planes` holds 3 n bf16 (6 n bytes), 16-byte aligned. */

@@ -4,12 +4,38 @@ There is deliberately no fallback: if the shared library is missing, or a tensor
 contiguous fp32 HIP tensor, the call raises.  The product path never computes on the CPU.
 """
 import ctypes as C
+import logging
 import os
 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MMNAS_LIB_PATH') or os.path.join(_HERE, 'lib', 'libmmnas_hip.so')   # (override: tuning builds)
+
+log = logging.getLogger('mmnas_amd')
+
+
+def _launch_configuration():
+    """HIP_FORCE_DEV_KERNARG=1 (kernel arguments written straight into device memory) is worth 20-40 % of a supernet step
+    on this pool (README: 6.1-7.3 ms instead of 5.1 with 0): a step is ~300 short dependent launches and each one's first
+    instruction waits for its argument block.  The HIP runtime reads the variable when it initialises, i.e. at the process's
+    first HIP call, so the LIBRARY sets it (when the user has not) as soon as it is imported -- `import mmnas.model...` in
+    the reference's scripts comes before the first tensor reaches the GPU -- instead of leaving it to bench.py.  Imported
+    after HIP is up with the variable unset, the library can only say so: one warning on the `mmnas_amd` logger.
+    Returns (value, source); `ops.runtime_config()` reports both."""
+    name = 'HIP_FORCE_DEV_KERNARG'
+    if name in os.environ:
+        return os.environ[name], 'inherited'
+    if torch.cuda.is_initialized():
+        log.warning('mmnas_amd was imported after HIP had initialised and %s is not set: kernel arguments go through host-visible '
+                    'memory, the ~300 short launches of a step run 20-40 %% slower.  Export %s=1 or import mmnas / mmnas_amd '
+                    'before the first CUDA call.', name, name)
+        return None, 'unset_after_hip_init'
+    os.environ[name] = '1'
+    return '1', 'set_by_library'
+
+
+KERNARG_VALUE, KERNARG_SOURCE = _launch_configuration()
 
 F_NORM, F_RESIDUAL, F_MASK, F_REL, F_SELF, F_TRAIN, F_RELRAW = 1, 2, 4, 8, 16, 32, 64
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
@@ -127,6 +153,8 @@ SYMBOLS = {
     'mmnas_dropout_mask': (_i, [_fp, _sz, _f, _u64, _u32, _fp]),
     'mmnas_gemm': (_i, [C.POINTER(GemmDesc), _fp]),
     'mmnas_split_planes': (_i, [_fp, _fp, _sz, _fp]),
+    'mmnas_gemm_ln': (_i, [C.POINTER(GemmDesc), _fp, _fp, _fp, _f, _fp]),
+    'mmnas_set_gemm_ln': (_i, [_i]),
     'mmnas_gemm_pair': (_i, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), _fp]),
     'mmnas_gemm_reload_tuning': (_i, []),
     'mmnas_lstm_supported': (_i, [_i, _i]),

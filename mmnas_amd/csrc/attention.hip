@@ -98,12 +98,14 @@ __device__ __forceinline__ void load_tiles2(float* __restrict__ da, const float*
 // ------------------------------------------------------------------------------------------
 // forward: grid (ceil(Sq / (32 NW)), H, B), block 64 NW.  NKC = key chunks of 32 (all keys).
 // ------------------------------------------------------------------------------------------
+#ifndef MMNAS_DBG_FWD
+#define MMNAS_DBG_FWD 0   // timing experiments only (wrong results): bit mask of forward phases left out (tools/mha_fwd_phases.sh)
+#endif
 template <int DHC, int NKC, int NW>
 __device__ __forceinline__ void mha_fwd_body(const MhaK& p, const int qblk) {
   constexpr int LD = DHC + 4, NT = 64 * NW, JC = DHC >= 32 ? DHC / 32 : 1;
   __shared__ __attribute__((aligned(16))) float Qs[32 * NW * LD];
   __shared__ __attribute__((aligned(16))) float KVs[32 * NKC * LD];
-  __shared__ float sMask[32 * NKC];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = qblk * 32 * NW;
   const int SqS = p.Sq, SkS = p.Sk;   // strides of the per-(batch, head) arrays; the lengths of this batch element:
@@ -114,8 +116,20 @@ __device__ __forceinline__ void mha_fwd_body(const MhaK& p, const int qblk) {
   if (q0 >= Sq || Sk <= 0) return;   // (packed rows: this query block lies behind the sequence's end; workgroup-uniform)
   const bool active = q0 + 32 * w < Sq;  // wave-uniform
 
-  for (int k = tid; k < 32 * NKC; k += NT)
-    sMask[k] = (p.mask && k < Sk && p.mask[(size_t)b * SkS + k]) ? 1.f : 0.f;
+  // Key mask and key range as BIT MASKS in scalar registers (one ballot per 64 keys, every wave its own copy), pre-shifted
+  // per lane half so that element (kc, r) tests a compile-time bit: bit 32 (kc & 1) + (r & 3) + 8 (r >> 2) of word kc >> 1.
+  // (Round 5 kept the mask as floats in LDS: one dependent ds_read per score element inside the softmax -- the forward phase
+  //  timing of tools/mha_fwd_phases.sh charged the softmax 7.7 us of the kernel's 21.)
+  constexpr int NMW = (NKC + 1) / 2;
+  unsigned long long mbits[NMW], vbits[NMW];
+#pragma unroll
+  for (int j = 0; j < NMW; ++j) {
+    const int key = 64 * j + lane;
+    const bool inr = key < Sk;
+    const bool mk = p.mask && inr && p.mask[(size_t)b * SkS + (inr ? key : 0)];
+    mbits[j] = __ballot(mk) >> (4 * hh);
+    vbits[j] = __ballot(inr) >> (4 * hh);
+  }
 
   f32x16 acc[NKC];
 #pragma unroll
@@ -123,13 +137,49 @@ __device__ __forceinline__ void mha_fwd_body(const MhaK& p, const int qblk) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[kc][r] = 0.f;
 
+  // One head-dim chunk (d_h <= 64: every attention of the workloads) and a V tile of <= 8 16-byte loads per thread: the V
+  // loads are issued HERE, behind the Q / K loads and in front of everything that waits -- round 5 issued them behind the
+  // softmax, so every workgroup (one per CU, one wave per SIMD: nothing else to run) sat out a second full memory round trip
+  // between its two MFMA phases.  The relation bias (NKC <= 4: 64 values per lane) is fetched in the same burst.
+  constexpr bool VPF = (32 * NKC * (DHC / 4) + NT - 1) / NT <= 8;
+  constexpr bool BPF = false;   // (bias prefetch: 64 more live registers spill the 2-workgroups-per-CU build; measured 30 us instead of 21)
+  const bool vpf = VPF && p.nch == 1;
+  const int qi = q0 + 32 * w + l31;
+  const bool qok = qi < Sq;
+  const size_t bh = (size_t)b * p.H + h;
+  const bool has_bias = p.biasT != nullptr;  // wave-uniform: hoisted so the bias loads issue as a batch
+  const int qic = qok ? qi : Sq - 1;
+  TileRegs<VPF ? 32 * NKC : 1, DHC, NT> tv;
+  float biasp[BPF ? NKC : 1][16];
+
   // ---- S^T = K Q^T over the head-dim chunks ----
   for (int c = 0; c < p.nch; ++c) {
     if (c) __syncthreads();
-    load_tiles2<32 * NW, 32 * NKC, DHC, NT>(Qs, p.Q + (qrow0 + q0) * p.ldq + h * p.dh + c * DHC, Sq - q0, p.ldq,
-                                            KVs, p.K + krow0 * p.ldk + h * p.dh + c * DHC, Sk, p.ldk, tid);
+    {
+      TileRegs<32 * NW, DHC, NT> ta;
+      TileRegs<32 * NKC, DHC, NT> tb;
+      tile_fetch<32 * NW, DHC, NT>(ta, p.Q + (qrow0 + q0) * p.ldq + h * p.dh + c * DHC, Sq - q0, p.ldq, tid);
+      tile_fetch<32 * NKC, DHC, NT>(tb, p.K + krow0 * p.ldk + h * p.dh + c * DHC, Sk, p.ldk, tid);
+      if (c == 0) {
+        if (VPF && vpf) tile_fetch<VPF ? 32 * NKC : 1, DHC, NT>(tv, p.V + krow0 * p.ldv + h * p.dh, Sk, p.ldv, tid);
+        if (BPF && has_bias && active) {
+#pragma unroll
+          for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = min(32 * kc + acc_row(r, hh), Sk - 1);
+              biasp[BPF ? kc : 0][r] = p.biasT[(bh * SkS + key) * SqS + qic];
+            }
+        }
+      }
+      tile_store<32 * NW, DHC, NT>(ta, Qs, tid);
+      tile_store<32 * NKC, DHC, NT>(tb, KVs, tid);
+    }
     __syncthreads();
     if (active) {
+#if MMNAS_DBG_FWD & 1
+      for (int kc = 0; kc < NKC; ++kc) acc[kc][0] = Qs[(32 * w + l31) * LD + kc] + KVs[l31 * LD + kc];
+#else
 #pragma unroll
       for (int s = 0; s < DHC / 8; ++s) {
         const float4 qf = *reinterpret_cast<const float4*>(Qs + (32 * w + l31) * LD + 8 * s + 4 * hh);
@@ -139,36 +189,35 @@ __device__ __forceinline__ void mha_fwd_body(const MhaK& p, const int qblk) {
           MFMA4(acc[kc], kf, qf)
         }
       }
+#endif
     }
   }
 
   // ---- softmax over the keys of this lane's query (registers + the other half-wave) ----
-  const int qi = q0 + 32 * w + l31;
-  const bool qok = qi < Sq;
-  const size_t bh = (size_t)b * p.H + h;
   float m = -INFINITY;
-  const bool has_bias = p.biasT != nullptr;  // wave-uniform: hoisted so the bias loads issue as a batch
-  const int qic = qok ? qi : Sq - 1;
+#if MMNAS_DBG_FWD & 2
+  float sum = 1.f, inv = 1.f;
+  if (qok && hh == 0) { p.stats[(bh * SqS + qi) * 2] = acc[0][0]; p.stats[(bh * SqS + qi) * 2 + 1] = inv; }
+#else
 #pragma unroll
   for (int kc = 0; kc < NKC; ++kc) {
     float bias[16];
     if (has_bias) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+        if (BPF) { bias[r] = biasp[BPF ? kc : 0][r]; continue; }
         const int key = min(32 * kc + acc_row(r, hh), Sk - 1);
         bias[r] = p.biasT[(bh * SkS + key) * SqS + qic];
       }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int key = 32 * kc + acc_row(r, hh);
+      constexpr unsigned long long one = 1ull;
+      const unsigned long long bit = one << (32 * (kc & 1) + (r & 3) + 8 * (r >> 2));
       float v = acc[kc][r] * p.scale;
       if (has_bias) v += bias[r];
-      if (key < Sk) {
-        if (sMask[key] != 0.f) v = -1e9f;
-      } else {
-        v = -INFINITY;
-      }
+      v = (mbits[kc >> 1] & bit) ? -1e9f : v;
+      v = (vbits[kc >> 1] & bit) ? v : -INFINITY;
       acc[kc][r] = v;
       m = fmaxf(m, v);
     }
@@ -189,22 +238,23 @@ __device__ __forceinline__ void mha_fwd_body(const MhaK& p, const int qblk) {
     p.stats[(bh * SqS + qi) * 2] = m;
     p.stats[(bh * SqS + qi) * 2 + 1] = inv;
   }
+  // (dropout index (bh Sq + q) Sk + key, key = 32 kc + (r & 3) + 8 (r >> 2) + 4 hh: pre-multiplied per lane, a constant per element)
+  const uint32_t dpre = drop_pre(p.drop, (uint32_t)((bh * SqS + qi) * SkS + 4 * hh));
 #pragma unroll
   for (int kc = 0; kc < NKC; ++kc)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float a = acc[kc][r] * inv;
-      if (p.drop.thresh) {
-        const int key = 32 * kc + acc_row(r, hh);
-        a *= drop_mult(p.drop, (uint32_t)((bh * SqS + qi) * SkS + key));
-      }
+      if (p.drop.thresh) a *= drop_mult_pre(p.drop, dpre + (uint32_t)(32 * kc + (r & 3) + 8 * (r >> 2)) * DROP_G);
       acc[kc][r] = a;
     }
+#endif
 
   // ---- O = A V, head-dim chunk by chunk (A tile = the accumulators, as MFMA A operand) ----
   for (int c = 0; c < p.nch; ++c) {
     __syncthreads();
-    load_tile<32 * NKC, DHC, NT>(KVs, p.V + krow0 * p.ldv + h * p.dh + c * DHC, Sk, p.ldv, tid);
+    if (VPF && vpf) tile_store<VPF ? 32 * NKC : 1, DHC, NT>(tv, KVs, tid);
+    else load_tile<32 * NKC, DHC, NT>(KVs, p.V + krow0 * p.ldv + h * p.dh + c * DHC, Sk, p.ldv, tid);
     __syncthreads();
     if (!active) continue;
     f32x16 o[JC];
@@ -212,17 +262,29 @@ __device__ __forceinline__ void mha_fwd_body(const MhaK& p, const int qblk) {
     for (int jc = 0; jc < JC; ++jc)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[jc][r] = 0.f;
+#if MMNAS_DBG_FWD & 4
+    for (int kc = 0; kc < NKC; ++kc) o[kc & (JC - 1)][kc] += acc[kc][3] + KVs[(32 * kc + l31) * LD + hh];
+#else
+    // (the B operands of a key chunk are read in ONE batch in front of its MFMAs: read -> wait -> MFMA pairs left every
+    //  product waiting out an LDS round trip -- the P V phase took 7.2 us against 3.4 us of MFMA time)
 #pragma unroll
-    for (int kc = 0; kc < NKC; ++kc)
+    for (int kc = 0; kc < NKC; ++kc) {
+      float bvv[16][JC];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = 32 * kc + acc_row(r, hh);
 #pragma unroll
-        for (int jc = 0; jc < JC; ++jc) {
-          const float bv = (DHC >= 32 || l31 < DHC) ? KVs[key * LD + 32 * jc + l31] : 0.f;
-          o[jc] = mfma32(acc[kc][r], bv, o[jc]);
-        }
+        for (int jc = 0; jc < JC; ++jc) bvv[r][jc] = (DHC >= 32 || l31 < DHC) ? KVs[key * LD + 32 * jc + l31] : 0.f;
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int jc = 0; jc < JC; ++jc) o[jc] = mfma32(acc[kc][r], bvv[r][jc], o[jc]);
+    }
+#endif
+#if MMNAS_DBG_FWD & 8
+    if (o[0][0] + o[JC - 1][5] == 12345.678f) p.O[(qrow0 + q0) * p.ldo] = o[0][1];
+#else
 #pragma unroll
     for (int jc = 0; jc < JC; ++jc) {
       const int col = 32 * jc + l31;
@@ -234,6 +296,7 @@ __device__ __forceinline__ void mha_fwd_body(const MhaK& p, const int qblk) {
         }
       }
     }
+#endif
   }
 }
 
@@ -718,7 +781,7 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
   const __amdgpu_buffer_rsrc_t bias_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.biasT ? p.biasT + bho : p.Q), 0, p.biasT ? plane : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t mask_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.mask ? p.mask + (size_t)b * SkS : (const uint8_t*)p.Q), 0, p.mask ? (unsigned)Sk : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t dbias_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(DB ? p.dbiasT + bho : p.dQ), 0, DB ? plane : 0u, 0x00020000);
-  const uint32_t drop_base = (uint32_t)((bh * SqS + qi) * SkS);
+  const uint32_t drop_pre0 = drop_pre(p.drop, (uint32_t)((bh * SqS + qi) * SkS + 4 * hh));   // pre-multiplied dropout index of key 4 hh
 
   // phase 1 of a tile: S^T = K Q^T and dA^T = V dO^T (64 MFMAs) + the tile's bias / mask operands
   auto P1 = [&](int k0, f32x16& acc, f32x16& dacc, float (&bias)[16], float (&mk)[16]) __attribute__((always_inline)) {
@@ -735,8 +798,11 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
 #pragma unroll
     for (int s8 = 0; s8 < NS; ++s8) {
       const int fo = 8 * s8 + 4 * hh;
-      const float4 kf = *reinterpret_cast<const float4*>(Ks + (k0 + l31) * LD + fo);
-      const float4 vf = *reinterpret_cast<const float4*>(Vs + (k0 + l31) * LD + fo);
+      // (f32x4, not float4: the HIP struct is taken apart into four scalar loads before instruction selection, and inside the
+      //  software-pipelined loop they came back as ds_read2_b32 pairs -- 32-bank accesses at a row stride of 68 words, 4-way
+      //  conflicts: the 0.285 SQ_LDS_BANK_CONFLICT fraction of rounds 3-5.  A first-class vector load stays one ds_read_b128.)
+      const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (k0 + l31) * LD + fo);
+      const f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + (k0 + l31) * LD + fo);
       MFMA4(acc, kf, qfr[s8])
       MFMA4(dacc, vf, gfr[s8])
     }
@@ -756,7 +822,8 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
       float v = acc[r] * p.scale + bias[r];
       v = masked ? -1e9f : v;
       const float pr = __expf(v - m) * inv;
-      const float dm = drop_mult(p.drop, drop_base + (uint32_t)key);   // (no dropout: thresh 0, scale 1 -> multiplier 1)
+      // (no dropout: thresh 0, scale 1 -> multiplier 1)
+      const float dm = drop_mult_pre(p.drop, drop_pre0 + (uint32_t)k0 * DROP_G + (uint32_t)((r & 3) + 8 * (r >> 2)) * DROP_G);
       const float dz = (ok && !masked) ? pr * (dacc[r] * dm - del) : 0.f;
       if (DB) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz), dbias_rs, ok ? (unsigned)(key * SqS + qi) * 4u : ~0u, 0, 0);
       acc[r] = dz * p.scale;

@@ -96,6 +96,12 @@ int layernorm_bwd_deferred(const float* x, const float* a, const float* dy, floa
                            hipStream_t st, AuxReduce* aux);
 
 
+// gemmln.hip: the merge / last FFN projection with its dropout + residual epilogue AND the LayerNorm behind it as one launch
+// (row panels of 32 x 256; N = 256 only).  gemm_ln_applies() says whether *d qualifies (and the switch MMNAS_GEMM_LN is on);
+// z = d->g[0].C (may be NULL: not stored), y = LayerNorm(z).
+bool gemm_ln_applies(const mmnas_gemm_desc* d);
+int gemm_ln(const mmnas_gemm_desc* d, const float* ln_a, const float* ln_b, float* y, int ldy, float eps, hipStream_t st);
+
 // AttFlat with one glimpse (head.hip): the glimpse-logit layer as a matrix-vector product / an outer product + reductions
 bool glimpse1_supported(int MID);
 int glimpse1_fwd(const float* h0, const float* w0, const float* b0, float* l0, long rows0, const float* h1, const float* w1,

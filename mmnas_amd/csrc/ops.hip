@@ -228,6 +228,8 @@ static int mmnas::att_fwd_impl(const mmnas_att_op* op, void* stream, bool defer_
   att_merge_group(op, L, &g.g[0]);
   if (fl & MMNAS_F_RESIDUAL) g.ldres = d;
   if (drop) { g.drop_p = op->drop_p; g.drop_site = 1; g.drop_seed = op->seed; }
+  // d = 256: the projection, its dropout + residual epilogue and the LayerNorm as ONE launch (gemmln.hip)
+  if (norm && !defer_ln && gemm_ln_applies(&g)) return gemm_ln(&g, op->ln_a, op->ln_b, op->y, d, op->eps, (hipStream_t)stream);
   if ((rc = mmnas_gemm(&g, stream))) return rc;
 
   if (norm && defer_ln) { *ln_done = false; return MMNAS_OK; }
@@ -518,6 +520,7 @@ static int mmnas::mlp_fwd_impl(const mmnas_mlp_op* op, void* stream, bool defer_
       g.relu = 1;
       g.g[0].C = L.h[i + 1];
     }
+    if (last && norm && !defer_ln && gemm_ln_applies(&g)) return gemm_ln(&g, op->ln_a, op->ln_b, op->y, d, op->eps, (hipStream_t)stream);
     if ((rc = mmnas_gemm(&g, stream))) return rc;
     in = L.h[i + 1];
   }

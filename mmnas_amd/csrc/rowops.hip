@@ -144,8 +144,11 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ x
       }
     }
   }
-  // reduce the per-wave column partials across the 4 waves, then one atomic per column per block
-  __shared__ float red[3][4][64 * 4];  // [which][wave][lane*4 + j], reused per i
+  // The per-wave column partials meet in LDS as 16-byte rows; thread (which = wave < 3, lane) adds the 4 partials of its 4
+  // columns with 16-byte reads (conflict-free) and leaves one 16-byte partial-row store (or 4 atomics).  Rounds 1-5 had wave
+  // 0 read them 4 bytes per lane at a stride of 16 bytes -- a 4-way bank conflict on every read (SQ_LDS_BANK_CONFLICT /
+  // SQ_LDS_IDX_ACTIVE = 0.49) -- and write 12 scalars per lane.
+  __shared__ __attribute__((aligned(16))) float red[3][4][64 * 4];  // [which][wave][lane*4 + j], reused per i
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (lane + 64 * i) * 4;
@@ -154,20 +157,18 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ x
     *reinterpret_cast<float4*>(&red[1][wave][lane * 4]) = acc_b[i];
     *reinterpret_cast<float4*>(&red[2][wave][lane * 4]) = acc_c[i];
     __syncthreads();
-    if (wave == 0 && c < d) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int o = lane * 4 + j;
-        const float sa = (red[0][0][o] + red[0][1][o]) + (red[0][2][o] + red[0][3][o]);
-        const float sb = (red[1][0][o] + red[1][1][o]) + (red[1][2][o] + red[1][3][o]);
-        const float sc = (red[2][0][o] + red[2][1][o]) + (red[2][2][o] + red[2][3][o]);
-        if (part) {  // per-block partial rows, summed by ln_bwd_reduce_kernel (no atomics, deterministic)
-          float* pr = part + (size_t)blockIdx.x * 3 * d + c + j;
-          pr[0] = sa; pr[d] = sb; pr[2 * d] = sc;
-        } else {
-          if (da) atomicAdd(da + c + j, sa);
-          if (db) atomicAdd(db + c + j, sb);
-          if (dcol) atomicAdd(dcol + c + j, sc);
+    if (wave < 3 && c < d) {
+      const f32x4 p0 = *reinterpret_cast<const f32x4*>(&red[wave][0][lane * 4]);
+      const f32x4 p1 = *reinterpret_cast<const f32x4*>(&red[wave][1][lane * 4]);
+      const f32x4 p2 = *reinterpret_cast<const f32x4*>(&red[wave][2][lane * 4]);
+      const f32x4 p3 = *reinterpret_cast<const f32x4*>(&red[wave][3][lane * 4]);
+      const f32x4 s4 = (p0 + p1) + (p2 + p3);
+      if (part) {  // per-block partial rows, summed by ln_bwd_reduce_kernel / the next pair launch (no atomics, deterministic)
+        *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 3 + wave) * d + c) = s4;
+      } else {
+        float* out = wave == 0 ? da : (wave == 1 ? db : dcol);
+        if (out) {
+          atomicAdd(out + c, s4.x); atomicAdd(out + c + 1, s4.y); atomicAdd(out + c + 2, s4.z); atomicAdd(out + c + 3, s4.w);
         }
       }
     }

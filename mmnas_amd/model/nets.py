@@ -365,7 +365,7 @@ class _Net(nn.Module):
         # (head_record() draws the head's dropout seeds: it stays BEHIND the backbone call, where the per-operator path draws
         #  them too -- the seed order is what lets dropout be replayed across the paths)
         if rg is not None and native_head and ops._sinked((self.attflat_x.mlp.fc.linear.weight,)):
-            y_pk = ops.linear(ops.pack_rows(frcn_feat, rg), self.imgfeat_linear.weight, self.imgfeat_linear.bias)
+            y_pk = ops.linear(ops.pack_rows_fn(frcn_feat, rg), self.imgfeat_linear.weight, self.imgfeat_linear.bias)
             packed = self.backnone.chain_packed(x_in, y_pk, x_mask, y_mask, x_rel_embed, y_rel_embed)
         if packed is not None:
             x_out, y_out = packed

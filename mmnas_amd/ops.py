@@ -39,6 +39,22 @@ _plan_cache = {}
 _sinks_on = [True]
 
 
+def runtime_config():
+    """What this process runs the library with: where the shared object came from, the launch configuration the library
+    established at import (`_lib._launch_configuration`: HIP_FORCE_DEV_KERNARG and who set it) and every MMNAS_* / HIP_* /
+    NCCL_* / RCCL_* switch of the environment.  bench.py records it; an integrator prints it once."""
+    return {
+        'lib_path': L.LIB_PATH,
+        'lib_loaded': L._lib is not None,
+        'abi_version': L.lib().mmnas_abi_version() if os.path.exists(L.LIB_PATH) else None,
+        'hip_force_dev_kernarg': os.environ.get('HIP_FORCE_DEV_KERNARG'),
+        'hip_force_dev_kernarg_source': L.KERNARG_SOURCE,
+        'hip_initialised': torch.cuda.is_initialized(),
+        'torch': torch.__version__, 'hip': getattr(torch.version, 'hip', None),
+        'env': {k: v for k, v in sorted(os.environ.items()) if k.startswith(('MMNAS_', 'HIP_', 'NCCL_', 'RCCL_', 'HSA_'))},
+    }
+
+
 class no_sinks:
     """Context manager: inside it the backward kernels hand every parameter gradient to autograd as a tensor instead
     of adding it straight into the flat gradient buffer.  Needed around `torch.autograd.grad(loss, params)`: a sink
@@ -1296,6 +1312,30 @@ class _UnpackRowsFn(torch.autograd.Function):
 
 def unpack_rows_fn(xp, rg, B, S):
     return _UnpackRowsFn.apply(xp, rg, B, S)
+
+
+class _PackRowsFn(torch.autograd.Function):
+    """pack_rows with a gradient: the stem packs the raw region features, which carry a graph when the box features ride in
+    them (C.BBOX_FEATURE: cat(frcn_feat, bboxfeat_linear(bbox_feat)), full_vqa.py:93-97) -- the raw call would cut it and
+    `bboxfeat_linear` would silently never train."""
+
+    @staticmethod
+    def forward(ctx, x, rg):
+        ctx.rg, ctx.shape = rg, x.shape
+        return pack_rows(_f32c(x), rg)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, S, _ = ctx.shape
+        return unpack_rows(_f32c(g), ctx.rg, B, S), None
+
+
+def pack_rows_fn(x, rg):
+    """[B, S, d] -> packed [rg.N, d]; differentiable when x needs a gradient, the raw kernel call otherwise."""
+    x = _f32c(x)
+    if x.requires_grad and torch.is_grad_enabled():
+        return _PackRowsFn.apply(x, rg)
+    return pack_rows(x, rg)
 
 
 class BackboneFn(torch.autograd.Function):

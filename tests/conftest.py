@@ -25,3 +25,19 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if 'gpu' in it.keywords:
             it.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Leave what check_grad_samples measured (worst gradient errors against the float64 yardstick) beside the run's other
+    outputs: gpurun_out/grad_check_stats.json (merged back from the GPU box; DESIGN 2 quotes it)."""
+    try:
+        from tests import util
+        if not util.GRAD_STATS:
+            return
+        import json
+        out = os.path.join(REPO, 'gpurun_out')
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'grad_check_stats.json'), 'w') as f:
+            json.dump(util.GRAD_STATS, f, indent=1, sort_keys=True)
+    except Exception:
+        pass

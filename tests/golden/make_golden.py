@@ -144,7 +144,10 @@ def grad_samples64(out, tag, net64, keys, store=None):
     oracle's, the HIP path's) are therefore judged against the float64 value with the ordinary tolerance on the entry OR a
     small multiple of fp32 round-off on the scale, whichever is larger (tests/util.py::check_grad_samples)."""
     g = dict(net64.named_parameters())
-    ks = [k for k in keys if any(s in k for s in GS64_KEYS) and g[k].grad is not None]
+    # round 6: EVERY parameter has its float64 samples (<= 64 per tensor), so that every gradient is judged against float64 at
+    # SURVEY 8(d)'s 1e-3 (VERDICT r5: judged against the reference's fp32 run the bound had to be 3e-3); the cancellation
+    # scale stays a property of the relation-path keys (zeros elsewhere: the scale term of the bound vanishes)
+    ks = [k for k in keys if g[k].grad is not None]
     parts = [esample64(g[k].grad) for k in ks]
     out[tag + 'gs64_keys'] = np.array(ks)
     out[tag + 'gs64'] = np.concatenate(parts) if parts else np.zeros(0, np.float64)
@@ -153,6 +156,9 @@ def grad_samples64(out, tag, net64, keys, store=None):
         scales = []
         for k in ks:
             mod, leaf = k.rsplit('.', 1)
+            if not any(s in k for s in GS64_KEYS):
+                scales.append(np.zeros(esample64(g[k].grad).size, np.float64))
+                continue
             x, gg = store[mod]['x'], store[mod]['g']
             ga = gg.abs().reshape(-1, gg.shape[-1])
             sc = ga.t() @ x.abs().reshape(-1, x.shape[-1]) if leaf == 'weight' else ga.sum(0)

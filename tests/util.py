@@ -71,11 +71,18 @@ REL_PATH_SELF_TOL = 1e-3
 KAPPA = 3e-4   # relation-path gradients: bound on |error| / (sum of the absolute values of the entry's terms)
 
 
-def check_grad_samples(npz, tag, grads, tol=3e-3, skip=lambda k: False, kappa=None):
+# what check_grad_samples measured in this process: tag -> worst relative error (non-relation keys), worst error / bound;
+# tests/conftest.py writes it to gpurun_out/grad_check_stats.json at the end of a session (the numbers DESIGN 2 quotes)
+GRAD_STATS = {}
+
+
+def check_grad_samples(npz, tag, grads, tol=1e-3, skip=lambda k: False, kappa=None):
     """Element-wise check of EVERY parameter gradient of a network against the reference's strided samples
     (`tag + 'gs_keys' / 'gs' / 'gs_off'`): a sign or permutation error inside a weight gradient keeps its norm, not these.
-    grads: name -> array (None / missing = no gradient).  Tolerance: `tol` of the tensor's largest sampled reference
-    element, floored at 1e-3 of the largest over all tensors (round-off-sized gradients).
+    grads: name -> array (None / missing = no gradient).  Tolerance: `tol` = 1e-3 (SURVEY 8(d)'s bar; round 6: EVERY key is
+    judged against the reference's FLOAT64 run -- `gs64*` now holds all parameters -- where rounds 3-5 judged most keys against
+    the reference's own fp32 run and needed 3e-3) of the tensor's largest sampled reference element, floored at 1e-3 of the
+    largest over all tensors (round-off-sized gradients).
 
     The relation-path gradients (`linear_r`, `linear_{x,y}_rel`) are 1/r-weighted sums of random sign behind
     log(clamp(relu(.))) that cancel to a small fraction of their terms.  For them the yardstick is the reference run in
@@ -98,6 +105,7 @@ def check_grad_samples(npz, tag, grads, tol=3e-3, skip=lambda k: False, kappa=No
                 scale64[str(k)] = sc[o64[i]:o64[i + 1]]
     top = float(np.max(np.abs(gs))) if gs.size else 0.0
     checked = 0
+    st = GRAD_STATS.setdefault(tag, {'worst_rel': 0.0, 'worst_key': None, 'worst_of_bound': 0.0, 'worst_of_bound_key': None, 'fp64_keys': 0, 'keys': 0})
     for i, k in enumerate(keys):
         if skip(k):
             continue
@@ -114,4 +122,12 @@ def check_grad_samples(npz, tag, grads, tol=3e-3, skip=lambda k: False, kappa=No
         assert not bad.any(), (k, float(err[bad].max()), float(np.max(np.abs(ref))), 'fp64 yardstick' if k in ref64 else 'fp32',
                                float(scale64[k][bad].max()) if k in scale64 else None)
         checked += 1
+        rel = float(err.max()) / max(float(np.max(np.abs(ref))), 1e-3 * top, 1e-30)      # the error the bound is written on
+        frac = float(np.max(err / bound))
+        st['keys'] += 1
+        st['fp64_keys'] += int(k in ref64)
+        if rel > st['worst_rel'] and not (k in scale64 and float(np.max(scale64[k])) > 0.0):
+            st['worst_rel'], st['worst_key'] = rel, k
+        if frac > st['worst_of_bound']:
+            st['worst_of_bound'], st['worst_of_bound_key'] = frac, k
     return checked
