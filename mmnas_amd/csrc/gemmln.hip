@@ -143,6 +143,25 @@ __global__ void __launch_bounds__(LN_NT, 1) gemm_ln_kernel(const GemmLnK p) {
   };
 
   // ---- K loop: two register stages ahead of the MFMA block, unrolled by two so the stages are static ----
+  // ---- epilogue operands, fetched HERE (the residual rows, bias, LayerNorm parameters: 16 16-byte loads per lane that the
+  //      epilogue would otherwise wait a full memory round trip for behind the last K-tile): this lane holds row m0 + l31,
+  //      register 4 g + e = column 32 wave + 8 g + 4 hh + e ----
+  const int row = m0 + l31;
+  const int cb = 32 * wave + 4 * hh;
+  const bool rok = row < M;
+  const bool has_res = p.residual != nullptr;
+  const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, has_res ? (unsigned)M * (unsigned)p.ldres * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t z_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.z, 0, p.z ? (unsigned)M * (unsigned)p.ldz * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (unsigned)M * (unsigned)p.ldy * 4u, 0x00020000);
+  float4 resv[4], biasv[4], lav[4], lbv[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int col = cb + 8 * g;
+    resv[g] = buf_load4(r_rs, rok ? (unsigned)(row * p.ldres + col) * 4u : ~0u);
+    biasv[g] = p.bias ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    lav[g] = *reinterpret_cast<const float4*>(p.ln_a + col);
+    lbv[g] = *reinterpret_cast<const float4*>(p.ln_b + col);
+  }
   // (nq is even -- host check -- so a half-iteration is ONE scheduling region: the 12 MFMAs of K-tile t and the conversion +
   //  LDS stores of K-tile t + 1 are issued interleaved, one MFMA, ten vector instructions, one store.  Left in program order
   //  every wave of the workgroup multiplied, then every wave converted, barrier: the matrix pipe idled through the conversion
@@ -182,23 +201,7 @@ __global__ void __launch_bounds__(LN_NT, 1) gemm_ln_kernel(const GemmLnK p) {
     }
   }
 
-  // ---- epilogue: this lane holds row m0 + l31, register 4 g + e = column 32 wave + 8 g + 4 hh + e ----
-  const int row = m0 + l31;
-  const int cb = 32 * wave + 4 * hh;
-  const bool rok = row < M;
-  const bool has_res = p.residual != nullptr;
-  const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, has_res ? (unsigned)M * (unsigned)p.ldres * 4u : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t z_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.z, 0, p.z ? (unsigned)M * (unsigned)p.ldz * 4u : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (unsigned)M * (unsigned)p.ldy * 4u, 0x00020000);
-  float4 resv[4], biasv[4], lav[4], lbv[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int col = cb + 8 * g;
-    resv[g] = buf_load4(r_rs, rok ? (unsigned)(row * p.ldres + col) * 4u : ~0u);
-    biasv[g] = p.bias ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-    lav[g] = *reinterpret_cast<const float4*>(p.ln_a + col);
-    lbv[g] = *reinterpret_cast<const float4*>(p.ln_b + col);
-  }
+  // ---- epilogue (its operands were fetched in front of the K loop) ----
   const bool has_drop = p.drop.thresh != 0;
   const uint32_t dpre = drop_pre(p.drop, (uint32_t)row * (uint32_t)LN_BN + (uint32_t)cb);
   float v[16];

@@ -1296,7 +1296,12 @@ static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
         mark_stream = rsc->side;
       } else if ((rc = chain_rel_bwd(RG, 1, st))) return rc;
     }
-    if (i0 == L.first_x && (rc = chain_rel_bwd(RG, 0, st))) return rc;
+    if (i0 == L.first_x && !RG.groups[0].empty()) {
+      // (every relation group shares ONE partial-row workspace: the image stream's launches on the side stream are joined
+      //  before the language stream's write into it -- ADVICE r5; the join at the end of the call then finds nothing pending)
+      if (rel_bwd_side) { if ((rc = ev_fork(rel_bwd_side->side, st, rel_bwd_side->ovl[3]))) return rc; rel_bwd_side = nullptr; }
+      if ((rc = chain_rel_bwd(RG, 0, st))) return rc;
+    }
     if (c->marks && c->marks[act_op] && hipEventRecord((hipEvent_t)c->marks[act_op], mark_stream) != hipSuccess) {
       set_error("chain_bwd: cannot record the mark event of operator %d", act_op);
       return MMNAS_E_LAUNCH;
@@ -1473,7 +1478,11 @@ extern "C" int mmnas_chain_bwd(const mmnas_chain* c, void* stream) {
         mark_stream = rsc->side;
       } else if ((r = chain_rel_bwd(RG, 1, s))) return r;
     }
-    if (i == L.first_x && (r = chain_rel_bwd(RG, 0, s))) return r;
+    if (i == L.first_x && !RG.groups[0].empty()) {
+      // (shared partial-row workspace: join the image stream's relation backward first, see chain_bwd_mixed)
+      if (rel_bwd_side) { if ((r = ev_fork(rel_bwd_side->side, s, rel_bwd_side->ovl[3]))) return r; rel_bwd_side = nullptr; }
+      if ((r = chain_rel_bwd(RG, 0, s))) return r;
+    }
     // (encoder / decoder overlap: an event behind operator i on ONE of the two streams says nothing about the operators
     //  with larger indices still running on the other -- the marks are recorded behind the join below instead)
     if (!ovl && c->marks && c->marks[i] && hipEventRecord((hipEvent_t)c->marks[i], mark_stream) != hipSuccess) {

@@ -186,6 +186,10 @@ def _chain_marks(red, op_params, bucket_of, buckets):
     return marks if any_mark else None
 
 
+# MMNAS_DP_TAIL_MAIN=0 restores round 5's end of step (everything on the communication stream, one scatter per bucket)
+_TAIL_ON_MAIN = os.environ.get('MMNAS_DP_TAIL_MAIN', '1') != '0'
+
+
 def _row_sparse_index(fg, comm, is_cuda):
     """Index (in fg.params) of the parameter whose gradient is exchanged as rows, or None.  The nets tag their word
     embedding (`weight._mmnas_row_sparse`): its gradient is the ~900 rows of the batch's tokens inside a 24 MB table, it
@@ -252,11 +256,18 @@ class RowExchange:
         idx_l, ip, idx_all = self._idx.pop(key)
         dy_l = dy.reshape(-1, E).contiguous()
         world = dist.get_world_size(red.group)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        cs = red.comm_stream
+        if _TAIL_ON_MAIN:
+            # the embedding's backward is the LAST node of backward: its rows are exchanged on the backward's own stream (the
+            # all-gather of the indices, issued in forward, is joined first) -- two stream hand-overs less at the end of the step
+            cs = torch.cuda.current_stream()
+            cs.wait_stream(red.comm_stream)
+        else:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            cs = red.comm_stream
         with torch.cuda.stream(cs):
-            cs.wait_event(ev)
+            if not _TAIL_ON_MAIN:
+                cs.wait_event(ev)
             gp = [torch.empty_like(dy_l) for _ in range(world)]
             dist.all_gather(gp, dy_l, group=red.group)
             dy_all = torch.cat(gp) if world > 1 else gp[0]
@@ -605,7 +616,14 @@ class SupernetReducer:
         if self.row_exchange is not None:
             self.row_exchange.begin()
         if self.staging is None:
-            self.staging = [torch.empty(max(c, 64), dtype=torch.float32, device=self.fg.flat.device) for c in self.cap]
+            # ONE staging tensor, a slice per bucket: the scatter back into the flat buffer at the end of the step is then one
+            # launch over all buckets' segments (round 5: one per bucket, all three behind the last all-reduce)
+            caps = [_align(max(c, 64)) for c in self.cap]
+            self.staging_all = torch.empty(sum(caps), dtype=torch.float32, device=self.fg.flat.device)
+            self.staging_base = [sum(caps[:b]) for b in range(self.n_buckets)]
+            self.staging = [self.staging_all[self.staging_base[b]:self.staging_base[b] + caps[b]] for b in range(self.n_buckets)]
+        self._scatter_table = self._segment_table([seg for b in range(self.n_buckets) for seg in self._segs[b]],
+                                                  [self.staging_base[b] + o for b in range(self.n_buckets) for o in self._seg_offsets(self._segs[b])])
 
     def _pending_params(self, b):
         return [i for i in self._armed if self.bucket_of_param.get(i) == b]
@@ -632,7 +650,7 @@ class SupernetReducer:
             self._arrived(i)
         return hook
 
-    def _launch(self, b):
+    def _launch(self, b, tail=False):
         if self._launched[b]:
             return
         self._launched[b] = True
@@ -643,6 +661,17 @@ class SupernetReducer:
         stg = self.staging[b][:total]
         avg = _has_avg(self.group)
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        if self.is_cuda and tail and self.inline and _TAIL_ON_MAIN:
+            # A bucket that is still open when backward has ended (always the stem's): nothing is left to overlap it with, so it
+            # is exchanged on the CALLER's stream -- main -> collective -> main, two stream hand-overs instead of the four of
+            # main -> communication stream -> collective -> communication stream -> main (each ~20 us of idle GPU at the very
+            # end of the step: profiles/r05_timeline_search_vqa_dp1.txt)
+            from . import ops
+            ops.side_stream_barrier(torch.cuda.current_stream())
+            self._pack(segs, stg, 0, table=self._tables[b])
+            dist.all_reduce(stg, op=op, group=self.group)
+            self._works.append(('inline', b, stg, not avg))
+            return
         if self.is_cuda:
             from . import ops
             ev = self._mark_ev.pop(b, None)      # recorded inside the backbone chain, behind the bucket's last operator
@@ -684,32 +713,54 @@ class SupernetReducer:
         if self.row_exchange is not None:
             self.row_exchange.finish()
         for b in range(self.n_buckets):
-            self._launch(b)
+            self._launch(b, tail=True)
         if self.is_cuda:
-            with torch.cuda.stream(self.comm_stream):
-                for w, b, stg, need_div in self._works:
-                    if w is None:
-                        continue             # (scattered back right behind its all-reduce: _launch)
-                    if w != 'inline':
-                        w.wait()
-                    self._pack(self._segs[b], stg, 1, 1.0 / self.world if need_div else 1.0, table=self._tables[b])
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            one = _TAIL_ON_MAIN and all(w == 'inline' for w, _, _, _ in self._works) and len(self._works) == sum(1 for sg in self._segs if sg and sum(n for _, n in sg))
+            if one:
+                # every bucket's all-reduce is stream-ordered (inline): join the communication stream once, then ONE scatter
+                # launch over all buckets' segments on the caller's stream
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+                need_div = self._works[0][3] if self._works else False
+                nseg = sum(len(sg) for sg in self._segs if sg)
+                if nseg:
+                    from . import _lib as L
+                    L.check(L.lib().mmnas_pack_segments_host(self._scatter_table, nseg, L.fptr(self.staging_all),
+                                                             float(1.0 / self.world if need_div else 1.0), 1, L.stream()))
+            else:
+                with torch.cuda.stream(self.comm_stream):
+                    for w, b, stg, need_div in self._works:
+                        if w is None:
+                            continue             # (scattered back right behind its all-reduce: _launch)
+                        if w != 'inline':
+                            w.wait()
+                        self._pack(self._segs[b], stg, 1, 1.0 / self.world if need_div else 1.0, table=self._tables[b])
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
         else:
             for w, b, stg, need_div in self._works:
                 w.wait()
                 self._pack(self._segs[b], stg, 1, 1.0 / self.world if need_div else 1.0)
         self._works = []
 
-    def _segment_table(self, segs):
+    @staticmethod
+    def _seg_offsets(segs):
+        off, out = 0, []
+        for _, n in segs:
+            out.append(off)
+            off += n
+        return out
+
+    def _segment_table(self, segs, stg_offsets=None):
+        """Kernel-argument table of (flat-buffer pointer, staging offset, length) per segment; stg_offsets: positions in the
+        staging tensor (default: packed back to back from 0)."""
         if not self.is_cuda:
             return None
         from . import _lib as L
         arr = (L.Segment * max(len(segs), 1))()
         base = self.fg.flat.data_ptr()
-        off = 0
+        if stg_offsets is None:
+            stg_offsets = self._seg_offsets(segs)
         for k, (o, n) in enumerate(segs):
-            arr[k].ptr, arr[k].offset, arr[k].n = base + 4 * o, off, n
-            off += n
+            arr[k].ptr, arr[k].offset, arr[k].n = base + 4 * o, stg_offsets[k], n
         return arr
 
     def _pack(self, segs, stg, direction, scale=1.0, table=None):

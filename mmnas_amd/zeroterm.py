@@ -131,6 +131,23 @@ class LazySum:
         return self.materialize() / k
 
     # -- everything else: the real tensor ------------------------------------------------------------------------------
+    # (comparisons, powers, abs, truth value, int(): Python looks dunders up on the TYPE, so __getattr__ below never sees
+    #  them -- `p.sum() > 0`, `p.sum() ** 2`, `abs(p.sum())`, `bool(p.sum())` raised TypeError)
+    def __lt__(self, o): return self.materialize() < (o.materialize() if isinstance(o, LazySum) else o)
+    def __le__(self, o): return self.materialize() <= (o.materialize() if isinstance(o, LazySum) else o)
+    def __gt__(self, o): return self.materialize() > (o.materialize() if isinstance(o, LazySum) else o)
+    def __ge__(self, o): return self.materialize() >= (o.materialize() if isinstance(o, LazySum) else o)
+    def __eq__(self, o): return self.materialize() == (o.materialize() if isinstance(o, LazySum) else o)
+    def __ne__(self, o): return self.materialize() != (o.materialize() if isinstance(o, LazySum) else o)
+    __hash__ = object.__hash__
+    def __pow__(self, k): return self.materialize() ** (k.materialize() if isinstance(k, LazySum) else k)
+    def __rpow__(self, k): return k ** self.materialize()
+    def __abs__(self): return abs(self.materialize())
+    def __pos__(self): return self
+    def __rtruediv__(self, o): return o / self.materialize()
+    def __bool__(self): return bool(self.materialize())
+    def __int__(self): return int(self.materialize().detach())
+
     def __float__(self):
         return float(self.materialize().detach())
 
@@ -156,9 +173,12 @@ class LazySum:
                 return b.__radd__(a)
             if isinstance(b, torch.Tensor) and isinstance(a, LazySum):
                 return a.__radd__(b)
-        # any other torch function that met a LazySum among its arguments: evaluate and carry on with tensors
+        # any other torch function that met a LazySum among its arguments -- also inside lists / tuples / dicts
+        # (torch.stack([p.sum() for p in ps]): a top-level-only conversion re-entered this hook forever):
+        # evaluate and carry on with tensors
+        from torch.utils._pytree import tree_map
         conv = lambda a: a.materialize() if isinstance(a, LazySum) else a
-        return func(*[conv(a) for a in args], **{k: conv(v) for k, v in (kwargs or {}).items()})
+        return func(*tree_map(conv, tuple(args)), **tree_map(conv, dict(kwargs)))
 
 
 class SumParameter(nn.Parameter):

@@ -83,6 +83,13 @@ def test_bench_default_line_is_the_supernet_weight_step_with_sub_records():
     assert line['full_record'] == 'gpurun_out/bench_full.json' and line['config']['hip_force_dev_kernarg'] == '1'
     assert 'NCCL_DEBUG' not in line['config']['rccl_env']
     assert line['cpu_baseline']['kind'] == 'port' and line['cpu_baseline']['value'] > 0 and 0 < line['roofline']['frac'] < 1
+    # round 6: what LIMITS the d = 256 GEMM class is in the line -- the measured share of per-launch fixed
+    # cost -- and the fraction of the pipe the products execute on stands next to `frac`; the library, not bench.py, set the
+    # kernel-argument placement
+    rl = line['roofline']
+    assert rl['bound'] == 'mfma' and rl['limited_by'] in ('latency / fixed cost', 'mfma issue (K loop)')
+    assert 0.02 < rl['fixed_cost_share'] < 0.9 and 1.0 < rl['fixed_cost_us_per_launch'] < 15.0 and 0 < rl['frac_bf16_div6'] < rl['frac']
+    assert line['config']['hip_force_dev_kernarg_source'] == 'set_by_library'
     assert set(line['sub']) == set(d['sub']) and all(s['value'] > 0 and s['ms_per_step'] > 0 for s in line['sub'].values())
     assert [l for l in p.stdout.splitlines() if l.strip()] == [l for l in p.stdout.splitlines() if l.startswith('{')], \
         'stdout must carry the one JSON line and nothing else: ' + p.stdout[-500:]
@@ -135,31 +142,38 @@ def test_bench_gpus_flag_self_spawns_ranks(tmp_path):
     assert d['config']['rccl_ranks'] == 2
 
 
-@pytest.mark.parametrize('workload', ['train_vqa', 'search_vqa', 'bilevel_vqa'])
-def test_bench_two_ranks_one_gpu(workload, tmp_path):
+@pytest.mark.parametrize('workload,world', [('train_vqa', 2), ('search_vqa', 2), ('bilevel_vqa', 2), ('search_vqa', 4), ('search_vqa', 8),
+                                            ('bilevel_vqa', 4)])
+def test_bench_two_ranks_one_gpu(workload, world, tmp_path):
+    """N ranks on the box's ONE GPU over gloo (RCCL refuses two ranks on a device), launched exactly as the driver launches
+    N > 1.  world 4 / 8 (round 6): the N > 2 branches of the harness -- rank counting, architecture comparison, per-rank
+    times, and the persistent LSTM with 4 / 8 processes' grids sharing the CUs: either every hand-off is met
+    (`lstm_timed_out` 0) or EVERY rank fell back to nn.LSTM together (`lstm_fallback`), never a hang or a NaN loss."""
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, MMNAS_BENCH_BACKEND='gloo', MMNAS_BENCH_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                        '--master-addr', '127.0.0.1', '--master-port', str(port), 'bench.py', '--gpus', '2',
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+                        '--master-addr', '127.0.0.1', '--master-port', str(port), 'bench.py', '--gpus', str(world),
                         '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--workload', workload, '--full-out', str(tmp_path / 'f.json')],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     d = _json_line(p.stdout, str(tmp_path / 'f.json'))
     if workload == 'bilevel_vqa':
-        _check(d, 2, steps=6, warmup=6)
+        _check(d, world, steps=6, warmup=6)
     else:
-        _check(d, 2)
-    assert d['config']['parallelism'] == 'dp2' and d['config']['grad_allreduce'] == 'gloo'
+        _check(d, world)
+    assert d['config']['parallelism'] == 'dp%d' % world and d['config']['grad_allreduce'] == 'gloo'
     # what the line says about the exchange is observed in the run: ranks counted by an all-reduce, the ranks' sampled
     # architectures compared before the timed blocks, the LSTM hand-off flag read after every block, each rank's own time
     c = d['config']
-    assert c['rccl_ranks'] == 2 and c['rank_id_sum_ok'] is True and c['lstm_timed_out'] == 0
+    assert c['rccl_ranks'] == world and c['rank_id_sum_ok'] is True
+    # 2 ranks: the two persistent grids are co-resident; more: a time-out is legitimate, but then all ranks fell back together
+    assert c['lstm_timed_out'] == 0 and (world > 2 or c['lstm_fallback'] is False), (c['lstm_timed_out'], c['lstm_fallback'])
     assert c['dp_rows'] in ('0', '1')
     if workload != 'train_vqa':
         assert c['same_architecture'] is True and c['dp_buckets'] == 3
     full = json.load(open(str(tmp_path / 'f.json')))
-    assert len(full['rank_ms_per_step']) == 2 and max(full['rank_ms_per_step']) == pytest.approx(full['ms_per_step'], rel=1e-3)
-    assert len(d['rank_ms_per_step']) == 2
+    assert len(full['rank_ms_per_step']) == world and max(full['rank_ms_per_step']) == pytest.approx(full['ms_per_step'], rel=1e-3)
+    assert len(d['rank_ms_per_step']) == world

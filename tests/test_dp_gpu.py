@@ -25,7 +25,9 @@ def _free_port():
     return p
 
 
-def _entry(rank, fn, port):
+def _entry(rank, fn, port, world=2):
+    global WORLD
+    WORLD = world          # (spawned children import this module afresh: the rank count travels as an argument)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     torch.cuda.set_device(0)
@@ -82,7 +84,7 @@ def _w_full(rank):
         assert red.row_exchange.done                       # the rows went through the exchange, not the dense fallback
         both = [torch.empty_like(net.embedding.weight.grad) for _ in range(WORLD)]
         dist.all_gather(both, net.embedding.weight.grad)
-        assert torch.equal(both[0], both[1])               # bitwise equal on the ranks, as an all-reduce's result is
+        assert all(torch.equal(both[0], b) for b in both[1:])   # bitwise equal on the ranks, as an all-reduce's result is
         bad = []
         for k, p in net.named_parameters():
             err = float((p.grad - want[k] / WORLD).abs().max())
@@ -119,7 +121,7 @@ def _w_supernet(rank):
     # every rank's flat buffer must now hold the mean of the two local buffers on the exchanged (active) segments
     both = [torch.zeros_like(local) for _ in range(WORLD)]
     dist.all_gather(both, local)
-    mean = (both[0] + both[1]) / WORLD
+    mean = sum(both[1:], both[0]) / WORLD
     segs = red.exchanged_segments()
     # the word embedding is not part of any bucket: its rows were exchanged inside backward (so `local` above may already
     # hold them -- it is checked separately below)
@@ -133,7 +135,7 @@ def _w_supernet(rank):
     assert sum(n for _, n in segs) >= sum(p.numel() for p in red._active)
     covered = 0
     for o, n in segs:
-        assert torch.allclose(red.fg.flat[o:o + n], mean[o:o + n], rtol=1e-5, atol=1e-7)
+        assert torch.allclose(red.fg.flat[o:o + n], mean[o:o + n], rtol=2e-5, atol=2e-7)
         covered += n
     assert covered < red.fg.total                # unsampled candidates were not exchanged ...
     mask = torch.ones(red.fg.total, dtype=torch.bool, device='cuda')
@@ -152,12 +154,12 @@ def _w_supernet(rank):
     net.unused_modules_back()
     parts = [torch.zeros_like(mine) for _ in range(WORLD)]
     dist.all_gather(parts, mine)
-    want = (parts[0] + parts[1]) / WORLD
+    want = sum(parts[1:], parts[0]) / WORLD
     assert float(want.abs().max()) > 0
     assert float((emb_avg - want).abs().max()) <= 1e-5 * float(want.abs().max())
     both_e = [torch.zeros_like(emb_avg) for _ in range(WORLD)]
     dist.all_gather(both_e, emb_avg)
-    assert torch.equal(both_e[0], both_e[1])             # bitwise equal on the ranks
+    assert all(torch.equal(both_e[0], b) for b in both_e[1:])   # bitwise equal on the ranks
 
 
 def _w_arch_then_weight(rank):
@@ -202,7 +204,7 @@ def _w_arch_then_weight(rank):
         assert torch.equal(red.fg.flat[eo:eo + en], want)
     both = [torch.zeros_like(want) for _ in range(WORLD)]
     dist.all_gather(both, want)
-    assert torch.equal(both[0], both[1])
+    assert all(torch.equal(both[0], b) for b in both[1:])
 
 
 def _w_itm_triplet(rank):
@@ -268,3 +270,14 @@ def test_two_ranks_on_one_gpu_ragged_decoder_stream(fn, monkeypatch):
     (different row counts per rank), the gradients that travel are the same."""
     monkeypatch.setenv('MMNAS_UNPAD', '1')
     mp.spawn(_entry, args=(fn, _free_port()), nprocs=WORLD, join=True)
+
+
+@pytest.mark.parametrize('world', [4, 8])
+@pytest.mark.parametrize('fn', ['_w_full', '_w_supernet', '_w_arch_then_weight'])
+def test_four_and_eight_ranks_on_one_gpu(fn, world):
+    """the N = 4 and N = 8 LOGIC -- the reference runs DistributedDataParallel over all 8 GPUs of a node
+    (search_vqa.py:58-59, 210, 279-337) and no multi-GPU box is reachable from here, so the world-4 / world-8 code paths (the
+    row exchange of 8 ranks' embedding rows, the bucket marks with 8 ranks, 8 flat buffers reduced to one mean) run as 4 / 8
+    fresh processes sharing the box's one GPU over gloo: averaged gradients equal the mean of the ranks' plain gradients,
+    embedding tables are bitwise equal across all ranks, every rank samples the same architecture."""
+    mp.spawn(_entry, args=(fn, _free_port(), world), nprocs=world, join=True)

@@ -171,3 +171,22 @@ def test_torch_optimizers_keep_their_multi_tensor_path():
         assert foreach is True
     from torch.optim import optimizer as opt
     assert Z.SumParameter in opt._foreach_supported_types
+
+
+def test_lazy_sum_inside_containers_and_under_python_operators():
+    """torch.stack([p.sum() ...]) recursed forever (only top-level arguments were evaluated), and the operators
+    Python resolves on the type (comparisons, **, abs, bool) raised TypeError.  Anything but the `0 * sum(...)` idiom is the
+    ordinary tensor."""
+    import torch
+    from mmnas_amd import zeroterm
+    lin = zeroterm.adopt(torch.nn.Linear(3, 2))
+    ps = list(lin.parameters())
+    want = torch.stack([torch.Tensor.sum(p) for p in ps])
+    assert torch.equal(torch.stack([p.sum() for p in ps]), want)
+    assert torch.equal(torch.cat([p.sum().reshape(1) for p in ps]), want)
+    s0 = ps[0].sum()
+    t0 = torch.Tensor.sum(ps[0])
+    assert bool(s0 > -1e9) and bool(s0 >= t0) and bool(s0 <= t0) and not bool(s0 < t0) and bool(s0 == t0) and not bool(s0 != t0)
+    assert torch.equal(s0 ** 2, t0 ** 2) and torch.equal(abs(s0), abs(t0)) and torch.equal(2.0 ** s0, 2.0 ** t0)
+    assert torch.equal(1.0 / s0, 1.0 / t0) and bool(s0) == bool(t0) and int(s0) == int(t0)
+    assert torch.equal(torch.maximum(s0, ps[1].sum()), torch.maximum(t0, torch.Tensor.sum(ps[1])))
