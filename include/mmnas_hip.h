@@ -124,7 +124,8 @@ int mmnas_gemm(const mmnas_gemm_desc* d, void* stream);
  * with the hand-written LayerNorm behind it (modules.py:44-56) as ONE launch.  *d describes the product exactly as for
  * mmnas_gemm (layout NT, one group; z = d->g[0].C with leading dimension ldc, may be NULL when nobody needs z); y has
  * d->N columns.  N = 256, K % 32 == 0 and 16-byte aligned operands run the row-panel kernel (32 x 256 panels, statistics
- * in-kernel); every other shape -- or MMNAS_GEMM_LN=0 / mmnas_set_gemm_ln(0) -- runs mmnas_gemm + mmnas_layernorm_fwd
+ * in-kernel) when the switch is ON (MMNAS_GEMM_LN=1 / mmnas_set_gemm_ln(1); default OFF: measured neutral on the supernet
+ * step, profiles/r06_ab.txt); every other shape -- or the switch off -- runs mmnas_gemm + mmnas_layernorm_fwd
  * (z must then be given, ldc = N).  mmnas_set_gemm_ln returns the previous setting. */
 int mmnas_gemm_ln(const mmnas_gemm_desc* d, const float* ln_a, const float* ln_b, float* y, float eps, void* stream);
 int mmnas_set_gemm_ln(int on);

@@ -947,6 +947,11 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_fused_kernel(const MhaK p) {
 //  barrier-separated read-modify-writes 60 us.  The second wave per SIMD buys less than its duplicate operand loads,
 //  half-lane LDS stores and extra barriers cost.  tools/mha_bench.py times the attention kernels alone.)
 
+// attention_bwd16.hip
+bool mha_bwd_b16_launch(int B, int H, int Sq, int Sk, int ldq, int ldk, int ldv, int ldo, const float* Q, const float* K, const float* V,
+                        const float* O, const float* dO, const uint8_t* mask, const float* biasT, const float* stats, float* dQ, float* dK,
+                        float* dV, float* dbiasT, DropCfg drop, float scale, const int* qoff, const int* koff, hipStream_t st);
+
 static int fill(const mmnas_mha_desc* d, MhaK& k, bool bwd) {
   MMNAS_REQUIRE(d, MMNAS_E_ARG, "mha: null descriptor");
   MMNAS_REQUIRE(d->B > 0 && d->H > 0 && d->Sq > 0 && d->Sk > 0, MMNAS_E_SHAPE, "mha: B=%d H=%d Sq=%d Sk=%d", d->B,
@@ -1079,6 +1084,10 @@ extern "C" int mmnas_mha_core_bwd(const mmnas_mha_desc* d, void* stream) {
   if (packed) MMNAS_REQUIRE((((uintptr_t)k.dK | (uintptr_t)k.dV) & 15) == 0, MMNAS_E_ARG, "mha_bwd: dK / dV alignment (packed rows run the fused kernel only)");
   if ((fused_on || packed) && k.dh == 64 && k.Sq <= 128 && k.Sk <= 128 && (((uintptr_t)k.dK | (uintptr_t)k.dV) & 15) == 0) {
     k.nch = 1;
+    // 65..128 keys (the image stream): all five products on the bf16 pipe as exactly split operands (attention_bwd16.hip)
+    if (mha_bwd_b16_launch(k.B, k.H, k.Sq, k.Sk, k.ldq, k.ldk, k.ldv, k.ldo, k.Q, k.K, k.V, (const float*)d->O, k.dO, k.mask, k.biasT,
+                           k.stats, k.dQ, k.dK, k.dV, k.dbiasT, k.drop, k.scale, k.qoff, k.koff, st))
+      return check_launch("mha_core_bwd");
     const dim3 grid(k.H, k.B);
     const int nkb = cdiv(k.Sk, 32);
     if (k.dbiasT) {

@@ -43,11 +43,16 @@ def main():
     opt = WarmupOptimizer(4e-4, torch.optim.Adam(net.net_parameters(), lr=0, betas=(0.9, 0.98), eps=1e-9), epoch_steps=1000, warmup=True)
     loss_fn = torch.nn.BCEWithLogitsLoss(reduction='sum')
 
-    def step(zero_sum=True, backward=True, optimize=True):
+    noop_logits = torch.zeros(64, bench.ANS, device=dev, requires_grad=True)
+
+    def step(zero_sum=True, backward=True, optimize=True, noop_forward=False):
         MixedOp.MODE = None
         net.reset_binary_gates()
         net.unused_modules_off()
-        pred = net(inp)
+        # noop_forward (--floor): the script's statements around a forward that does NOTHING -- what is left is torch's own
+        # share of the unchanged loop (699 parameters: the zero-term node, zero_grad, clip_grad_norm_, Adam.step) plus the
+        # sampling / module switching of this library's MixedOp mirror
+        pred = noop_logits * 1.0 if noop_forward else net(inp)
         loss = loss_fn(pred, tgt)
         if zero_sum:
             loss += 0 * sum(p.sum() for p in net.alpha_prob_parameters())
@@ -103,6 +108,18 @@ def main():
     print('# host issue ms / wall ms per step (queue drained before every step), B = 64, HSIZE 256, %d parameter tensors (%d of them alpha)'
           % (len(list(net.parameters())), 2 * len(net.redundant_modules)))
     res = {}
+    if '--floor' in sys.argv:
+        # the floor under `search_vqa_dropin` -- every statement of search_vqa.py:279-301 with the forward
+        # replaced by a no-op (so backward has only the zero-term node and the loss to run)
+        res['full'] = measure(lambda: step())
+        res['floor'] = measure(lambda: step(noop_forward=True))
+        res['floor_no_zero_sum'] = measure(lambda: step(noop_forward=True, zero_sum=False))
+        print('%-18s host %6.2f ms   wall %6.2f ms   (every statement, real forward)' % ('full', *res['full']))
+        print('%-18s host %6.2f ms   wall %6.2f ms   (every statement, no-op forward: torch\'s share + sampling)' % ('floor', *res['floor']))
+        print('%-18s host %6.2f ms   wall %6.2f ms   (the same without the three `0 * sum(p.sum())` lines)' % ('floor_no_zero_sum', *res['floor_no_zero_sum']))
+        print('# search_vqa_dropin - floor = %.2f ms: the per-operator path\'s own host time (forward + backward nodes of ~30 operators)'
+              % (res['full'][1] - res['floor'][1]))
+        return
     for name, kw in (('full', {}), ('no_zero_sum', dict(zero_sum=False)), ('fwd_bwd', dict(zero_sum=False, optimize=False)),
                      ('forward', dict(zero_sum=False, optimize=False, backward=False))):
         if name in ('fwd_bwd',):

@@ -42,7 +42,15 @@ def main():
     # measured on one MI355X (profiles/r04_bench.json): backward of the supernet step ~ 3.6 ms of the 5.4 ms step, of which
     # the backbone ~ 3.0 ms; training step: backward ~ 7.7 of 11.5 ms
     out = {}
-    for name, bwd_ms, backbone_ms in (('search_vqa', 3.6, 3.0), ('train_vqa', 7.7, 7.0)):
+    # round 6: the step times of this round's build (`--search-ms` / `--train-ms`, defaults = profiles/r06 bench on the box of
+    # the refresh); backward / backbone shares are the measured proportions of the round-3 timelines (backward 0.667 of the
+    # supernet step, the backbone 0.833 of it; 0.67 / 0.91 for the training step) -- a MODEL of where the marks fall, not a
+    # multi-GPU measurement: no curve was measured (no multi-GPU box is reachable from the build container)
+    def arg(flag, dflt):
+        return float(sys.argv[sys.argv.index(flag) + 1]) if flag in sys.argv else dflt
+    s_ms, t_ms = arg('--search-ms', 4.45), arg('--train-ms', 10.4)
+    tag = sys.argv[sys.argv.index('--tag') + 1] if '--tag' in sys.argv else 'r06'
+    for name, bwd_ms, backbone_ms in (('search_vqa', 0.667 * s_ms, 0.667 * 0.833 * s_ms), ('train_vqa', 0.67 * t_ms, 0.67 * 0.91 * t_ms)):
         if name == 'search_vqa':
             cfg = bench.make_cfg('search')
             net = Net_Search(cfg, init)
@@ -107,7 +115,8 @@ def main():
             rowb = bench.B_DEFAULT * bench.SX * (300 * 4 + 8)
             print('  N=%d: dense ring all-reduce %.3f ms (exposed: the table completes last) vs row all-gather %.3f ms' % (
                 n, 1e3 * t_ring(out[name]['embedding_dense_bytes'], n), 1e3 * (n - 1) * rowb / LINK))
-    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r04_exchange_budget.json'), 'w'), indent=1, default=str)
+    out['_model'] = dict(search_step_ms=s_ms, train_step_ms=t_ms, link_GBps=LINK / 1e9, note='predicted from one-GPU timings; never measured on more than one GPU')
+    json.dump(out, open(os.path.join(ROOT, 'profiles', tag + '_exchange_budget.json'), 'w'), indent=1, default=str)
 
 
 if __name__ == '__main__':

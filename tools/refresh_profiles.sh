@@ -6,7 +6,7 @@
 # the bench lines themselves (the default line with its CPU baselines last: it reads the traffic files written before).
 # Raw traces stay in /tmp; only summaries are written to profiles/.  Counters are collected with --kernel-trace only.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 ROOT=$PWD
 export TMPDIR=/tmp
 W=/tmp/mmnas_prof
@@ -57,8 +57,13 @@ python3 tools/rel_bench.py > profiles/${R}_rel_microbench.txt 2>/dev/null
 { echo "# MMNAS_ZERO_TERMS=1 (default: SumParameter / LazySum, mmnas_amd/zeroterm.py)"; python3 tools/dropin_host_split.py 2>/dev/null
   echo; echo "# MMNAS_ZERO_TERMS=0 (plain parameters: the three 0 * sum(p.sum()) lines run as written)"; MMNAS_ZERO_TERMS=0 python3 tools/dropin_host_split.py 2>/dev/null; } > profiles/${R}_host_dropin.txt
 python3 tools/dropin_host_split.py --statements > profiles/${R}_host_dropin_statements.txt 2>/dev/null
-[ -z "${SKIP_AB:-}" ] && bash tools/hoist_ab.sh > profiles/${R}_hoist_ab.txt 2>&1
-[ -z "${SKIP_AB:-}" ] && bash tools/small_bwd_ab.sh > profiles/${R}_small_bwd_ab.txt 2>&1
+python3 tools/dropin_host_split.py --floor > profiles/${R}_host_dropin_floor.txt 2>/dev/null
+python3 tools/ln_bench.py > profiles/${R}_ln_microbench.txt 2>/dev/null
+python3 tools/gemm_ln_bench.py > profiles/${R}_gemm_ln_microbench.txt 2>/dev/null
+[ -f mmnas_amd/lib/libmmnas_hip_fwd1.so ] && bash tools/mha_fwd_phases.sh > profiles/${R}_mha_fwd_phases.txt 2>&1
+[ -z "${SKIP_AB:-}" ] && bash tools/r06_ab.sh > profiles/${R}_ab.txt 2>&1
+[ -n "${OLD_AB:-}" ] && bash tools/hoist_ab.sh > profiles/${R}_hoist_ab.txt 2>&1       # (round 5's A/Bs: OLD_AB=1)
+[ -n "${OLD_AB:-}" ] && bash tools/small_bwd_ab.sh > profiles/${R}_small_bwd_ab.txt 2>&1
 (cd /tmp && GEMM_PMC_LAYOUTS=1 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $W/pmc_gemm_lds -o t -- python3 $ROOT/tools/gemm_pmc.py > $W/pmc_gemm_lds.log 2>&1)
 (cd /tmp && GEMM_PMC_LAYOUTS=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace -d $W/pmc_gemm_mfma -o t -- python3 $ROOT/tools/gemm_pmc.py > $W/pmc_gemm_mfma.log 2>&1)
 python3 tools/pmc_counters.py profiles/${R}_pmc_gemm_layouts.json $W/pmc_gemm_lds $W/pmc_gemm_mfma
