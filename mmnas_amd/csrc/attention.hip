@@ -952,6 +952,10 @@ bool mha_bwd_b16_launch(int B, int H, int Sq, int Sk, int ldq, int ldk, int ldv,
                         const float* O, const float* dO, const uint8_t* mask, const float* biasT, const float* stats, float* dQ, float* dK,
                         float* dV, float* dbiasT, DropCfg drop, float scale, const int* qoff, const int* koff, hipStream_t st);
 
+bool mha_fwd_b16_launch(int B, int H, int Sq, int Sk, int ldq, int ldk, int ldv, int ldo, const float* Q, const float* K, const float* V,
+                        const uint8_t* mask, const float* biasT, float* O, float* stats, DropCfg drop, float scale, const int* qoff,
+                        const int* koff, hipStream_t st);
+
 static int fill(const mmnas_mha_desc* d, MhaK& k, bool bwd) {
   MMNAS_REQUIRE(d, MMNAS_E_ARG, "mha: null descriptor");
   MMNAS_REQUIRE(d->B > 0 && d->H > 0 && d->Sq > 0 && d->Sk > 0, MMNAS_E_SHAPE, "mha: B=%d H=%d Sq=%d Sk=%d", d->B,
@@ -1065,6 +1069,10 @@ extern "C" int mmnas_mha_core_fwd(const mmnas_mha_desc* d, void* stream) {
   const double bhqk = (double)k.B * k.H * k.Sq * k.Sk;
   ProfScope ps(MMNAS_K_MHA_FWD, 4.0 * bhqk * k.dh,
                4.0 * ((double)k.B * k.H * k.dh * (2.0 * k.Sq + 2.0 * k.Sk) + (k.biasT ? bhqk : 0.0)), st);
+  // d_h = 64, 65..128 keys (the image stream): both products on the bf16 pipe as exactly split operands (attention_bwd16.hip)
+  if (k.dh == 64 && mha_fwd_b16_launch(k.B, k.H, k.Sq, k.Sk, k.ldq, k.ldk, k.ldv, k.ldo, k.Q, k.K, k.V, k.mask, k.biasT, k.O, k.stats,
+                                       k.drop, k.scale, k.qoff, k.koff, st))
+    return check_launch("mha_core_fwd");
   if (k.dh >= 64) { k.nch = k.dh / 64; launch_fwd<64>(k, st); }
   else if (k.dh == 32) { k.nch = 1; launch_fwd<32>(k, st); }
   else { k.nch = 1; launch_fwd<16>(k, st); }

@@ -367,6 +367,216 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_b16_kernel(const MhaB16K p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Forward on the same scheme (d_h = 64, 65..128 keys, <= 128 queries): a wave owns 32 QUERIES (its Q rows are pre-split B
+// fragments in registers); K and V of the head sit in LDS as split images.  S^T = K Q^T reads K by rows (ds_read_b128);
+// the softmax runs in registers with the query on the lane (attention.hip's forward, unchanged arithmetic); the probability
+// tile is split in registers and is the A operand of O = A V, whose B operand is V read by COLUMNS (transpose reads).
+// 192 bf16 MFMAs of 32 cycles per wave where the fp32 kernel issues 256 fp32 MFMAs of 64.
+// ------------------------------------------------------------------------------------------
+struct MhaF16K {
+  int B, H, Sq, Sk, ldq, ldk, ldv, ldo;
+  const float* Q; const float* K; const float* V; const uint8_t* mask; const float* biasT;
+  float* O; float* stats;
+  DropCfg drop; float scale;
+  const int* qoff; const int* koff;
+};
+
+__global__ void __launch_bounds__(256, 1) mha_fwd_b16_kernel(const MhaF16K p) {
+  __shared__ __attribute__((aligned(16))) char Ki[128 * B16_RSB];
+  __shared__ __attribute__((aligned(16))) char Vi[128 * B16_RSB];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y, h = blockIdx.x;
+  const int SqS = p.Sq, SkS = p.Sk;
+  int Sq = p.Sq, Sk = p.Sk;
+  size_t qrow0 = (size_t)b * p.Sq, krow0 = (size_t)b * p.Sk;
+  if (p.qoff) { const int o = p.qoff[b]; Sq = p.qoff[b + 1] - o; qrow0 = (size_t)o; }
+  if (p.koff) { const int o = p.koff[b]; Sk = p.koff[b + 1] - o; krow0 = (size_t)o; }
+  if (Sq <= 0 || Sk <= 0) return;
+  const size_t bh = (size_t)b * p.H + h;
+  const int hc = h * 64;
+  const int qi = 32 * w + l31;
+  const bool qok = qi < Sq;
+
+  // ---- every global load first: this lane's query row (fragments), the K / V tiles of the head, the bias ----
+  float4 qraw[8];
+  {
+    const float* qr = p.Q + (qrow0 + (qok ? qi : 0)) * p.ldq + hc + 8 * hh;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) { qraw[2 * s4] = *reinterpret_cast<const float4*>(qr + 16 * s4); qraw[2 * s4 + 1] = *reinterpret_cast<const float4*>(qr + 16 * s4 + 4); }
+  }
+  float4 kv[8], vv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int f = tid + 256 * i, row = f >> 4, c4 = f & 15;
+    const bool ok = row < Sk;
+    const size_t r = krow0 + (ok ? row : 0);
+    kv[i] = *reinterpret_cast<const float4*>(p.K + r * p.ldk + hc + 4 * c4);
+    vv[i] = *reinterpret_cast<const float4*>(p.V + r * p.ldv + hc + 4 * c4);
+    if (!ok) { kv[i] = make_float4(0.f, 0.f, 0.f, 0.f); vv[i] = kv[i]; }
+  }
+  // the relation bias of this lane's query against all 128 keys, fetched with everything else (64 values per lane; the
+  // kernel has the whole register file: one wave per SIMD)
+  const bool has_bias = p.biasT != nullptr;
+  const int qic = qok ? qi : Sq - 1;
+  float biasv[4][16];
+  if (has_bias) {
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = min(32 * kc + acc_row(r, hh), Sk - 1);
+        biasv[kc][r] = p.biasT[(bh * SkS + key) * SqS + qic];
+      }
+  }
+  // key mask / key range as bit masks (one ballot per 64 keys), pre-shifted per lane half: element (kc, r) tests bit
+  // 32 (kc & 1) + (r & 3) + 8 (r >> 2) of word kc >> 1 (attention.hip's forward)
+  unsigned long long mbits[2], vbits[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int key = 64 * j + lane;
+    const bool inr = key < Sk;
+    const bool mk = p.mask && inr && p.mask[(size_t)b * SkS + (inr ? key : 0)];
+    mbits[j] = __ballot(mk) >> (4 * hh);
+    vbits[j] = __ballot(inr) >> (4 * hh);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int f = tid + 256 * i, row = f >> 4, c4 = f & 15;
+    unsigned a0, a1, a2, b0, b1, b2;
+    split_pair<3>(kv[i].x, kv[i].y, a0, a1, a2);
+    split_pair<3>(kv[i].z, kv[i].w, b0, b1, b2);
+    char* d = Ki + row * B16_RSB + c4 * 8;
+    *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
+    *reinterpret_cast<uint2*>(d + 128) = make_uint2(a1, b1);
+    *reinterpret_cast<uint2*>(d + 256) = make_uint2(a2, b2);
+    split_pair<3>(vv[i].x, vv[i].y, a0, a1, a2);
+    split_pair<3>(vv[i].z, vv[i].w, b0, b1, b2);
+    d = Vi + row * B16_RSB + c4 * 8;
+    *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
+    *reinterpret_cast<uint2*>(d + 128) = make_uint2(a1, b1);
+    *reinterpret_cast<uint2*>(d + 256) = make_uint2(a2, b2);
+  }
+  bf16x8 qB[4][3];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    float4 x0 = qraw[2 * s4], x1 = qraw[2 * s4 + 1];
+    if (!qok) { x0 = make_float4(0.f, 0.f, 0.f, 0.f); x1 = x0; }
+    const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    split8(xs, qB[s4][0], qB[s4][1], qB[s4][2]);
+  }
+  __syncthreads();
+
+  // ---- S^T = K Q^T: A = row reads of the K image (key block kc), B = this lane's query fragments ----
+  f32x16 acc[4];
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[kc][r] = 0.f;
+    const char* krow = Ki + (32 * kc + l31) * B16_RSB + 16 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 kf[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) kf[c] = *reinterpret_cast<const bf16x8*>(krow + c * 128 + 32 * ks);
+      acc[kc] = mfma6(kf, qB[ks], acc[kc]);
+    }
+  }
+  // ---- softmax over the keys of this lane's query (registers + the other half-wave) ----
+  float m = -INFINITY;
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      constexpr unsigned long long one = 1ull;
+      const unsigned long long bit = one << (32 * (kc & 1) + (r & 3) + 8 * (r >> 2));
+      float v = acc[kc][r] * p.scale;
+      if (has_bias) v += biasv[kc][r];
+      v = (mbits[kc >> 1] & bit) ? -1e9f : v;
+      v = (vbits[kc >> 1] & bit) ? v : -INFINITY;
+      acc[kc][r] = v;
+      m = fmaxf(m, v);
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __expf(acc[kc][r] - m);
+      acc[kc][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  if (qok && hh == 0) {
+    p.stats[(bh * SqS + qi) * 2] = m;
+    p.stats[(bh * SqS + qi) * 2 + 1] = inv;
+  }
+  const uint32_t dpre = drop_pre(p.drop, (uint32_t)((bh * SqS + qi) * SkS + 4 * hh));
+  // ---- O = A V: the probability tile (split in registers) as A operand, V by columns ----
+  f32x16 o[2];
+#pragma unroll
+  for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[jc][r] = 0.f;
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) {
+    float xs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float a = acc[kc][r] * inv;
+      if (p.drop.thresh) a *= drop_mult_pre(p.drop, dpre + (uint32_t)(32 * kc + (r & 3) + 8 * (r >> 2)) * DROP_G);
+      xs[r] = a;
+    }
+    bf16x8 aP[2][3];
+    split8(xs, aP[0][0], aP[0][1], aP[0][2]);
+    split8(xs + 8, aP[1][0], aP[1][1], aP[1][2]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int jc = 0; jc < 2; ++jc) {
+        bf16x8 vT[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vT[c] = tr_frag(Vi, 32 * kc + 16 * u + 4 * hh, 32 * jc, c, lane);
+        o[jc] = mfma6(aP[u], vT, o[jc]);
+      }
+  }
+  // the output tile leaves as whole 256-byte rows: through the K image's LDS (free once every wave has its scores: barrier),
+  // [query][64 + 4 pad] fp32 per wave, read back 16 bytes per lane
+  __syncthreads();
+  float* Ot = reinterpret_cast<float*>(Ki) + w * (32 * 68);
+#pragma unroll
+  for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ot[acc_row(r, hh) * 68 + 32 * jc + l31] = o[jc][r];
+  // (the wave reads back what it wrote: same-wave LDS accesses stay in order)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int f = lane + 64 * i, row = f >> 4, c4 = f & 15;
+    const int q = 32 * w + row;
+    const float4 v4 = *reinterpret_cast<const float4*>(Ot + row * 68 + 4 * c4);
+    if (q < Sq) *reinterpret_cast<float4*>(p.O + (qrow0 + q) * p.ldo + hc + 4 * c4) = v4;
+  }
+}
+
+bool mha_fwd_b16_launch(int B, int H, int Sq, int Sk, int ldq, int ldk, int ldv, int ldo, const float* Q, const float* K, const float* V,
+                        const uint8_t* mask, const float* biasT, float* O, float* stats, DropCfg drop, float scale, const int* qoff,
+                        const int* koff, hipStream_t st) {
+  static const int on = [] { const char* e = getenv("MMNAS_MHA_FWD_B16"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (!on || Sq > 128 || Sk > 128 || Sk <= 64) return false;
+  if ((long)B * H > 320) return false;    // (one workgroup per CU: two rounds of workgroups lose to the fp32 kernel's two per CU -- 33.2 vs 31.8 us at 512)
+  if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) != 0 || (ldq | ldk | ldv | ldo) % 4 != 0) return false;
+  MhaF16K k;
+  memset(&k, 0, sizeof(k));
+  k.B = B; k.H = H; k.Sq = Sq; k.Sk = Sk; k.ldq = ldq; k.ldk = ldk; k.ldv = ldv; k.ldo = ldo;
+  k.Q = Q; k.K = K; k.V = V; k.mask = mask; k.biasT = biasT; k.O = O; k.stats = stats; k.drop = drop; k.scale = scale;
+  k.qoff = qoff; k.koff = koff;
+  MMNAS_LAUNCH(mha_fwd_b16_kernel, dim3(H, B), dim3(256), 0, st, k);
+  return true;
+}
+
 // attention.hip hands over the (validated) problem; returns false when the shape is outside this kernel's range
 bool mha_bwd_b16_launch(int B, int H, int Sq, int Sk, int ldq, int ldk, int ldv, int ldo, const float* Q, const float* K, const float* V,
                         const float* O, const float* dO, const uint8_t* mask, const float* biasT, const float* stats, float* dQ, float* dK,

@@ -14,7 +14,7 @@ rm -rf $W; mkdir -p $W profiles
 for wl in search_vqa arch_vqa train_vqa search_vqa_unpad train_vqa_unpad; do
   cmd="bench.py --workload $wl --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline"
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace_$wl -o t -- python3 $ROOT/$cmd > $W/trace_$wl.log 2>&1)
-  python3 tools/summarize_prof.py $W/trace_$wl profiles/${R}_$wl auto \
+  SUMMARIZE_PASSES=3,10,3,10 python3 tools/summarize_prof.py $W/trace_$wl profiles/${R}_$wl auto \
     "rocprofv3 --kernel-trace --stats -- python3 $cmd  (3 warm-up + 10 timed + 3 empty-queue + 10 roofline-pass steps)"
   marker=onehot_rows; [ $wl = train_vqa ] && marker=row_is_zero; [ $wl = train_vqa_unpad ] && marker=row_is_zero
   python3 tools/step_timeline.py $W/trace_$wl $marker > profiles/${R}_timeline_$wl.txt

@@ -46,10 +46,43 @@ def main():
     lines = ['# rocprofv3 --kernel-trace --stats summary', '', '`%s`' % cmd, '',
              'steps profiled (warm-up included): %d (%s); device-busy time %.2f ms/step' % (steps, how, tot / steps / 1e6), '',
              '| ms/step | launches/step | avg us | % | kernel |', '|---|---|---|---|---|']
+    # Which PASS of the command a kernel's launches belong to (the per-step averages above are over ALL steps of the
+    # command -- warm-up, timed, empty-queue and roofline-pass steps; `__amd_rocclr_copyBuffer` is not in a timed step at all).
+    # The passes are given as step counts, SUMMARIZE_PASSES="3,10,3,10" = warm-up, timed, empty-queue, roofline pass; steps are
+    # delimited in the trace by the launches of the per-step marker kernel (lstm_seq_fwd_kernel).
+    per_pass = {}
+    passes = [int(x) for x in os.environ.get('SUMMARIZE_PASSES', '').split(',') if x]
+    if passes and sum(passes) == steps:
+        tr = sorted(csv.DictReader(open(trace)), key=lambda r: int(r['Start_Timestamp']))
+        marks = [int(r['Start_Timestamp']) for r in tr if 'lstm_seq_fwd_kernel' in r['Kernel_Name']]
+        bounds, acc = [], 0
+        for n in passes:
+            bounds.append((acc, acc + n))
+            acc += n
+        timed_lo, timed_hi = bounds[1]
+        t0 = marks[timed_lo]
+        t1 = marks[timed_hi] if timed_hi < len(marks) else None
+        for r in tr:
+            ts = int(r['Start_Timestamp'])
+            if ts >= t0 and (t1 is None or ts < t1):
+                k = r['Kernel_Name']
+                per_pass[k] = per_pass.get(k, 0) + 1
+        lines[-2] = '| ms/step | launches/step | launches/step in the %d TIMED steps | avg us | %% | kernel |' % passes[1]
+        lines[-1] = '|---|---|---|---|---|---|'
     for r in rows[:25]:
         name = r['Name'].replace('void ', '').replace('|', '/')[:110]
-        lines.append('| %.3f | %.1f | %.1f | %.1f | `%s` |' % (float(r['TotalDurationNs']) / steps / 1e6, int(r['Calls']) / steps,
-                                                              float(r['AverageNs']) / 1e3, float(r['Percentage']), name))
+        if per_pass:
+            lines.append('| %.3f | %.1f | %.1f | %.1f | %.1f | `%s` |' % (float(r['TotalDurationNs']) / steps / 1e6, int(r['Calls']) / steps,
+                                                                        per_pass.get(r['Name'], 0) / passes[1], float(r['AverageNs']) / 1e3,
+                                                                        float(r['Percentage']), name))
+        else:
+            lines.append('| %.3f | %.1f | %.1f | %.1f | `%s` |' % (float(r['TotalDurationNs']) / steps / 1e6, int(r['Calls']) / steps,
+                                                                  float(r['AverageNs']) / 1e3, float(r['Percentage']), name))
+    if per_pass:
+        cb = sum(v for k, v in per_pass.items() if 'copyBuffer' in k)
+        lines += ['', '(`__amd_rocclr_copyBuffer`: %.1f launches per TIMED step -- the launches in the first column come from the roofline '
+                  'pass, whose per-launch HIP events the runtime resolves with buffer copies, and from the warm-up; they are not part of '
+                  'the step `value` times.)' % (cb / passes[1])]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
         n = r['Kernel_Name']
