@@ -28,15 +28,21 @@ def _grad_dict(net):
     return {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
 
 
-def _additive(g_all, g_lo, g_hi, tol=2e-3):
+def _additive(g_all, g_lo, g_hi, tol=2e-3, tag=None):
     gmax = max(float(v.abs().max()) for v in g_all.values())
-    bad = []
+    bad, worst = [], (0.0, None)
     for k, v in g_all.items():
         lo, hi = g_lo.get(k), g_hi.get(k)
         s = (lo if lo is not None else 0) + (hi if hi is not None else 0)
         err = float((v - s).abs().max())
-        if err > tol * max(float(v.abs().max()), 1e-3 * gmax):
+        den = max(float(v.abs().max()), 1e-3 * gmax)
+        if err / den > worst[0]:
+            worst = (err / den, k)
+        if err > tol * den:
             bad.append((k, err, float(v.abs().max())))
+    if tag:      # (what was measured, for DESIGN 2: tests/conftest.py writes it beside the gradient statistics)
+        from tests import util
+        util.GRAD_STATS['additive|' + tag] = {'worst_rel': worst[0], 'worst_key': worst[1], 'tol': tol}
     assert not bad, bad[:6]
 
 
@@ -307,10 +313,11 @@ def test_vgd_full_size():
     _, _, _, g_lo = run(full[:B // 2], avg=False)
     _, _, _, g_hi = run(full[B // 2:], avg=False)
     # (the GEMM schedule -- whole tiles / streamed tail / split-K pieces -- depends on the row count, so the half batches
-    #  sum in another order than the full one; through 30 LayerNorm'd layers and their ReLU gates that is 1-5e-3 of a
-    #  gradient at this size: 2e-3 held with the default products, 5e-3 measured on the fp32 MFMA.  A batch-dependence
-    #  bug would be O(1).)
-    _additive(g_all, g_lo, g_hi, tol=1e-2)
+    #  sum in another order than the full one; through 30 LayerNorm'd layers and their ReLU gates that is 1-2e-3 of a
+    #  gradient at this size with the default products (5e-3 was measured on the fp32 MFMA, MMNAS_GEMM_SPLIT=0, which this
+    #  test does not run).  Round 6: the bound is 3e-3 (it was a blanket 1e-2); the measured worst entry is
+    #  written to gpurun_out/grad_check_stats.json.  A batch-dependence bug would be O(1).)
+    _additive(g_all, g_lo, g_hi, tol=3e-3, tag='vgd_full_size')
 
 
 def test_itm_triplet_step_full_size():
@@ -339,7 +346,7 @@ def test_itm_triplet_step_full_size():
     l_lo, g_lo = run(full[:B // 2])
     l_hi, g_hi = run(full[B // 2:])
     assert abs(l_lo + l_hi - loss) <= 1e-4 * abs(loss)
-    _additive(g_all, g_lo, g_hi)
+    _additive(g_all, g_lo, g_hi, tag='supernet_full_size')
     # the same step through the data-parallel reducer (flat gradient buffer, backbone / head chains taken three times
     # per backward: the sinks ACCUMULATE over the three forwards)
     red = dp.GradReducer(list(net.parameters()))

@@ -304,8 +304,11 @@ def test_flat_adam_dense_mode_is_torch_adam_with_zero_gradients():
 @pytest.mark.parametrize('products', [6, 0, 3])
 def test_itm_triplet_step_vs_reference(products, monkeypatch):
     """BASELINE configs[4] (train_itm.py:380-391) against the reference's own step.  products: the default 6 bf16-MFMA
-    products per fp32 product, the fp32 MFMA, and -- the reference runs this configuration in fp16 -- the 3-product form
-    (16 mantissa bits of every operand kept, fp32 accumulation: finer than fp16's 11 bits), all at the same 1e-3 tolerance."""
+    products per fp32 product, the fp32 MFMA, and the 3-product form (16 mantissa bits of every operand kept, fp32
+    accumulation), all at the same 1e-3 tolerance.  (The reference itself is fp32 throughout -- no `half` / `amp` anywhere in
+    it; "fp16 MFMA" is BASELINE.json's wording for configs[4].  The 3-product form is this library's experiment for
+    that label -- finer than fp16's 11 bits -- not a restatement of something the reference does; there is no fp16-operand
+    path.)"""
     import mmnas_amd._lib as L
     from mmnas.model.full_itm import Net_Full
     from mmnas.utils.itm_loss import BCE_Loss
