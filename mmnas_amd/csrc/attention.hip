@@ -956,6 +956,10 @@ bool mha_fwd_b16_launch(int B, int H, int Sq, int Sk, int ldq, int ldk, int ldv,
                         const uint8_t* mask, const float* biasT, float* O, float* stats, DropCfg drop, float scale, const int* qoff,
                         const int* koff, hipStream_t st);
 
+bool mha_fwd_b16_pair(int B, int H, int Sq, int Sk, int ld, const float* const* Q, const float* const* K, const float* const* V,
+                      const uint8_t* const* mask, const float* const* biasT, float* const* O, float* const* stats, const DropCfg* drop,
+                      float scale, const int* qoff, const int* koff, hipStream_t st);
+
 static int fill(const mmnas_mha_desc* d, MhaK& k, bool bwd) {
   MMNAS_REQUIRE(d, MMNAS_E_ARG, "mha: null descriptor");
   MMNAS_REQUIRE(d->B > 0 && d->H > 0 && d->Sq > 0 && d->Sk > 0, MMNAS_E_SHAPE, "mha: B=%d H=%d Sq=%d Sk=%d", d->B,
@@ -1050,6 +1054,17 @@ int mha_core_fwd_pair(const mmnas_mha_desc* d0, const mmnas_mha_desc* d1, hipStr
   }
   k0.nch = k1.nch = 1;
   const double bhqk = (double)k0.B * k0.H * k0.Sq * k0.Sk;
+  if (k0.ldq == k0.ldk && k0.ldq == k0.ldv && k0.ldq == k0.ldo && k1.ldq == k0.ldq && k1.ldk == k0.ldq && k1.ldv == k0.ldq && k1.ldo == k0.ldq &&
+      k0.qoff == k1.qoff && k0.koff == k1.koff) {   // round 6: both cores on the bf16 pipe, two workgroups per CU
+    const float* Qs[2] = {k0.Q, k1.Q}; const float* Ks[2] = {k0.K, k1.K}; const float* Vs[2] = {k0.V, k1.V};
+    const uint8_t* Ms[2] = {k0.mask, k1.mask}; const float* Bs[2] = {k0.biasT, k1.biasT};
+    float* Os[2] = {k0.O, k1.O}; float* Ss[2] = {k0.stats, k1.stats};
+    const DropCfg Ds[2] = {k0.drop, k1.drop};
+    ProfScope ps16(MMNAS_K_MHA_FWD, 8.0 * bhqk * k0.dh,
+                   4.0 * (2.0 * (double)k0.B * k0.H * k0.dh * (2.0 * k0.Sq + 2.0 * k0.Sk) + (k0.biasT ? bhqk : 0.0) + (k1.biasT ? bhqk : 0.0)), st);
+    if (mha_fwd_b16_pair(k0.B, k0.H, k0.Sq, k0.Sk, k0.ldq, Qs, Ks, Vs, Ms, Bs, Os, Ss, Ds, k0.scale, k0.qoff, k0.koff, st))
+      return check_launch("mha_core_fwd_pair");
+  }
   ProfScope ps(MMNAS_K_MHA_FWD, 8.0 * bhqk * k0.dh,
                4.0 * (2.0 * (double)k0.B * k0.H * k0.dh * (2.0 * k0.Sq + 2.0 * k0.Sk) + (k0.biasT ? bhqk : 0.0) + (k1.biasT ? bhqk : 0.0)), st);
   const int nqb = cdiv(k0.Sq, 128);

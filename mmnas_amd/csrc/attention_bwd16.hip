@@ -382,11 +382,14 @@ struct MhaF16K {
   const int* qoff; const int* koff;
 };
 
-__global__ void __launch_bounds__(256, 1) mha_fwd_b16_kernel(const MhaF16K p) {
-  __shared__ __attribute__((aligned(16))) char Ki[128 * B16_RSB];
-  __shared__ __attribute__((aligned(16))) char Vi[128 * B16_RSB];
+// ONEBUF: ONE image buffer -- K first, V stored over it behind the score products (its rows wait in registers) -- 51 KB of LDS
+// and <= 256 registers: TWO workgroups per CU.  For launches of more than one round of workgroups (H = 8 at B = 64) and for the
+// architecture step's two-cores-in-one-launch form, where the second workgroup of a CU hides the first one's latencies; the
+// two-buffer form (one barrier less, the relation bias fetched up front) stays for launches that are one round anyway.
+template <bool ONEBUF>
+__device__ __forceinline__ void mha_fwd_b16_body(const MhaF16K& p, const int h, char* Ki, char* Vi) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.y, h = blockIdx.x;
+  const int b = blockIdx.y;
   const int SqS = p.Sq, SkS = p.Sk;
   int Sq = p.Sq, Sk = p.Sk;
   size_t qrow0 = (size_t)b * p.Sq, krow0 = (size_t)b * p.Sk;
@@ -419,14 +422,14 @@ __global__ void __launch_bounds__(256, 1) mha_fwd_b16_kernel(const MhaF16K p) {
   // kernel has the whole register file: one wave per SIMD)
   const bool has_bias = p.biasT != nullptr;
   const int qic = qok ? qi : Sq - 1;
-  float biasv[4][16];
-  if (has_bias) {
+  float biasv[ONEBUF ? 1 : 4][16];
+  if (!ONEBUF && has_bias) {
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = min(32 * kc + acc_row(r, hh), Sk - 1);
-        biasv[kc][r] = p.biasT[(bh * SkS + key) * SqS + qic];
+        biasv[ONEBUF ? 0 : kc][r] = p.biasT[(bh * SkS + key) * SqS + qic];
       }
   }
   // key mask / key range as bit masks (one ballot per 64 keys), pre-shifted per lane half: element (kc, r) tests bit
@@ -450,12 +453,14 @@ __global__ void __launch_bounds__(256, 1) mha_fwd_b16_kernel(const MhaF16K p) {
     *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
     *reinterpret_cast<uint2*>(d + 128) = make_uint2(a1, b1);
     *reinterpret_cast<uint2*>(d + 256) = make_uint2(a2, b2);
-    split_pair<3>(vv[i].x, vv[i].y, a0, a1, a2);
-    split_pair<3>(vv[i].z, vv[i].w, b0, b1, b2);
-    d = Vi + row * B16_RSB + c4 * 8;
-    *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
-    *reinterpret_cast<uint2*>(d + 128) = make_uint2(a1, b1);
-    *reinterpret_cast<uint2*>(d + 256) = make_uint2(a2, b2);
+    if (!ONEBUF) {
+      split_pair<3>(vv[i].x, vv[i].y, a0, a1, a2);
+      split_pair<3>(vv[i].z, vv[i].w, b0, b1, b2);
+      d = Vi + row * B16_RSB + c4 * 8;
+      *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
+      *reinterpret_cast<uint2*>(d + 128) = make_uint2(a1, b1);
+      *reinterpret_cast<uint2*>(d + 256) = make_uint2(a2, b2);
+    }
   }
   bf16x8 qB[4][3];
 #pragma unroll
@@ -482,16 +487,37 @@ __global__ void __launch_bounds__(256, 1) mha_fwd_b16_kernel(const MhaF16K p) {
       acc[kc] = mfma6(kf, qB[ks], acc[kc]);
     }
   }
+  if (ONEBUF) {   // every wave has its scores: the V image takes the K image's place
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = tid + 256 * i, row = f >> 4, c4 = f & 15;
+      unsigned a0, a1, a2, b0, b1, b2;
+      split_pair<3>(vv[i].x, vv[i].y, a0, a1, a2);
+      split_pair<3>(vv[i].z, vv[i].w, b0, b1, b2);
+      char* d = Vi + row * B16_RSB + c4 * 8;
+      *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
+      *reinterpret_cast<uint2*>(d + 128) = make_uint2(a1, b1);
+      *reinterpret_cast<uint2*>(d + 256) = make_uint2(a2, b2);
+    }
+  }
   // ---- softmax over the keys of this lane's query (registers + the other half-wave) ----
   float m = -INFINITY;
 #pragma unroll
   for (int kc = 0; kc < 4; ++kc) {
+    if (ONEBUF && has_bias) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = min(32 * kc + acc_row(r, hh), Sk - 1);
+        biasv[0][r] = p.biasT[(bh * SkS + key) * SqS + qic];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       constexpr unsigned long long one = 1ull;
       const unsigned long long bit = one << (32 * (kc & 1) + (r & 3) + 8 * (r >> 2));
       float v = acc[kc][r] * p.scale;
-      if (has_bias) v += biasv[kc][r];
+      if (has_bias) v += biasv[ONEBUF ? 0 : kc][r];
       v = (mbits[kc >> 1] & bit) ? -1e9f : v;
       v = (vbits[kc >> 1] & bit) ? v : -INFINITY;
       acc[kc][r] = v;
@@ -515,6 +541,7 @@ __global__ void __launch_bounds__(256, 1) mha_fwd_b16_kernel(const MhaF16K p) {
     p.stats[(bh * SqS + qi) * 2 + 1] = inv;
   }
   const uint32_t dpre = drop_pre(p.drop, (uint32_t)((bh * SqS + qi) * SkS + 4 * hh));
+  if (ONEBUF) __syncthreads();   // the V image is complete
   // ---- O = A V: the probability tile (split in registers) as A operand, V by columns ----
   f32x16 o[2];
 #pragma unroll
@@ -561,19 +588,54 @@ __global__ void __launch_bounds__(256, 1) mha_fwd_b16_kernel(const MhaF16K p) {
   }
 }
 
-bool mha_fwd_b16_launch(int B, int H, int Sq, int Sk, int ldq, int ldk, int ldv, int ldo, const float* Q, const float* K, const float* V,
-                        const uint8_t* mask, const float* biasT, float* O, float* stats, DropCfg drop, float scale, const int* qoff,
-                        const int* koff, hipStream_t st) {
-  static const int on = [] { const char* e = getenv("MMNAS_MHA_FWD_B16"); return (e && e[0] == '0') ? 0 : 1; }();
-  if (!on || Sq > 128 || Sk > 128 || Sk <= 64) return false;
-  if ((long)B * H > 320) return false;    // (one workgroup per CU: two rounds of workgroups lose to the fp32 kernel's two per CU -- 33.2 vs 31.8 us at 512)
+__global__ void __launch_bounds__(256, 1) mha_fwd_b16_kernel(const MhaF16K p) {
+  __shared__ __attribute__((aligned(16))) char Ki[128 * B16_RSB];
+  __shared__ __attribute__((aligned(16))) char Vi[128 * B16_RSB];
+  mha_fwd_b16_body<false>(p, blockIdx.x, Ki, Vi);
+}
+// one image buffer, two workgroups per CU; blockIdx.x = head of problem 0, then head of problem 1 (nh0 = p0.H; p1 unused when
+// the grid has only p0.H columns)
+__global__ void __launch_bounds__(256, 2) mha_fwd_b16_two_kernel(const MhaF16K p0, const MhaF16K p1, const int nh0) {
+  __shared__ __attribute__((aligned(16))) char KVi[128 * B16_RSB];
+  if ((int)blockIdx.x < nh0) mha_fwd_b16_body<true>(p0, blockIdx.x, KVi, KVi);
+  else mha_fwd_b16_body<true>(p1, (int)blockIdx.x - nh0, KVi, KVi);
+}
+
+static bool fwd16_fill(MhaF16K& k, int B, int H, int Sq, int Sk, int ldq, int ldk, int ldv, int ldo, const float* Q, const float* K, const float* V,
+                       const uint8_t* mask, const float* biasT, float* O, float* stats, DropCfg drop, float scale, const int* qoff, const int* koff) {
+  if (Sq > 128 || Sk > 128 || Sk <= 64) return false;
   if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) != 0 || (ldq | ldk | ldv | ldo) % 4 != 0) return false;
-  MhaF16K k;
   memset(&k, 0, sizeof(k));
   k.B = B; k.H = H; k.Sq = Sq; k.Sk = Sk; k.ldq = ldq; k.ldk = ldk; k.ldv = ldv; k.ldo = ldo;
   k.Q = Q; k.K = K; k.V = V; k.mask = mask; k.biasT = biasT; k.O = O; k.stats = stats; k.drop = drop; k.scale = scale;
   k.qoff = qoff; k.koff = koff;
-  MMNAS_LAUNCH(mha_fwd_b16_kernel, dim3(H, B), dim3(256), 0, st, k);
+  return true;
+}
+static bool fwd16_on() {
+  static const int on = [] { const char* e = getenv("MMNAS_MHA_FWD_B16"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on != 0;
+}
+
+bool mha_fwd_b16_launch(int B, int H, int Sq, int Sk, int ldq, int ldk, int ldv, int ldo, const float* Q, const float* K, const float* V,
+                        const uint8_t* mask, const float* biasT, float* O, float* stats, DropCfg drop, float scale, const int* qoff,
+                        const int* koff, hipStream_t st) {
+  MhaF16K k;
+  if (!fwd16_on() || !fwd16_fill(k, B, H, Sq, Sk, ldq, ldk, ldv, ldo, Q, K, V, mask, biasT, O, stats, drop, scale, qoff, koff)) return false;
+  static const int two_from = [] { const char* e = getenv("MMNAS_MHA_FWD_B16_TWO"); return e && e[0] ? atoi(e) : 320; }();
+  if ((long)B * H > two_from) MMNAS_LAUNCH(mha_fwd_b16_two_kernel, dim3(H, B), dim3(256), 0, st, k, k, H);   // more than one round: two per CU
+  else MMNAS_LAUNCH(mha_fwd_b16_kernel, dim3(H, B), dim3(256), 0, st, k);
+  return true;
+}
+
+// attention.hip: two cores of one geometry in one launch (the mixed chain); false = not this kernel's shapes
+bool mha_fwd_b16_pair(int B, int H, int Sq, int Sk, int ld, const float* const* Q, const float* const* K, const float* const* V,
+                      const uint8_t* const* mask, const float* const* biasT, float* const* O, float* const* stats, const DropCfg* drop,
+                      float scale, const int* qoff, const int* koff, hipStream_t st) {
+  MhaF16K k0, k1;
+  if (!fwd16_on()) return false;
+  if (!fwd16_fill(k0, B, H, Sq, Sk, ld, ld, ld, ld, Q[0], K[0], V[0], mask[0], biasT[0], O[0], stats[0], drop[0], scale, qoff, koff)) return false;
+  if (!fwd16_fill(k1, B, H, Sq, Sk, ld, ld, ld, ld, Q[1], K[1], V[1], mask[1], biasT[1], O[1], stats[1], drop[1], scale, qoff, koff)) return false;
+  MMNAS_LAUNCH(mha_fwd_b16_two_kernel, dim3(2 * H, B), dim3(256), 0, st, k0, k1, H);
   return true;
 }
 
