@@ -441,6 +441,8 @@ def main():
                          'line says which in dtype and config')
     ap.add_argument('--no-prof', action='store_true', help='skip the roofline pass (per-launch HIP events)')
     ap.add_argument('--full-out', default=None, help='where the full record goes (default gpurun_out/bench_full.json)')
+    ap.add_argument('--no-fixed-cost', action='store_true', help='skip the per-launch fixed-cost microbenchmark behind roofline.fixed_cost_share '
+                    '(~1900 extra GEMM launches: keep them out of a kernel trace of the steps)')
     ap.add_argument('--repeats', type=int, default=5, help='timed blocks of --steps steps each; value = the median block')
     args = ap.parse_args()
 
@@ -979,7 +981,7 @@ def main():
                                # THAT pass is kept under its own name
                                'share_of_step_time': (gm['ms'] / psteps) / (1000.0 * elapsed / nsteps),
                                'share_of_instrumented_pass': gm['ms'] * 1e-3 / prof_elapsed}
-            if wl in ('search_vqa', 'arch_vqa', 'bilevel_vqa', 'train_vqa') and world == 1:
+            if wl in ('search_vqa', 'arch_vqa', 'bilevel_vqa', 'train_vqa') and world == 1 and not args.no_fixed_cost:
                 # What limits the class: at d = 256 a launch is ~4.5 us of fixed cost around 8 K-tiles, and halving the MFMA
                 # work moves the step by 2 % (profiles/r05_bench_search_vqa_gemm_split3.json) -- the class is priced against
                 # the MFMA peak (`bound`, the contract's word for which roofline `peak` is) but LIMITED by launch latency /

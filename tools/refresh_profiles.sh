@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 W=/tmp/mmnas_prof
 rm -rf $W; mkdir -p $W profiles
 for wl in search_vqa arch_vqa train_vqa search_vqa_unpad train_vqa_unpad; do
-  cmd="bench.py --workload $wl --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline"
+  cmd="bench.py --workload $wl --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-fixed-cost"
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace_$wl -o t -- python3 $ROOT/$cmd > $W/trace_$wl.log 2>&1)
   SUMMARIZE_PASSES=3,10,3,10 python3 tools/summarize_prof.py $W/trace_$wl profiles/${R}_$wl auto \
     "rocprofv3 --kernel-trace --stats -- python3 $cmd  (3 warm-up + 10 timed + 3 empty-queue + 10 roofline-pass steps)"
@@ -20,7 +20,7 @@ for wl in search_vqa arch_vqa train_vqa search_vqa_unpad train_vqa_unpad; do
   python3 tools/step_timeline.py $W/trace_$wl $marker > profiles/${R}_timeline_$wl.txt
   [ -n "${SKIP_PMC:-}" ] && continue
   case $wl in *_unpad) continue;; esac   # (the ragged records: kernel statistics and timeline only)
-  small="bench.py --workload $wl --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-prof"
+  small="bench.py --workload $wl --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-prof --no-fixed-cost"
   for c in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d $W/pmc_${wl}_$c -o t -- python3 $ROOT/$small > $W/pmc_${wl}_$c.log 2>&1)
   done
@@ -42,7 +42,7 @@ done
 (cd /tmp && rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $W/trace_stream -o t -- python3 $ROOT/bench.py --workload search_vqa_stream --steps 8 --warmup 3 --repeats 1 --no-cpu-baseline --no-prof > $W/trace_stream.log 2>&1)
 python3 tools/copy_overlap.py $W/trace_stream > profiles/${R}_timeline_search_vqa_stream.txt 2>&1
 if [ -z "${SKIP_PMC:-}" ]; then
-  small="bench.py --workload bilevel_vqa --steps 6 --warmup 6 --repeats 1 --no-cpu-baseline --no-prof"   # (one round = 5 weight + 1 arch steps)
+  small="bench.py --workload bilevel_vqa --steps 6 --warmup 6 --repeats 1 --no-cpu-baseline --no-prof --no-fixed-cost"   # (one round = 5 weight + 1 arch steps)
   for c in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d $W/pmc_bilevel_vqa_$c -o t -- python3 $ROOT/$small > $W/pmc_bilevel_vqa_$c.log 2>&1)
   done
