@@ -135,6 +135,15 @@ def run():
     out['emb_ws'] = lib.mmnas_embedding_bwd_det_ws_floats(896, 300)
     assert out['emb_ws'] == 896 * 300 and out['mix_ws'] > 0 and out['ln_ws'] > 0
     assert lib.mmnas_abi_version() >= 1
+    # round 6: the row-panel product's switch and its argument checks (host-only: nothing is launched)
+    prev = lib.mmnas_set_gemm_ln(1)
+    assert prev in (0, 1) and lib.mmnas_set_gemm_ln(prev) == 1
+    gd = L.GemmDesc()
+    gd.layout, gd.ngroups, gd.nseg, gd.N, gd.K, gd.lda, gd.ldb, gd.ldc = L.GEMM_NT, 1, 1, 256, 256, 256, 256, 256
+    assert lib.mmnas_gemm_ln(C.byref(gd), None, None, None, 1e-6, None) != 0 and 'null pointer' in err()
+    gd.ngroups = 2
+    one = C.c_void_p(16)
+    assert lib.mmnas_gemm_ln(C.byref(gd), one, one, one, 1e-6, None) != 0 and 'one group' in err()
     return out
 
 
