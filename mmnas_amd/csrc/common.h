@@ -107,9 +107,16 @@ bool glimpse1_supported(int MID);
 int glimpse1_fwd(const float* h0, const float* w0, const float* b0, float* l0, long rows0, const float* h1, const float* w1,
                  const float* b1, float* l1, long rows1, int MID, hipStream_t st);
 // mixed.hip: mmnas_node_mix_bwd with the gate-gradient reduction left pending (partials in ws), and the reduction of many nodes
+// lnb (round 6, architecture step): the sampled candidate's LayerNorm backward inside the same launch -- the kernel writes dz /
+// dt / the parameter partials [nwg][3][d] (exactly ln_bwd_kernel's, <= 512 workgroups) instead of d_active
+struct NodeLnBwd {
+  float* dz; float* dt;    // gradient wrt the candidate's pre-LayerNorm sum; the same behind its output dropout (NULL: no dropout)
+  float* part;             // partial rows (mmnas_layernorm_bwd_ws_floats(M, d) floats)
+  DropCfg drop;            // the candidate's output dropout (site 1)
+};
 int node_mix_bwd_impl(const float* const* z, const float* const* ln_a, const float* const* ln_b, int n, const float* gate,
                       const float* dout, float* d_active, int active, float* dgate, float* ws, int M, int d, float eps,
-                      hipStream_t stream, bool reduce, int* nwg_out);
+                      hipStream_t stream, bool reduce, int* nwg_out, const NodeLnBwd* lnb = nullptr);
 int mixed_reduce_many(const float* const* parts, float* const* dgates, const int* nwg, const int* n, int count, hipStream_t st);
 int mha_core_fwd_pair(const mmnas_mha_desc* d0, const mmnas_mha_desc* d1, hipStream_t st);   // attention.hip: two cores, one launch
 int transpose2d(const float* in, float* out, int R, int C, hipStream_t st);   // head.hip: out[c][r] = in[r][c]

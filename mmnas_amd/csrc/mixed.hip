@@ -211,17 +211,34 @@ __global__ void __launch_bounds__(256) node_mix_fwd_kernel(NodeMixArgs p, const 
   }
 }
 
-// part[blockIdx.x][j] = sum over this workgroup's rows of <dout, LN_j(z_j)>; d_active = gate[active] * dout
-template <int NV>
+// part[blockIdx.x][j] = sum over this workgroup's rows of <dout, LN_j(z_j)>; d_active = gate[active] * dout.
+// LNB (round 6): the sampled candidate's LayerNorm BACKWARD happens here as well -- its row z_active is already in registers
+// for the gate's inner product, and d_active = gate[active] * dout would only be written to be read back by the candidate's
+// own ln_bwd launch (8 us + a launch boundary per node of the architecture step).  With LNB the kernel writes dz (gradient
+// wrt z_active), dt (the same behind the candidate's output dropout, replayed; NULL: none) and leaves the LayerNorm
+// parameter partials [workgroup][3][d] (dln_a, dln_b, column sums of dt) exactly as ln_bwd_kernel (rowops.hip) does -- the
+// same arithmetic operation for operation, the same row -> workgroup map (<= 512 workgroups) -- and d_active is not written.
+template <int NV, bool LNB>
 __global__ void __launch_bounds__(256) node_mix_bwd_kernel(NodeMixArgs p, const float* __restrict__ gate, const float* __restrict__ dout,
                                                            float* __restrict__ d_active, int active, float* __restrict__ part,
-                                                           int M, int d, float eps) {
+                                                           int M, int d, float eps, float* __restrict__ ln_dz, float* __restrict__ ln_dt,
+                                                           float* __restrict__ ln_part, DropCfg ln_drop) {
   __shared__ float red[4][MAXC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float s[MAXC];
 #pragma unroll
   for (int j = 0; j < MAXC; ++j) s[j] = 0.f;
-  const float ga = d_active ? gate[active] : 0.f;
+  const float ga = (d_active || LNB) ? gate[active] : 0.f;
+  float4 acc_a[NV], acc_b[NV], acc_c[NV], lnav[NV], lnbv[NV];
+  if (LNB) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      acc_a[i] = make_float4(0.f, 0.f, 0.f, 0.f); acc_b[i] = acc_a[i]; acc_c[i] = acc_a[i];
+      lnav[i] = (c < d) ? *reinterpret_cast<const float4*>(p.a[active] + c) : acc_a[i];
+      lnbv[i] = (c < d) ? *reinterpret_cast<const float4*>(p.b[active] + c) : acc_a[i];
+    }
+  }
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     float4 g4[NV];
     const float* dr = dout + (size_t)row * d;
@@ -241,7 +258,7 @@ __global__ void __launch_bounds__(256) node_mix_bwd_kernel(NodeMixArgs p, const 
           v[j][i] = (c < d) ? *reinterpret_cast<const float4*>(zr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
-    if (d_active) {
+    if (d_active && !LNB) {
       float* ar = d_active + (size_t)row * d;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -252,6 +269,63 @@ __global__ void __launch_bounds__(256) node_mix_bwd_kernel(NodeMixArgs p, const 
 #pragma unroll
     for (int j = 0; j < MAXC; ++j)
       if (j < p.n && p.z[j]) {
+        if (LNB && j == active) {
+          // LayerNorm forward (for the gate's inner product) AND backward of the sampled candidate: ln_fwd / ln_bwd_kernel's
+          // arithmetic on the row in registers; g = ga * dout is the gradient of the candidate's output
+          float4* vv = v[j];
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < NV; ++i) t += (vv[i].x + vv[i].y) + (vv[i].z + vv[i].w);
+          const float mean = wave_sum(t) / (float)d;
+          float ss = 0.f, sg = 0.f, sgc = 0.f;
+          float4 gy[NV];
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            gy[i] = make_float4(ga * g4[i].x, ga * g4[i].y, ga * g4[i].z, ga * g4[i].w);
+            if (c < d) {
+              vv[i].x -= mean; vv[i].y -= mean; vv[i].z -= mean; vv[i].w -= mean;
+              ss += (vv[i].x * vv[i].x + vv[i].y * vv[i].y) + (vv[i].z * vv[i].z + vv[i].w * vv[i].w);
+              const float gx = gy[i].x * lnav[i].x, gyy = gy[i].y * lnav[i].y, gz = gy[i].z * lnav[i].z, gw = gy[i].w * lnav[i].w;
+              sg += (gx + gyy) + (gz + gw);
+              sgc += (gx * vv[i].x + gyy * vv[i].y) + (gz * vv[i].z + gw * vv[i].w);
+            }
+          }
+          ss = wave_sum(ss); sg = wave_sum(sg); sgc = wave_sum(sgc);
+          const float sd = sqrtf(ss / (float)(d - 1));
+          const float sden = sd + eps;
+          const float inv = 1.0f / sden;
+          const float mg = sg / (float)d;
+          const float k2 = sgc / ((float)(d - 1) * sd * sden * sden);
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < d) {
+              // the candidate's output row (ln_fwd's expression) for the gate gradient
+              s[j] += (g4[i].x * (lnav[i].x * vv[i].x * inv + lnbv[i].x) + g4[i].y * (lnav[i].y * vv[i].y * inv + lnbv[i].y)) +
+                      (g4[i].z * (lnav[i].z * vv[i].z * inv + lnbv[i].z) + g4[i].w * (lnav[i].w * vv[i].w * inv + lnbv[i].w));
+              float4 o;
+              o.x = (gy[i].x * lnav[i].x - mg) * inv - vv[i].x * k2;
+              o.y = (gy[i].y * lnav[i].y - mg) * inv - vv[i].y * k2;
+              o.z = (gy[i].z * lnav[i].z - mg) * inv - vv[i].z * k2;
+              o.w = (gy[i].w * lnav[i].w - mg) * inv - vv[i].w * k2;
+              *reinterpret_cast<float4*>(ln_dz + (size_t)row * d + c) = o;
+              acc_a[i].x += gy[i].x * vv[i].x * inv; acc_a[i].y += gy[i].y * vv[i].y * inv;
+              acc_a[i].z += gy[i].z * vv[i].z * inv; acc_a[i].w += gy[i].w * vv[i].w * inv;
+              acc_b[i].x += gy[i].x; acc_b[i].y += gy[i].y; acc_b[i].z += gy[i].z; acc_b[i].w += gy[i].w;
+              if (ln_dt) {
+                if (ln_drop.thresh) {
+                  const uint32_t base = (uint32_t)row * (uint32_t)d + (uint32_t)c;
+                  o.x *= drop_mult(ln_drop, base); o.y *= drop_mult(ln_drop, base + 1);
+                  o.z *= drop_mult(ln_drop, base + 2); o.w *= drop_mult(ln_drop, base + 3);
+                }
+                *reinterpret_cast<float4*>(ln_dt + (size_t)row * d + c) = o;
+                acc_c[i].x += o.x; acc_c[i].y += o.y; acc_c[i].z += o.z; acc_c[i].w += o.w;
+              }
+            }
+          }
+          continue;
+        }
         if (p.a[j]) node_ln_row<NV>(v[j], p.a[j], p.b[j], lane, d, eps);
 #pragma unroll
         for (int i = 0; i < NV; ++i)
@@ -266,6 +340,25 @@ __global__ void __launch_bounds__(256) node_mix_bwd_kernel(NodeMixArgs p, const 
   __syncthreads();
   if (threadIdx.x < MAXC)
     part[(size_t)blockIdx.x * MAXC + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (LNB) {   // the LayerNorm parameter partials of this workgroup: ln_bwd_kernel's reduction (16-byte reads, one row store per wave < 3)
+    __shared__ __attribute__((aligned(16))) float lred[3][4][64 * 4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      __syncthreads();
+      *reinterpret_cast<float4*>(&lred[0][wave][lane * 4]) = acc_a[i];
+      *reinterpret_cast<float4*>(&lred[1][wave][lane * 4]) = acc_b[i];
+      *reinterpret_cast<float4*>(&lred[2][wave][lane * 4]) = acc_c[i];
+      __syncthreads();
+      if (wave < 3 && c < d) {
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(&lred[wave][0][lane * 4]);
+        const f32x4 p1 = *reinterpret_cast<const f32x4*>(&lred[wave][1][lane * 4]);
+        const f32x4 p2 = *reinterpret_cast<const f32x4*>(&lred[wave][2][lane * 4]);
+        const f32x4 p3 = *reinterpret_cast<const f32x4*>(&lred[wave][3][lane * 4]);
+        *reinterpret_cast<f32x4*>(ln_part + ((size_t)blockIdx.x * 3 + wave) * d + c) = (p0 + p1) + (p2 + p3);
+      }
+    }
+  }
 }
 
 // one thread per node (row): 'full'-mode architecture gradient + Adam
@@ -388,9 +481,6 @@ extern "C" int mmnas_node_mix_fwd(const float* const* z, const float* const* ln_
 
 namespace mmnas {
 // reduce == false: the partial sums stay in ws[0 .. *nwg_out * MAXC) for mixed_reduce_many()
-int node_mix_bwd_impl(const float* const* z, const float* const* ln_a, const float* const* ln_b, int n, const float* gate,
-                      const float* dout, float* d_active, int active, float* dgate, float* ws, int M, int d, float eps,
-                      hipStream_t stream, bool reduce, int* nwg_out);
 int mixed_reduce_many(const float* const* parts, float* const* dgates, const int* nwg, const int* n, int count, hipStream_t st) {
   for (int i0 = 0; i0 < count; i0 += MMNAS_MIX_REDUCE_MAX) {
     MixReduceJobs jobs;
@@ -411,7 +501,7 @@ extern "C" int mmnas_node_mix_bwd(const float* const* z, const float* const* ln_
 
 int mmnas::node_mix_bwd_impl(const float* const* z, const float* const* ln_a, const float* const* ln_b, int n, const float* gate,
                              const float* dout, float* d_active, int active, float* dgate, float* ws, int M, int d, float eps,
-                             hipStream_t stream, bool reduce, int* nwg_out) {
+                             hipStream_t stream, bool reduce, int* nwg_out, const NodeLnBwd* lnb) {
   NodeMixArgs a;
   int rc = node_args(a, z, ln_a, ln_b, n, d, "mmnas_node_mix_bwd");
   if (rc) return rc;
@@ -420,14 +510,23 @@ int mmnas::node_mix_bwd_impl(const float* const* z, const float* const* ln_a, co
   if (nwg_out) *nwg_out = 0;
   if (M == 0) return MMNAS_OK;
   hipStream_t st = stream;
+  const bool fuse = lnb && lnb->dz;
+  if (fuse) MMNAS_REQUIRE(active >= 0 && active < n && z[active] && ln_a[active] && ln_b[active] && lnb->part && d <= 256, MMNAS_E_ARG,
+                          "mmnas_node_mix_bwd: the fused LayerNorm backward needs a normalised active candidate (d <= 256)");
   int g = cdiv(M, 4);
   if (g > 2048) g = 2048;
+  if (fuse && g > 512) g = 512;      // ln_bwd_kernel's row -> workgroup map: the partial rows fit mmnas_layernorm_bwd_ws_floats
   if (nwg_out) *nwg_out = g;
-  ProfScope ps(MMNAS_K_ROWOPS, (2.0 * n + 8.0 * n) * M * d, 4.0 * (n + 2) * M * d, st, "node_mix_bwd");
+  ProfScope ps(MMNAS_K_ROWOPS, (2.0 * n + 8.0 * n) * M * d + (fuse ? 16.0 * M * d : 0.0), 4.0 * (n + 2 + (fuse ? 1 : 0)) * M * d, st, "node_mix_bwd");
   const dim3 grid(g), block(256);
-  if (d <= 256) MMNAS_LAUNCH((node_mix_bwd_kernel<1>), grid, block, 0, st, a, gate, dout, d_active, active, ws, M, d, eps);
-  else if (d <= 512) MMNAS_LAUNCH((node_mix_bwd_kernel<2>), grid, block, 0, st, a, gate, dout, d_active, active, ws, M, d, eps);
-  else MMNAS_LAUNCH((node_mix_bwd_kernel<4>), grid, block, 0, st, a, gate, dout, d_active, active, ws, M, d, eps);
+  float* const ndz = fuse ? lnb->dz : nullptr; float* const ndt = fuse ? lnb->dt : nullptr; float* const npart = fuse ? lnb->part : nullptr;
+  const DropCfg ndrop = fuse ? lnb->drop : make_drop(0.f, 0, 0);
+  // (d <= 256 only: the two-chunk instantiation <2, true> crashes this compiler's machine copy propagation, as a [2][NV] row
+  //  array did in rowops.hip; the supernet -- the one user of mixed chains -- is 256 wide)
+  if (fuse) MMNAS_LAUNCH((node_mix_bwd_kernel<1, true>), grid, block, 0, st, a, gate, dout, d_active, active, ws, M, d, eps, ndz, ndt, npart, ndrop);
+  else if (d <= 256) MMNAS_LAUNCH((node_mix_bwd_kernel<1, false>), grid, block, 0, st, a, gate, dout, d_active, active, ws, M, d, eps, ndz, ndt, npart, ndrop);
+  else if (d <= 512) MMNAS_LAUNCH((node_mix_bwd_kernel<2, false>), grid, block, 0, st, a, gate, dout, d_active, active, ws, M, d, eps, ndz, ndt, npart, ndrop);
+  else MMNAS_LAUNCH((node_mix_bwd_kernel<4, false>), grid, block, 0, st, a, gate, dout, d_active, active, ws, M, d, eps, ndz, ndt, npart, ndrop);
   if (reduce) MMNAS_LAUNCH(mixed_sum_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, g, n, dgate);
   return check_launch("node_mix_bwd");
 }

@@ -270,7 +270,10 @@ struct SideQueue {
 // behind the stream's last relation operator turns every operator's dbiasT into its dWr / dbr and the shared dWy / dby.
 // kv_defer (backbone chains, guided operators): dK / dV stay in the scratch block; the chain turns every guided operator's
 // pair into its key / value source gradient and dWk / dWv by grouped launches behind the last guided operator's backward.
-static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* sq, bool acc_kv = false, bool rel_defer = false, bool kv_defer = false) {
+// ln_pre (mixed chains, round 6): the LayerNorm backward already ran inside the node's mix kernel -- dz / dt of the scratch block
+// are filled and *ln_pre is the pending parameter reduction; op->dy is not read.
+static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* sq, bool acc_kv = false, bool rel_defer = false, bool kv_defer = false,
+                        const AuxReduce* ln_pre = nullptr) {
   const bool side = sq != nullptr && !sq->rel_only;
   const bool side_rel = sq != nullptr;
   int rc = att_check(op, "att_op_bwd");
@@ -289,7 +292,7 @@ static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* s
 
   // Short sequences (the language stream): steps 1, 2, 4 and the data-gradient half of 5 + 6 as ONE launch (small.hip), then
   // the four weight gradients as one grouped launch that carries the LayerNorm parameter reduction.
-  if (!sq && self && !rel && sa_small_bwd_applies(op)) {
+  if (!ln_pre && !sq && self && !rel && sa_small_bwd_applies(op)) {
     float* const dt_out = drop ? L.dt : (norm ? L.dz : nullptr);
     if ((rc = sa_small_bwd(op, L.Q, L.K, L.V, L.stats, L.z, dt_out, L.dQ, L.dK, L.dV, norm ? L.lnws : nullptr, stream))) return rc;
     mmnas_gemm_desc w4;
@@ -311,7 +314,10 @@ static int att_bwd_impl(const mmnas_att_op* op, hipStream_t stream, SideQueue* s
   const float* dt = op->dy;   // gradient wrt core
   AuxReduce lnred;   // the LayerNorm parameter-gradient reduction rides on the first gradient-pair launch below
   lnred.part = nullptr;
-  if (norm) {
+  if (norm && ln_pre) {
+    lnred = *ln_pre;
+    dz = L.dz; dt = drop ? L.dt : L.dz;
+  } else if (norm) {
     if ((rc = layernorm_bwd_deferred(L.z, op->ln_a, op->dy, L.dz, op->dln_a, op->dln_b, drop ? L.dt : nullptr, nullptr,
                                      L.lnws, drop ? op->drop_p : 0.f, op->seed, 1, Mq, d, op->eps, (hipStream_t)stream, &lnred)))
       return rc;
@@ -530,7 +536,7 @@ static int mmnas::mlp_fwd_impl(const mmnas_mlp_op* op, void* stream, bool defer_
 }
 
 namespace mmnas {
-static int mlp_bwd_impl(const mmnas_mlp_op* op, hipStream_t stream, SideQueue* sq) {
+static int mlp_bwd_impl(const mmnas_mlp_op* op, hipStream_t stream, SideQueue* sq, const AuxReduce* ln_pre = nullptr) {
   const bool side = sq != nullptr && !sq->rel_only;
   int rc = mlp_check(op, "mlp_op_bwd");
   if (rc) return rc;
@@ -553,8 +559,9 @@ static int mlp_bwd_impl(const mmnas_mlp_op* op, hipStream_t stream, SideQueue* s
     // the column sums of the dropped gradient are the last layer's bias gradient: fused when a
     // separate dt buffer exists
     float* dcol = (drop && op->db[nl - 1]) ? op->db[nl - 1] : nullptr;
-    if ((rc = layernorm_bwd_deferred(L.z, op->ln_a, op->dy, L.dz, op->dln_a, op->dln_b, drop ? L.dt : nullptr, dcol,
-                                     L.lnws, drop ? op->drop_p : 0.f, op->seed, 1, M, d, op->eps, (hipStream_t)stream, &lnred)))
+    if (ln_pre) lnred = *ln_pre;     // (mixed chains: done inside the node's mix kernel, dcol among its partial rows)
+    else if ((rc = layernorm_bwd_deferred(L.z, op->ln_a, op->dy, L.dz, op->dln_a, op->dln_b, drop ? L.dt : nullptr, dcol,
+                                          L.lnws, drop ? op->drop_p : 0.f, op->seed, 1, M, d, op->eps, (hipStream_t)stream, &lnred)))
       return rc;
     dz = L.dz; dt = drop ? L.dt : L.dz;
     last_bias_done = dcol != nullptr;
@@ -913,6 +920,11 @@ static int chain_rel_bwd(const RelGroups& G, int stream_y, hipStream_t st) {
 // then projects only its queries.  Backward: behind the LAST guided operator's backward (the first in chain order), the
 // key / value source gradients dxkv_n = dK_n Wk_n + dV_n Wv_n into per-operator buffers and dWk_n / dWv_n, 4 operators per
 // gradient-pair launch; one add_many launch sums the buffers (and the head's gradient) into the encoder's output gradient.
+static int g_node_lnb = -1;   // MMNAS_NODE_LNB, default 1: the sampled candidate's LayerNorm backward inside the node's mix kernel
+static bool node_lnb_on() {
+  if (g_node_lnb < 0) { const char* e = getenv("MMNAS_NODE_LNB"); g_node_lnb = (e && e[0] ? atoi(e) : 1) ? 1 : 0; }
+  return g_node_lnb != 0;
+}
 static int g_guided_hoist = -1;   // MMNAS_GUIDED_HOIST, default 1
 static bool guided_hoist_on() {
   if (g_guided_hoist < 0) { const char* e = getenv("MMNAS_GUIDED_HOIST"); g_guided_hoist = (e && e[0] ? atoi(e) : 1) ? 1 : 0; }
@@ -1254,18 +1266,16 @@ static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
     float* dact = (float*)(base + L.ndact[i0]);
     const int M = oy ? (int)chain_rows_y(c) : c->B * c->Sx;
     const size_t grow = (size_t)c->ops[i0].node * c->gate_width;
-    {
-      float* wsk = (float*)(base + L.mixws) + (size_t)k * mmnas_mixed_sum_ws_floats();
-      int nwg = 0;
-      if ((rc = node_mix_bwd_impl(zs, as, bs, width, c->gate + grow, cur_dy, dact, act, c->dgate + grow, wsk, M, c->d, eps, st, false, &nwg)))
-        return rc;
-      if (nwg > 0) { red_part[n_red] = wsk; red_out[n_red] = c->dgate + grow; red_nwg[n_red] = nwg; red_n[n_red] = width; ++n_red; }
-    }
-    // the sampled candidate's backward
+    // the sampled candidate: its descriptor first -- its LayerNorm backward rides in the node's mix kernel (round 6) unless the
+    // candidate takes the one-launch short-sequence backward, which does its own
     const mmnas_chain_op& o = c->ops[act_op];
     mmnas_att_op a; mmnas_mlp_op m;
     chain_op_setup(c, act_op, a, m);
     float* dx = i0 == L.first_x ? c->dx_in : (i0 == L.first_y ? c->dy_in : (float*)(base + L.dx[act_op]));
+    NodeLnBwd lnb;
+    lnb.dz = nullptr;
+    AuxReduce lnpre;
+    lnpre.part = nullptr;
     if (o.kind == MMNAS_CHAIN_ATT) {
       const bool self = a.flags & MMNAS_F_SELF;
       a.xq = nin;
@@ -1274,16 +1284,46 @@ static int chain_bwd_mixed(const mmnas_chain* c, hipStream_t st, const ChainLayo
       a.dy = dact; a.dxq = dx;
       a.dxkv = self ? nullptr : dpre;
       a.drel = nullptr;
-      if ((rc = att_bwd_impl(&a, st, nullptr, !self, RG.hoisted[act_op], GS.hoisted[act_op]))) return rc;
+      if (node_lnb_on() && (a.flags & MMNAS_F_NORM) && c->d <= 256 && !(self && !(a.flags & MMNAS_F_REL) && sa_small_bwd_applies(&a))) {
+        const AttLayout AL = att_layout(&a);
+        const bool drop = (a.flags & MMNAS_F_TRAIN) && a.drop_p > 0.f;
+        lnb.dz = AL.dz; lnb.dt = drop ? AL.dt : nullptr; lnb.part = AL.lnws;
+        lnb.drop = make_drop(drop ? a.drop_p : 0.f, a.seed, 1);
+        lnpre.part = AL.lnws; lnpre.d = c->d;
+        lnpre.out[0] = a.dln_a; lnpre.out[1] = a.dln_b; lnpre.out[2] = nullptr;
+      }
+    } else {
+      m.x = nin; m.save = base + L.save[act_op]; m.ws = base + L.ws[act_op];
+      m.dy = dact; m.dx = dx;
+      if (node_lnb_on() && (m.flags & MMNAS_F_NORM) && c->d <= 256) {
+        const MlpLayout ML = mlp_layout(&m);
+        const bool drop = (m.flags & MMNAS_F_TRAIN) && m.drop_p > 0.f;
+        lnb.dz = ML.dz; lnb.dt = drop ? ML.dt : nullptr; lnb.part = ML.lnws;
+        lnb.drop = make_drop(drop ? m.drop_p : 0.f, m.seed, 1);
+        lnpre.part = ML.lnws; lnpre.d = c->d;
+        lnpre.out[0] = m.dln_a; lnpre.out[1] = m.dln_b; lnpre.out[2] = (drop && m.db[m.nl - 1]) ? m.db[m.nl - 1] : nullptr;
+      }
+    }
+    {
+      float* wsk = (float*)(base + L.mixws) + (size_t)k * mmnas_mixed_sum_ws_floats();
+      int nwg = 0;
+      if ((rc = node_mix_bwd_impl(zs, as, bs, width, c->gate + grow, cur_dy, dact, act, c->dgate + grow, wsk, M, c->d, eps, st, false, &nwg,
+                                  lnb.dz ? &lnb : nullptr)))
+        return rc;
+      if (nwg > 0) { red_part[n_red] = wsk; red_out[n_red] = c->dgate + grow; red_nwg[n_red] = nwg; red_n[n_red] = width; ++n_red; }
+      lnpre.nrows = nwg;
+    }
+    // the sampled candidate's backward
+    if (o.kind == MMNAS_CHAIN_ATT) {
+      const bool self = a.flags & MMNAS_F_SELF;
+      if ((rc = att_bwd_impl(&a, st, nullptr, !self, RG.hoisted[act_op], GS.hoisted[act_op], lnb.dz ? &lnpre : nullptr))) return rc;
       if (GS.n && act_op == Gm) {
         float* g0 = (float*)(base + L.encdy);
         if ((rc = chain_guided_kv_bwd(c, L, GS, x_final, c->dx_out, GS.n < L.n_guided ? dpre : nullptr, g0, st))) return rc;
         enc_grad = g0;
       }
     } else {
-      m.x = nin; m.save = base + L.save[act_op]; m.ws = base + L.ws[act_op];
-      m.dy = dact; m.dx = dx;
-      if ((rc = mlp_bwd_impl(&m, st, nullptr))) return rc;
+      if ((rc = mlp_bwd_impl(&m, st, nullptr, lnb.dz ? &lnpre : nullptr))) return rc;
     }
     cur_dy = dx;
     hipStream_t mark_stream = st;
