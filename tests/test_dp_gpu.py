@@ -275,8 +275,9 @@ def test_two_ranks_on_one_gpu_ragged_decoder_stream(fn, monkeypatch):
 # World 8 on ONE device is opt-in (MMNAS_TEST_WORLD8=1): with eight HIP processes sharing the box's one GPU a process is
 # aborted by the runtime with HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in about one run of three -- with this round's kernels
 # switched off as well as on (profiles/r06_world8_on_one_gpu.txt: MMNAS_MHA_BWD_B16=0/1, MMNAS_LSTM=0), never with four
-# processes and never with one: eight processes' queues oversubscribe the device and are time-sliced by wave save / restore,
-# which is not how eight ranks on eight GPUs run.  When it does not abort, world 8 passes every assertion below.
+# processes and never with one -- and on another box of the pool not once in 28 runs of eight: a property of the box (eight
+# processes' queues oversubscribe one device and are time-sliced by wave save / restore, which is not how eight ranks on eight
+# GPUs run), so the default suite must not depend on it.  When it does not abort, world 8 passes every assertion below.
 WORLDS = [4, 8] if os.environ.get('MMNAS_TEST_WORLD8') == '1' else [4]
 
 

@@ -874,7 +874,11 @@ def _mha_ref(Q, K, V, mask, biasT, H, dh, dmask=None):
     (1, 2, 130, 130, 64, True, False, 0.0), (2, 2, 50, 200, 64, True, True, 0.2), (2, 4, 70, 33, 32, True, False, 0.0),
     # few keys, many queries: query-split dK/dV workgroups, all head-dim chunk widths
     (2, 4, 100, 14, 32, True, False, 0.1), (2, 8, 100, 20, 16, True, True, 0.0), (2, 2, 40, 10, 64, False, False, 0.0),
-    (1, 2, 150, 31, 128, True, False, 0.0)])
+    (1, 2, 150, 31, 128, True, False, 0.0),
+    # round 6: the bf16-pipe cores (d_h = 64, 65..128 keys, <= 128 queries): dropout + bias + mask together, fewer queries than
+    # keys, the range's ends (65 / 128 keys; a wave without keys at 96; one query; 128 queries), a fully padded sample
+    (2, 4, 100, 100, 64, True, True, 0.1), (2, 2, 36, 100, 64, True, False, 0.1), (3, 1, 128, 65, 64, True, True, 0.0),
+    (2, 2, 1, 96, 64, False, False, 0.0), (2, 4, 97, 128, 64, True, False, 0.3), (2, 3, 128, 128, 64, False, True, 0.0)])
 def test_mha_core(B, H, Sq, Sk, dh, use_mask, use_bias, p):
     import ctypes as C
     import mmnas_amd._lib as L
