@@ -109,3 +109,23 @@ def test_summarize_prof_counts_its_steps_in_the_trace():
     assert steps == 26 and 'lstm_seq_fwd_kernel' in how
     assert m.steps_from_trace(rows, '23')[0] == 26          # a literal that disagrees with the trace loses
     assert m.steps_from_trace(rows, 'auto/2')[0] == 13
+
+
+def test_compact_line_keeps_what_limits_the_gemm_class():
+    """the line says what LIMITS the d = 256 GEMM class -- `limited_by`, the measured `fixed_cost_share`
+    and per-launch fixed cost -- with `frac_bf16_div6` next to `frac`, and who set the kernel-argument placement; checked on the
+    round's committed full record (the GPU suite asserts the same on a live run)."""
+    import json
+    b = _bench()
+    rec = json.load(open(os.path.join(ROOT, 'profiles', 'r06_bench.json')))
+    line = json.dumps(b.compact_line(rec, 'gpurun_out/bench_full.json'), separators=(',', ':'))
+    assert len(line) < b.LINE_LIMIT
+    rl = json.loads(line)['roofline']
+    keys = list(rl)
+    assert rl['bound'] == 'mfma' and rl['limited_by'] == 'latency / fixed cost'
+    assert 0.05 < rl['fixed_cost_share'] < 0.5 and 2.0 < rl['fixed_cost_us_per_launch'] < 8.0
+    assert keys.index('frac_bf16_div6') == keys.index('frac') + 1 and 0 < rl['frac_bf16_div6'] < rl['frac'] < 1
+    # share = launches per step x fixed cost / the class's time per step, all three in the record
+    gm = rec['kernel_classes']['gemm']
+    assert abs(rl['fixed_cost_share'] - rl['launches_per_step'] * rl['fixed_cost_us_per_launch'] * 1e-3 / gm['ms_per_step']) < 2e-3
+    assert json.loads(line)['config']['hip_force_dev_kernarg_source'] in ('set_by_library', 'inherited')
