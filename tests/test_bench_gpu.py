@@ -88,7 +88,7 @@ def test_bench_default_line_is_the_supernet_weight_step_with_sub_records():
     # kernel-argument placement
     rl = line['roofline']
     assert rl['bound'] == 'mfma' and rl['limited_by'] in ('latency / fixed cost', 'mfma issue (K loop)')
-    assert 0.02 < rl['fixed_cost_share'] < 0.9 and 1.0 < rl['fixed_cost_us_per_launch'] < 15.0 and 0 < rl['frac_bf16_div6'] < rl['frac']
+    assert 0.01 < rl['fixed_cost_share'] < 0.95 and 0.5 < rl['fixed_cost_us_per_launch'] < 20.0 and 0 < rl['frac_bf16_div6'] < rl['frac']
     assert line['config']['hip_force_dev_kernarg_source'] == 'set_by_library'
     assert set(line['sub']) == set(d['sub']) and all(s['value'] > 0 and s['ms_per_step'] > 0 for s in line['sub'].values())
     assert [l for l in p.stdout.splitlines() if l.strip()] == [l for l in p.stdout.splitlines() if l.startswith('{')], \
@@ -114,7 +114,7 @@ def test_bench_default_line_is_the_supernet_weight_step_with_sub_records():
     # the exchange machinery really ran: RCCL, one rank, collectives forced
     for k in ('search_vqa_dp1', 'train_vqa_dp1'):
         assert d['sub'][k]['config'] == {'grad_allreduce': 'rccl', 'rccl_ranks': 1, 'force_collectives': True}
-        assert 0.9 < d['sub'][k]['ms_per_step_vs_plain'] < 1.5
+        assert 0.8 < d['sub'][k]['ms_per_step_vs_plain'] < 1.5    # (1.02-1.07 measured; the plain record is the first 0.15 s of GPU work of a cold process: +-10 %)
     assert d['sub']['search_vqa_stream']['ms_per_step_vs_plain'] < 1.25
     tp = d['roofline']['traffic_pmc']
     assert tp is None or 'source_commit' in tp
