@@ -32,6 +32,16 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int B16_RSB = 400;         // bytes per image row: 3 parts x 128 B + 16 B pad (100 words: ds_read_b128 rows conflict-free)
+// The forward's images (round 6, second layout): 448-byte rows (112 words = 48 mod 64: the four rows of a transposed read
+// start 16 banks apart -- conflict-free where the 400-byte rows overlap by half) with the 16-byte chunk c of a part stored at
+// position c ^ ((row >> 2) & 3): the XOR keeps a row read's 16 lanes (rows of all residues mod 16) on 16 different 4-bank
+// slots -- row & 3 picks the 16-bank window, (row >> 2) & 3 the slot inside it -- and only permutes chunks inside the aligned
+// 64-byte window a transposed read covers (its four rows share (row >> 2) & 3), so both read kinds are conflict-free.  The
+// backward keeps 400-byte rows: two 448-byte images + its 32 KB accumulator + the transposition images are 1 KB over 160 KB.
+constexpr int F16_RSB = 448;
+__device__ __forceinline__ int f16_off(int row, int part, int chunk) {   // byte offset of 16-byte chunk `chunk` (0..7) of a part
+  return row * F16_RSB + part * 128 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
 
 
 // eight fp32 values (k-slots 0..7 of one MFMA) -> their three bf16 parts as MFMA fragments
@@ -63,6 +73,19 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, int row0, int colbase
   const char* a0 = img + (row0 + q) * B16_RSB + part * 128 + (colbase + 16 * g1 + 4 * p) * 2;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * B16_RSB));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// the same for the forward's swizzled 448-byte rows (row0 a multiple of 4: the block's rows share their XOR)
+__device__ __forceinline__ bf16x8 tr_frag_f(const char* img, int row0, int colbase, int part, int lane) {
+  const int q = (lane & 15) >> 2, p = lane & 3, g1 = (lane >> 4) & 1;
+  const int col = colbase + 16 * g1 + 4 * p;           // 4 consecutive 16-bit columns = 8 bytes inside chunk col >> 3
+  const char* a0 = img + f16_off(row0 + q, part, col >> 3) + ((col >> 2) & 1) * 8;
+  const char* a1 = img + f16_off(row0 + 8 + q, part, col >> 3) + ((col >> 2) & 1) * 8;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
@@ -449,14 +472,14 @@ __device__ __forceinline__ void mha_fwd_b16_body(const MhaF16K& p, const int h, 
     unsigned a0, a1, a2, b0, b1, b2;
     split_pair<3>(kv[i].x, kv[i].y, a0, a1, a2);
     split_pair<3>(kv[i].z, kv[i].w, b0, b1, b2);
-    char* d = Ki + row * B16_RSB + c4 * 8;
+    char* d = Ki + f16_off(row, 0, c4 >> 1) + (c4 & 1) * 8;
     *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
     *reinterpret_cast<uint2*>(d + 128) = make_uint2(a1, b1);
     *reinterpret_cast<uint2*>(d + 256) = make_uint2(a2, b2);
     if (!ONEBUF) {
       split_pair<3>(vv[i].x, vv[i].y, a0, a1, a2);
       split_pair<3>(vv[i].z, vv[i].w, b0, b1, b2);
-      d = Vi + row * B16_RSB + c4 * 8;
+      d = Vi + f16_off(row, 0, c4 >> 1) + (c4 & 1) * 8;
       *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
       *reinterpret_cast<uint2*>(d + 128) = make_uint2(a1, b1);
       *reinterpret_cast<uint2*>(d + 256) = make_uint2(a2, b2);
@@ -478,12 +501,11 @@ __device__ __forceinline__ void mha_fwd_b16_body(const MhaF16K& p, const int h, 
   for (int kc = 0; kc < 4; ++kc) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[kc][r] = 0.f;
-    const char* krow = Ki + (32 * kc + l31) * B16_RSB + 16 * hh;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 kf[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) kf[c] = *reinterpret_cast<const bf16x8*>(krow + c * 128 + 32 * ks);
+      for (int c = 0; c < 3; ++c) kf[c] = *reinterpret_cast<const bf16x8*>(Ki + f16_off(32 * kc + l31, c, 2 * ks + hh));
       acc[kc] = mfma6(kf, qB[ks], acc[kc]);
     }
   }
@@ -495,7 +517,7 @@ __device__ __forceinline__ void mha_fwd_b16_body(const MhaF16K& p, const int h, 
       unsigned a0, a1, a2, b0, b1, b2;
       split_pair<3>(vv[i].x, vv[i].y, a0, a1, a2);
       split_pair<3>(vv[i].z, vv[i].w, b0, b1, b2);
-      char* d = Vi + row * B16_RSB + c4 * 8;
+      char* d = Vi + f16_off(row, 0, c4 >> 1) + (c4 & 1) * 8;
       *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
       *reinterpret_cast<uint2*>(d + 128) = make_uint2(a1, b1);
       *reinterpret_cast<uint2*>(d + 256) = make_uint2(a2, b2);
@@ -566,7 +588,7 @@ __device__ __forceinline__ void mha_fwd_b16_body(const MhaF16K& p, const int h, 
       for (int jc = 0; jc < 2; ++jc) {
         bf16x8 vT[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) vT[c] = tr_frag(Vi, 32 * kc + 16 * u + 4 * hh, 32 * jc, c, lane);
+        for (int c = 0; c < 3; ++c) vT[c] = tr_frag_f(Vi, 32 * kc + 16 * u + 4 * hh, 32 * jc, c, lane);
         o[jc] = mfma6(aP[u], vT, o[jc]);
       }
   }
@@ -589,14 +611,14 @@ __device__ __forceinline__ void mha_fwd_b16_body(const MhaF16K& p, const int h, 
 }
 
 __global__ void __launch_bounds__(256, 1) mha_fwd_b16_kernel(const MhaF16K p) {
-  __shared__ __attribute__((aligned(16))) char Ki[128 * B16_RSB];
-  __shared__ __attribute__((aligned(16))) char Vi[128 * B16_RSB];
+  __shared__ __attribute__((aligned(16))) char Ki[128 * F16_RSB];
+  __shared__ __attribute__((aligned(16))) char Vi[128 * F16_RSB];
   mha_fwd_b16_body<false>(p, blockIdx.x, Ki, Vi);
 }
 // one image buffer, two workgroups per CU; blockIdx.x = head of problem 0, then head of problem 1 (nh0 = p0.H; p1 unused when
 // the grid has only p0.H columns)
 __global__ void __launch_bounds__(256, 2) mha_fwd_b16_two_kernel(const MhaF16K p0, const MhaF16K p1, const int nh0) {
-  __shared__ __attribute__((aligned(16))) char KVi[128 * B16_RSB];
+  __shared__ __attribute__((aligned(16))) char KVi[128 * F16_RSB];
   if ((int)blockIdx.x < nh0) mha_fwd_b16_body<true>(p0, blockIdx.x, KVi, KVi);
   else mha_fwd_b16_body<true>(p1, (int)blockIdx.x - nh0, KVi, KVi);
 }
