@@ -32,12 +32,21 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int B16_RSB = 400;         // bytes per image row: 3 parts x 128 B + 16 B pad (100 words: ds_read_b128 rows conflict-free)
+// The backward's images PERMUTE the rows inside every group of 16: logical row 8 a + 4 b + q (the four rows q of one
+// transposed read share a, b) sits at physical row 4 q + 2 a + b.  The four rows of a transposed read are then 4 physical
+// rows = 400 words = 16 banks apart -- conflict-free, where consecutive rows overlap by half (conflict fraction of the
+// kernel 0.147 -> 0.000, profiles/r06_attention_b16_lds.txt) -- and a row read still covers the 16 rows of a group.  No extra
+// LDS (448-byte rows would need the CU's last KB), no arithmetic in the loops (a per-lane constant plus the block's base).
+// (The forward's XOR scheme inside THIS kernel gave run-to-run different results under the software-pipelined schedule --
+//  B16_VPM 8 and 12, not 0 and 4, not with any phase left out -- although its addresses replay correctly on the host and no
+//  LDS word is read before it is written: docs/LAB_NOTES.md, "Round 6 notebook".  Not understood, not shipped.)
+__device__ __forceinline__ int b16_prow(int row) { return (row & ~15) | ((row & 3) << 2) | ((row >> 2) & 3); }
 // The forward's images (round 6, second layout): 448-byte rows (112 words = 48 mod 64: the four rows of a transposed read
 // start 16 banks apart -- conflict-free where the 400-byte rows overlap by half) with the 16-byte chunk c of a part stored at
 // position c ^ ((row >> 2) & 3): the XOR keeps a row read's 16 lanes (rows of all residues mod 16) on 16 different 4-bank
 // slots -- row & 3 picks the 16-bank window, (row >> 2) & 3 the slot inside it -- and only permutes chunks inside the aligned
 // 64-byte window a transposed read covers (its four rows share (row >> 2) & 3), so both read kinds are conflict-free.  The
-// backward keeps 400-byte rows: two 448-byte images + its 32 KB accumulator + the transposition images are 1 KB over 160 KB.
+// backward keeps 400-byte rows and permutes rows instead (b16_prow): two 448-byte images + its accumulators are 1 KB over 160 KB.
 constexpr int F16_RSB = 448;
 __device__ __forceinline__ int f16_off(int row, int part, int chunk) {   // byte offset of 16-byte chunk `chunk` (0..7) of a part
   return row * F16_RSB + part * 128 + ((chunk ^ ((row >> 2) & 3)) << 4);
@@ -68,11 +77,12 @@ __device__ __forceinline__ f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[
 // rows(t) = t for t < 4, 8 + (t - 4) for t >= 4 (the accumulator rows (t & 3) + 8 (t >> 2) of a 32x32 tile), col = this lane's
 // output row.  Two ds_read_b64_tr_b16: per group of 16 lanes a block of 4 rows x 16 columns arrives column-major -- lane
 // 4 q + p of the group supplies the address of row q, columns 4 p .. 4 p + 3; lane i receives column i of the 4 rows.
+// (row0 = 0 or 4 mod 16: logical row0 + 8 + q is two physical rows behind logical row0 + q)
 __device__ __forceinline__ bf16x8 tr_frag(const char* img, int row0, int colbase, int part, int lane) {
   const int q = (lane & 15) >> 2, p = lane & 3, g1 = (lane >> 4) & 1;
-  const char* a0 = img + (row0 + q) * B16_RSB + part * 128 + (colbase + 16 * g1 + 4 * p) * 2;
+  const char* a0 = img + b16_prow(row0 + q) * B16_RSB + part * 128 + (colbase + 16 * g1 + 4 * p) * 2;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * B16_RSB));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 2 * B16_RSB));
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
@@ -177,13 +187,13 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_b16_kernel(const MhaB16K p) {
       unsigned a0, a1, a2, b0, b1, b2;
       split_pair<3>(qv[i].x, qv[i].y, a0, a1, a2);
       split_pair<3>(qv[i].z, qv[i].w, b0, b1, b2);
-      char* d = Qi + row * B16_RSB + c4 * 8;
+      char* d = Qi + b16_prow(row) * B16_RSB + c4 * 8;
       *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
       *reinterpret_cast<uint2*>(d + 128) = make_uint2(a1, b1);
       *reinterpret_cast<uint2*>(d + 256) = make_uint2(a2, b2);
       split_pair<3>(gv[i].x, gv[i].y, a0, a1, a2);
       split_pair<3>(gv[i].z, gv[i].w, b0, b1, b2);
-      d = Gi + row * B16_RSB + c4 * 8;
+      d = Gi + b16_prow(row) * B16_RSB + c4 * 8;
       *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
       *reinterpret_cast<uint2*>(d + 128) = make_uint2(a1, b1);
       *reinterpret_cast<uint2*>(d + 256) = make_uint2(a2, b2);
@@ -251,8 +261,8 @@ __global__ void __launch_bounds__(256, 1) mha_bwd_b16_kernel(const MhaB16K p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; dacc[r] = 0.f; }
 #if !(B16_DBG & 1)
-    const char* qrow = Qi + qi * B16_RSB + 16 * hh;
-    const char* grow = Gi + qi * B16_RSB + 16 * hh;
+    const char* qrow = Qi + b16_prow(qi) * B16_RSB + 16 * hh;
+    const char* grow = Gi + b16_prow(qi) * B16_RSB + 16 * hh;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 qf[3], gf[3];

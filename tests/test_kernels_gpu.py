@@ -924,6 +924,44 @@ def test_mha_core(B, H, Sq, Sk, dh, use_mask, use_bias, p):
         assert rel_err(dbT.cpu().numpy(), bt.grad.numpy()) < 1e-4
 
 
+@pytest.mark.parametrize('Sq,Sk,use_bias,p', [(100, 100, True, 0.1), (128, 128, False, 0.0), (36, 65, True, 0.0)])
+def test_mha_b16_cores_run_to_run_identical(Sq, Sk, use_bias, p):
+    """The bf16-pipe cores have no atomics and no order-dependent sums: six runs of the forward and of the backward on the
+    same inputs are bitwise equal.  (Round 6: an image layout tried in the backward gave run-to-run different dQ / dK / dV
+    under the kernel's software-pipelined schedule while every single-shape accuracy test of another schedule passed --
+    docs/LAB_NOTES.md; this is the guard.)"""
+    import ctypes as C
+    import mmnas_amd._lib as L
+    B, H, dh = 8, 4, 64
+    rs = np.random.RandomState(Sq + 3 * Sk)
+    di = H * dh
+    Qd, Kd, Vd, dOd = g(rnd(rs, B, Sq, di)), g(rnd(rs, B, Sk, di)), g(rnd(rs, B, Sk, di)), g(rnd(rs, B, Sq, di))
+    bd = g(rnd(rs, B, H, Sk, Sq) * 2) if use_bias else None
+    first = None
+    for _ in range(6):
+        O_ = torch.empty(B, Sq, di, device=DEV)
+        stats = torch.empty(B, H, Sq, 2, device=DEV)
+        d = L.MhaDesc()
+        d.B, d.H, d.Sq, d.Sk, d.dh = B, H, Sq, Sk, dh
+        d.ldq = d.ldk = d.ldv = d.ldo = di
+        d.Q, d.K, d.V, d.mask, d.biasT, d.O, d.lse = (L.fptr(Qd), L.fptr(Kd), L.fptr(Vd), L.ptr(None), L.fptr(bd),
+                                                     L.fptr(O_), L.fptr(stats))
+        d.drop_p, d.drop_site, d.drop_seed = p, 0, 4242
+        L.check(L.lib().mmnas_mha_core_fwd(C.byref(d), L.stream()))
+        dQ, dK, dV = torch.empty_like(Qd), torch.empty_like(Kd), torch.empty_like(Vd)
+        dbT = torch.empty(B, H, Sk, Sq, device=DEV) if use_bias else None
+        delta = torch.empty(B, H, Sq, device=DEV)
+        d.dO, d.dQ, d.dK, d.dV, d.dbiasT, d.delta = L.fptr(dOd), L.fptr(dQ), L.fptr(dK), L.fptr(dV), L.fptr(dbT), L.fptr(delta)
+        L.check(L.lib().mmnas_mha_core_bwd(C.byref(d), L.stream()))
+        out = [O_, dQ, dK, dV] + ([dbT] if use_bias else [])
+        assert all(bool(torch.isfinite(t).all()) for t in out)
+        if first is None:
+            first = [t.clone() for t in out]
+        else:
+            for a, b in zip(first, out):
+                assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('B,H,Sqm,Skm,packed_q,packed_k,use_bias,p', [
     (5, 4, 100, 100, True, True, False, 0.0), (5, 4, 100, 100, True, True, True, 0.1), (4, 8, 100, 14, True, False, False, 0.0),
     (3, 2, 36, 50, True, True, True, 0.0), (6, 4, 14, 14, True, True, False, 0.0), (4, 4, 128, 128, True, True, False, 0.2)])
