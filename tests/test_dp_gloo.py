@@ -1,5 +1,6 @@
-"""Data-parallel gradient exchange (mmnas_amd/dp.py) on 2 CPU processes over gloo: the same code
-path that runs over RCCL on the GPUs, minus the HIP pack kernel (CPU tensors use the host copy)."""
+"""Data-parallel gradient exchange (mmnas_amd/dp.py) on 2 and 4 CPU processes over gloo: the same code
+path that runs over RCCL on the GPUs, minus the HIP pack kernel (CPU tensors use the host copy).
+The workers read the world size from MMNAS_GLOO_WORLD (the spawned interpreters import this module anew)."""
 import os
 import socket
 
@@ -11,7 +12,8 @@ import torch.multiprocessing as mp
 
 from tests.golden import cases
 
-WORLD = 2
+WORLD = int(os.environ.get('MMNAS_GLOO_WORLD', '2'))
+WORLDS = [2, 4]
 
 
 def _free_port():
@@ -22,8 +24,16 @@ def _free_port():
     return p
 
 
-def _run(fn, port):
-    mp.spawn(_entry, args=(fn, port), nprocs=WORLD, join=True)
+def _run(fn, port, world=2):
+    old = os.environ.get('MMNAS_GLOO_WORLD')
+    os.environ['MMNAS_GLOO_WORLD'] = str(world)
+    try:
+        mp.spawn(_entry, args=(fn, port), nprocs=world, join=True)
+    finally:
+        if old is None:
+            os.environ.pop('MMNAS_GLOO_WORLD', None)
+        else:
+            os.environ['MMNAS_GLOO_WORLD'] = old
 
 
 def _entry(rank, fn, port):
@@ -97,14 +107,14 @@ def _w_supernet_reducer(rank):
         p.grad.fill_(float(rank + 1) * (1 + k % 5))
     red.finish_weight_step()
     for k, p in enumerate(live):
-        assert torch.allclose(p.grad, torch.full_like(p.grad, 1.5 * (1 + k % 5))), k
+        assert torch.allclose(p.grad, torch.full_like(p.grad, 0.5 * (WORLD + 1) * (1 + k % 5))), k
     assert all(p.grad is None for p in unsampled)
     # arch step: only the alpha_gate gradients travel
     for m in net.redundant_modules:
         m.alpha_gate.grad = torch.full((m.n_choices,), float(rank))
     red.reduce_alpha_gate_grads()
     for m in net.redundant_modules:
-        assert torch.allclose(m.alpha_gate.grad, torch.full((m.n_choices,), 0.5))
+        assert torch.allclose(m.alpha_gate.grad, torch.full((m.n_choices,), 0.5 * (WORLD - 1)))
     # a rank that sampled differently is detected
     if rank == 1:
         m = net.redundant_modules[0]
@@ -228,24 +238,28 @@ def _w_supernet_reducer_overlapped_buckets(rank):
         m.alpha_gate._mmnas_gate_grad = row
     red.reduce_alpha_gate_grads()
     for i, m in enumerate(net.redundant_modules):
-        assert torch.allclose(m.alpha_gate.grad, torch.full((m.n_choices,), 0.5 + i))
+        assert torch.allclose(m.alpha_gate.grad, torch.full((m.n_choices,), 0.5 * (WORLD - 1) + i))
         assert m.alpha_gate.grad.data_ptr() == block[i].data_ptr()
 
 
-def test_grad_reducer_buckets_overlap_and_average():
-    _run('_w_grad_reducer', _free_port())
+@pytest.mark.parametrize('world', WORLDS)
+def test_grad_reducer_buckets_overlap_and_average(world):
+    _run('_w_grad_reducer', _free_port(), world)
 
 
-def test_supernet_reducer_sampled_segments_and_alpha():
-    _run('_w_supernet_reducer', _free_port())
+@pytest.mark.parametrize('world', WORLDS)
+def test_supernet_reducer_sampled_segments_and_alpha(world):
+    _run('_w_supernet_reducer', _free_port(), world)
 
 
-def test_zero_grad_between_begin_step_and_backward():
-    _run('_w_zero_grad_between_begin_and_backward', _free_port())
+@pytest.mark.parametrize('world', WORLDS)
+def test_zero_grad_between_begin_step_and_backward(world):
+    _run('_w_zero_grad_between_begin_and_backward', _free_port(), world)
 
 
-def test_supernet_reducer_overlapped_buckets_real_backward():
-    _run('_w_supernet_reducer_overlapped_buckets', _free_port())
+@pytest.mark.parametrize('world', WORLDS)
+def test_supernet_reducer_overlapped_buckets_real_backward(world):
+    _run('_w_supernet_reducer_overlapped_buckets', _free_port(), world)
 
 
 def test_single_process_is_a_noop():
