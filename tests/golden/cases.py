@@ -219,6 +219,13 @@ FULL_CASES = (
     ('search', 'vqa', None, 256, 2, 14, 100, 'full'),
 )
 FULL_SEED0 = 9500
+# the same at the FULL batch of BASELINE configs[2] (supernet weight step, HSIZE 256) and configs[1] (train_vqa, HSIZE 512): B = 64
+# (make_golden.gen_nets_full64 -> nets_full64.npz; the reference runs these on the CPU in a minute or two each)
+FULL64_CASES = (
+    ('search', 'vqa', None, 256, 64, 14, 100, None),
+    ('full', 'vqa', 'mmnas_vqa', 512, 64, 14, 100, None),
+)
+FULL64_SEED0 = 9700
 
 
 def full_case_tag(spec):

@@ -494,14 +494,16 @@ def gen_nets():
 
 
 
-def gen_nets_full():
+def gen_nets_full(case_list=None, seed0=None, fname='nets_full.npz'):
     """Whole networks at the dimensions the entry scripts run (cases.FULL_CASES), fp32 and float64 reference runs."""
+    case_list = cases.FULL_CASES if case_list is None else case_list
+    seed0 = cases.FULL_SEED0 if seed0 is None else seed0
     out = {}
     full = {'vqa': full_vqa.Net_Full, 'vgd': full_vgd.Net_Full, 'itm': full_itm.Net_Full}
     MixedOp = RMIX.MixedOp
-    for i, spec in enumerate(cases.FULL_CASES):
+    for i, spec in enumerate(case_list):
         kind, task, arch, d, B, Sx, Sy, mode = spec
-        seed = cases.FULL_SEED0 + i
+        seed = seed0 + i
         c = cases.net_case_full(spec, seed)
         tag = cases.full_case_tag(spec)
         init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
@@ -557,8 +559,16 @@ def gen_nets_full():
         print(tag, 'loss', loss.item(), 'loss64', loss64.item(), 'max |pred - pred64|',
               float(np.max(np.abs(np.asarray(out.get(tag + 'pred', out.get(tag + 'scores'))) -
                                   np.asarray(out.get(tag + 'pred64', out.get(tag + 'scores64')))))))
-    np.savez_compressed(os.path.join(HERE, 'nets_full.npz'), **out)
-    print('nets_full.npz', len(out), 'arrays')
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, len(out), 'arrays')
+
+
+def gen_nets_full64():
+    """The headline shapes at the FULL batch of BASELINE configs[2] / configs[1] (B = 64): the supernet weight step at HSIZE 256 and the
+    fixed-architecture VQA net at HSIZE 512, 100 regions, 14 tokens, 3129 answers -- the reference itself run on the CPU in fp32
+    and in float64 (a minute or two and a few GB each: not part of the default list, not regenerated by the CPU suite unless
+    MMNAS_REGEN_FULL64=1)."""
+    gen_nets_full(cases.FULL64_CASES, cases.FULL64_SEED0, 'nets_full64.npz')
 
 
 def _inject(mops, flat_plan, MixedOp, mode):

@@ -38,11 +38,11 @@ def _loss(task, pred, target):
     return (scores * t).sum() + 0.5 * (reg ** 2).sum()
 
 
-def _run(spec, route, monkeypatch):
+def _run(spec, route, monkeypatch, fname='nets_full.npz'):
     from mmnas_amd import dp, ops
     from mmnas.model.mixed import MixedOp
     kind, task, arch, d, B, Sx, Sy, mode = spec
-    npz = load('nets_full.npz')
+    npz = load(fname)
     tag = cases.full_case_tag(spec)
     c = cases.net_case_full(spec, int(npz[tag + 'seed']))
     search = kind == 'search'
@@ -145,3 +145,16 @@ def test_mcan_batch4_is_baseline_config0():
     assert spec[:3] == ('full', 'vqa', 'mcan') and spec[4:7] == (4, 14, 36)
     c = cases.net_case_full(spec, cases.FULL_SEED0)
     assert c['inputs'][0].shape == (4, 36, 2048) and c['inputs'][3].shape == (4, 14) and c['cfg'].HSIZE == 512
+
+
+IDS64 = [cases.full_case_tag(s).rstrip('|') for s in cases.FULL64_CASES]
+
+
+@pytest.mark.parametrize('route', ['per_operator', 'chain', 'ragged'])
+@pytest.mark.parametrize('spec', cases.FULL64_CASES, ids=IDS64)
+def test_network_at_the_full_batch_vs_reference(spec, route, monkeypatch):
+    """BASELINE configs[2] / configs[1] at their OWN batch (B = 64): the supernet weight step at HSIZE 256 and the fixed-architecture
+    VQA net at HSIZE 512 against the reference's run of exactly these shapes on the CPU, fp32 and float64
+    (tests/golden/nets_full64.npz, make_golden.gen_nets_full64; round 6 -- until then every full-size check was a property check
+    and the reference goldens stopped at B = 4)."""
+    _check(spec, route, _run(spec, route, monkeypatch, 'nets_full64.npz'))

@@ -309,6 +309,23 @@ def test_golden_recipe_regenerates_bit_exact(tmp_path):
             assert np.array_equal(new[k], old[k]), (w, k)
 
 
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'mmnas')) or os.environ.get('MMNAS_REGEN_FULL64') != '1',
+                    reason='opt-in (MMNAS_REGEN_FULL64=1, needs the reference tree): the reference at B = 64 on the CPU, two minutes')
+def test_full_batch_golden_regenerates_bit_exact(tmp_path):
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import tests.golden.make_golden as mg\n"
+            "mg.HERE = %r\n"
+            "mg.gen_nets_full64()\n" % (REPO, str(tmp_path)))
+    r = subprocess.run([sys.executable, '-c', code], cwd=str(tmp_path), env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'),
+                       capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    new = np.load(os.path.join(str(tmp_path), 'nets_full64.npz'))
+    old = np.load(os.path.join(GOLDEN, 'nets_full64.npz'))
+    assert sorted(new.files) == sorted(old.files)
+    for k in new.files:
+        assert np.array_equal(new[k], old[k]), k
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # whole networks at the entry scripts' own dimensions (nets_full.npz)
 # ---------------------------------------------------------------------------------------------------------------------
@@ -317,9 +334,19 @@ def test_oracle_nets_at_production_dimensions(spec):
     """The CPU restatement against the reference at HSIZE 512 / 256, 100 regions + 14 tokens (ITM 36 + 50), 3129 answers,
     B = 2-4 (configs[0] literally: arch/mcan.json, B = 4, 36 regions): logits, loss, every parameter's gradient norm, strided
     element samples of every gradient (the relation-path ones against the reference's float64 run)."""
+    _oracle_full_case(spec, 'nets_full.npz')
+
+
+def test_oracle_supernet_weight_step_at_the_full_batch():
+    """BASELINE configs[2] at its own batch: the supernet weight step at B = 64 (HSIZE 256, 100 regions, 14 tokens, 3129 answers)
+    -- the CPU restatement against the reference's own run of exactly that (tests/golden/nets_full64.npz; round 6)."""
+    _oracle_full_case(cases.FULL64_CASES[0], 'nets_full64.npz')
+
+
+def _oracle_full_case(spec, fname):
     from tests import oracle_runner as R
     from tests.util import check_grad_samples
-    npz = load('nets_full.npz')
+    npz = load(fname)
     kind, task, arch, d, B, Sx, Sy, mode = spec
     tag = cases.full_case_tag(spec)
     c = cases.net_case_full(spec, int(npz[tag + 'seed']))
