@@ -219,11 +219,14 @@ FULL_CASES = (
     ('search', 'vqa', None, 256, 2, 14, 100, 'full'),
 )
 FULL_SEED0 = 9500
-# the same at the FULL batch of BASELINE configs[2] (supernet weight step, HSIZE 256) and configs[1] (train_vqa, HSIZE 512): B = 64
+# the same at the FULL batch of BASELINE configs[2] (supernet weight step, HSIZE 256), configs[1] (train_vqa, HSIZE 512), configs[3]
+# (train_vgd) and configs[4] (train_itm, B = 160): B = 64 / 160
 # (make_golden.gen_nets_full64 -> nets_full64.npz; the reference runs these on the CPU in a minute or two each)
 FULL64_CASES = (
     ('search', 'vqa', None, 256, 64, 14, 100, None),
     ('full', 'vqa', 'mmnas_vqa', 512, 64, 14, 100, None),
+    ('full', 'vgd', 'mmnas_vgd', 512, 64, 15, 100, None),      # configs[3]: train_vgd at its batch
+    ('full', 'itm', 'mmnas_itm', 512, 160, 50, 36, None),      # configs[4]: train_itm at its batch (one forward of the net)
 )
 FULL64_SEED0 = 9700
 
