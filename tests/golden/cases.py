@@ -227,6 +227,7 @@ FULL64_CASES = (
     ('full', 'vqa', 'mmnas_vqa', 512, 64, 14, 100, None),
     ('full', 'vgd', 'mmnas_vgd', 512, 64, 15, 100, None),      # configs[3]: train_vgd at its batch
     ('full', 'itm', 'mmnas_itm', 512, 160, 50, 36, None),      # configs[4]: train_itm at its batch (one forward of the net)
+    ('search', 'vqa', None, 256, 64, 14, 100, 'full'),         # configs[2]'s architecture step (MODE 'full': all 96 candidates)
 )
 FULL64_SEED0 = 9700
 

@@ -118,6 +118,17 @@ def check_grad_samples(npz, tag, grads, tol=1e-3, skip=lambda k: False, kappa=No
         bound = tol * max(float(np.max(np.abs(ref))), 1e-3 * top) * np.ones_like(err)
         if k in scale64:
             bound = np.maximum(bound, (KAPPA if kappa is None else kappa) * scale64[k])
+        if k in ref64:
+            # An element where the reference's OWN fp32 run is more than half the bound away from its float64 run has no valid
+            # float64 yardstick: a branch upstream (ReLU, the 1e-6 clamp, a masked maximum) fell on different sides in the two
+            # precisions.  Both runs are the reference; such an element is judged against the fp32 run at the same bound.  (Round
+            # 6, the arch step at B = 64: ONE sample of embedding.weight, 8.5e-3 of 3.8 apart in the reference itself -- and the
+            # GPU result within 1e-5 of the reference's fp32 value.)
+            ref32 = gs[off[i]:off[i + 1]].astype(np.float64)
+            flipped = np.abs(ref32 - ref) > 0.5 * bound
+            if flipped.any():
+                err = np.where(flipped, np.abs(mine.astype(np.float64) - ref32), err)
+                st['fp32_yardstick_elements'] = st.get('fp32_yardstick_elements', 0) + int(flipped.sum())
         bad = err > bound
         assert not bad.any(), (k, float(err[bad].max()), float(np.max(np.abs(ref))), 'fp64 yardstick' if k in ref64 else 'fp32',
                                float(scale64[k][bad].max()) if k in scale64 else None)
