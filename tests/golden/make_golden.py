@@ -494,7 +494,7 @@ def gen_nets():
 
 
 
-def gen_nets_full(case_list=None, seed0=None, fname='nets_full.npz'):
+def gen_nets_full(case_list=None, seed0=None, fname='nets_full.npz', keep_pred64=True):
     """Whole networks at the dimensions the entry scripts run (cases.FULL_CASES), fp32 and float64 reference runs."""
     case_list = cases.FULL_CASES if case_list is None else case_list
     seed0 = cases.FULL_SEED0 if seed0 is None else seed0
@@ -540,6 +540,10 @@ def gen_nets_full(case_list=None, seed0=None, fname='nets_full.npz'):
         else:
             out[tag + 'pred'] = pred.detach().numpy()
             out[tag + 'pred64'] = pred64.detach().numpy()
+            pred64_np = out[tag + 'pred64']
+            if not keep_pred64:      # (1.6 MB per case at B = 64 and read by no test: the float64 logits' distance is stored instead)
+                out[tag + 'pred_vs_pred64'] = np.float64(np.max(np.abs(out[tag + 'pred'].astype(np.float64) - pred64_np)))
+                del out[tag + 'pred64']
         out[tag + 'loss'] = np.float64(loss.item())
         out[tag + 'loss64'] = np.float64(loss64.item())
         if kind == 'search':
@@ -556,9 +560,9 @@ def gen_nets_full(case_list=None, seed0=None, fname='nets_full.npz'):
         out[tag + 'gradnorms64'] = np.array([gn64[k] for k in keys], np.float64)
         grad_samples(out, tag, net)
         grad_samples64(out, tag, net64, [str(k) for k in out[tag + 'gs_keys']], store)
+        p64 = pred64[0] if task == 'vgd' else pred64
         print(tag, 'loss', loss.item(), 'loss64', loss64.item(), 'max |pred - pred64|',
-              float(np.max(np.abs(np.asarray(out.get(tag + 'pred', out.get(tag + 'scores'))) -
-                                  np.asarray(out.get(tag + 'pred64', out.get(tag + 'scores64')))))))
+              float(np.max(np.abs(np.asarray(out.get(tag + 'pred', out.get(tag + 'scores'))) - p64.detach().numpy()))))
     np.savez_compressed(os.path.join(HERE, fname), **out)
     print(fname, len(out), 'arrays')
 
@@ -568,7 +572,7 @@ def gen_nets_full64():
     fixed-architecture VQA net at HSIZE 512, 100 regions, 14 tokens, 3129 answers -- the reference itself run on the CPU in fp32
     and in float64 (a minute or two and a few GB each: not part of the default list, not regenerated by the CPU suite unless
     MMNAS_REGEN_FULL64=1)."""
-    gen_nets_full(cases.FULL64_CASES, cases.FULL64_SEED0, 'nets_full64.npz')
+    gen_nets_full(cases.FULL64_CASES, cases.FULL64_SEED0, 'nets_full64.npz', keep_pred64=False)
 
 
 def _inject(mops, flat_plan, MixedOp, mode):
