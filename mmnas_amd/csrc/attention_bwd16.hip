@@ -32,24 +32,20 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int B16_RSB = 400;         // bytes per image row: 3 parts x 128 B + 16 B pad (100 words: ds_read_b128 rows conflict-free)
-// The backward's images PERMUTE the rows inside every group of 16: logical row 8 a + 4 b + q (the four rows q of one
+// The images of both kernels PERMUTE the rows inside every group of 16: logical row 8 a + 4 b + q (the four rows q of one
 // transposed read share a, b) sits at physical row 4 q + 2 a + b.  The four rows of a transposed read are then 4 physical
-// rows = 400 words = 16 banks apart -- conflict-free, where consecutive rows overlap by half (conflict fraction of the
-// kernel 0.147 -> 0.000, profiles/r06_attention_b16_lds.txt) -- and a row read still covers the 16 rows of a group.  No extra
-// LDS (448-byte rows would need the CU's last KB), no arithmetic in the loops (a per-lane constant plus the block's base).
-// (The forward's XOR scheme inside THIS kernel gave run-to-run different results under the software-pipelined schedule --
-//  B16_VPM 8 and 12, not 0 and 4, not with any phase left out -- although its addresses replay correctly on the host and no
-//  LDS word is read before it is written: docs/LAB_NOTES.md, "Round 6 notebook".  Not understood, not shipped.)
+// rows = 400 words = 16 banks apart -- conflict-free, where consecutive rows overlap by half (conflict fractions as first
+// written: 0.147 backward / 0.24 forward; now 0.000, profiles/r06_attention_b16_lds.txt) -- and a row read still covers the
+// 16 rows of a group.  No extra LDS, no arithmetic in the loops (a per-lane constant plus the block's base).
+// (Tried first: 448-byte rows with the 16-byte chunk c of a part at position c ^ ((row >> 2) & 3) -- conflict-free as well.
+//  In the FORWARD it passed every test; in the BACKWARD the same scheme gave run-to-run different results under some
+//  instruction schedules -- B16_VPM 8 and 12, not 0 and 4; on 400-byte rows only with scheduling barriers around the
+//  transposition image -- although the addresses replay correctly on the host, no LDS word is read before it is written
+//  and every vmcnt / lgkmcnt wait of the listing checks out: docs/LAB_NOTES.md, "Round 6 notebook".  Not understood; the
+//  XOR scheme is shipped in neither kernel.)
 __device__ __forceinline__ int b16_prow(int row) { return (row & ~15) | ((row & 3) << 2) | ((row >> 2) & 3); }
-// The forward's images (round 6, second layout): 448-byte rows (112 words = 48 mod 64: the four rows of a transposed read
-// start 16 banks apart -- conflict-free where the 400-byte rows overlap by half) with the 16-byte chunk c of a part stored at
-// position c ^ ((row >> 2) & 3): the XOR keeps a row read's 16 lanes (rows of all residues mod 16) on 16 different 4-bank
-// slots -- row & 3 picks the 16-bank window, (row >> 2) & 3 the slot inside it -- and only permutes chunks inside the aligned
-// 64-byte window a transposed read covers (its four rows share (row >> 2) & 3), so both read kinds are conflict-free.  The
-// backward keeps 400-byte rows and permutes rows instead (b16_prow): two 448-byte images + its accumulators are 1 KB over 160 KB.
-constexpr int F16_RSB = 448;
-__device__ __forceinline__ int f16_off(int row, int part, int chunk) {   // byte offset of 16-byte chunk `chunk` (0..7) of a part
-  return row * F16_RSB + part * 128 + ((chunk ^ ((row >> 2) & 3)) << 4);
+__device__ __forceinline__ int b16_off(int row, int part, int chunk) {   // byte offset of 16-byte chunk `chunk` (0..7) of a part
+  return b16_prow(row) * B16_RSB + part * 128 + (chunk << 4);
 }
 
 
@@ -83,19 +79,6 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, int row0, int colbase
   const char* a0 = img + b16_prow(row0 + q) * B16_RSB + part * 128 + (colbase + 16 * g1 + 4 * p) * 2;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 2 * B16_RSB));
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
-}
-
-// the same for the forward's swizzled 448-byte rows (row0 a multiple of 4: the block's rows share their XOR)
-__device__ __forceinline__ bf16x8 tr_frag_f(const char* img, int row0, int colbase, int part, int lane) {
-  const int q = (lane & 15) >> 2, p = lane & 3, g1 = (lane >> 4) & 1;
-  const int col = colbase + 16 * g1 + 4 * p;           // 4 consecutive 16-bit columns = 8 bytes inside chunk col >> 3
-  const char* a0 = img + f16_off(row0 + q, part, col >> 3) + ((col >> 2) & 1) * 8;
-  const char* a1 = img + f16_off(row0 + 8 + q, part, col >> 3) + ((col >> 2) & 1) * 8;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
@@ -482,14 +465,14 @@ __device__ __forceinline__ void mha_fwd_b16_body(const MhaF16K& p, const int h, 
     unsigned a0, a1, a2, b0, b1, b2;
     split_pair<3>(kv[i].x, kv[i].y, a0, a1, a2);
     split_pair<3>(kv[i].z, kv[i].w, b0, b1, b2);
-    char* d = Ki + f16_off(row, 0, c4 >> 1) + (c4 & 1) * 8;
+    char* d = Ki + b16_off(row, 0, c4 >> 1) + (c4 & 1) * 8;
     *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
     *reinterpret_cast<uint2*>(d + 128) = make_uint2(a1, b1);
     *reinterpret_cast<uint2*>(d + 256) = make_uint2(a2, b2);
     if (!ONEBUF) {
       split_pair<3>(vv[i].x, vv[i].y, a0, a1, a2);
       split_pair<3>(vv[i].z, vv[i].w, b0, b1, b2);
-      d = Vi + f16_off(row, 0, c4 >> 1) + (c4 & 1) * 8;
+      d = Vi + b16_off(row, 0, c4 >> 1) + (c4 & 1) * 8;
       *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
       *reinterpret_cast<uint2*>(d + 128) = make_uint2(a1, b1);
       *reinterpret_cast<uint2*>(d + 256) = make_uint2(a2, b2);
@@ -515,7 +498,7 @@ __device__ __forceinline__ void mha_fwd_b16_body(const MhaF16K& p, const int h, 
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 kf[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) kf[c] = *reinterpret_cast<const bf16x8*>(Ki + f16_off(32 * kc + l31, c, 2 * ks + hh));
+      for (int c = 0; c < 3; ++c) kf[c] = *reinterpret_cast<const bf16x8*>(Ki + b16_off(32 * kc + l31, c, 2 * ks + hh));
       acc[kc] = mfma6(kf, qB[ks], acc[kc]);
     }
   }
@@ -527,7 +510,7 @@ __device__ __forceinline__ void mha_fwd_b16_body(const MhaF16K& p, const int h, 
       unsigned a0, a1, a2, b0, b1, b2;
       split_pair<3>(vv[i].x, vv[i].y, a0, a1, a2);
       split_pair<3>(vv[i].z, vv[i].w, b0, b1, b2);
-      char* d = Vi + f16_off(row, 0, c4 >> 1) + (c4 & 1) * 8;
+      char* d = Vi + b16_off(row, 0, c4 >> 1) + (c4 & 1) * 8;
       *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
       *reinterpret_cast<uint2*>(d + 128) = make_uint2(a1, b1);
       *reinterpret_cast<uint2*>(d + 256) = make_uint2(a2, b2);
@@ -598,7 +581,7 @@ __device__ __forceinline__ void mha_fwd_b16_body(const MhaF16K& p, const int h, 
       for (int jc = 0; jc < 2; ++jc) {
         bf16x8 vT[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) vT[c] = tr_frag_f(Vi, 32 * kc + 16 * u + 4 * hh, 32 * jc, c, lane);
+        for (int c = 0; c < 3; ++c) vT[c] = tr_frag(Vi, 32 * kc + 16 * u + 4 * hh, 32 * jc, c, lane);
         o[jc] = mfma6(aP[u], vT, o[jc]);
       }
   }
@@ -621,14 +604,14 @@ __device__ __forceinline__ void mha_fwd_b16_body(const MhaF16K& p, const int h, 
 }
 
 __global__ void __launch_bounds__(256, 1) mha_fwd_b16_kernel(const MhaF16K p) {
-  __shared__ __attribute__((aligned(16))) char Ki[128 * F16_RSB];
-  __shared__ __attribute__((aligned(16))) char Vi[128 * F16_RSB];
+  __shared__ __attribute__((aligned(16))) char Ki[128 * B16_RSB];
+  __shared__ __attribute__((aligned(16))) char Vi[128 * B16_RSB];
   mha_fwd_b16_body<false>(p, blockIdx.x, Ki, Vi);
 }
 // one image buffer, two workgroups per CU; blockIdx.x = head of problem 0, then head of problem 1 (nh0 = p0.H; p1 unused when
 // the grid has only p0.H columns)
 __global__ void __launch_bounds__(256, 2) mha_fwd_b16_two_kernel(const MhaF16K p0, const MhaF16K p1, const int nh0) {
-  __shared__ __attribute__((aligned(16))) char KVi[128 * F16_RSB];
+  __shared__ __attribute__((aligned(16))) char KVi[128 * B16_RSB];
   if ((int)blockIdx.x < nh0) mha_fwd_b16_body<true>(p0, blockIdx.x, KVi, KVi);
   else mha_fwd_b16_body<true>(p1, (int)blockIdx.x - nh0, KVi, KVi);
 }
