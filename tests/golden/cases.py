@@ -312,12 +312,19 @@ TRAJ_FULL_KEYS = ('proj.bias', 'proj_norm.a_2', 'linear_y_rel.weight', 'imgfeat_
                   'backnone.cells_dec.0.dag.3.0.candidate_ops.2.mhatt.linear_merge.weight')
 
 
-def traj_setup(seed=9100):
-    """Weights + batch of the weight steps, batch of the arch step, and the four injected samples."""
-    c = net_case('vqa', None, seed, search=True)
-    rs = np.random.RandomState(seed + 50000)
+def traj_setup(seed=9100, full64=False):
+    """Weights + batch of the weight steps, batch of the arch step, and the four injected samples.  full64: the same at
+    BASELINE configs[2]'s own dimensions and batch (HSIZE 256, B = 64, 100 regions, 14 tokens, 3129 answers; traj64.npz)."""
+    if full64:
+        spec = ('search', 'vqa', None, 256, 64, 14, 100, None)
+        c = net_case_full(spec, seed + 700)
+        c2 = net_case_full(spec, seed + 701)
+        rs = np.random.RandomState(seed + 50700)
+    else:
+        c = net_case('vqa', None, seed, search=True)
+        c2 = net_case('vqa', None, seed + 1, search=True)   # only its inputs/target are used (the eval_loader batch)
+        rs = np.random.RandomState(seed + 50000)
     plans = [search_plan(rs, None), search_plan(rs, None), search_plan(rs, 'full'), search_plan(rs, None)]
-    c2 = net_case('vqa', None, seed + 1, search=True)   # only its inputs/target are used (the eval_loader batch)
     return c, c2, plans
 
 

@@ -642,7 +642,7 @@ def gen_train_traj():
     print('train_traj.npz', len(out), 'arrays; losses', losses)
 
 
-def gen_traj():
+def gen_traj(full64=False, fname='traj.npz'):
     """Capture (v): the reference's own statement sequence (search_vqa.py:279-337) on the reference Net_Search with the
     reference WarmupOptimizer (mmnas/utils/optimizer.py) over torch Adam: weight step, weight step (another sample),
     'full' arch step, then the forward loss of a third weight step.  Samples injected, dropout 0, single process."""
@@ -650,7 +650,7 @@ def gen_traj():
     import torch.optim as Optim
     out = {}
     MixedOp = RMIX.MixedOp
-    c, c2, plans = cases.traj_setup()
+    c, c2, plans = cases.traj_setup(full64=full64)
     init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
             'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
     net = hygr_vqa.Net_Search(c['cfg'], init)
@@ -720,8 +720,14 @@ def gen_traj():
     out['traj|lr'] = np.array([net_optim.rate(s) for s in (1, 2, 3)], np.float64)
     for i, pl in enumerate(plans):
         out['traj|plan%d' % i] = np.array([a[0] for a, _ in pl['enc'] + pl['dec']], np.int64)
-    np.savez_compressed(os.path.join(HERE, 'traj.npz'), **out)
-    print('traj.npz', len(out), 'arrays; losses', losses, 'grad norms', gnorms)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, len(out), 'arrays; losses', losses, 'grad norms', gnorms)
+
+
+def gen_traj64():
+    """The same loop at BASELINE configs[2]'s own dimensions and batch (HSIZE 256, B = 64, 100 regions, 14 tokens, 3129 answers):
+    the reference on the CPU, about two minutes (not in the default list; bit-exact regeneration is opt-in like nets_full64)."""
+    gen_traj(full64=True, fname='traj64.npz')
 
 
 def _extract_functions(path, names):

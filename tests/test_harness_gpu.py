@@ -27,11 +27,15 @@ def _plan_list(plan):
     return plan['enc'] + plan['dec']
 
 
-def test_bilevel_trajectory_vs_reference_loop():
+@pytest.mark.parametrize('full64', [False, True], ids=['small', 'B64_production_dimensions'])
+def test_bilevel_trajectory_vs_reference_loop(full64):
+    """full64 (round 6, tests/golden/traj64.npz): the same statements at BASELINE configs[2]'s own dimensions and batch -- HSIZE
+    256, B = 64, 100 regions, 14 tokens, 3129 answers -- against the reference's own loop run on the CPU."""
     from mmnas.model.hygr_vqa import Net_Search
     from mmnas_amd.harness import SearchLoop
     from tests.test_oracle_golden2 import check_trajectory
-    c, c2, plans = cases.traj_setup()
+    fname = 'traj64.npz' if full64 else 'traj.npz'
+    c, c2, plans = cases.traj_setup(full64=full64)
     H = cases.TRAJ_HYPER
     net = _build(Net_Search, c)
     loop = SearchLoop(net, net_lr=H['net_lr'], net_betas=H['net_betas'], net_eps=H['net_eps'], clip=H['clip'],
@@ -61,8 +65,8 @@ def test_bilevel_trajectory_vs_reference_loop():
         snap('a')
         loss = loop.weight_step(inp, tgt, optimize=False, plan=_plan_list(plans[3]))
         res['losses'].append(float(loss.detach()))
-        assert loop.net_optim._step == 2 and abs(loop.net_optim._rate - load('traj.npz')['traj|lr'][1]) < 1e-12
-        check_trajectory(res)
+        assert loop.net_optim._step == 2 and abs(loop.net_optim._rate - load(fname)['traj|lr'][1]) < 1e-12
+        check_trajectory(res, fname=fname)
     finally:
         loop.reducer.fg.disable_sinks()
 

@@ -77,11 +77,11 @@ SHIFT_INVARIANT = ('attflat_x.mlp.linear.bias', 'attflat_y.mlp.linear.bias')
 NEAR_INVARIANT = ('attflat_x.mlp.fc.linear.bias', 'attflat_y.mlp.fc.linear.bias')
 
 
-def check_trajectory(res, tol_loss=2e-4, tol_delta=2e-2):
+def check_trajectory(res, tol_loss=2e-4, tol_delta=2e-2, fname='traj.npz'):
     """Shared with the GPU replay (tests/test_harness_gpu.py::test_bilevel_trajectory_vs_reference_loop).  Adam normalises every coordinate's first step to +-lr,
     so coordinates whose gradient is round-off-sized move by a full step in a direction the summation order decides:
     parameter motion is compared as per-tensor delta norms and, for the listed small tensors, element-wise."""
-    npz = load('traj.npz')
+    npz = load(fname)
     ref = npz['traj|losses']
     for i, (a, b) in enumerate(zip(res['losses'], ref)):
         assert abs(a - b) <= tol_loss * abs(b), ('loss', i, a, b)
@@ -315,15 +315,17 @@ def test_full_batch_golden_regenerates_bit_exact(tmp_path):
     code = ("import sys; sys.path.insert(0, %r)\n"
             "import tests.golden.make_golden as mg\n"
             "mg.HERE = %r\n"
-            "mg.gen_nets_full64()\n" % (REPO, str(tmp_path)))
+            "mg.gen_nets_full64()\n"
+            "mg.gen_traj64()\n" % (REPO, str(tmp_path)))
     r = subprocess.run([sys.executable, '-c', code], cwd=str(tmp_path), env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'),
                        capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stderr[-2000:]
-    new = np.load(os.path.join(str(tmp_path), 'nets_full64.npz'))
-    old = np.load(os.path.join(GOLDEN, 'nets_full64.npz'))
-    assert sorted(new.files) == sorted(old.files)
-    for k in new.files:
-        assert np.array_equal(new[k], old[k]), k
+    for w in ('nets_full64.npz', 'traj64.npz'):
+        new = np.load(os.path.join(str(tmp_path), w))
+        old = np.load(os.path.join(GOLDEN, w))
+        assert sorted(new.files) == sorted(old.files), w
+        for k in new.files:
+            assert np.array_equal(new[k], old[k]), (w, k)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
