@@ -345,8 +345,12 @@ TRAIN_FULL_KEYS = ('proj.bias', 'proj_norm.a_2', 'linear_y_rel.weight', 'imgfeat
                    'backnone.cells_enc.0.dag.0.0.ln.a_2', 'backnone.cells_dec.0.dag.0.0.mhatt.linear_merge.weight')
 
 
-def train_traj_setup(seed=9300):
-    """Weights + two batches (steps alternate between them) for arch/mmnas_vqa.json."""
+def train_traj_setup(seed=9300, full64=False):
+    """Weights + two batches (steps alternate between them) for arch/mmnas_vqa.json.  full64: at BASELINE configs[1]'s own
+    dimensions and batch (HSIZE 512, B = 64, 100 regions, 14 tokens, 3129 answers; train_traj64.npz)."""
+    if full64:
+        spec = ('full', 'vqa', 'mmnas_vqa', 512, 64, 14, 100, None)
+        return net_case_full(spec, seed + 700), net_case_full(spec, seed + 701)
     c = net_case('vqa', 'mmnas_vqa', seed)
     c2 = net_case('vqa', 'mmnas_vqa', seed + 1)    # only its inputs / target are used
     return c, c2

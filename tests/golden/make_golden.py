@@ -587,7 +587,7 @@ def _inject(mops, flat_plan, MixedOp, mode):
                 prm.grad = None
 
 
-def gen_train_traj():
+def gen_train_traj(full64=False, fname='train_traj.npz'):
     """The reference's fixed-architecture training statements (train_vqa.py:291-311) on the reference Net_Full with the
     reference WarmupOptimizer over torch Adam: zero_grad, forward, loss (+ the `0 * sum` line), backward, clip_grad_norm_,
     step -- four steps over two alternating batches (the warm-up rate changes every step: epoch_steps = 1), decay(0.2) as
@@ -595,7 +595,7 @@ def gen_train_traj():
     from mmnas.utils.optimizer import WarmupOptimizer
     import torch.optim as Optim
     out = {}
-    c, c2 = cases.train_traj_setup()
+    c, c2 = cases.train_traj_setup(full64=full64)
     init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
             'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
     net = full_vqa.Net_Full(c['cfg'], init)
@@ -638,8 +638,14 @@ def gen_train_traj():
     out['train|losses'] = np.array(losses)
     out['train|grad_norms'] = np.array(gnorms)
     out['train|rates'] = np.array(rates)
-    np.savez_compressed(os.path.join(HERE, 'train_traj.npz'), **out)
-    print('train_traj.npz', len(out), 'arrays; losses', losses)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, len(out), 'arrays; losses', losses)
+
+
+def gen_train_traj64():
+    """The same five steps at BASELINE configs[1]'s own dimensions and batch (HSIZE 512, B = 64, 100 regions, 14 tokens, 3129
+    answers): the reference on the CPU, about two minutes (not in the default list)."""
+    gen_train_traj(full64=True, fname='train_traj64.npz')
 
 
 def gen_traj(full64=False, fname='traj.npz'):

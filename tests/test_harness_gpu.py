@@ -71,13 +71,15 @@ def test_bilevel_trajectory_vs_reference_loop(full64):
         loop.reducer.fg.disable_sinks()
 
 
-def test_training_loop_trajectory_vs_reference_loop():
+@pytest.mark.parametrize('full64', [False, True], ids=['small', 'B64_production_dimensions'])
+def test_training_loop_trajectory_vs_reference_loop(full64):
     """tests/golden/train_traj.npz: the reference's own train_vqa.py statements (Net_Full + WarmupOptimizer + torch Adam +
-    clip_grad_norm_), five steps with a decay before the last, replayed through harness.TrainLoop = GradReducer + FlatAdam."""
+    clip_grad_norm_), five steps with a decay before the last, replayed through harness.TrainLoop = GradReducer + FlatAdam.
+    full64 (round 6, train_traj64.npz): the same at BASELINE configs[1]'s own dimensions and batch (HSIZE 512, B = 64)."""
     from mmnas.model.full_vqa import Net_Full
     from mmnas_amd.harness import TrainLoop
     from tests.test_oracle_golden2 import check_train_trajectory
-    c, c2 = cases.train_traj_setup()
+    c, c2 = cases.train_traj_setup(full64=full64)
     H = cases.TRAIN_HYPER
     net = _build(Net_Full, c)
     loop = TrainLoop(net, lr=H['lr'], betas=H['betas'], eps=H['eps'], clip=H['clip'], epoch_steps=H['epoch_steps'], warmup=True)
@@ -95,7 +97,7 @@ def test_training_loop_trajectory_vs_reference_loop():
             res['rates'].append(loop.net_optim._rate)
             if i in (0, 3, 4):
                 res['snap']['s%d' % (i + 1)] = {k: named[k].detach().cpu().clone() for k in named}
-        check_train_trajectory(res)
+        check_train_trajectory(res, fname='train_traj64.npz' if full64 else 'train_traj.npz', stray=2e-4 if full64 else 0.0)   # (measured: 16 of 262144 coordinates of the one large tensor at step 1, 3 at steps 4 / 5)
     finally:
         loop.reducer.fg.disable_sinks()
 

@@ -156,11 +156,11 @@ def oracle_train_trajectory():
     return res
 
 
-def check_train_trajectory(res, tol_loss=2e-4, tol_delta=2e-2, tol_near=0.3):
+def check_train_trajectory(res, tol_loss=2e-4, tol_delta=2e-2, tol_near=0.3, fname='train_traj.npz', stray=0.0):
     """Shared with the GPU replay (tests/test_harness_gpu.py); tolerances as for check_trajectory, except that the
     round-off-driven AttFlat hidden biases (NEAR_INVARIANT) have five steps instead of two to drift: 13 % measured for
     the fp64-free oracle against the reference at step 4."""
-    npz = load('train_traj.npz')
+    npz = load(fname)
     for i, (a, b) in enumerate(zip(res['losses'], npz['train|losses'])):
         assert abs(a - b) <= tol_loss * abs(b), ('loss', i, a, b)
     assert rel_err(np.array(res['gnorms']), npz['train|grad_norms']) < 1e-3
@@ -179,7 +179,17 @@ def check_train_trajectory(res, tol_loss=2e-4, tol_delta=2e-2, tol_near=0.3):
         for k in cases.TRAIN_FULL_KEYS:
             want = npz['train|%s|P:%s' % (tag, k)]
             d0 = np.abs(want - res['P0'][k].numpy()).max()
-            assert np.abs(snap[k].numpy() - want).max() <= 5e-2 * d0 + 1e-7, (tag, k)
+            err = np.abs(snap[k].numpy() - want)
+            # `stray` (the B = 64 file only): the fraction of a tensor's coordinates that may miss the 5 % -- Adam normalises every
+            # coordinate's step to ~lr, so a coordinate whose clipped gradient is round-off-sized takes a step whose length and sign
+            # the summation order decides (check_trajectory's element anchors allow the same); none may be further off than a
+            # full step in the other direction
+            bad = err > 5e-2 * d0 + 1e-7
+            TRAIN_STRAYS[(fname, tag, k)] = (int(bad.sum()), int(bad.size), float(err.max() / max(d0, 1e-30)))
+            assert bad.mean() <= stray and err.max() <= 2.1 * d0 + 1e-7, (tag, k, int(bad.sum()), bad.size, float(err.max()), float(d0))
+
+
+TRAIN_STRAYS = {}
 
 
 def test_oracle_training_loop_vs_reference_trajectory():
@@ -316,11 +326,12 @@ def test_full_batch_golden_regenerates_bit_exact(tmp_path):
             "import tests.golden.make_golden as mg\n"
             "mg.HERE = %r\n"
             "mg.gen_nets_full64()\n"
-            "mg.gen_traj64()\n" % (REPO, str(tmp_path)))
+            "mg.gen_traj64()\n"
+            "mg.gen_train_traj64()\n" % (REPO, str(tmp_path)))
     r = subprocess.run([sys.executable, '-c', code], cwd=str(tmp_path), env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'),
                        capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stderr[-2000:]
-    for w in ('nets_full64.npz', 'traj64.npz'):
+    for w in ('nets_full64.npz', 'traj64.npz', 'train_traj64.npz'):
         new = np.load(os.path.join(str(tmp_path), w))
         old = np.load(os.path.join(GOLDEN, w))
         assert sorted(new.files) == sorted(old.files), w
