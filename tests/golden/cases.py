@@ -382,6 +382,17 @@ def loader_glove(V, seed):
     return e
 
 
+def losses_cases(full64=False):
+    """(ITM positive batch, ITM negative batch, VGD batch) of make_golden.gen_losses: small (losses.npz) or at BASELINE configs[4] /
+    configs[3]'s own dimensions and batch (ITM: HSIZE 512, B = 160, 50 tokens, 36 regions; VGD: B = 64, 15 tokens, 100 regions;
+    losses64.npz)."""
+    if full64:
+        itm = ('full', 'itm', 'mmnas_itm', 512, 160, 50, 36, None)
+        vgd = ('full', 'vgd', 'mmnas_vgd', 512, 64, 15, 100, None)
+        return net_case_full(itm, 9901), net_case_full(itm, 9902), net_case_full(vgd, 9903)
+    return net_case('itm', 'mmnas_itm', 9201), net_case('itm', 'mmnas_itm', 9202), net_case('vgd', 'mmnas_vgd', 9203)
+
+
 def vgd_targets(c, seed):
     """The VGD step's supervision tensors (train_vgd.py:309-313): soft scores, score mask, box targets, box mask."""
     rs = np.random.RandomState(seed)

@@ -792,15 +792,14 @@ def gen_loader():
     print('loader.npz', len(out), 'arrays')
 
 
-def gen_losses():
+def gen_losses(full64=False, fname='losses.npz'):
     """Task harness steps: the ITM triplet step with BCE_Loss (train_itm.py:380-391, mmnas/utils/itm_loss.py:4-24) and
     the VGD loss (train_vgd.py:252-256,316-333: KLDiv on masked log-scores + 0.5 * SmoothL1 on masked boxes, LOSS_AVG)."""
     from mmnas.utils.itm_loss import BCE_Loss
     from types import SimpleNamespace
     out = {}
     # --- ITM: three forwards, one backward
-    c = cases.net_case('itm', 'mmnas_itm', 9201)
-    neg = cases.net_case('itm', 'mmnas_itm', 9202)
+    c, neg, c_vgd = cases.losses_cases(full64)
     init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
             'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
     net = full_itm.Net_Full(c['cfg'], init)
@@ -821,7 +820,7 @@ def gen_losses():
     out['itm|gradnorms'] = np.array([0.0 if g[k].grad is None else float(g[k].grad.double().norm()) for k in keys])
     out['itm|g:proj.weight'] = g['proj.weight'].grad.numpy()
     # --- VGD loss
-    c = cases.net_case('vgd', 'mmnas_vgd', 9203)
+    c = c_vgd
     init = {'token_size': c['token_size'], 'ans_size': c['ans_size'],
             'pretrained_emb': np.zeros((c['token_size'], c['cfg'].WORD_EMBED_SIZE), np.float32)}
     net = full_vgd.Net_Full(c['cfg'], init)
@@ -844,8 +843,14 @@ def gen_losses():
     g = dict(net.named_parameters())
     out['vgd|gradnorm_keys'] = np.array(keys)
     out['vgd|gradnorms'] = np.array([0.0 if g[k].grad is None else float(g[k].grad.double().norm()) for k in keys])
-    np.savez_compressed(os.path.join(HERE, 'losses.npz'), **out)
-    print('losses.npz', len(out), 'arrays')
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, len(out), 'arrays')
+
+
+def gen_losses64():
+    """The ITM triplet step (three forwards of B = 160, one backward: configs[4]) and the VGD loss step (B = 64: configs[3]) at the
+    entry scripts' own dimensions: the reference on the CPU, a minute or two (not in the default list)."""
+    gen_losses(full64=True, fname='losses64.npz')
 
 
 if __name__ == '__main__':

@@ -349,10 +349,9 @@ def test_itm_triplet_step_single_pass_bf16_products(monkeypatch):
         L.lib().mmnas_gemm_reload_tuning()
 
 
-def _itm_triplet_check(Net_Full, BCE_Loss, itm_triplet_step, tol=TOL, gtol=2e-3):
-    npz = load('losses.npz')
-    c = cases.net_case('itm', 'mmnas_itm', 9201)
-    neg = cases.net_case('itm', 'mmnas_itm', 9202)
+def _itm_triplet_check(Net_Full, BCE_Loss, itm_triplet_step, tol=TOL, gtol=2e-3, full64=False):
+    npz = load('losses64.npz' if full64 else 'losses.npz')
+    c, neg, _ = cases.losses_cases(full64)
     net = _build(Net_Full, c)
     pos = tuple(T(a).to(DEV) for a in c['inputs']); ng = tuple(T(a).to(DEV) for a in neg['inputs'])
     loss = itm_triplet_step(net, BCE_Loss(), pos, ng)
@@ -368,11 +367,21 @@ def _itm_triplet_check(Net_Full, BCE_Loss, itm_triplet_step, tol=TOL, gtol=2e-3)
     assert rel_err(named['proj.weight'].grad.cpu().numpy(), npz['itm|g:proj.weight']) < tol
 
 
-def test_vgd_loss_vs_reference():
+def test_itm_triplet_step_at_the_full_batch_vs_reference():
+    """BASELINE configs[4] at its own dimensions and batch: three forwards of B = 160 (50 tokens, 36 regions, HSIZE 512), BCE_Loss,
+    one backward -- against the reference's own step on the CPU (tests/golden/losses64.npz, make_golden.gen_losses64; round 6)."""
+    from mmnas.model.full_itm import Net_Full
+    from mmnas.utils.itm_loss import BCE_Loss
+    from mmnas_amd.harness import itm_triplet_step
+    _itm_triplet_check(Net_Full, BCE_Loss, itm_triplet_step, full64=True)
+
+
+@pytest.mark.parametrize('full64', [False, True], ids=['small', 'B64_production_dimensions'])
+def test_vgd_loss_vs_reference(full64):
     from mmnas.model.full_vgd import Net_Full
     from mmnas_amd.harness import vgd_loss
-    npz = load('losses.npz')
-    c = cases.net_case('vgd', 'mmnas_vgd', 9203)
+    npz = load('losses64.npz' if full64 else 'losses.npz')
+    c = cases.losses_cases(full64)[2]
     t = {k: T(v).to(DEV) for k, v in cases.vgd_targets(c, 9204).items()}
     net = _build(Net_Full, c)
     ps, pr = net(tuple(T(a).to(DEV) for a in c['inputs']))

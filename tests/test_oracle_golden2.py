@@ -226,8 +226,7 @@ def _gradnorm_check(npz, tag, grads, P):
 
 def test_itm_triplet_step():
     npz = load('losses.npz')
-    c = cases.net_case('itm', 'mmnas_itm', 9201)
-    neg = cases.net_case('itm', 'mmnas_itm', 9202)
+    c, neg, _ = cases.losses_cases()
     P = {k: T(v).clone().requires_grad_(True) for k, v in c['P'].items()}
     pos = tuple(T(a) for a in c['inputs']); ng = tuple(T(a) for a in neg['inputs'])
     f = lambda inp: O.net_forward('itm', P, c['cfg'], inp, genotype=c['genotype'])
@@ -242,7 +241,7 @@ def test_itm_triplet_step():
 
 def test_vgd_loss():
     npz = load('losses.npz')
-    c = cases.net_case('vgd', 'mmnas_vgd', 9203)
+    c = cases.losses_cases()[2]
     t = cases.vgd_targets(c, 9204)
     P = {k: T(v).clone().requires_grad_(True) for k, v in c['P'].items()}
     ps, pr = O.net_forward('vgd', P, c['cfg'], tuple(T(a) for a in c['inputs']), genotype=c['genotype'])
@@ -327,11 +326,12 @@ def test_full_batch_golden_regenerates_bit_exact(tmp_path):
             "mg.HERE = %r\n"
             "mg.gen_nets_full64()\n"
             "mg.gen_traj64()\n"
-            "mg.gen_train_traj64()\n" % (REPO, str(tmp_path)))
+            "mg.gen_train_traj64()\n"
+            "mg.gen_losses64()\n" % (REPO, str(tmp_path)))
     r = subprocess.run([sys.executable, '-c', code], cwd=str(tmp_path), env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'),
                        capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stderr[-2000:]
-    for w in ('nets_full64.npz', 'traj64.npz', 'train_traj64.npz'):
+    for w in ('nets_full64.npz', 'traj64.npz', 'train_traj64.npz', 'losses64.npz'):
         new = np.load(os.path.join(str(tmp_path), w))
         old = np.load(os.path.join(GOLDEN, w))
         assert sorted(new.files) == sorted(old.files), w
