@@ -521,8 +521,9 @@ def test_search_loop_mode_two_follows_the_per_module_statements():
         loop.reducer.fg.disable_sinks()
 
 
+@pytest.mark.parametrize('full64', [False, True], ids=['small', 'B64_production_dimensions'])
 @pytest.mark.parametrize('which', ['bilevel', 'train'])
-def test_reference_loop_trajectories_with_the_ragged_decoder_stream(which):
+def test_reference_loop_trajectories_with_the_ragged_decoder_stream(which, full64):
     """The reference's OWN loops (traj.npz: search_vqa.py:279-337; train_traj.npz: train_vqa.py:291-311) replayed with the ragged decoder stream on (ops.set_unpad): losses, gradient norms, per-tensor parameter
     motion and post-step alphas of the padded reference computation are met on the valid rows alone -- and the chain really
     ran packed."""
@@ -533,9 +534,9 @@ def test_reference_loop_trajectories_with_the_ragged_decoder_stream(which):
     prev = ops.set_unpad(True)
     try:
         if which == 'bilevel':
-            test_bilevel_trajectory_vs_reference_loop()
+            test_bilevel_trajectory_vs_reference_loop(full64)
         else:
-            test_training_loop_trajectory_vs_reference_loop()
+            test_training_loop_trajectory_vs_reference_loop(full64)
     finally:
         ops.set_unpad(prev)
         ops.BackboneFn.apply = orig
